@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ref: needs oracle/_ref (the compiled reference)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def ref(orc):
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    return orc.ref()
