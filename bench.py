@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""bench.py — TempestSDR hot path on MI355X: IQ Msamples/s (+ frames/s).
+
+One "step" = one pass of the whole hot path over one HBM-resident batch of
+synthetic IQ (BASELINE.json configs[2]: 100 MS/s, 1920x1080@60 raster, i.e.
+h=1125 total lines -> 2962x1125 frames):
+
+    a1+a2  fused AM demod + area resample      IQ -> pixel stream   (600 chunks)
+    a3..a8 dsp_post_process, library-default stage order, every frame delivered
+    a9..a12 FFT autocorrelation of EVERY 3.1/55 s capture window + lag accumulation
+            (+ RCCL all-reduce of the per-lag sums when N > 1) + argmax
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
+torch.distributed.run (one rank per GPU).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: its HIP runtime is the one the process uses)
+
+from tempestsdr_amd import gpu, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synth_iq_torch(fs, mode, fv, nsamples, start, seed, device, noise=0.02):
+    """tempestsdr_amd.synth.synth_iq on the device (same model; float math on GPU)."""
+    tw, th, aw, ah = synth.MODES[mode]
+    out = torch.empty(2 * nsamples, dtype=torch.float32, device=device)
+    step = 1 << 24
+    f_p = tw * th * fv
+    for s in range(0, nsamples, step):
+        n = min(step, nsamples - s)
+        i = torch.arange(start + s, start + s + n, dtype=torch.int64, device=device)
+        k = torch.floor(i.to(torch.float64) * (f_p / fs)).to(torch.int64)
+        x = k % tw
+        y = (k // tw) % th
+        a = torch.where(((x * 8) // aw) % 2 == 0, 0.3, 0.8).to(torch.float64)
+        check = (((x // 16) + (y // 16)) % 2).to(torch.float64) * 0.2 - 0.1
+        a = a + torch.where(y >= ah // 2, check, torch.zeros_like(check))
+        a = torch.where((x < aw) & (y < ah), a, torch.full_like(a, 0.05))
+        # counter-based noise: a cheap integer hash of the absolute sample index
+        z = (i * (-7046029254386353131) + seed) & 0x7FFFFFFFFFFFFFFF
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B
+        z = (z & 0x7FFFFFFFFFFFFFFF)
+        z = z ^ (z >> 27)
+        u = (z & 0xFFFFFF).to(torch.float64) / float(1 << 24)
+        a = a + (u - 0.5) * (noise * 12 ** 0.5)
+        phi = 0.37 * i.to(torch.float64)
+        out[2 * s:2 * (s + n):2] = (a * torch.cos(phi)).to(torch.float32)
+        out[2 * s + 1:2 * (s + n):2] = (a * torch.sin(phi)).to(torch.float32)
+    return out
+
+
+class DevPtr:
+    """Adapter: a torch tensor seen as a tsdrgpu DeviceArray (pointer + offsets)."""
+
+    def __init__(self, t):
+        self.t = t
+        self.ptr = t.data_ptr()
+        self.count = t.numel()
+        self.itemsize = t.element_size()
+
+    def at(self, off):
+        return self.ptr + int(off) * self.itemsize
+
+
+def geometry(fs, h, fv):
+    width = int(2 * (fs / (fv * h)))  # TSDRLibrary.c:543-546
+    return width
+
+
+def cpu_baseline(iq_host, fs, h, fv, nframes, nwindows):
+    """The reference's own functions (oracle/_ref) — or the oracle port when the
+    compiled reference is absent — timed single-threaded on a bounded sample."""
+    from oracle import oracle as orc
+    use_ref = orc.have_ref()
+    geo = orc.geometry(fs, h, fv)
+    w = geo.width
+    chunk = orc.chunk_size(fs, fv)
+    P = w * h
+    up, down = w * h * fv, float(fs)
+    nsamp_frames = int(np.ceil(nframes * P / (up / down) / chunk)) * chunk
+    iq = iq_host[:2 * nsamp_frames].copy()
+    t0 = time.perf_counter()
+    if use_ref:
+        r = orc.ref()
+        mag = iq.copy()
+        r.complex_to_real(mag, nsamp_frames)
+        mag = mag[:nsamp_frames]
+        rs = r.ref_resampler_new()
+        outs = []
+        buf = np.zeros(int(chunk * up / down) + 16, np.float32)
+        for s in range(0, nsamp_frames, chunk):
+            n = r.ref_resampler_process(rs, mag[s:s + chunk], chunk, buf, up, down, 0)
+            outs.append(buf[:n].copy())
+        pix = np.concatenate(outs)
+        t = r.ref_new(h, fv, fs, 0.0, None)
+        done = 0
+        while (done + 1) * P <= pix.size and done < nframes:
+            r.ref_post_process(t, pix[done * P:(done + 1) * P].copy(), 0.0, 0.1, 0, 0)
+            done += 1
+        r.ref_free(t)
+    else:
+        pix, _ = orc.demod_resample_stream(iq, geo)
+        pp = orc.PostProcess(geo)
+        done = 0
+        while (done + 1) * P <= pix.size and done < nframes:
+            pp.run(pix[done * P:(done + 1) * P].copy(), 0.0)
+            done += 1
+    t_frames = time.perf_counter() - t0
+    samples_frames = done * P / (up / down)
+
+    cap = orc.capture_size(fs)
+    flo, flen, llo, llen = orc.lag_windows(fs)
+    t0 = time.perf_counter()
+    fr, ln = np.zeros(flen), np.zeros(llen)
+    for k in range(nwindows):
+        seg = iq_host[2 * k * cap:2 * (k + 1) * cap]
+        if use_ref:
+            m = seg.copy()
+            r.complex_to_real(m, cap)
+            corr = np.zeros(2 * cap, np.float32)
+            r.fft_autocorrelation(corr, m[:cap].copy(), cap)
+            r.ref_accumulate(fr, corr, flo, flen, k + 1)
+            r.ref_accumulate(ln, corr, llo, llen, k + 1)
+        else:
+            ac = orc.Autocorr(fs) if k == 0 else ac
+            ac.run(orc.am_demod(seg))
+    t_ac = time.perf_counter() - t0
+    # seconds of CPU per input sample for each leg (every window is correlated, like the GPU run)
+    per_sample = t_frames / samples_frames + t_ac / (nwindows * cap)
+    return {
+        "value": round(1e-6 / per_sample, 3), "unit": "Msamples/s", "cores": 1,
+        "kind": "reference" if use_ref else "port",
+        "sample": f"{done} frames ({t_frames:.2f} s) + {nwindows} autocorrelation windows ({t_ac:.2f} s) "
+                  f"of the same 100 MS/s stream, single thread, -O3 no fast-math",
+        "frame_path_Msps": round(samples_frames / t_frames / 1e6, 2),
+        "autocorr_s_per_window": round(t_ac / nwindows, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seconds", type=float, default=1.0, help="signal seconds per batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    fs, h, fv, mode = 100_000_000, 1125, 60.0, "1920x1080"
+    W = geometry(fs, h, fv)
+    P = W * h
+    chunk = int(0.1 * fs / fv)  # TSDRLibrary.c:335
+    nchunks = int(args.seconds * fs) // chunk
+    nsamples = nchunks * chunk
+    up, down = W * h * fv, float(fs)
+
+    g = gpu.TsdrGpu(local)
+    # each rank owns a different slice of the stream (weak scaling: fixed work per GPU)
+    iq = synth_iq_torch(fs, mode, fv, nsamples, rank * nsamples, 0x5EED0003, dev)
+    torch.cuda.synchronize()
+    d_iq = DevPtr(iq)
+
+    rs = gpu.Resampler(g)
+    pp = gpu.PostProcess(g)
+    ac = gpu.Autocorr(g, fs)
+    nwin = nsamples // ac.capture
+    max_pix = int(nsamples * (up / down)) + 64
+    pix = torch.empty(max_pix, dtype=torch.float32, device=dev)
+    frames_cap = max_pix // P + 1
+    out = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
+    d_pix, d_out = DevPtr(pix), DevPtr(out)
+    plots_ptr, plots_n = ac.device_plots()
+    red = torch.zeros(plots_n, dtype=torch.float64, device=dev) if world > 1 else None
+
+    carry = 0  # pixels left over from the previous step (a frame straddling two batches)
+    frames_done = 0
+
+    def step():
+        nonlocal carry, frames_done
+        # a1+a2: the new pixels are appended behind the carried remainder
+        n = rs.process(d_iq, 1, chunk, nchunks, up, down, 0, d_pix, out_offset=carry)
+        avail = carry + n
+        F = avail // P
+        pp.run(d_pix, F, W, h, d_out, motionblur=0.0, want_info=False)
+        rem = avail - F * P
+        if rem:
+            g._ck(g.lib.tsdrgpu_copy(g.h, d_pix.at(0), d_pix.at(F * P), rem * 4))
+        carry = rem
+        frames_done += F
+        if world > 1:
+            ac.reset()
+            ac.run(d_iq, 1, ac.capture, nwin, mode=1)
+            g._ck(g.lib.tsdrgpu_copy(g.h, red.data_ptr(), plots_ptr, plots_n * 8))
+            g.sync()
+            dist.all_reduce(red)  # RCCL over xGMI: per-lag |R| sums of all ranks' windows
+            torch.cuda.synchronize()
+            g._ck(g.lib.tsdrgpu_copy(g.h, plots_ptr, red.data_ptr(), plots_n * 8))
+            ac.finalize_sums(nwin * world)
+        else:
+            ac.run(d_iq, 1, ac.capture, nwin, mode=0)
+        return ac.argmax()
+
+    def barrier():
+        g.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    frames_done = 0
+    g.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fi, li = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = g.profile_end()
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        fr = torch.tensor([frames_done], dtype=torch.float64, device=dev)
+        dist.all_reduce(fr)
+        frames_total = float(fr.item())
+    else:
+        frames_total = float(frames_done)
+
+    if rank == 0:
+        total_samples = float(nsamples) * args.steps * world
+        ms_step = dt / args.steps * 1e3
+        # ---- roofline of the dominant kernel (live HIP-event timings of the timed region)
+        N, L = ac.n, ac.flen + ac.llen
+        S = fs / fv
+        fft_launches = prof.get("k_fft_pass", (0, 1))[1] / max(1, args.steps)
+        alg_bytes = {
+            # autocorrelation 28N+16L per window, spread over the FFT pass launches
+            "k_fft_pass": (28.0 * N + 16.0 * L) * nwin / max(1.0, fft_launches),
+            # frame path 8S+16P per frame = resample (8S+4P) + stats (4P) + normalise/IIR pass (8P)
+            "k_rs_area": (8.0 * S + 4.0 * P) * (nsamples / S),
+            "k_frame_stats": 4.0 * P * (frames_total / world / args.steps),
+            "k_frame_pass": 8.0 * P * (frames_total / world / args.steps),
+        }
+        dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
+        roofline = None
+        if dom in alg_bytes:
+            avg_ms = prof[dom][0] / prof[dom][1]
+            ach = alg_bytes[dom] / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom)
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes[dom])}
+        frame_kernels_ms = sum(prof.get(k, (0, 0))[0] for k in
+                               ("k_rs_tail+k_rs_chain", "k_rs_area", "k_frame_stats", "k_frame_reduce", "k_chain", "k_frame_pass"))
+        frame_path_bytes = (8.0 * S + 16.0 * P) * frames_total / world
+        stage_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
+
+        flag, llag = ac.flo + fi, ac.llo + li
+        res = {
+            "metric": "IQ Msamples/s (+ reconstructed frames/s), 1080p60 target: demod+resample+frame post-processing+full autocorrelation",
+            "value": round(total_samples / dt / 1e6, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 100 MS/s synthetic IQ, 1920x1080@60 raster "
+                                   f"(h=1125 -> {W}x{h} frames), {args.seconds:g} s batch resident in HBM, "
+                                   f"{nchunks} resample chunks, {nwin} autocorrelation windows of N=2^{int(np.log2(N))} per step",
+                       "samples_per_step_per_gpu": nsamples, "stage_order": "library default (autogain, sync, IIR)"},
+            "frames_per_s": round(frames_total / dt, 1),
+            "realtime_factor": round(total_samples / dt / fs / world, 2),
+            "roofline": roofline,
+            "frame_path": {"kernels_ms_per_step": round(frame_kernels_ms / args.steps, 3),
+                           "achieved_GBs": round(frame_path_bytes / (frame_kernels_ms * 1e-3) / 1e9, 1) if frame_kernels_ms else None,
+                           "frac": round(frame_path_bytes / (frame_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_kernels_ms else None,
+                           "alg_bytes_per_frame": int(8 * S + 16 * P)},
+            "stage_ms_per_step": stage_ms,
+            "detected": {"frame_lag": int(flag), "line_lag": int(llag), "framerate": round(fs / flag, 4),
+                         "height": int(round(flag / llag)), "linerate": round(fs / llag, 2)},
+            "device": g.device_name(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                half = min(nsamples, 50_000_000)
+                host = iq[:2 * half].cpu().numpy()
+                res["cpu_baseline"] = cpu_baseline(host, fs, h, fv, nframes=int(half / S), nwindows=max(1, half // ac.capture))
+                res["cpu_baseline"]["cores_on_box"] = os.cpu_count()
+            except Exception as e:  # the baseline is a reported number, never the product path
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    g.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

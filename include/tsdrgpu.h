@@ -1,0 +1,189 @@
+/*
+ * tsdrgpu.h — C ABI of the MI355X (gfx950) implementation of TempestSDR's DSP
+ * hot path.  Plain pointers and sizes only; every pointer named d_* is a HIP
+ * device pointer, h_* a host pointer.  All calls are asynchronous on the
+ * context's stream unless stated; tsdrgpu_sync() waits for them.
+ *
+ * Each entry point names the reference code (file:line under
+ * TempestSDR/src/ of martinmarinov/TempestSDR) it replaces.  The reference has
+ * no FFI of its own for these stages (they are internal C functions behind the
+ * tsdr_* API, include/TSDRLibrary.h); this header is what a maintainer would
+ * bind instead of those internals, and what
+ * libTSDRLibrary.so in this repository — the drop-in for the tsdr_* API — is
+ * built on.
+ *
+ * Return value: 0 (TSDRGPU_OK) or a negative TSDRGPU_E* code;
+ * tsdrgpu_last_error() gives the text.  There is no CPU fallback: without a
+ * HIP device tsdrgpu_create() fails.
+ */
+#ifndef TSDRGPU_H_
+#define TSDRGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSDRGPU_OK 0
+#define TSDRGPU_EHIP (-1)     /* a HIP runtime call failed */
+#define TSDRGPU_EINVAL (-2)   /* bad argument */
+#define TSDRGPU_ENOMEM (-3)   /* device/host allocation failed */
+#define TSDRGPU_ESTATE (-4)   /* object not configured for this call */
+
+typedef struct tsdrgpu tsdrgpu_t;                     /* device context: device, stream, scratch */
+typedef struct tsdrgpu_resampler tsdrgpu_resampler_t; /* dsp_resample_t on the device */
+typedef struct tsdrgpu_postproc tsdrgpu_postproc_t;   /* dsp_postprocess_t on the device */
+typedef struct tsdrgpu_autocorr tsdrgpu_autocorr_t;   /* frameratedetector numerics on the device */
+
+/* ---- context and memory ------------------------------------------------- */
+int tsdrgpu_create(tsdrgpu_t **out, int device);
+void tsdrgpu_destroy(tsdrgpu_t *g);
+const char *tsdrgpu_last_error(tsdrgpu_t *g);
+int tsdrgpu_sync(tsdrgpu_t *g);
+void *tsdrgpu_stream(tsdrgpu_t *g); /* the hipStream_t all work is queued on */
+int tsdrgpu_device_name(tsdrgpu_t *g, char *buf, size_t buflen);
+
+int tsdrgpu_alloc(tsdrgpu_t *g, void **d_ptr, size_t bytes);
+int tsdrgpu_free(tsdrgpu_t *g, void *d_ptr);
+int tsdrgpu_alloc_host(tsdrgpu_t *g, void **h_ptr, size_t bytes); /* pinned */
+int tsdrgpu_free_host(tsdrgpu_t *g, void *h_ptr);
+int tsdrgpu_upload(tsdrgpu_t *g, void *d_dst, const void *h_src, size_t bytes);
+int tsdrgpu_download(tsdrgpu_t *g, void *h_dst, const void *d_src, size_t bytes);
+int tsdrgpu_copy(tsdrgpu_t *g, void *d_dst, const void *d_src, size_t bytes);
+int tsdrgpu_zero(tsdrgpu_t *g, void *d_ptr, size_t bytes);
+
+/* event timing on the context's stream (used by bench.py for the roofline leg) */
+int tsdrgpu_timer_start(tsdrgpu_t *g);
+int tsdrgpu_timer_stop_ms(tsdrgpu_t *g, float *ms); /* synchronises */
+
+/* optional per-stage event profiler: while enabled every kernel launch group is
+ * bracketed by a HIP event pair on the stream.  tsdrgpu_profile_end()
+ * synchronises and reports, per stage, the summed duration and launch count.
+ * Stage names are the kernel names (k_fft_pass, k_frame_pass, ...). */
+typedef struct tsdrgpu_profile_entry {
+    char name[32];
+    double total_ms;
+    int launches;
+} tsdrgpu_profile_entry_t;
+int tsdrgpu_profile_begin(tsdrgpu_t *g);
+int tsdrgpu_profile_end(tsdrgpu_t *g, tsdrgpu_profile_entry_t *h_entries, int max_entries, int *h_count);
+
+/* ---- a1: AM demodulation -------------------------------------------------- */
+/* am_demod, TSDRLibrary.c:244-262 (== complex_to_real, fft.c:24-32):
+ * d_out[i] = sqrtf(I*I + Q*Q), float32, bit-exact.  d_out must not overlap d_iq
+ * (the reference's in-place form is inherently sequential). */
+int tsdrgpu_am_demod(tsdrgpu_t *g, const float *d_iq, float *d_out, int64_t nsamples);
+
+/* ---- a2: fractional area resampler ----------------------------------------- */
+/* dsp_resample_t / dsp_resample_process, dsp.c:250-307.  One call replays
+ * `nchunks` consecutive dsp_resample_process calls of `chunk` input samples each
+ * (the library polls 0.1 frame at a time, TSDRLibrary.c:335-340), carrying
+ * `offset` (host, double) and `contrib` (device) exactly like the reference.
+ *   d_in        magnitude samples (in_is_iq = 0) or interleaved IQ
+ *               (in_is_iq = 1: am_demod is fused, a1+a2)
+ *   d_out       pixel stream; out_capacity floats
+ *   h_n_out     total pixels written (known on the host immediately: the
+ *               counts depend on sizes and phases, not on data)
+ */
+int tsdrgpu_resampler_create(tsdrgpu_t *g, tsdrgpu_resampler_t **out);
+void tsdrgpu_resampler_destroy(tsdrgpu_resampler_t *rs);
+int tsdrgpu_resampler_reset(tsdrgpu_resampler_t *rs); /* dsp_resample_init, dsp.c:250-254 */
+int tsdrgpu_resampler_setstate(tsdrgpu_resampler_t *rs, double contrib, double offset);
+int tsdrgpu_resampler_getstate(tsdrgpu_resampler_t *rs, double *contrib, double *offset); /* syncs */
+int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int in_is_iq, uint32_t chunk,
+                     int nchunks, double upsample_by, double downsample_by, int nearest,
+                     float *d_out, int64_t out_capacity, int64_t *h_n_out);
+/* Pixel count the next `nchunks` calls would produce, without running them. */
+int64_t tsdrgpu_resample_count(tsdrgpu_resampler_t *rs, uint32_t chunk, int nchunks,
+                               double upsample_by, double downsample_by);
+
+/* ---- a3..a8: frame post-processing ------------------------------------------ */
+/* dsp_post_process, dsp.c:134-239, with dsp_autogain_run (dsp.c:41-94),
+ * dsp_average_v_h (dsp.c:96-110), syncdetector_run incl. gaussianblur,
+ * findthesweetspot, frameratepll (syncdetector.c:26-225, gaussian.c:18-79) and
+ * dsp_timelowpass_run (dsp.c:22-33), all on the device. */
+typedef struct tsdrgpu_pp_params {
+    int lowpass_before_sync;  /* PARAM_LOW_PASS_BEFORE_SYNC */
+    int autogain_after_proc;  /* PARAM_AUTOGAIN_AFTER_PROCESSING */
+    int autoshift;            /* PARAM_INT_AUTOSHIFT */
+    int pll;                  /* PARAM_INT_FRAMERATE_PLL */
+    int superresolution;      /* PARAM_AUTOCORR_SUPERRESOLUTION (suppresses green lines) */
+    float motionblur;         /* tsdr_motionblur coefficient */
+    float lowpasscoeff;       /* NORMALISATION_LOWPASS_COEFF = 0.1f, TSDRLibrary.c:37 */
+} tsdrgpu_pp_params_t;
+
+/* What the reference leaves in dsp_postprocess_t / announces after a frame. */
+typedef struct tsdrgpu_pp_frameinfo {
+    float lastmin, lastmax;   /* dsp_autogain_t after this frame */
+    int dx, vx, stripx;       /* sync.db_x: dx, vx, curr_stripsize */
+    int dy, vy, stripy;       /* sync.db_y */
+    int locked;               /* sync.state */
+    int pll_fired;            /* frameratepll nudged the refresh rate */
+    double avg_speed;         /* sync.avg_speed */
+    double frameratediff;     /* amount subtracted from refreshrate (0 when !pll_fired) */
+} tsdrgpu_pp_frameinfo_t;
+
+int tsdrgpu_postproc_create(tsdrgpu_t *g, tsdrgpu_postproc_t **out);
+void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp);
+int tsdrgpu_postproc_reset(tsdrgpu_postproc_t *pp); /* dsp_post_process_init, dsp.c:112-132 */
+/* Runs `nframes` consecutive frames (d_frames: nframes*width*height floats,
+ * raster order) through dsp_post_process in order, as one batch of launches.
+ * d_out receives every frame's result (what the reference hands to the video
+ * thread).  h_info (nframes entries, may be NULL): when given, the call
+ * synchronises and fills it.  The refresh-rate PLL's effect on width/refresh
+ * is the caller's job (apply h_info[i].frameratediff, TSDRLibrary.c:540-550),
+ * so with params->pll the caller should pass one frame at a time. */
+int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width,
+                         int height, const tsdrgpu_pp_params_t *params, float *d_out,
+                         tsdrgpu_pp_frameinfo_t *h_info);
+/* strips of the last frame run (after blur + markers), for stage-level tests */
+int tsdrgpu_postproc_strips(tsdrgpu_postproc_t *pp, float *h_colsum, float *h_rowsum); /* syncs */
+
+/* ---- a9..a12: FFT autocorrelation ---------------------------------------------- */
+/* fft_perform, fft.c:96-176: in-place complex FFT of n = 2^m points on
+ * interleaved float32 (forward scaled by 1/n, inverse unscaled). */
+int tsdrgpu_fft(tsdrgpu_t *g, float *d_iq, uint32_t n, int inverse);
+
+/* frameratedetector_runontodata numerics (frameratedetector.c:87-126):
+ * fft_autocorrelation (fft.c:49-64) of each capture window, then accummulate
+ * (frameratedetector.c:34-62) into the frame- and line-lag plots. */
+int tsdrgpu_autocorr_create(tsdrgpu_t *g, tsdrgpu_autocorr_t **out, uint32_t samplerate);
+void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac);
+int tsdrgpu_autocorr_reset(tsdrgpu_autocorr_t *ac); /* PARAM_AUTOCORR_PLOTS_RESET */
+/* geometry: lags [frame_lo, frame_lo+frame_len), [line_lo, ...), capture size
+ * (3.1*fs/55) and the FFT length n = largest 2^m <= capture size */
+int tsdrgpu_autocorr_geometry(tsdrgpu_autocorr_t *ac, int32_t *frame_lo, int32_t *frame_len,
+                              int32_t *line_lo, int32_t *line_len, uint32_t *capture,
+                              uint32_t *fft_n);
+/* d_in: magnitude samples (in_is_iq=0) or interleaved IQ (demod fused).
+ * Window w starts at sample w*stride.  mode 0: running mean, bit-for-bit the
+ * reference's recurrence; mode 1: plain sums (for sharded runs: all-reduce
+ * the sums, then tsdrgpu_autocorr_finalize_sums). */
+int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, int64_t stride,
+                         int nwindows, int mode);
+int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line,
+                           uint64_t *h_calls); /* syncs */
+/* device plots: frame_len + line_len doubles, contiguous (frame first) */
+int tsdrgpu_autocorr_device_plots(tsdrgpu_autocorr_t *ac, double **d_plots, int64_t *count);
+int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t total_windows);
+/* argmax (lowest index wins ties, PlotVisualizer.java:233-236); syncs */
+int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, int32_t *line_idx);
+/* the raw correlation of the LAST window run (2*n floats), for stage tests */
+int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **d_corr, uint32_t *n);
+
+/* ---- a13/a14: super-bandwidth stitch --------------------------------------------- */
+/* superb_ondataready, superbandwidth.c:121-152 (complex_to_abs_diff :67-81,
+ * superb_bestfit :83-119, fft_crosscorrelation fft.c:69-93).  d_hops: nhops
+ * device buffers of 2*gathered floats (modified in place like the reference).
+ * d_out: nhops*2*n floats with n = largest 2^m <= gathered.  h_offsets[nhops]:
+ * best offsets in floats.  Synchronises (the offsets steer the rotation). */
+int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered,
+                          int samples_in_frame, float *d_out, int32_t *h_offsets,
+                          uint32_t *h_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSDRGPU_H_ */

@@ -1,0 +1,70 @@
+"""Builds the gfx950 shared libraries IN-TREE (they travel to the GPU box with
+the gpurun snapshot; a JIT cache would not):
+
+  tempestsdr_amd/libtsdrgpu.so     HIP kernels + the tsdrgpu_* C ABI (include/tsdrgpu.h)
+  tempestsdr_amd/libTSDRLibrary.so the drop-in tsdr_* host library (C) on top of it
+
+hipcc cross-compiles for gfx950 without a GPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+          "-fhip-fp32-correctly-rounded-divide-sqrt", "-I" + os.path.join(ROOT, "include")]
+# bit-exact stages: no FMA contraction (the reference is built without it)
+STRICT = ["-ffp-contract=off"]
+
+HIP_SOURCES = [("tsdrgpu_core.hip", STRICT), ("tsdrgpu_frame.hip", STRICT), ("tsdrgpu_fft.hip", [])]
+LIB = os.path.join(HERE, "libtsdrgpu.so")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    return hs
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    procs = []
+    for src, extra in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + _headers()):
+            cmd = [HIPCC] + COMMON + extra + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("compile failed: " + " ".join(cmd))
+    if force or _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    host = os.path.join(CSRC, "host")
+    if os.path.isdir(host) and os.path.exists(os.path.join(host, "Makefile")):
+        subprocess.run(["make", "-C", host, "-s"], check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

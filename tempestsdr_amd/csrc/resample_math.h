@@ -1,0 +1,132 @@
+// resample_math.h — closed-form, per-output-pixel evaluation of the reference's
+// sequential area resampler (dsp_resample_process, TempestSDR/src/dsp.c:250-307).
+//
+// The reference walks the INPUT samples in order, carrying `pix` (next output
+// pixel) and `contrib` (unfinished pixel).  Which sample emits which pixel, and
+// through which branch, depends only on (r, o, size) — never on the data — so a
+// thread can recover, for ONE output pixel p, exactly the f64 expression the
+// sequential loop would have evaluated:
+//
+//   hi_m1(id) = (id*r + o) + r - 1.0        ("idcheck2", dsp.c:283)
+//   E(p)      = min{ id : p < hi_m1(id) }   sample during which p is stored
+//   pix_in(id)= first pixel not stored before sample id
+//             = min{ q >= 0 : q >= hi_m1(id-1) }
+//   p is stored by the "finish a straddling pixel" branch (dsp.c:288-292) iff
+//   p == pix_in(E) and p < lo(E); then value = contrib + v*((1.0-lo)+p), where
+//   contrib is rebuilt by replaying the tail terms (dsp.c:299-302) of the
+//   samples since the last sample that took that branch.  Otherwise the pixel
+//   lies wholly inside sample E and the value is v (dsp.c:294-297).
+//
+// Every comparison and arithmetic expression below is the reference's own f64
+// expression (compile with -ffp-contract=off), so results — including the
+// aligned edge cases where r*size is an integer — are bit-identical.
+//
+// All functions are host+device so the CPU-only test-suite can exercise the
+// same code (tests/emu/) that the HIP kernels run.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TSDR_HD __host__ __device__ inline
+#else
+#define TSDR_HD inline
+#endif
+
+struct RsChunk {
+    long long in_off;   // first input sample of the chunk in the input stream
+    long long out_off;  // first output pixel of the chunk in the output stream
+    unsigned size;      // input samples in the chunk
+    unsigned n_out;     // announced output count, (int)((size-offset)*r)   dsp.c:262
+    double o;           // -offset*r  ("offset_sample", dsp.c:272)
+};
+
+struct RsGeom {
+    double r;  // upsample_by/downsample_by
+    double o;
+    unsigned size;
+};
+
+TSDR_HD double rs_lo(const RsGeom &g, long long id) { return (double)id * g.r + g.o; }
+TSDR_HD double rs_hi(const RsGeom &g, long long id) { return rs_lo(g, id) + g.r; }
+TSDR_HD double rs_him1(const RsGeom &g, long long id) { return rs_lo(g, id) + g.r - 1.0; }
+
+// smallest integer q >= 0 with q >= x  (q compared as double, like `pid < idcheck2`)
+TSDR_HD double rs_first_not_below(double x)
+{
+    if (!(x > 0.0)) return 0.0;
+    double c = (double)(long long)x;  // trunc; x > 0
+    if (c < x) c += 1.0;
+    return c;
+}
+
+TSDR_HD double rs_pix_in(const RsGeom &g, long long id)
+{
+    return (id <= 0) ? 0.0 : rs_first_not_below(rs_him1(g, id - 1));
+}
+
+// did sample `id` take the straddling-pixel branch (dsp.c:288)?
+TSDR_HD bool rs_fired(const RsGeom &g, long long id)
+{
+    const double pin = rs_pix_in(g, id);
+    return pin < rs_lo(g, id) && pin < rs_him1(g, id);
+}
+
+// E(p); returns g.size when no sample of this chunk stores p
+TSDR_HD long long rs_owner(const RsGeom &g, double p)
+{
+    long long id = (long long)((p + 1.0 - g.r - g.o) / g.r) + 1;
+    if (id < 0) id = 0;
+    if (id > (long long)g.size) id = g.size;
+    while (id > 0 && p < rs_him1(g, id - 1)) id--;
+    while (id < (long long)g.size && !(p < rs_him1(g, id))) id++;
+    return id;
+}
+
+// `contrib` as the reference holds it when sample `id` begins (id may be
+// g.size: the value carried out of the chunk).  in(j) returns sample j as float.
+// *used_in (optional) tells whether the chunk's incoming contrib took part.
+template <class In>
+TSDR_HD double rs_contrib_before(const RsGeom &g, long long id, double contrib_in, In in,
+                                 bool *used_in = nullptr)
+{
+    long long j0 = id - 1;
+    while (j0 >= 0 && !rs_fired(g, j0)) j0--;
+    if (used_in) *used_in = (j0 < 0);
+    double contrib = (j0 >= 0) ? 0.0 : contrib_in;
+    for (long long j = (j0 >= 0 ? j0 : 0); j < id; j++) {
+        const double v = (double)in(j);
+        const double pix = rs_pix_in(g, j + 1);
+        const double lo = rs_lo(g, j), hi = lo + g.r;
+        if (pix < hi && pix > lo)
+            contrib += (hi - pix) * v;
+        else
+            contrib += g.r * v;
+    }
+    return contrib;
+}
+
+// Value of output pixel p of the chunk; returns false when the reference's
+// loop never stores it (aligned edge case) — the caller then writes 0.0f.
+template <class In>
+TSDR_HD bool rs_area_pixel(const RsGeom &g, unsigned p, double contrib_in, In in, float *out)
+{
+    const double pd = (double)p;
+    const long long id = rs_owner(g, pd);
+    if (id >= (long long)g.size) return false;
+    const double v = (double)in(id);
+    const double lo = rs_lo(g, id);
+    const bool first = (id == 0) ? (p == 0) : (p == 0 || (pd - 1.0) < rs_him1(g, id - 1));
+    if (first && pd < lo) {
+        const double contrib = rs_contrib_before(g, id, contrib_in, in);
+        *out = (float)(contrib + v * (1.0 - lo + pd));
+    } else {
+        *out = (float)v;
+    }
+    return true;
+}
+
+// nearest-neighbour branch, dsp.c:274-276
+TSDR_HD long long rs_nearest_src(unsigned size, unsigned n_out, unsigned p)
+{
+    return (long long)(((uint64_t)size * p) / n_out);
+}

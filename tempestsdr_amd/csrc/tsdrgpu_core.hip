@@ -1,0 +1,558 @@
+// tsdrgpu_core.hip — context, memory, AM demodulation and the fractional area
+// resampler for gfx950.  See include/tsdrgpu.h for the contract of each entry
+// point and the reference code it replaces.
+#include "tsdrgpu_internal.h"
+#include "resample_math.h"
+
+// ---------------------------------------------------------------------------
+// context / memory
+// ---------------------------------------------------------------------------
+extern "C" int tsdrgpu_create(tsdrgpu_t **out, int device)
+{
+    if (!out) return TSDRGPU_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return TSDRGPU_EHIP;  // no CPU fallback
+    if (device < 0 || device >= count) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = (tsdrgpu_t *)calloc(1, sizeof(tsdrgpu_t));
+    if (!g) return TSDRGPU_ENOMEM;
+    g->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&g->prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&g->t0) != hipSuccess || hipEventCreate(&g->t1) != hipSuccess) {
+        free(g);
+        return TSDRGPU_EHIP;
+    }
+    *out = g;
+    return TSDRGPU_OK;
+}
+
+extern "C" void tsdrgpu_destroy(tsdrgpu_t *g)
+{
+    if (!g) return;
+    hipSetDevice(g->device);
+    hipStreamSynchronize(g->stream);
+    for (int i = 0; i < g->cap_spans; i++) {
+        if (g->spans[i].a) hipEventDestroy(g->spans[i].a);
+        if (g->spans[i].b) hipEventDestroy(g->spans[i].b);
+    }
+    free(g->spans);
+    hipEventDestroy(g->t0);
+    hipEventDestroy(g->t1);
+    hipStreamDestroy(g->stream);
+    free(g);
+}
+
+extern "C" const char *tsdrgpu_last_error(tsdrgpu_t *g) { return g ? g->err : "no context"; }
+extern "C" void *tsdrgpu_stream(tsdrgpu_t *g) { return g ? (void *)g->stream : nullptr; }
+
+extern "C" int tsdrgpu_sync(tsdrgpu_t *g)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_device_name(tsdrgpu_t *g, char *buf, size_t buflen)
+{
+    if (!g || !buf || !buflen) return TSDRGPU_EINVAL;
+    snprintf(buf, buflen, "%s (%s, %d CUs)", g->prop.name, g->prop.gcnArchName, g->prop.multiProcessorCount);
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_alloc(tsdrgpu_t *g, void **d_ptr, size_t bytes)
+{
+    if (!g || !d_ptr) return TSDRGPU_EINVAL;
+    HIP_TRY(g, hipSetDevice(g->device));
+    if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "hipMalloc", "out of device memory");
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_free(tsdrgpu_t *g, void *d_ptr)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    if (d_ptr) HIP_TRY(g, hipFree(d_ptr));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_alloc_host(tsdrgpu_t *g, void **h_ptr, size_t bytes)
+{
+    if (!g || !h_ptr) return TSDRGPU_EINVAL;
+    if (hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "hipHostMalloc", "out of pinned memory");
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_free_host(tsdrgpu_t *g, void *h_ptr)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    if (h_ptr) HIP_TRY(g, hipHostFree(h_ptr));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_upload(tsdrgpu_t *g, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    if (bytes) HIP_TRY(g, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g->stream));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_download(tsdrgpu_t *g, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    if (bytes) HIP_TRY(g, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g->stream));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_copy(tsdrgpu_t *g, void *d_dst, const void *d_src, size_t bytes)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    if (bytes) HIP_TRY(g, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g->stream));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_zero(tsdrgpu_t *g, void *d_ptr, size_t bytes)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    if (bytes) HIP_TRY(g, hipMemsetAsync(d_ptr, 0, bytes, g->stream));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_timer_start(tsdrgpu_t *g)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    HIP_TRY(g, hipEventRecord(g->t0, g->stream));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_timer_stop_ms(tsdrgpu_t *g, float *ms)
+{
+    if (!g || !ms) return TSDRGPU_EINVAL;
+    HIP_TRY(g, hipEventRecord(g->t1, g->stream));
+    HIP_TRY(g, hipEventSynchronize(g->t1));
+    HIP_TRY(g, hipEventElapsedTime(ms, g->t0, g->t1));
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// event profiler
+// ---------------------------------------------------------------------------
+static const char *const kStageNames[PROF_COUNT] = {"k_demod", "k_rs_tail+k_rs_chain", "k_rs_area", "k_rs_nearest",
+                                                    "k_frame_stats", "k_frame_reduce", "k_chain", "k_frame_pass",
+                                                    "k_fft_pass", "k_accumulate", "superb_misc"};
+
+ProfScope::ProfScope(tsdrgpu_t *g_, int stage) : g(g_), idx(-1)
+{
+    if (!g || !g->prof_on) return;
+    if (g->nspans == g->cap_spans) {
+        const int cap = g->cap_spans ? g->cap_spans * 2 : 1024;
+        ProfSpan *n = (ProfSpan *)realloc(g->spans, sizeof(ProfSpan) * cap);
+        if (!n) return;
+        for (int i = g->cap_spans; i < cap; i++) n[i].a = n[i].b = nullptr;
+        g->spans = n;
+        g->cap_spans = cap;
+    }
+    ProfSpan &sp = g->spans[g->nspans];
+    if (!sp.a && (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess)) return;
+    sp.stage = stage;
+    if (hipEventRecord(sp.a, g->stream) != hipSuccess) return;
+    idx = g->nspans++;
+}
+ProfScope::~ProfScope()
+{
+    if (idx >= 0) (void)hipEventRecord(g->spans[idx].b, g->stream);
+}
+
+extern "C" int tsdrgpu_profile_begin(tsdrgpu_t *g)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    g->nspans = 0;
+    g->prof_on = 1;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_profile_end(tsdrgpu_t *g, tsdrgpu_profile_entry_t *h_entries, int max_entries, int *h_count)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    g->prof_on = 0;
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    double total[PROF_COUNT] = {0};
+    int launches[PROF_COUNT] = {0};
+    for (int i = 0; i < g->nspans; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g->spans[i].a, g->spans[i].b) == hipSuccess) {
+            total[g->spans[i].stage] += ms;
+            launches[g->spans[i].stage]++;
+        }
+    }
+    int n = 0;
+    for (int s = 0; s < PROF_COUNT && n < max_entries; s++) {
+        if (!launches[s]) continue;
+        if (h_entries) {
+            snprintf(h_entries[n].name, sizeof(h_entries[n].name), "%s", kStageNames[s]);
+            h_entries[n].total_ms = total[s];
+            h_entries[n].launches = launches[s];
+        }
+        n++;
+    }
+    if (h_count) *h_count = n;
+    g->nspans = 0;
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// staging ring
+// ---------------------------------------------------------------------------
+int staging_init(tsdrgpu_t *g, StagingRing *r)
+{
+    memset(r, 0, sizeof(*r));
+    for (int i = 0; i < StagingRing::SLOTS; i++) HIP_TRY(g, hipEventCreateWithFlags(&r->ev[i], hipEventDisableTiming));
+    return TSDRGPU_OK;
+}
+void staging_free(StagingRing *r)
+{
+    for (int i = 0; i < StagingRing::SLOTS; i++) {
+        if (r->h[i]) hipHostFree(r->h[i]);
+        if (r->d[i]) hipFree(r->d[i]);
+        if (r->ev[i]) hipEventDestroy(r->ev[i]);
+    }
+    memset(r, 0, sizeof(*r));
+}
+int staging_acquire(tsdrgpu_t *g, StagingRing *r, size_t bytes)
+{
+    const int s = r->next;
+    r->next = (r->next + 1) % StagingRing::SLOTS;
+    if (r->used[s]) {
+        HIP_TRY(g, hipEventSynchronize(r->ev[s]));
+        r->used[s] = false;
+    }
+    if (r->cap[s] < bytes) {
+        if (r->h[s]) hipHostFree(r->h[s]);
+        if (r->d[s]) hipFree(r->d[s]);
+        r->h[s] = r->d[s] = nullptr;
+        r->cap[s] = 0;
+        size_t cap = bytes < 4096 ? 4096 : bytes + bytes / 2;
+        if (hipHostMalloc(&r->h[s], cap, hipHostMallocDefault) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "staging", "pinned");
+        if (hipMalloc(&r->d[s], cap) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "staging", "device");
+        r->cap[s] = cap;
+    }
+    return s;
+}
+int staging_push(tsdrgpu_t *g, StagingRing *r, int slot, size_t bytes)
+{
+    HIP_TRY(g, hipMemcpyAsync(r->d[slot], r->h[slot], bytes, hipMemcpyHostToDevice, g->stream));
+    return TSDRGPU_OK;
+}
+int staging_release(tsdrgpu_t *g, StagingRing *r, int slot)
+{
+    HIP_TRY(g, hipEventRecord(r->ev[slot], g->stream));
+    r->used[slot] = true;
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a1  AM demodulation: out[i] = sqrtf(I*I + Q*Q)     TSDRLibrary.c:244-262
+// HBM-bound: 8 B read + 4 B written per sample.  16-byte loads/stores when the
+// pointers allow; products, sum and sqrt are separate correctly-rounded f32
+// operations (-ffp-contract=off), so the result is bit-identical to the CPU's.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float demod1(float re, float im) { return sqrtf(re * re + im * im); }
+
+__global__ __launch_bounds__(256) void k_demod_vec4(const float4 *__restrict__ iq, float4 *__restrict__ out, long long nquads)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += stride) {
+        const float4 a = iq[2 * i];
+        const float4 b = iq[2 * i + 1];
+        float4 o;
+        o.x = demod1(a.x, a.y);
+        o.y = demod1(a.z, a.w);
+        o.z = demod1(b.x, b.y);
+        o.w = demod1(b.z, b.w);
+        out[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_demod_scalar(const float2 *__restrict__ iq, float *__restrict__ out, long long first, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float2 a = iq[i];
+        out[i] = demod1(a.x, a.y);
+    }
+}
+
+static unsigned stream_grid(long long work_items, unsigned block, const tsdrgpu_t *g)
+{
+    long long blocks = (work_items + block - 1) / block;
+    const long long cap = (long long)g->prop.multiProcessorCount * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+extern "C" int tsdrgpu_am_demod(tsdrgpu_t *g, const float *d_iq, float *d_out, int64_t n)
+{
+    if (!g || !d_iq || !d_out || n < 0) return TSDRGPU_EINVAL;
+    if (n == 0) return TSDRGPU_OK;
+    ProfScope prof(g, PROF_DEMOD);
+    long long done = 0;
+    if ((((uintptr_t)d_iq) & 15) == 0 && (((uintptr_t)d_out) & 15) == 0 && n >= 4) {
+        const long long nquads = n / 4;
+        k_demod_vec4<<<stream_grid(nquads, 256, g), 256, 0, g->stream>>>((const float4 *)d_iq, (float4 *)d_out, nquads);
+        KERNEL_CHECK(g, "k_demod_vec4");
+        done = nquads * 4;
+    }
+    if (done < n) {
+        k_demod_scalar<<<stream_grid(n - done, 256, g), 256, 0, g->stream>>>((const float2 *)d_iq, d_out, done, n);
+        KERNEL_CHECK(g, "k_demod_scalar");
+    }
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a2  fractional area resampler                        dsp.c:250-307
+// One thread per output pixel; the closed form in resample_math.h reproduces
+// the sequential loop's f64 expressions.  A chunk table (host-built, because the
+// per-chunk phase recurrence is pure f64 bookkeeping, dsp.c:262,272,306) tells
+// each block which dsp_resample_process call it belongs to.
+// ---------------------------------------------------------------------------
+struct tsdrgpu_resampler {
+    tsdrgpu_t *g;
+    double offset;      // dsp_resample_t.offset (host side: data independent)
+    double *d_contrib;  // dsp_resample_t.contrib (device side: data dependent)
+    double *d_cin;      // per-chunk incoming contrib
+    double *d_tail;     // per-chunk outgoing contrib when it does not depend on the incoming one
+    unsigned char *d_need;
+    int cap_chunks;
+    StagingRing ring;
+};
+
+template <bool IQ>
+struct SampleLoad {
+    const float *base;
+    __device__ __forceinline__ float operator()(long long j) const
+    {
+        if (IQ) {
+            const float2 s = ((const float2 *)base)[j];
+            return demod1(s.x, s.y);
+        }
+        return base[j];
+    }
+};
+
+// phase 1: every chunk's outgoing contrib, in parallel
+template <bool IQ>
+__global__ void k_rs_tail(const RsChunk *__restrict__ chunks, int nchunks, double r, const float *__restrict__ in,
+                          double *__restrict__ tail, unsigned char *__restrict__ need)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const RsChunk ch = chunks[c];
+    RsGeom g;
+    g.r = r;
+    g.o = ch.o;
+    g.size = ch.size;
+    SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
+    bool used = false;
+    tail[c] = rs_contrib_before(g, (long long)ch.size, 0.0, ld, &used);
+    need[c] = used ? 1 : 0;
+}
+
+// phase 2: chain them (a scalar recurrence; chunks that need their incoming
+// contrib — no pixel finished inside the chunk — are replayed here)
+template <bool IQ>
+__global__ void k_rs_chain(const RsChunk *__restrict__ chunks, int nchunks, double r, const float *__restrict__ in,
+                           const double *__restrict__ tail, const unsigned char *__restrict__ need,
+                           double *__restrict__ cin, double *__restrict__ contrib_state)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double c_in = *contrib_state;
+    for (int c = 0; c < nchunks; c++) {
+        cin[c] = c_in;
+        if (need[c]) {
+            const RsChunk ch = chunks[c];
+            RsGeom g;
+            g.r = r;
+            g.o = ch.o;
+            g.size = ch.size;
+            SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
+            c_in = rs_contrib_before(g, (long long)ch.size, c_in, ld);
+        } else {
+            c_in = tail[c];
+        }
+    }
+    *contrib_state = c_in;
+}
+
+template <bool IQ>
+__global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chunks, double r, const float *__restrict__ in,
+                                                 const double *__restrict__ cin, float *__restrict__ out)
+{
+    const RsChunk ch = chunks[blockIdx.y];
+    RsGeom g;
+    g.r = r;
+    g.o = ch.o;
+    g.size = ch.size;
+    SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
+    const double c_in = cin[blockIdx.y];
+    float *dst = out + ch.out_off;
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < ch.n_out; p += gridDim.x * blockDim.x) {
+        float v;
+        dst[p] = rs_area_pixel(g, p, c_in, ld, &v) ? v : 0.0f;
+    }
+}
+
+template <bool IQ>
+__global__ __launch_bounds__(256) void k_rs_nearest(const RsChunk *__restrict__ chunks, const float *__restrict__ in,
+                                                    float *__restrict__ out)
+{
+    const RsChunk ch = chunks[blockIdx.y];
+    SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
+    float *dst = out + ch.out_off;
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < ch.n_out; p += gridDim.x * blockDim.x)
+        dst[p] = ld(rs_nearest_src(ch.size, ch.n_out, p));
+}
+
+extern "C" int tsdrgpu_resampler_create(tsdrgpu_t *g, tsdrgpu_resampler_t **out)
+{
+    if (!g || !out) return TSDRGPU_EINVAL;
+    tsdrgpu_resampler_t *rs = (tsdrgpu_resampler_t *)calloc(1, sizeof(*rs));
+    if (!rs) return TSDRGPU_ENOMEM;
+    rs->g = g;
+    int rc = staging_init(g, &rs->ring);
+    if (rc) { free(rs); return rc; }
+    if (hipMalloc(&rs->d_contrib, sizeof(double)) != hipSuccess) { staging_free(&rs->ring); free(rs); return TSDRGPU_ENOMEM; }
+    *out = rs;
+    return tsdrgpu_resampler_reset(rs);
+}
+
+extern "C" void tsdrgpu_resampler_destroy(tsdrgpu_resampler_t *rs)
+{
+    if (!rs) return;
+    hipStreamSynchronize(rs->g->stream);
+    staging_free(&rs->ring);
+    hipFree(rs->d_contrib);
+    hipFree(rs->d_cin);
+    hipFree(rs->d_tail);
+    hipFree(rs->d_need);
+    free(rs);
+}
+
+extern "C" int tsdrgpu_resampler_setstate(tsdrgpu_resampler_t *rs, double contrib, double offset)
+{
+    if (!rs) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = rs->g;
+    rs->offset = offset;
+    HIP_TRY(g, hipMemcpyAsync(rs->d_contrib, &contrib, sizeof(double), hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));  // `contrib` is a stack variable
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_resampler_reset(tsdrgpu_resampler_t *rs) { return tsdrgpu_resampler_setstate(rs, 0.0, 0.0); }
+
+extern "C" int tsdrgpu_resampler_getstate(tsdrgpu_resampler_t *rs, double *contrib, double *offset)
+{
+    if (!rs) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = rs->g;
+    if (offset) *offset = rs->offset;
+    if (contrib) {
+        HIP_TRY(g, hipMemcpyAsync(contrib, rs->d_contrib, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(g, hipStreamSynchronize(g->stream));
+    }
+    return TSDRGPU_OK;
+}
+
+// the host half of dsp_resample_process: counts and phases (dsp.c:258-262,272,306)
+static int64_t build_chunks(double *offset_io, uint32_t chunk, int nchunks, double up, double down, RsChunk *tab)
+{
+    const double r = up / down;
+    const double rinv = down / up;
+    double offset = *offset_io;
+    long long in_off = 0, out_off = 0;
+    for (int c = 0; c < nchunks; c++) {
+        const uint32_t n_out = (uint32_t)(int)(((double)chunk - offset) * r);
+        if (tab) {
+            tab[c].in_off = in_off;
+            tab[c].out_off = out_off;
+            tab[c].size = chunk;
+            tab[c].n_out = n_out;
+            tab[c].o = -offset * r;
+        }
+        offset += n_out * rinv - chunk;
+        in_off += chunk;
+        out_off += n_out;
+    }
+    *offset_io = offset;
+    return out_off;
+}
+
+extern "C" int64_t tsdrgpu_resample_count(tsdrgpu_resampler_t *rs, uint32_t chunk, int nchunks, double up, double down)
+{
+    if (!rs || nchunks < 0 || !(up > 0) || !(down > 0)) return -1;
+    double off = rs->offset;
+    return build_chunks(&off, chunk, nchunks, up, down, nullptr);
+}
+
+extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int in_is_iq, uint32_t chunk, int nchunks,
+                                double up, double down, int nearest, float *d_out, int64_t out_capacity,
+                                int64_t *h_n_out)
+{
+    if (!rs || !d_in || !d_out || chunk == 0 || nchunks < 0 || nchunks > 65535 || !(up > 0) || !(down > 0))
+        return rs ? tsdr_fail(rs->g, TSDRGPU_EINVAL, "tsdrgpu_resample", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = rs->g;
+    if (h_n_out) *h_n_out = 0;
+    if (nchunks == 0) return TSDRGPU_OK;
+
+    double probe = rs->offset;
+    const int64_t total = build_chunks(&probe, chunk, nchunks, up, down, nullptr);
+    if (total > out_capacity) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resample", "output buffer too small");
+
+    const size_t bytes = sizeof(RsChunk) * (size_t)nchunks;
+    const int slot = staging_acquire(g, &rs->ring, bytes);
+    if (slot < 0) return slot;
+    RsChunk *tab = (RsChunk *)rs->ring.h[slot];
+    build_chunks(&rs->offset, chunk, nchunks, up, down, tab);
+    unsigned max_out = 0;
+    for (int c = 0; c < nchunks; c++) max_out = tab[c].n_out > max_out ? tab[c].n_out : max_out;
+    int rc = staging_push(g, &rs->ring, slot, bytes);
+    if (rc) return rc;
+    const RsChunk *d_tab = (const RsChunk *)rs->ring.d[slot];
+
+    if (rs->cap_chunks < nchunks) {
+        hipFree(rs->d_cin); hipFree(rs->d_tail); hipFree(rs->d_need);
+        rs->d_cin = rs->d_tail = nullptr; rs->d_need = nullptr; rs->cap_chunks = 0;
+        const int cap = nchunks + 64;
+        if (hipMalloc(&rs->d_cin, sizeof(double) * cap) != hipSuccess || hipMalloc(&rs->d_tail, sizeof(double) * cap) != hipSuccess ||
+            hipMalloc(&rs->d_need, cap) != hipSuccess)
+            return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_resample", "chunk scratch");
+        rs->cap_chunks = cap;
+    }
+
+    const double r = up / down;
+    const unsigned bx = ceil_div_u(max_out ? max_out : 1, 256);
+    dim3 grid(bx, (unsigned)nchunks);
+    if (nearest) {
+        // dsp.c:274-276: contrib is untouched in this mode
+        if (max_out) {
+            ProfScope prof(g, PROF_RS_NEAREST);
+            if (in_is_iq) k_rs_nearest<true><<<grid, 256, 0, g->stream>>>(d_tab, d_in, d_out);
+            else k_rs_nearest<false><<<grid, 256, 0, g->stream>>>(d_tab, d_in, d_out);
+            KERNEL_CHECK(g, "k_rs_nearest");
+        }
+    } else {
+        const unsigned tb = ceil_div_u((unsigned)nchunks, 128);
+        {
+            ProfScope prof(g, PROF_RS_CARRY);
+            if (in_is_iq) {
+                k_rs_tail<true><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need);
+                k_rs_chain<true><<<1, 64, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+            } else {
+                k_rs_tail<false><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need);
+                k_rs_chain<false><<<1, 64, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+            }
+        }
+        if (max_out) {
+            ProfScope prof(g, PROF_RS_AREA);
+            if (in_is_iq) k_rs_area<true><<<grid, 256, 0, g->stream>>>(d_tab, r, d_in, rs->d_cin, d_out);
+            else k_rs_area<false><<<grid, 256, 0, g->stream>>>(d_tab, r, d_in, rs->d_cin, d_out);
+        }
+        KERNEL_CHECK(g, "k_rs_area");
+    }
+    rc = staging_release(g, &rs->ring, slot);
+    if (rc) return rc;
+    if (h_n_out) *h_n_out = total;
+    return TSDRGPU_OK;
+}

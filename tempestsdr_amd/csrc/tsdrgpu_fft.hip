@@ -1,0 +1,617 @@
+// tsdrgpu_fft.hip — FFT engine, autocorrelation and lag-window accumulation for
+// gfx950: fft_perform / fft_autocorrelation (TempestSDR/src/fft.c:49-64,96-176)
+// and accummulate (frameratedetector.c:34-62).
+//
+// Engine (round 1): out-of-place Stockham autosort, radix 16/8/4/2 butterflies
+// held in registers, one pass over HBM per radix stage, ping-pong between two
+// buffers; many windows per launch (blockIdx.y).  Twiddles come from
+// sincospif() of an exactly representable dyadic fraction.  Data is float32
+// complex like the reference's storage; the reference rounds to f32 after every
+// radix-2 stage with f64 butterflies, so the two differ at the 1e-7 level of
+// the largest term (tolerance stated in tests/test_gpu_autocorr.py).
+#include "tsdrgpu_internal.h"
+
+struct tsdrgpu_autocorr {
+    tsdrgpu_t *g;
+    uint32_t samplerate;
+    int32_t frame_lo, frame_len, line_lo, line_len;
+    uint32_t capture, n;
+    uint64_t calls;
+    double *d_plots;   // frame_len + line_len
+    float2 *d_a, *d_b; // ping-pong work buffers, cap_windows * n each
+    int cap_windows;
+    float2 *d_last;    // where the last window's correlation lives
+    int *d_arg;
+    int *h_arg;
+};
+
+// ---------------------------------------------------------------------------
+// small DFTs in registers (forward, e^{-2 pi i/R})
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+
+__device__ __forceinline__ void dft2(float2 &a, float2 &b)
+{
+    const float2 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+
+__device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+{
+    // outputs in natural order
+    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
+    const float2 s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+    a0 = cadd(s02, s13);
+    a1 = cadd(d02, d13);
+    a2 = csub(s02, s13);
+    a3 = csub(d02, d13);
+}
+
+template <int R>
+__device__ __forceinline__ void dft_reg(float2 (&v)[R]);
+
+template <>
+__device__ __forceinline__ void dft_reg<2>(float2 (&v)[2]) { dft2(v[0], v[1]); }
+template <>
+__device__ __forceinline__ void dft_reg<4>(float2 (&v)[4]) { dft4(v[0], v[1], v[2], v[3]); }
+
+template <>
+__device__ __forceinline__ void dft_reg<8>(float2 (&v)[8])
+{
+    // 8 = 2 x 4: X[k1 + 2*k2] = sum_{n2<4} w8^{n2*k1} (sum_{n1<2} x[4*n1+n2] w2^{n1 k1}) w4^{n2 k2}
+    const float h = 0.70710678118654752440f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft2(v[n2], v[n2 + 4]);
+    // twiddles w8^{n2} on the k1 = 1 row (v[4..7])
+    v[5] = cmul(v[5], make_float2(h, -h));
+    v[6] = mul_mi(v[6]);
+    v[7] = cmul(v[7], make_float2(-h, -h));
+    dft4(v[0], v[1], v[2], v[3]);  // k1 = 0 -> X[0], X[2], X[4], X[6]
+    dft4(v[4], v[5], v[6], v[7]);  // k1 = 1 -> X[1], X[3], X[5], X[7]
+    const float2 x0 = v[0], x2 = v[1], x4 = v[2], x6 = v[3];
+    const float2 x1 = v[4], x3 = v[5], x5 = v[6], x7 = v[7];
+    v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6; v[7] = x7;
+}
+
+template <>
+__device__ __forceinline__ void dft_reg<16>(float2 (&v)[16])
+{
+    // 16 = 4 x 4: a[n2][k1] = DFT4 over n1 of x[4*n1+n2]; times w16^{n2*k1}; X[k1+4*k2] = DFT4 over n2
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft4(v[n2], v[n2 + 4], v[n2 + 8], v[n2 + 12]);
+    // now v[n2 + 4*k1] = a[n2][k1]; multiply by w16^{n2*k1}
+    v[5] = cmul(v[5], make_float2(c1, -s1));     // n2=1,k1=1: w^1
+    v[6] = cmul(v[6], make_float2(h, -h));       // n2=2,k1=1: w^2
+    v[7] = cmul(v[7], make_float2(s1, -c1));     // n2=3,k1=1: w^3
+    v[9] = cmul(v[9], make_float2(h, -h));       // n2=1,k1=2: w^2
+    v[10] = mul_mi(v[10]);                       // n2=2,k1=2: w^4
+    v[11] = cmul(v[11], make_float2(-h, -h));    // n2=3,k1=2: w^6
+    v[13] = cmul(v[13], make_float2(s1, -c1));   // n2=1,k1=3: w^3
+    v[14] = cmul(v[14], make_float2(-h, -h));    // n2=2,k1=3: w^6
+    v[15] = cmul(v[15], make_float2(-c1, s1));   // n2=3,k1=3: w^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+    // v[4*k1 + k2] = X[k1 + 4*k2] -> transpose to natural order
+    float2 t[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) t[k1 + 4 * k2] = v[4 * k1 + k2];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = t[i];
+}
+
+// ---------------------------------------------------------------------------
+// one Stockham pass of radix R over `batch` transforms of n points
+//   thread j (< n/R): k = j mod Ns; reads x[j + t*n/R], multiplies by
+//   w_{Ns*R}^{t*k}, R-point DFT, writes y[(j-k)*R + k + u*Ns]
+// IN_MODE 0: complex input; 1: real float input (imag = 0); 2: interleaved IQ,
+// magnitude taken on the fly (am_demod fused, TSDRLibrary.c:244-262)
+// OUT_MAG: store (|v|*scale, 0) — fft_complex_to_absolute_complex, fft.c:34-45
+// ---------------------------------------------------------------------------
+template <int R, int IN_MODE, bool OUT_MAG>
+__global__ __launch_bounds__(256) void k_fft_pass(const void *__restrict__ xin, long long in_stride, float2 *__restrict__ y,
+                                                  unsigned n, unsigned Ns, int conj_in, int conj_out, float scale)
+{
+    const unsigned T = n / R;
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    const unsigned b = blockIdx.y;
+    float2 v[R];
+    if (IN_MODE == 0) {
+        const float2 *x = (const float2 *)xin + (long long)b * in_stride;
+#pragma unroll
+        for (int t = 0; t < R; t++) v[t] = x[j + t * T];
+    } else if (IN_MODE == 1) {
+        const float *x = (const float *)xin + (long long)b * in_stride;
+#pragma unroll
+        for (int t = 0; t < R; t++) v[t] = make_float2(x[j + t * T], 0.f);
+    } else {
+        const float2 *x = (const float2 *)xin + (long long)b * in_stride;
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            const float2 s = x[j + t * T];
+            v[t] = make_float2(sqrtf(s.x * s.x + s.y * s.y), 0.f);
+        }
+    }
+    if (conj_in) {
+#pragma unroll
+        for (int t = 0; t < R; t++) v[t].y = -v[t].y;
+    }
+    const unsigned k = j & (Ns - 1);
+    if (Ns > 1) {
+        const unsigned span = Ns * R;  // power of two
+        const float inv = -2.0f / (float)span;
+#pragma unroll
+        for (int t = 1; t < R; t++) {
+            const unsigned m = (t * k) & (span - 1);
+            float s, c;
+            sincospif((float)m * inv, &s, &c);
+            v[t] = cmul(v[t], make_float2(c, s));
+        }
+    }
+    dft_reg<R>(v);
+    float2 *yo = y + (long long)b * n + ((j - k) * R + k);
+#pragma unroll
+    for (int u = 0; u < R; u++) {
+        float2 o = v[u];
+        if (OUT_MAG) {
+            o.x *= scale;
+            o.y *= scale;
+            o = make_float2(sqrtf(o.x * o.x + o.y * o.y), 0.f);
+        } else {
+            if (conj_out) o.y = -o.y;
+            o.x *= scale;
+            o.y *= scale;
+        }
+        yo[(long long)u * Ns] = o;
+    }
+}
+
+struct PassPlan {
+    int radix[32];
+    int count;
+};
+
+static PassPlan plan_passes(uint32_t n)
+{
+    PassPlan p;
+    p.count = 0;
+    int m = 0;
+    while ((1u << m) < n) m++;
+    // small remainder first (its writes are the least coalesced while Ns is small anyway)
+    int rem = m % 4;
+    if (rem) p.radix[p.count++] = 1 << rem;
+    for (int i = 0; i < m / 4; i++) p.radix[p.count++] = 16;
+    if (p.count == 0) p.radix[p.count++] = 1;  // n == 1
+    return p;
+}
+
+template <int IN_MODE, bool OUT_MAG>
+static void launch_pass(hipStream_t st, int R, const void *x, long long in_stride, float2 *y, unsigned n, unsigned Ns, int batch,
+                        int conj_in, int conj_out, float scale)
+{
+    const unsigned T = n / R;
+    dim3 grid((T + 255) / 256, batch);
+    switch (R) {
+        case 2: k_fft_pass<2, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+        case 4: k_fft_pass<4, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+        case 8: k_fft_pass<8, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+        default: k_fft_pass<16, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+    }
+}
+
+// Runs all passes of `batch` n-point transforms.  Input: `in` (mode per
+// in_mode, window b at in + b*in_stride elements).  Work buffers a, b (batch*n
+// float2 each).  Returns the buffer that holds the result.
+static float2 *run_fft(tsdrgpu_t *g, const void *in, int in_mode, long long in_stride, float2 *a, float2 *b, uint32_t n, int batch,
+                       int inverse, bool mag_out, float scale)
+{
+    const PassPlan p = plan_passes(n);
+    unsigned Ns = 1;
+    const void *src = in;
+    long long sstride = in_stride;
+    int smode = in_mode;
+    float2 *dst = (in == (const void *)a) ? b : a;
+    for (int i = 0; i < p.count; i++) {
+        const int R = p.radix[i];
+        const bool first = i == 0, last = i == p.count - 1;
+        const int cin = (inverse && first) ? 1 : 0, cout = (inverse && last) ? 1 : 0;
+        const float sc = last ? scale : 1.0f;
+        ProfScope prof(g, PROF_FFT_PASS);
+        if (R == 1) {  // n == 1: copy
+            (void)hipMemcpyAsync(dst, src, sizeof(float2) * batch, hipMemcpyDeviceToDevice, g->stream);
+        } else if (last && mag_out) {
+            if (smode == 0) launch_pass<0, true>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else if (smode == 1) launch_pass<1, true>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else launch_pass<2, true>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+        } else {
+            if (smode == 0) launch_pass<0, false>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else if (smode == 1) launch_pass<1, false>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else launch_pass<2, false>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+        }
+        Ns *= R;
+        src = dst;
+        sstride = n;
+        smode = 0;
+        dst = (dst == a) ? b : a;
+    }
+    return (float2 *)src;
+}
+
+// ---------------------------------------------------------------------------
+// tsdrgpu_fft: fft_perform (fft.c:96-176) on a caller buffer
+// ---------------------------------------------------------------------------
+extern "C" int tsdrgpu_fft(tsdrgpu_t *g, float *d_iq, uint32_t n, int inverse)
+{
+    if (!g || !d_iq || n == 0 || (n & (n - 1))) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_fft", "n must be a power of two") : TSDRGPU_EINVAL;
+    if (n == 1) return TSDRGPU_OK;
+    float2 *tmp = nullptr;
+    if (hipMalloc(&tmp, sizeof(float2) * (size_t)n * 2) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_fft", "work buffer");
+    // pass 1 reads the caller's buffer, the rest ping-pongs inside tmp
+    float2 *res = run_fft(g, d_iq, 0, n, tmp, tmp + n, n, 1, inverse, false, inverse ? 1.0f : 1.0f / (float)n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(d_iq, res, sizeof(float2) * (size_t)n, hipMemcpyDeviceToDevice, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_fft", hipGetErrorString(e));
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// accummulate (frameratedetector.c:34-62) over a batch of windows, in window
+// order, so the running mean's f64 rounding matches the reference's recurrence.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_accumulate(const float2 *__restrict__ corr, unsigned n, int nwindows, int frame_lo,
+                                                    int frame_len, int line_lo, int line_len, double *__restrict__ plots,
+                                                    unsigned long long calls_before, int mode)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame_len + line_len) return;
+    const int lag = (i < frame_len) ? (frame_lo + i) : (line_lo + (i - frame_len));
+    double acc = plots[i];
+    for (int w = 0; w < nwindows; w++) {
+        const float2 c = corr[(long long)w * n + lag];
+        const double re = c.x, im = c.y;
+        const double now = sqrt(re * re + im * im);
+        if (mode == 0) {
+            const unsigned long long calls = calls_before + w + 1;
+            acc = (acc * (double)(calls - 1) + now) / (double)calls;
+        } else {
+            acc += now;
+        }
+    }
+    plots[i] = acc;
+}
+
+__global__ void k_scale_plots(double *plots, int count, double divisor)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) plots[i] = plots[i] / divisor;
+}
+
+// argmax with lowest-index tie-break; one workgroup per plot
+__global__ __launch_bounds__(1024) void k_argmax(const double *__restrict__ plots, int frame_len, int line_len, int *__restrict__ out)
+{
+    const double *p = blockIdx.x == 0 ? plots : plots + frame_len;
+    const int len = blockIdx.x == 0 ? frame_len : line_len;
+    double best = -1.0;
+    int at = 0x7fffffff;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        const double v = p[i];
+        if (v > best) { best = v; at = i; }
+    }
+    __shared__ double sb[16];
+    __shared__ int si[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(at, o, 64);
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = at; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++)
+            if (sb[w] > best || (sb[w] == best && si[w] < at)) { best = sb[w]; at = si[w]; }
+        out[blockIdx.x] = (len > 0) ? at : -1;
+    }
+}
+
+extern "C" int tsdrgpu_autocorr_create(tsdrgpu_t *g, tsdrgpu_autocorr_t **out, uint32_t samplerate)
+{
+    if (!g || !out || samplerate == 0) return TSDRGPU_EINVAL;
+    tsdrgpu_autocorr_t *ac = (tsdrgpu_autocorr_t *)calloc(1, sizeof(*ac));
+    if (!ac) return TSDRGPU_ENOMEM;
+    ac->g = g;
+    ac->samplerate = samplerate;
+    // frameratedetector.c:20-24,91-95,160
+    const int maxlength = samplerate / (double)(55);
+    const int minlength = samplerate / (double)(87);
+    const int height_maxlength = samplerate / (double)(590 * 55);
+    const int height_minlength = samplerate / (double)(1500 * 87);
+    ac->frame_lo = minlength;
+    ac->frame_len = maxlength - minlength;
+    ac->line_lo = height_minlength;
+    ac->line_len = height_maxlength - height_minlength;
+    ac->capture = (uint32_t)(3.1 * samplerate / (double)(55));
+    uint32_t m = 0, sz = ac->capture;  // fft_getrealsize, fft.c:5-11
+    while ((sz /= 2) != 0) m++;
+    ac->n = 1u << m;
+    const size_t L = (size_t)ac->frame_len + ac->line_len;
+    if (ac->frame_len <= 0 || ac->line_len <= 0 || (uint32_t)(ac->frame_lo + ac->frame_len) > ac->n) {
+        free(ac);
+        return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_create", "sample rate too low for the lag windows");
+    }
+    if (hipMalloc(&ac->d_plots, sizeof(double) * L) != hipSuccess || hipMalloc(&ac->d_arg, 2 * sizeof(int)) != hipSuccess ||
+        hipHostMalloc(&ac->h_arg, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        free(ac);
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_create", "plots");
+    }
+    *out = ac;
+    return tsdrgpu_autocorr_reset(ac);
+}
+
+extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
+{
+    if (!ac) return;
+    (void)hipStreamSynchronize(ac->g->stream);
+    (void)hipFree(ac->d_plots);
+    (void)hipFree(ac->d_a);
+    (void)hipFree(ac->d_b);
+    (void)hipFree(ac->d_arg);
+    (void)hipHostFree(ac->h_arg);
+    free(ac);
+}
+
+extern "C" int tsdrgpu_autocorr_reset(tsdrgpu_autocorr_t *ac)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    ac->calls = 0;  // extbuffer "cleartozero" semantics, extbuffer.c:68-81
+    HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len), g->stream));
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_geometry(tsdrgpu_autocorr_t *ac, int32_t *frame_lo, int32_t *frame_len, int32_t *line_lo,
+                                         int32_t *line_len, uint32_t *capture, uint32_t *fft_n)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    if (frame_lo) *frame_lo = ac->frame_lo;
+    if (frame_len) *frame_len = ac->frame_len;
+    if (line_lo) *line_lo = ac->line_lo;
+    if (line_len) *line_len = ac->line_len;
+    if (capture) *capture = ac->capture;
+    if (fft_n) *fft_n = ac->n;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, int64_t stride, int nwindows, int mode)
+{
+    if (!ac || !d_in || nwindows < 0 || stride < 0) return ac ? tsdr_fail(ac->g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "bad argument") : TSDRGPU_EINVAL;
+    if (nwindows == 0) return TSDRGPU_OK;
+    tsdrgpu_t *g = ac->g;
+    if (nwindows > 65535) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "too many windows in one call");
+    if (ac->cap_windows < nwindows) {
+        (void)hipStreamSynchronize(g->stream);
+        (void)hipFree(ac->d_a);
+        (void)hipFree(ac->d_b);
+        ac->d_a = ac->d_b = nullptr;
+        ac->cap_windows = 0;
+        if (hipMalloc(&ac->d_a, sizeof(float2) * (size_t)ac->n * nwindows) != hipSuccess ||
+            hipMalloc(&ac->d_b, sizeof(float2) * (size_t)ac->n * nwindows) != hipSuccess)
+            return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_run", "work buffers");
+        ac->cap_windows = nwindows;
+    }
+    // forward FFT scaled by 1/n, magnitude fused into its last pass (fft.c:57-60) ...
+    float2 *spec = run_fft(g, d_in, in_is_iq ? 2 : 1, stride, ac->d_a, ac->d_b, ac->n, nwindows, 0, true, 1.0f / (float)ac->n);
+    // ... unscaled inverse FFT (fft.c:63)
+    float2 *corr = run_fft(g, spec, 0, ac->n, ac->d_a, ac->d_b, ac->n, nwindows, 1, false, 1.0f);
+    KERNEL_CHECK(g, "fft passes");
+    const int L = ac->frame_len + ac->line_len;
+    ProfScope prof(g, PROF_ACCUMULATE);
+    k_accumulate<<<(L + 255) / 256, 256, 0, g->stream>>>(corr, ac->n, nwindows, ac->frame_lo, ac->frame_len, ac->line_lo,
+                                                         ac->line_len, ac->d_plots, (unsigned long long)ac->calls, mode);
+    KERNEL_CHECK(g, "k_accumulate");
+    ac->calls += (uint64_t)nwindows;
+    ac->d_last = corr + (size_t)(nwindows - 1) * ac->n;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line, uint64_t *h_calls)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    if (h_frame) HIP_TRY(g, hipMemcpyAsync(h_frame, ac->d_plots, sizeof(double) * ac->frame_len, hipMemcpyDeviceToHost, g->stream));
+    if (h_line) HIP_TRY(g, hipMemcpyAsync(h_line, ac->d_plots + ac->frame_len, sizeof(double) * ac->line_len, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (h_calls) *h_calls = ac->calls;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_device_plots(tsdrgpu_autocorr_t *ac, double **d_plots, int64_t *count)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    if (d_plots) *d_plots = ac->d_plots;
+    if (count) *count = (int64_t)ac->frame_len + ac->line_len;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t total_windows)
+{
+    if (!ac || total_windows == 0) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    const int L = ac->frame_len + ac->line_len;
+    k_scale_plots<<<(L + 255) / 256, 256, 0, g->stream>>>(ac->d_plots, L, (double)total_windows);
+    KERNEL_CHECK(g, "k_scale_plots");
+    ac->calls = total_windows;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, int32_t *line_idx)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    k_argmax<<<2, 1024, 0, g->stream>>>(ac->d_plots, ac->frame_len, ac->line_len, ac->d_arg);
+    KERNEL_CHECK(g, "k_argmax");
+    HIP_TRY(g, hipMemcpyAsync(ac->h_arg, ac->d_arg, 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (frame_idx) *frame_idx = ac->h_arg[0];
+    if (line_idx) *line_idx = ac->h_arg[1];
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **d_corr, uint32_t *n)
+{
+    if (!ac || !ac->d_last) return TSDRGPU_ESTATE;
+    if (d_corr) *d_corr = (const float *)ac->d_last;
+    if (n) *n = ac->n;
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a13/a14  super-bandwidth stitch — superbandwidth.c:67-152, fft.c:69-93
+// ---------------------------------------------------------------------------
+// complex_to_abs_diff (superbandwidth.c:67-81): first difference of magnitudes;
+// element 0 is seeded with |z0|^2 (kept literally).
+__global__ __launch_bounds__(256) void k_abs_diff(const float2 *__restrict__ z, float2 *__restrict__ out, unsigned n)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 c = z[i];
+    const float cur = sqrtf(c.x * c.x + c.y * c.y);
+    float prev;
+    if (i == 0) prev = c.x * c.x + c.y * c.y;
+    else {
+        const float2 p = z[i - 1];
+        prev = sqrtf(p.x * p.x + p.y * p.y);
+    }
+    out[i] = make_float2(cur - prev, 0.f);
+}
+
+// A * conj(B)-style product of fft_crosscorrelation (fft.c:80-89), in place in a
+__global__ __launch_bounds__(256) void k_mul_conj(float2 *__restrict__ a, const float2 *__restrict__ b, unsigned n)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 x = a[i], y = b[i];
+    a[i] = make_float2(x.x * y.x + x.y * y.y, x.x * y.y - x.y * y.x);
+}
+
+// superb_bestfit's peak search (superbandwidth.c:100-116): first maximum of |.|
+__global__ __launch_bounds__(1024) void k_argmax_abs(const float2 *__restrict__ z, unsigned n, int *__restrict__ out_floats)
+{
+    float best = -1.f;
+    int at = 0x7fffffff;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+        const float2 c = z[i];
+        const float v = sqrtf(c.x * c.x + c.y * c.y);
+        if (v > best) { best = v; at = (int)i; }
+    }
+    __shared__ float sb[16];
+    __shared__ int si[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(at, o, 64);
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = at; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++)
+            if (sb[w] > best || (sb[w] == best && si[w] < at)) { best = sb[w]; at = si[w]; }
+        *out_floats = 2 * at;  // the reference returns the offset in floats
+    }
+}
+
+// circular left rotation by *off floats (superbandwidth.c:135-137)
+__global__ __launch_bounds__(256) void k_rotate(const float *__restrict__ in, float *__restrict__ out, unsigned nfloats,
+                                                const int *__restrict__ off)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nfloats) return;
+    unsigned s = i + (unsigned)*off;
+    if (s >= nfloats) s -= nfloats;
+    out[i] = in[s];
+}
+
+static uint32_t pow2_floor(uint32_t v)  // fft_getrealsize, fft.c:5-11
+{
+    uint32_t m = 0;
+    while ((v /= 2) != 0) m++;
+    return 1u << m;
+}
+
+extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered, int samples_in_frame,
+                                     float *d_out, int32_t *h_offsets, uint32_t *h_total)
+{
+    if (!g || !d_hops || nhops < 1 || nhops > 64 || gathered < 2 || samples_in_frame < 1 || !d_out)
+        return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_superb_stitch", "bad argument") : TSDRGPU_EINVAL;
+    const uint32_t per = pow2_floor((uint32_t)gathered);  // superbandwidth.c:124
+    const uint32_t total = (uint32_t)nhops * per;
+    const uint32_t nfl = per * 2;
+    // superb_bestfit sizes (superbandwidth.c:84-86)
+    int bsize = ((int)nfl / samples_in_frame) * samples_in_frame;
+    if (bsize < 2) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_superb_stitch", "hop shorter than one frame");
+    const uint32_t bfl = pow2_floor((uint32_t)bsize);
+    const uint32_t bn = bfl / 2;  // complex samples cross-correlated
+
+    float2 *w = nullptr;  // [A bn][B bn][tmp1 max][tmp2 max]
+    const size_t big = per > bn ? per : bn;
+    int *d_off = nullptr;
+    if (hipMalloc(&w, sizeof(float2) * (2 * (size_t)bn + 4 * big)) != hipSuccess || hipMalloc(&d_off, sizeof(int) * nhops) != hipSuccess) {
+        if (w) (void)hipFree(w);
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_superb_stitch", "work buffers");
+    }
+    float2 *A = w, *B = w + bn, *T1 = w + 2 * (size_t)bn, *T2 = T1 + big, *T3 = T2 + big, *T4 = T3 + big;
+    hipStream_t st = g->stream;
+    (void)hipMemsetAsync(d_off, 0, sizeof(int) * nhops, st);
+
+    float2 *spec0 = nullptr;
+    for (int i = 1; i < nhops; i++) {
+        k_abs_diff<<<(bn + 255) / 256, 256, 0, st>>>((const float2 *)d_hops[0], A, bn);
+        k_abs_diff<<<(bn + 255) / 256, 256, 0, st>>>((const float2 *)d_hops[i], B, bn);
+        float2 *fa = run_fft(g, A, 0, bn, T1, T2, bn, 1, 0, false, 1.0f / (float)bn);
+        float2 *fb = run_fft(g, B, 0, bn, T3, T4, bn, 1, 0, false, 1.0f / (float)bn);
+        k_mul_conj<<<(bn + 255) / 256, 256, 0, st>>>(fa, fb, bn);
+        float2 *other = (fa == T1) ? T2 : T1;
+        float2 *xc = run_fft(g, fa, 0, bn, fa, other, bn, 1, 1, false, 1.0f);
+        k_argmax_abs<<<1, 1024, 0, st>>>(xc, bn, d_off + i);
+        // rotate hop i, then forward FFT of `per` points back into the hop buffer
+        k_rotate<<<(nfl + 255) / 256, 256, 0, st>>>(d_hops[i], (float *)T1, nfl, d_off + i);
+        float2 *sp = run_fft(g, T1, 0, per, T1, T2, per, 1, 0, false, 1.0f / (float)per);
+        (void)hipMemcpyAsync(d_hops[i], sp, sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
+    }
+    {
+        (void)hipMemcpyAsync(T1, d_hops[0], sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
+        spec0 = run_fft(g, T1, 0, per, T1, T2, per, 1, 0, false, 1.0f / (float)per);
+        (void)hipMemcpyAsync(d_hops[0], spec0, sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
+    }
+    // concatenate the spectra in hop order, no fftshift (superbandwidth.c:143-144)
+    for (int i = 0; i < nhops; i++)
+        (void)hipMemcpyAsync(d_out + (size_t)i * per * 2, d_hops[i], sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
+    // inverse FFT over the largest power of two <= total (fft_perform truncates, fft.c:101-105)
+    const uint32_t nfft = pow2_floor(total);
+    float2 *big2 = nullptr;
+    hipError_t e = hipMalloc(&big2, sizeof(float2) * (size_t)nfft * 2);
+    if (e == hipSuccess) {
+        float2 *res = run_fft(g, d_out, 0, nfft, big2, big2 + nfft, nfft, 1, 1, false, 1.0f);
+        (void)hipMemcpyAsync(d_out, res, sizeof(float2) * nfft, hipMemcpyDeviceToDevice, st);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (h_offsets && e == hipSuccess) e = hipMemcpyAsync(h_offsets, d_off, sizeof(int) * nhops, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    else (void)hipStreamSynchronize(st);
+    (void)hipFree(w);
+    (void)hipFree(d_off);
+    if (big2) (void)hipFree(big2);
+    if (e != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_superb_stitch", hipGetErrorString(e));
+    if (h_total) *h_total = total;
+    return TSDRGPU_OK;
+}

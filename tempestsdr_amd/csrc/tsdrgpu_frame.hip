@@ -1,0 +1,765 @@
+// tsdrgpu_frame.hip — frame post-processing on gfx950: dsp_post_process
+// (TempestSDR/src/dsp.c:134-239) and everything it calls.
+//
+// The reference handles one frame at a time on one core: two full passes for
+// autogain, one for the row/column collapse, the sync detector on the two
+// strips, an optional roll / line paint, and the temporal IIR.  Here a BATCH of
+// F consecutive frames is pushed through three kinds of launches:
+//
+//   k_frame_stats   (big, HBM-bound)   per-tile min/max + row/column partial sums
+//   k_frame_reduce  (small)            per-frame min/max and raw strips
+//   k_chain         (2 workgroups)     the frame-to-frame recurrences: autogain IIR
+//                                      state, sync detector (blur, sliding-window
+//                                      best fit, dx low-pass) and the framerate PLL
+//   k_frame_pass    (big, HBM-bound)   normalise + roll/lines + temporal IIR, all F
+//                                      frames per thread so the IIR state stays in
+//                                      registers
+//
+// Only the recurrences are sequential; they touch O(width+height) data per frame.
+#include "tsdrgpu_internal.h"
+
+#define PIX_G 512.0f
+#define PIX_B 1024.0f
+
+#define TILE_W 256
+#define TILE_H 32
+
+struct PpState {  // dsp_autogain_t + syncdetector_t, device resident
+    float lastmax, lastmin;
+    int dx_x, vx_x, strip_x;
+    int dx_y, vx_y, strip_y;
+    int locked;
+    double avg_speed;
+};
+
+struct ChainOut {  // per frame, written by k_chain, read by k_frame_pass
+    float lastmin, lastmax, span;
+    int dx, vx, stripx;
+    int dy, vy, stripy;
+    int locked, pll_fired;
+    double avg_speed, frameratediff;
+};
+
+struct tsdrgpu_postproc {
+    tsdrgpu_t *g;
+    PpState *d_state;
+    float *d_screen;   // dsp_postprocess_t.screenbuffer (IIR state)
+    size_t cap_screen;
+    float *d_tmp1, *d_tmp2;  // intermediates for the non-default stage orders (F frames each)
+    size_t cap_tmp1, cap_tmp2;
+    // statistics scratch
+    float *d_bmin, *d_bmax;
+    float *d_colp, *d_rowp;
+    size_t cap_bmin, cap_bmax, cap_colp, cap_rowp;
+    float *d_fmin, *d_fmax;
+    double *d_strip_x, *d_strip_y;  // [F][3][n]: non-sentinel sum, sentinel sum, sentinel count
+    size_t cap_fmin, cap_fmax, cap_sx, cap_sy;
+    float *d_work;  // chain scratch: blurred strips + prefix sums
+    size_t cap_work;
+    ChainOut *d_chain;
+    ChainOut *h_chain;  // pinned mirror
+    size_t cap_chain;
+    int width, height;
+    int lowpass_before_sync;
+    float taps[5];
+};
+
+// ---------------------------------------------------------------------------
+// k_frame_stats: one workgroup per TILE_W x TILE_H tile of one frame.
+// Wave w takes rows w, w+4, ...; lane l takes columns l, l+64, l+128, l+192 of
+// the tile, so every load instruction covers 256 contiguous bytes.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ frames, long long fstride, int W, int H,
+                                                     int tiles_x, int tiles_y, float *__restrict__ bmin,
+                                                     float *__restrict__ bmax, float *__restrict__ colp,
+                                                     float *__restrict__ rowp, int want_strips)
+{
+    const int tx = blockIdx.x, ty = blockIdx.y, f = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *src = frames + (long long)f * fstride;
+    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+
+    float cns[4] = {0, 0, 0, 0}, cs[4] = {0, 0, 0, 0}, cc[4] = {0, 0, 0, 0};
+    float lo = INFINITY, hi = -INFINITY;
+
+    for (int yy = wave; yy < TILE_H; yy += 4) {
+        const int y = y0 + yy;
+        if (y >= H) break;
+        const float *row = src + (long long)y * W;
+        float rns = 0.f, rs = 0.f, rc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = x0 + lane + 64 * j;
+            if (x < W) {
+                const float v = row[x];
+                const bool sent = (v > 250.0f) || (v < -250.0f);  // dsp.c:57
+                if (sent) {
+                    cs[j] += v; cc[j] += 1.f; rs += v; rc += 1.f;
+                } else {
+                    cns[j] += v; rns += v;
+                    lo = fminf(lo, v);
+                    hi = fmaxf(hi, v);
+                }
+            }
+        }
+        if (want_strips) {
+            rns = wave_sum(rns);
+            const bool any_sent = __any(rc != 0.f);
+            if (any_sent) { rs = wave_sum(rs); rc = wave_sum(rc); }
+            if (lane == 0) {
+                float *rp = rowp + ((long long)(f * tiles_x + tx) * 3) * H;
+                rp[y] = rns;
+                rp[H + y] = any_sent ? rs : 0.f;
+                rp[2 * H + y] = any_sent ? rc : 0.f;
+            }
+        }
+    }
+
+    __shared__ float sh[3][4][TILE_W];
+    __shared__ float shmin[4], shmax[4];
+    if (want_strips) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            sh[0][wave][lane + 64 * j] = cns[j];
+            sh[1][wave][lane + 64 * j] = cs[j];
+            sh[2][wave][lane + 64 * j] = cc[j];
+        }
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if (lane == 0) { shmin[wave] = lo; shmax[wave] = hi; }
+    __syncthreads();
+    if (want_strips) {
+        const int x = x0 + threadIdx.x;
+        if (x < W) {
+            float *cp = colp + ((long long)(f * tiles_y + ty) * 3) * W;
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                cp[q * W + x] = sh[q][0][threadIdx.x] + sh[q][1][threadIdx.x] + sh[q][2][threadIdx.x] + sh[q][3][threadIdx.x];
+        }
+    }
+    if (threadIdx.x == 0) {
+        const long long b = (long long)f * tiles_x * tiles_y + (long long)ty * tiles_x + tx;
+        bmin[b] = fminf(fminf(shmin[0], shmin[1]), fminf(shmin[2], shmin[3]));
+        bmax[b] = fmaxf(fmaxf(shmax[0], shmax[1]), fmaxf(shmax[2], shmax[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_frame_reduce: grid (F, 3): y=0 min/max of the frame, y=1 column strips,
+// y=2 row strips (f64 sums over the tile partials).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x, int tiles_y, const float *__restrict__ bmin,
+                                                      const float *__restrict__ bmax, const float *__restrict__ colp,
+                                                      const float *__restrict__ rowp, float *__restrict__ fmin_,
+                                                      float *__restrict__ fmax_, double *__restrict__ strip_x,
+                                                      double *__restrict__ strip_y, int want_strips)
+{
+    const int f = blockIdx.x;
+    if (blockIdx.y == 0) {
+        const int nblk = tiles_x * tiles_y;
+        float lo = INFINITY, hi = -INFINITY;
+        for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+            lo = fminf(lo, bmin[(long long)f * nblk + b]);
+            hi = fmaxf(hi, bmax[(long long)f * nblk + b]);
+        }
+        __shared__ float slo[4], shi[4];
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            fmin_[f] = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+            fmax_[f] = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+        }
+    } else if (want_strips) {
+        const bool cols = blockIdx.y == 1;
+        const int n = cols ? W : H;
+        const int parts = cols ? tiles_y : tiles_x;
+        const float *src = (cols ? colp : rowp) + (long long)f * parts * 3 * n;
+        double *dst = (cols ? strip_x : strip_y) + (long long)f * 3 * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                double acc = 0.0;
+                for (int p = 0; p < parts; p++) acc += (double)src[((long long)p * 3 + q) * n + i];
+                dst[q * n + i] = acc;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_chain: the sequential part.  Workgroup 0: autogain + x strip + PLL;
+// workgroup 1: autogain (recomputed, it is a scalar recurrence) + y strip.
+// ---------------------------------------------------------------------------
+#define CHAIN_T 1024
+
+__device__ __forceinline__ double wave_incl_scan(double v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+struct FitBest {
+    double fit;
+    int q;
+};
+__device__ __forceinline__ FitBest better(FitBest a, FitBest b)
+{
+    // larger fit wins; on equal fits the earlier position (syncdetector.c:53 uses `>`)
+    if (b.fit > a.fit || (b.fit == a.fit && b.q < a.q)) return b;
+    return a;
+}
+
+struct ChainShared {
+    double wsum[16];
+    FitBest wbest[5][16];
+    double total;
+    FitBest best[5];
+    int sizes[5];
+    int cur;
+};
+
+// One findthesweetspot call (syncdetector.c:71-119) executed by the whole
+// workgroup.  `data` holds the collapsed strip (n floats, global scratch),
+// `blur` receives the blurred strip (+ the two markers), `prefix` n+1 doubles.
+__device__ void chain_sweetspot(ChainShared &S, const float *__restrict__ data, float *__restrict__ blur,
+                                double *__restrict__ prefix, int n, int minsize, double lowpass, const float *taps,
+                                int &dx, int &vx, int &cur_strip)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (minsize < 1) minsize = 1;
+    const int half = n >> 1;
+    int cur = cur_strip;
+    if (cur < minsize) cur = minsize; else if (cur > half) cur = half;
+
+    // gaussianblur (gaussian.c:18-79): out[(i+2)%n] = sum_k taps[k]*in[(i+k)%n], left to right in f32
+    for (int i = tid; i < n; i += CHAIN_T) {
+        const float a = data[i % n], b = data[(i + 1) % n], c = data[(i + 2) % n];
+        const float d = data[(i + 3) % n], e = data[(i + 4) % n];
+        blur[(i + 2) % n] = a * taps[0] + b * taps[1] + c * taps[2] + d * taps[3] + e * taps[4];
+    }
+    __syncthreads();
+
+    // prefix sums in f64 (block scan): thread t owns [t*per, (t+1)*per)
+    const int per = (n + CHAIN_T - 1) / CHAIN_T;
+    const int b0 = tid * per;
+    double local = 0.0;
+    for (int i = b0; i < b0 + per && i < n; i++) local += (double)blur[i];
+    const double incl = wave_incl_scan(local, lane);
+    double excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0;
+    if (lane == 63) S.wsum[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        double w = (lane < 16) ? S.wsum[lane] : 0.0;
+        w = wave_incl_scan(w, lane);
+        if (lane < 16) S.wsum[lane] = w;
+    }
+    __syncthreads();
+    {
+        double run = excl + (wave ? S.wsum[wave - 1] : 0.0);
+        for (int i = b0; i < b0 + per && i < n; i++) {
+            prefix[i] = run;
+            run += (double)blur[i];
+        }
+        if (tid == 0) {
+            S.total = S.wsum[15];
+            prefix[n] = S.wsum[15];
+            S.sizes[0] = cur;
+            const int trial[4] = {cur - 4, cur + 4, cur >> 1, cur << 1};
+            for (int t = 0; t < 4; t++) {
+                const int s = trial[t];
+                S.sizes[t + 1] = (s >= minsize && s < half && s != cur) ? s : 0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // findbestfit (syncdetector.c:26-58) for the (up to) five strip sizes at once.
+    const float totalf = (float)S.total;  // narrowed to float by the callee's parameter type
+    FitBest mine[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { mine[k].fit = -1.0; mine[k].q = 0x7fffffff; }
+    for (int q = tid; q < n; q += CHAIN_T) {
+        const double pq = prefix[q];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int s = S.sizes[k];
+            if (s > 0) {
+                const int e = q + s;
+                const double sum = (e <= n) ? (prefix[e] - pq) : (prefix[n] - pq + prefix[e - n]);
+                const double d = ((double)totalf - sum) / (double)(n - s) - sum / (double)s;
+                const double fit = d * d;
+                if (fit > mine[k].fit) { mine[k].fit = fit; mine[k].q = q; }  // q ascending per thread
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        FitBest b = mine[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            FitBest other;
+            other.fit = __shfl_down(b.fit, o, 64);
+            other.q = __shfl_down(b.q, o, 64);
+            b = better(b, other);
+        }
+        if (lane == 0) S.wbest[k][wave] = b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 0; k < 5; k++) {
+            FitBest b = S.wbest[k][0];
+            for (int w = 1; w < 16; w++) b = better(b, S.wbest[k][w]);
+            S.best[k] = b;
+        }
+        // choose among sizes in the reference's order with its strict `>`
+        double bestfit = S.best[0].fit;
+        int bestq = S.best[0].q, bestsize = S.sizes[0];
+        for (int k = 1; k < 5; k++)
+            if (S.sizes[k] > 0 && S.best[k].fit > bestfit) {
+                bestfit = S.best[k].fit;
+                bestq = S.best[k].q;
+                bestsize = S.sizes[k];
+            }
+        // window start q is labelled with the index just removed (q-1), start 0 with 0
+        const int beststart = bestq > 0 ? bestq - 1 : 0;
+        blur[beststart] = PIX_B;
+        blur[(beststart + bestsize) % n] = PIX_B;
+
+        const int h2 = n / 2;
+        int centre = (beststart + bestsize / 2) % n;
+        const int rawdiff = centre - dx;
+        if (rawdiff > h2) dx += n;
+        else if (rawdiff < -h2) centre += n;
+        const int last = dx;
+        dx = (int)(((long long)round(centre * lowpass + (1.0 - lowpass) * dx)) % ((long long)n));
+        const int rawvx = dx - last;
+        vx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
+        S.cur = bestsize;
+        S.sizes[0] = dx;
+        S.sizes[1] = vx;
+    }
+    __syncthreads();
+    cur_strip = S.cur;
+    dx = S.sizes[0];
+    vx = S.sizes[1];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(CHAIN_T) void k_chain(int F, int W, int H, const float *__restrict__ frames, long long fstride,
+                                                   const float *__restrict__ fmin_, const float *__restrict__ fmax_,
+                                                   const double *__restrict__ strip_x, const double *__restrict__ strip_y,
+                                                   float *__restrict__ work, PpState *__restrict__ state,
+                                                   ChainOut *__restrict__ out, int do_autogain, int do_sync,
+                                                   int strips_normalised, int pll_enabled, float norm, float t0, float t1,
+                                                   float t2, float t3, float t4)
+{
+    __shared__ ChainShared S;
+    const bool xblock = blockIdx.x == 0;
+    const int n = xblock ? W : H;
+    const float taps[5] = {t0, t1, t2, t3, t4};
+    // scratch: [data n][blur n] floats then prefix (n+1) doubles, per workgroup
+    const size_t per_block = (size_t)((2 * n + 2 + 1) / 2 * 2) * sizeof(float) + (size_t)(n + 1) * sizeof(double);
+    const int nmax = W > H ? W : H;
+    const size_t stride_block = (size_t)((2 * nmax + 2 + 1) / 2 * 2) * sizeof(float) + (size_t)(nmax + 1) * sizeof(double);
+    (void)per_block;
+    char *base = (char *)work + (size_t)blockIdx.x * stride_block;
+    float *data = (float *)base;
+    float *blur = data + n;
+    double *prefix = (double *)(base + (size_t)((2 * nmax + 2 + 1) / 2 * 2) * sizeof(float));
+
+    PpState st = *state;  // every thread carries the scalar state in registers
+    int dx = xblock ? st.dx_x : st.dx_y;
+    int vx = xblock ? st.vx_x : st.vx_y;
+    int cur = xblock ? st.strip_x : st.strip_y;
+    float lastmax = st.lastmax, lastmin = st.lastmin;
+    double avg_speed = st.avg_speed;
+    int locked = st.locked;
+
+    for (int f = 0; f < F; f++) {
+        float span = (lastmax == lastmin) ? 1.0f : (lastmax - lastmin);
+        if (do_autogain) {
+            // dsp.c:50-66: min/max start from v[0] even when it is a sentinel
+            const float v0 = frames[(long long)f * fstride];
+            const float hi = fmaxf(v0, fmax_[f]);
+            const float lo = fminf(v0, fmin_[f]);
+            const float keep = 1.0f - norm;
+            lastmax = keep * lastmax + norm * hi;
+            lastmin = keep * lastmin + norm * lo;
+            span = (lastmax == lastmin) ? 1.0f : (lastmax - lastmin);
+        }
+        int fired = 0;
+        double diff = 0.0;
+        if (do_sync) {
+            const double *sp = (xblock ? strip_x : strip_y) + (long long)f * 3 * n;
+            const double cnt_all = (double)(xblock ? H : W);
+            for (int i = threadIdx.x; i < n; i += CHAIN_T) {
+                const double ns = sp[i], s = sp[n + i], c = sp[2 * n + i];
+                double v;
+                if (strips_normalised)  // strip of the autogained frame from the raw frame's sums
+                    v = (ns - (cnt_all - c) * (double)lastmin) / (double)span + s;
+                else
+                    v = ns + s;
+                data[i] = (float)v;
+            }
+            __syncthreads();
+            if (xblock)
+                chain_sweetspot(S, data, blur, prefix, n, (int)(W * 0.05f), 0.9, taps, dx, vx, cur);
+            else
+                chain_sweetspot(S, data, blur, prefix, n, (int)(H * 0.01f), 0.1, taps, dx, vx, cur);
+            if (xblock) {
+                // frameratepll, syncdetector.c:133-153
+                avg_speed = avg_speed * 0.99 + 0.01 * vx;
+                locked = (avg_speed < 0.5 && avg_speed > -0.5) ? 1 : 0;
+                if (pll_enabled && vx != 0) {
+                    diff = locked ? (avg_speed * 0.000001) : (vx * 0.00001);
+                    fired = 1;
+                }
+            }
+        }
+        if (threadIdx.x == 0) {
+            ChainOut *o = &out[f];
+            // each launch fills only the fields of the recurrences it ran
+            if (xblock && do_autogain) { o->lastmin = lastmin; o->lastmax = lastmax; o->span = span; }
+            if (xblock && do_sync) {
+                o->dx = dx; o->vx = vx; o->stripx = cur;
+                o->locked = locked; o->pll_fired = fired;
+                o->avg_speed = avg_speed; o->frameratediff = diff;
+            }
+            if (!xblock && do_sync) { o->dy = dx; o->vy = vx; o->stripy = cur; }
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (xblock) {
+            state->lastmax = lastmax; state->lastmin = lastmin;
+            state->dx_x = dx; state->vx_x = vx; state->strip_x = cur;
+            state->locked = locked; state->avg_speed = avg_speed;
+        } else {
+            state->dx_y = dx; state->vx_y = vx; state->strip_y = cur;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_frame_pass: elementwise work of dsp_post_process for F frames.
+//   v = src_f[map(p)]                       map: identity | 2-D roll (syncdetector.c:187-207)
+//   v = sentinel(v) ? v : (v-lastmin)/span  if NORMALISE      (dsp.c:74)
+//   v = 512 on column dx / row dy           if LINES          (syncdetector.c:209-223)
+//   s = s*a + v*(1.0-a)                     if IIR            (dsp.c:29-32, mixed f32/f64)
+//   dst_f[p] = IIR ? s : v
+// Each thread keeps its pixels' IIR state in registers across the F frames.
+// ---------------------------------------------------------------------------
+#define PASS_NORMALISE 1
+#define PASS_ROLL 2
+#define PASS_LINES 4
+#define PASS_IIR 8
+
+template <int FLAGS>
+__global__ __launch_bounds__(256) void k_frame_pass(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
+                                                    long long dstride, int F, int W, int H,
+                                                    const ChainOut *__restrict__ chain, float *__restrict__ screen, float a)
+{
+    const int P = W * H;
+    const double one_minus_a = 1.0 - a;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int y = p / W, x = p - y * W;
+        float s = (FLAGS & PASS_IIR) ? screen[p] : 0.f;
+        for (int f = 0; f < F; f++) {
+            const float *in = src + (long long)f * sstride;
+            int sp = p;
+            int dx = 0, dy = 0;
+            if (FLAGS & (PASS_ROLL | PASS_LINES)) { dx = chain[f].dx; dy = chain[f].dy; }
+            if (FLAGS & PASS_ROLL) {
+                int sx = x + dx; if (sx >= W) sx -= W;
+                int sy = y + dy; if (sy >= H) sy -= H;
+                sp = sy * W + sx;
+            }
+            float v = in[sp];
+            if (FLAGS & PASS_NORMALISE) {
+                const float lastmin = chain[f].lastmin, span = chain[f].span;
+                v = (v > 250.0f || v < -250.0f) ? v : ((v - lastmin) / span);
+            }
+            if (FLAGS & PASS_LINES) {
+                if (x == dx || y == dy) v = PIX_G;
+            }
+            if (FLAGS & PASS_IIR) {
+                s = (float)((double)(s * a) + (double)v * one_minus_a);
+                v = s;
+            }
+            dst[(long long)f * dstride + p] = v;
+        }
+        if (FLAGS & PASS_IIR) screen[p] = s;
+    }
+}
+
+typedef void (*pass_fn)(const float *, long long, float *, long long, int, int, int, const ChainOut *, float *, float);
+
+static pass_fn pick_pass(int flags)
+{
+    switch (flags) {
+#define CASE(f) case f: return k_frame_pass<f>;
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+#undef CASE
+    }
+    return nullptr;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static void gaussian_taps(float taps[5])
+{
+    // gaussian.c:17-28 — CALC_GAUSSCOEFF(5,i) = expf(-2.0f*1.0f*1.0f*i*i/(5*5)), textual expansion
+    const float e2 = expf(-2.0f * 1.0f * 1.0f * -2 * -2 / (5 * 5));
+    const float e1 = expf(-2.0f * 1.0f * 1.0f * -1 * -1 / (5 * 5));
+    const float e0 = expf(-2.0f * 1.0f * 1.0f * 0 * 0 / (5 * 5));
+    const float f1 = expf(-2.0f * 1.0f * 1.0f * 1 * 1 / (5 * 5));
+    const float f2 = expf(-2.0f * 1.0f * 1.0f * 2 * 2 / (5 * 5));
+    const float norm = e2 + e1 + e0 + f1 + f2;
+    taps[0] = e2 / norm; taps[1] = e1 / norm; taps[2] = e0 / norm; taps[3] = f1 / norm; taps[4] = f2 / norm;
+}
+
+extern "C" int tsdrgpu_postproc_create(tsdrgpu_t *g, tsdrgpu_postproc_t **out)
+{
+    if (!g || !out) return TSDRGPU_EINVAL;
+    tsdrgpu_postproc_t *pp = (tsdrgpu_postproc_t *)calloc(1, sizeof(*pp));
+    if (!pp) return TSDRGPU_ENOMEM;
+    pp->g = g;
+    gaussian_taps(pp->taps);
+    if (hipMalloc(&pp->d_state, sizeof(PpState)) != hipSuccess) { free(pp); return TSDRGPU_ENOMEM; }
+    *out = pp;
+    return tsdrgpu_postproc_reset(pp);
+}
+
+extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
+{
+    if (!pp) return;
+    (void)hipStreamSynchronize(pp->g->stream);
+    void *bufs[] = {pp->d_state, pp->d_screen, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
+                    pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (pp->h_chain) (void)hipHostFree(pp->h_chain);
+    free(pp);
+}
+
+extern "C" int tsdrgpu_postproc_reset(tsdrgpu_postproc_t *pp)
+{
+    if (!pp) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    // dsp_post_process_init (dsp.c:112-132): autogain 0/0, sync detector zeroed, sizes forgotten
+    HIP_TRY(g, hipMemsetAsync(pp->d_state, 0, sizeof(PpState), g->stream));
+    pp->width = pp->height = 0;
+    pp->lowpass_before_sync = 0;
+    if (pp->d_screen) HIP_TRY(g, hipMemsetAsync(pp->d_screen, 0, pp->cap_screen * sizeof(float), g->stream));
+    return TSDRGPU_OK;
+}
+
+template <class T>
+static int ensure(tsdrgpu_t *g, T **buf, size_t *cap, size_t need, bool zero = false)
+{
+    if (*cap >= need && *buf) return TSDRGPU_OK;
+    if (*buf) {
+        (void)hipStreamSynchronize(g->stream);
+        (void)hipFree(*buf);
+    }
+    *buf = nullptr;
+    *cap = 0;
+    if (hipMalloc((void **)buf, need * sizeof(T)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "device scratch");
+    *cap = need;
+    if (zero) HIP_TRY(g, hipMemsetAsync(*buf, 0, need * sizeof(T), g->stream));
+    return TSDRGPU_OK;
+}
+
+static int launch_stats(tsdrgpu_postproc_t *pp, const float *frames, long long fstride, int F, int W, int H, int want_strips)
+{
+    tsdrgpu_t *g = pp->g;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+    dim3 grid(tiles_x, tiles_y, F);
+    {
+        ProfScope prof(g, PROF_FRAME_STATS);
+        k_frame_stats<<<grid, 256, 0, g->stream>>>(frames, fstride, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp,
+                                               pp->d_rowp, want_strips);
+    }
+    KERNEL_CHECK(g, "k_frame_stats");
+    ProfScope prof(g, PROF_FRAME_REDUCE);
+    k_frame_reduce<<<dim3(F, 3), 256, 0, g->stream>>>(W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
+                                                      pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, want_strips);
+    KERNEL_CHECK(g, "k_frame_reduce");
+    return TSDRGPU_OK;
+}
+
+static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long fstride, int F, int W, int H, int do_autogain,
+                        int do_sync, int strips_normalised, const tsdrgpu_pp_params_t *prm)
+{
+    tsdrgpu_t *g = pp->g;
+    ProfScope prof(g, PROF_CHAIN);
+    k_chain<<<2, CHAIN_T, 0, g->stream>>>(F, W, H, frames, fstride, pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y,
+                                          pp->d_work, pp->d_state, pp->d_chain, do_autogain, do_sync, strips_normalised,
+                                          prm->pll, prm->lowpasscoeff, pp->taps[0], pp->taps[1], pp->taps[2], pp->taps[3],
+                                          pp->taps[4]);
+    KERNEL_CHECK(g, "k_chain");
+    return TSDRGPU_OK;
+}
+
+static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long long sstride, float *dst, long long dstride,
+                       int F, int W, int H, float a)
+{
+    tsdrgpu_t *g = pp->g;
+    pass_fn fn = pick_pass(flags);
+    if (!fn) return tsdr_fail(g, TSDRGPU_EINVAL, "k_frame_pass", "unsupported flag combination");
+    const long long P = (long long)W * H;
+    long long blocks = (P + 255) / 256;
+    const long long cap = (long long)g->prop.multiProcessorCount * 8;
+    if (blocks > cap) blocks = cap;
+    ProfScope prof(g, PROF_FRAME_PASS);
+    fn<<<(unsigned)blocks, 256, 0, g->stream>>>(src, sstride, dst, dstride, F, W, H, pp->d_chain, pp->d_screen, a);
+    KERNEL_CHECK(g, "k_frame_pass");
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int F, int W, int H,
+                                    const tsdrgpu_pp_params_t *prm, float *d_out, tsdrgpu_pp_frameinfo_t *h_info)
+{
+    if (!pp || !d_frames || !d_out || !prm || F < 0 || W <= 0 || H <= 0)
+        return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "bad argument") : TSDRGPU_EINVAL;
+    if (F == 0) return TSDRGPU_OK;
+    tsdrgpu_t *g = pp->g;
+    const size_t P = (size_t)W * H;
+    int rc;
+
+    // buffer (re)sizing, dsp.c:152-173: the screen buffer is zeroed only when it has to grow
+    if (H != pp->height || W != pp->width) {
+        pp->height = H;
+        pp->width = W;
+        if (P > pp->cap_screen && (rc = ensure(g, &pp->d_screen, &pp->cap_screen, P, true))) return rc;
+    }
+    if (prm->lowpass_before_sync || prm->autogain_after_proc) {
+        if ((rc = ensure(g, &pp->d_tmp1, &pp->cap_tmp1, P * (size_t)F, true))) return rc;
+        if ((rc = ensure(g, &pp->d_tmp2, &pp->cap_tmp2, P * (size_t)F, true))) return rc;
+    }
+    if (pp->lowpass_before_sync != prm->lowpass_before_sync) {  // dsp.c:178-186
+        pp->lowpass_before_sync = prm->lowpass_before_sync;
+        HIP_TRY(g, hipMemsetAsync(pp->d_screen, 0, P * sizeof(float), g->stream));
+    }
+
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+    const size_t nblk = (size_t)F * tiles_x * tiles_y;
+    if ((rc = ensure(g, &pp->d_bmin, &pp->cap_bmin, nblk))) return rc;
+    if ((rc = ensure(g, &pp->d_bmax, &pp->cap_bmax, nblk))) return rc;
+    if ((rc = ensure(g, &pp->d_colp, &pp->cap_colp, (size_t)F * tiles_y * 3 * W))) return rc;
+    if ((rc = ensure(g, &pp->d_rowp, &pp->cap_rowp, (size_t)F * tiles_x * 3 * H))) return rc;
+    if ((rc = ensure(g, &pp->d_fmin, &pp->cap_fmin, (size_t)F))) return rc;
+    if ((rc = ensure(g, &pp->d_fmax, &pp->cap_fmax, (size_t)F))) return rc;
+    if ((rc = ensure(g, &pp->d_strip_x, &pp->cap_sx, (size_t)F * 3 * W))) return rc;
+    if ((rc = ensure(g, &pp->d_strip_y, &pp->cap_sy, (size_t)F * 3 * H))) return rc;
+    {
+        const int nmax = W > H ? W : H;
+        const size_t per = (size_t)((2 * nmax + 2 + 1) / 2 * 2) * sizeof(float) + (size_t)(nmax + 1) * sizeof(double);
+        if ((rc = ensure(g, &pp->d_work, &pp->cap_work, (2 * per + 64) / sizeof(float)))) return rc;
+    }
+    if ((size_t)F > pp->cap_chain) {
+        if (pp->d_chain) { (void)hipStreamSynchronize(g->stream); (void)hipFree(pp->d_chain); (void)hipHostFree(pp->h_chain); }
+        pp->d_chain = nullptr; pp->h_chain = nullptr; pp->cap_chain = 0;
+        if (hipMalloc(&pp->d_chain, sizeof(ChainOut) * F) != hipSuccess || hipHostMalloc(&pp->h_chain, sizeof(ChainOut) * F, hipHostMallocDefault) != hipSuccess)
+            return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "chain buffers");
+        pp->cap_chain = F;
+    }
+
+    const float a = prm->motionblur;
+    const int lbs = prm->lowpass_before_sync, aap = prm->autogain_after_proc;
+    const int map = prm->autoshift ? PASS_ROLL : 0;
+    const long long Ps = (long long)P;
+
+    if (!lbs && !aap) {
+        // order A (library default): autogain -> collapse -> sync -> IIR; result = screenbuffer
+        const int lines = (!prm->autoshift && a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+        if ((rc = launch_stats(pp, d_frames, Ps, F, W, H, 1))) return rc;
+        if ((rc = launch_chain(pp, d_frames, Ps, F, W, H, 1, 1, 1, prm))) return rc;
+        if ((rc = launch_pass(pp, PASS_NORMALISE | map | lines | PASS_IIR, d_frames, Ps, d_out, Ps, F, W, H, a))) return rc;
+    } else if (!lbs && aap) {
+        // order B: collapse(raw) -> sync -> IIR -> autogain(screen); result = sendbuffer
+        const int lines = (!prm->autoshift && a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+        if ((rc = launch_stats(pp, d_frames, Ps, F, W, H, 1))) return rc;
+        if ((rc = launch_chain(pp, d_frames, Ps, F, W, H, 0, 1, 0, prm))) return rc;
+        if ((rc = launch_pass(pp, map | lines | PASS_IIR, d_frames, Ps, pp->d_tmp1, Ps, F, W, H, a))) return rc;
+        if ((rc = launch_stats(pp, pp->d_tmp1, Ps, F, W, H, 0))) return rc;
+        if ((rc = launch_chain(pp, pp->d_tmp1, Ps, F, W, H, 1, 0, 0, prm))) return rc;
+        if ((rc = launch_pass(pp, PASS_NORMALISE, pp->d_tmp1, Ps, d_out, Ps, F, W, H, a))) return rc;
+    } else if (lbs && !aap) {
+        // order C (GUI default): autogain -> IIR -> collapse(screen) -> sync; result = corrected / screen
+        const int lines = (!prm->autoshift && !prm->superresolution) ? PASS_LINES : 0;
+        if ((rc = launch_stats(pp, d_frames, Ps, F, W, H, 0))) return rc;
+        if ((rc = launch_chain(pp, d_frames, Ps, F, W, H, 1, 0, 0, prm))) return rc;
+        if ((rc = launch_pass(pp, PASS_NORMALISE | PASS_IIR, d_frames, Ps, pp->d_tmp1, Ps, F, W, H, a))) return rc;
+        if ((rc = launch_stats(pp, pp->d_tmp1, Ps, F, W, H, 1))) return rc;
+        if ((rc = launch_chain(pp, pp->d_tmp1, Ps, F, W, H, 0, 1, 0, prm))) return rc;
+        if ((rc = launch_pass(pp, map | lines, pp->d_tmp1, Ps, d_out, Ps, F, W, H, a))) return rc;
+    } else {
+        // order D: IIR -> collapse(screen) -> sync -> autogain(sync result); result = sendbuffer
+        const int lines = (!prm->autoshift && !prm->superresolution) ? PASS_LINES : 0;
+        if ((rc = launch_pass(pp, PASS_IIR, d_frames, Ps, pp->d_tmp1, Ps, F, W, H, a))) return rc;
+        if ((rc = launch_stats(pp, pp->d_tmp1, Ps, F, W, H, 1))) return rc;
+        if ((rc = launch_chain(pp, pp->d_tmp1, Ps, F, W, H, 0, 1, 0, prm))) return rc;
+        if ((rc = launch_pass(pp, map | lines, pp->d_tmp1, Ps, pp->d_tmp2, Ps, F, W, H, a))) return rc;
+        if ((rc = launch_stats(pp, pp->d_tmp2, Ps, F, W, H, 0))) return rc;
+        if ((rc = launch_chain(pp, pp->d_tmp2, Ps, F, W, H, 1, 0, 0, prm))) return rc;
+        if ((rc = launch_pass(pp, PASS_NORMALISE, pp->d_tmp2, Ps, d_out, Ps, F, W, H, a))) return rc;
+    }
+
+    if (h_info) {
+        // the chain record is complete after the last k_chain; convert on the host after the caller syncs
+        HIP_TRY(g, hipMemcpyAsync(pp->h_chain, pp->d_chain, sizeof(ChainOut) * F, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(g, hipStreamSynchronize(g->stream));
+        for (int f = 0; f < F; f++) {
+            const ChainOut &c = pp->h_chain[f];
+            tsdrgpu_pp_frameinfo_t &o = h_info[f];
+            o.lastmin = c.lastmin; o.lastmax = c.lastmax;
+            o.dx = c.dx; o.vx = c.vx; o.stripx = c.stripx;
+            o.dy = c.dy; o.vy = c.vy; o.stripy = c.stripy;
+            o.locked = c.locked; o.pll_fired = c.pll_fired;
+            o.avg_speed = c.avg_speed; o.frameratediff = c.frameratediff;
+        }
+    }
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_strips(tsdrgpu_postproc_t *pp, float *h_colsum, float *h_rowsum)
+{
+    if (!pp || !pp->d_work || pp->width <= 0) return TSDRGPU_ESTATE;
+    tsdrgpu_t *g = pp->g;
+    const int W = pp->width, H = pp->height;
+    const int nmax = W > H ? W : H;
+    const size_t stride_block = (size_t)((2 * nmax + 2 + 1) / 2 * 2) * sizeof(float) + (size_t)(nmax + 1) * sizeof(double);
+    const char *base = (const char *)pp->d_work;
+    if (h_colsum) HIP_TRY(g, hipMemcpyAsync(h_colsum, (const float *)base + W, sizeof(float) * W, hipMemcpyDeviceToHost, g->stream));
+    if (h_rowsum) HIP_TRY(g, hipMemcpyAsync(h_rowsum, (const float *)(base + stride_block) + H, sizeof(float) * H, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    return TSDRGPU_OK;
+}

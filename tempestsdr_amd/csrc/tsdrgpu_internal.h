@@ -1,0 +1,96 @@
+// tsdrgpu_internal.h — shared by the .hip translation units of libtsdrgpu.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/tsdrgpu.h"
+
+#define TSDR_WAVE 64
+
+// stage ids for the optional event profiler (tsdrgpu_profile_*)
+enum ProfStage {
+    PROF_DEMOD = 0,
+    PROF_RS_CARRY,
+    PROF_RS_AREA,
+    PROF_RS_NEAREST,
+    PROF_FRAME_STATS,
+    PROF_FRAME_REDUCE,
+    PROF_CHAIN,
+    PROF_FRAME_PASS,
+    PROF_FFT_PASS,
+    PROF_ACCUMULATE,
+    PROF_SUPERB_MISC,
+    PROF_COUNT
+};
+
+struct ProfSpan {
+    int stage;
+    hipEvent_t a, b;
+};
+
+struct tsdrgpu {
+    int device;
+    hipStream_t stream;
+    hipEvent_t t0, t1;
+    char err[512];
+    hipDeviceProp_t prop;
+    // profiler
+    int prof_on;
+    ProfSpan *spans;
+    int nspans, cap_spans;
+};
+
+// RAII span: records an event pair around the launches issued in its scope
+struct ProfScope {
+    tsdrgpu_t *g;
+    int idx;
+    ProfScope(tsdrgpu_t *g_, int stage);
+    ~ProfScope();
+};
+
+static inline int tsdr_fail(tsdrgpu_t *g, int code, const char *what, const char *detail)
+{
+    if (g) snprintf(g->err, sizeof(g->err), "%s: %s", what, detail ? detail : "");
+    return code;
+}
+
+#define HIP_TRY(g, call)                                                              \
+    do {                                                                              \
+        hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) return tsdr_fail((g), TSDRGPU_EHIP, #call, hipGetErrorString(e__)); \
+    } while (0)
+
+#define KERNEL_CHECK(g, name)                                                         \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) return tsdr_fail((g), TSDRGPU_EHIP, name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline unsigned ceil_div_u(unsigned long long a, unsigned long long b)
+{
+    return (unsigned)((a + b - 1) / b);
+}
+
+// A small pinned staging area for tables that kernels read (chunk tables, ...),
+// recycled round-robin; an event per slot guards reuse.
+struct StagingRing {
+    static const int SLOTS = 4;
+    void *h[SLOTS];
+    void *d[SLOTS];
+    size_t cap[SLOTS];
+    hipEvent_t ev[SLOTS];
+    bool used[SLOTS];
+    int next;
+};
+
+int staging_init(tsdrgpu_t *g, StagingRing *r);
+void staging_free(StagingRing *r);
+// returns slot index or <0; after filling h[slot], call staging_push
+int staging_acquire(tsdrgpu_t *g, StagingRing *r, size_t bytes);
+int staging_push(tsdrgpu_t *g, StagingRing *r, int slot, size_t bytes);  // async H2D + nothing else
+int staging_release(tsdrgpu_t *g, StagingRing *r, int slot);            // record event after the consumer launch
+
+// FFT engine (tsdrgpu_fft.hip), used by autocorrelation and super-bandwidth
+struct FftPlan;

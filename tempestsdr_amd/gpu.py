@@ -1,0 +1,393 @@
+"""ctypes binding of tempestsdr_amd/libtsdrgpu.so (C ABI: include/tsdrgpu.h).
+
+This is the host-side mirror used by the tests and bench.py; the method names
+follow the reference's stage functions (am_demod, dsp_resample_process,
+dsp_post_process, fft_perform, fft_autocorrelation/accummulate,
+superb_ondataready) so the parity tests read like calls into the reference.
+
+There is NO fallback: if the HIP library is missing or no GPU is present the
+constructor raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtsdrgpu.so")
+
+vp = C.c_void_p
+
+
+class PPParams(C.Structure):
+    _fields_ = [("lowpass_before_sync", C.c_int), ("autogain_after_proc", C.c_int),
+                ("autoshift", C.c_int), ("pll", C.c_int), ("superresolution", C.c_int),
+                ("motionblur", C.c_float), ("lowpasscoeff", C.c_float)]
+
+
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int)]
+
+
+class PPFrameInfo(C.Structure):
+    _fields_ = [("lastmin", C.c_float), ("lastmax", C.c_float),
+                ("dx", C.c_int), ("vx", C.c_int), ("stripx", C.c_int),
+                ("dy", C.c_int), ("vy", C.c_int), ("stripy", C.c_int),
+                ("locked", C.c_int), ("pll_fired", C.c_int),
+                ("avg_speed", C.c_double), ("frameratediff", C.c_double)]
+
+
+_SIGS = {
+    "tsdrgpu_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "tsdrgpu_destroy": (None, [vp]),
+    "tsdrgpu_last_error": (C.c_char_p, [vp]),
+    "tsdrgpu_sync": (C.c_int, [vp]),
+    "tsdrgpu_stream": (vp, [vp]),
+    "tsdrgpu_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "tsdrgpu_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_size_t]),
+    "tsdrgpu_free": (C.c_int, [vp, vp]),
+    "tsdrgpu_alloc_host": (C.c_int, [vp, C.POINTER(vp), C.c_size_t]),
+    "tsdrgpu_free_host": (C.c_int, [vp, vp]),
+    "tsdrgpu_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tsdrgpu_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tsdrgpu_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tsdrgpu_zero": (C.c_int, [vp, vp, C.c_size_t]),
+    "tsdrgpu_timer_start": (C.c_int, [vp]),
+    "tsdrgpu_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "tsdrgpu_profile_begin": (C.c_int, [vp]),
+    "tsdrgpu_profile_end": (C.c_int, [vp, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
+    "tsdrgpu_am_demod": (C.c_int, [vp, vp, vp, C.c_int64]),
+    "tsdrgpu_resampler_create": (C.c_int, [vp, C.POINTER(vp)]),
+    "tsdrgpu_resampler_destroy": (None, [vp]),
+    "tsdrgpu_resampler_reset": (C.c_int, [vp]),
+    "tsdrgpu_resampler_setstate": (C.c_int, [vp, C.c_double, C.c_double]),
+    "tsdrgpu_resampler_getstate": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "tsdrgpu_resample": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_double, C.c_double,
+                                   C.c_int, vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "tsdrgpu_resample_count": (C.c_int64, [vp, C.c_uint32, C.c_int, C.c_double, C.c_double]),
+    "tsdrgpu_postproc_create": (C.c_int, [vp, C.POINTER(vp)]),
+    "tsdrgpu_postproc_destroy": (None, [vp]),
+    "tsdrgpu_postproc_reset": (C.c_int, [vp]),
+    "tsdrgpu_postproc_run": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams), vp,
+                                       C.POINTER(PPFrameInfo)]),
+    "tsdrgpu_postproc_strips": (C.c_int, [vp, vp, vp]),
+    "tsdrgpu_fft": (C.c_int, [vp, vp, C.c_uint32, C.c_int]),
+    "tsdrgpu_autocorr_create": (C.c_int, [vp, C.POINTER(vp), C.c_uint32]),
+    "tsdrgpu_autocorr_destroy": (None, [vp]),
+    "tsdrgpu_autocorr_reset": (C.c_int, [vp]),
+    "tsdrgpu_autocorr_geometry": (C.c_int, [vp] + [C.POINTER(C.c_int32)] * 4 + [C.POINTER(C.c_uint32)] * 2),
+    "tsdrgpu_autocorr_run": (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "tsdrgpu_autocorr_plots": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
+    "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
+    "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
+    "tsdrgpu_autocorr_argmax": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tsdrgpu_autocorr_last_corr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]),
+    "tsdrgpu_superb_stitch": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp,
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m tempestsdr_amd.build` "
+                               "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError = the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+class TsdrGpuError(RuntimeError):
+    pass
+
+
+class DeviceArray:
+    """A typed device allocation owned by a TsdrGpu context."""
+
+    def __init__(self, ctx, count, dtype):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self.count = int(count)
+        p = vp()
+        ctx._ck(ctx.lib.tsdrgpu_alloc(ctx.h, C.byref(p), max(1, self.count) * self.dtype.itemsize))
+        self.ptr = p.value
+        ctx._adopt(self)
+
+    def destroy(self):
+        self.free()
+
+    @property
+    def nbytes(self):
+        return self.count * self.dtype.itemsize
+
+    def at(self, elem_offset):
+        return self.ptr + int(elem_offset) * self.dtype.itemsize
+
+    def upload(self, host, elem_offset=0):
+        host = np.ascontiguousarray(host, self.dtype)
+        assert elem_offset + host.size <= self.count
+        self.ctx._ck(self.ctx.lib.tsdrgpu_upload(self.ctx.h, self.at(elem_offset), host.ctypes.data, host.nbytes))
+        self.ctx.sync()  # pageable source: keep it alive until the copy is done
+        return self
+
+    def download(self, count=None, elem_offset=0):
+        count = self.count - elem_offset if count is None else int(count)
+        out = np.empty(count, self.dtype)
+        self.ctx._ck(self.ctx.lib.tsdrgpu_download(self.ctx.h, out.ctypes.data, self.at(elem_offset), out.nbytes))
+        self.ctx.sync()
+        return out
+
+    def zero(self):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_zero(self.ctx.h, self.ptr, self.nbytes))
+
+    def free(self):
+        if self.ptr and self.ctx.h:
+            self.ctx.lib.tsdrgpu_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class TsdrGpu:
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = vp()
+        rc = self.lib.tsdrgpu_create(C.byref(h), device)
+        if rc != 0:
+            raise TsdrGpuError(f"tsdrgpu_create({device}) failed with {rc}: no usable HIP device "
+                               "(this package has no CPU path)")
+        self.h = h
+        self._children = []  # weakrefs to objects that hold this context inside the C library
+
+    def _adopt(self, child):
+        import weakref
+        if len(self._children) > 4096:
+            self._children = [r for r in self._children if r() is not None]
+        self._children.append(weakref.ref(child))
+
+    def profile_begin(self):
+        self._ck(self.lib.tsdrgpu_profile_begin(self.h))
+
+    def profile_end(self):
+        """{kernel name: (total_ms, launches)} for everything queued since profile_begin()."""
+        ent = (ProfileEntry * 32)()
+        n = C.c_int()
+        self._ck(self.lib.tsdrgpu_profile_end(self.h, ent, 32, C.byref(n)))
+        return {ent[i].name.decode(): (ent[i].total_ms, ent[i].launches) for i in range(n.value)}
+
+    def close(self):
+        """Destroys dependants first: the C objects keep a pointer to the context."""
+        if getattr(self, "h", None):
+            for ref in self._children:
+                child = ref()
+                if child is not None:
+                    child.destroy()
+            self._children = []
+            self.lib.tsdrgpu_destroy(self.h)
+            self.h = None
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise TsdrGpuError(f"tsdrgpu error {rc}: {self.lib.tsdrgpu_last_error(self.h).decode()}")
+
+    def sync(self):
+        self._ck(self.lib.tsdrgpu_sync(self.h))
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._ck(self.lib.tsdrgpu_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def stream(self):
+        return self.lib.tsdrgpu_stream(self.h)
+
+    def empty(self, count, dtype=np.float32):
+        return DeviceArray(self, count, dtype)
+
+    def to_device(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype or host.dtype)
+        return DeviceArray(self, host.size, host.dtype).upload(host)
+
+    def timer_start(self):
+        self._ck(self.lib.tsdrgpu_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._ck(self.lib.tsdrgpu_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- a1 ----------------------------------------------------------------
+    def am_demod(self, d_iq, d_out, nsamples, iq_offset=0, out_offset=0):
+        self._ck(self.lib.tsdrgpu_am_demod(self.h, d_iq.at(iq_offset), d_out.at(out_offset), nsamples))
+
+    # ---- a13/a14 -------------------------------------------------------------
+    def fft_perform(self, d_iq, n, inverse, offset=0):
+        self._ck(self.lib.tsdrgpu_fft(self.h, d_iq.at(offset), n, int(inverse)))
+
+    def superb_stitch(self, d_hops, gathered, samples_in_frame, d_out):
+        ptrs = (vp * len(d_hops))(*[h.ptr for h in d_hops])
+        offs = (C.c_int32 * len(d_hops))()
+        total = C.c_uint32()
+        self._ck(self.lib.tsdrgpu_superb_stitch(self.h, ptrs, len(d_hops), gathered, samples_in_frame,
+                                                d_out.ptr, offs, C.byref(total)))
+        return np.array(list(offs), np.int32), total.value
+
+
+class Resampler:
+    """dsp_resample_t + dsp_resample_process on the device (dsp.c:250-307)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = vp()
+        ctx._ck(ctx.lib.tsdrgpu_resampler_create(ctx.h, C.byref(h)))
+        self.h = h
+        ctx._adopt(self)
+
+    def destroy(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.tsdrgpu_resampler_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_resampler_reset(self.h))
+
+    def set_state(self, contrib, offset):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_resampler_setstate(self.h, contrib, offset))
+
+    def state(self):
+        c, o = C.c_double(), C.c_double()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_resampler_getstate(self.h, C.byref(c), C.byref(o)))
+        return c.value, o.value
+
+    def count(self, chunk, nchunks, up, down):
+        return self.ctx.lib.tsdrgpu_resample_count(self.h, chunk, nchunks, up, down)
+
+    def process(self, d_in, in_is_iq, chunk, nchunks, up, down, nearest, d_out, in_offset=0, out_offset=0):
+        n = C.c_int64()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_resample(self.h, d_in.at(in_offset), int(in_is_iq), chunk, nchunks, up,
+                                                   down, int(nearest), d_out.at(out_offset),
+                                                   d_out.count - out_offset, C.byref(n)))
+        return n.value
+
+
+class PostProcess:
+    """dsp_postprocess_t + dsp_post_process on the device (dsp.c:112-239)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = vp()
+        ctx._ck(ctx.lib.tsdrgpu_postproc_create(ctx.h, C.byref(h)))
+        self.h = h
+        ctx._adopt(self)
+
+    def destroy(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.tsdrgpu_postproc_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_reset(self.h))
+
+    def run(self, d_frames, nframes, width, height, d_out, motionblur=0.0, lowpasscoeff=0.1,
+            lowpass_before_sync=0, autogain_after_proc=0, autoshift=0, pll=0, superres=0,
+            want_info=True, frames_offset=0, out_offset=0):
+        prm = PPParams(lowpass_before_sync, autogain_after_proc, autoshift, pll, superres, motionblur, lowpasscoeff)
+        info = (PPFrameInfo * nframes)() if want_info else None
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_run(self.h, d_frames.at(frames_offset), nframes, width, height,
+                                                       C.byref(prm), d_out.at(out_offset), info))
+        return list(info) if want_info else None
+
+    def strips(self, width, height):
+        c = np.empty(width, np.float32)
+        r = np.empty(height, np.float32)
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_strips(self.h, c.ctypes.data, r.ctypes.data))
+        return c, r
+
+
+class Autocorr:
+    """frameratedetector numerics on the device (frameratedetector.c:26-126)."""
+
+    def __init__(self, ctx, samplerate):
+        self.ctx = ctx
+        h = vp()
+        ctx._ck(ctx.lib.tsdrgpu_autocorr_create(ctx.h, C.byref(h), int(samplerate)))
+        self.h = h
+        ctx._adopt(self)
+        a = [C.c_int32() for _ in range(4)]
+        b = [C.c_uint32() for _ in range(2)]
+        ctx._ck(ctx.lib.tsdrgpu_autocorr_geometry(h, *[C.byref(x) for x in a + b]))
+        self.flo, self.flen, self.llo, self.llen = [x.value for x in a]
+        self.capture, self.n = [x.value for x in b]
+
+    def destroy(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.tsdrgpu_autocorr_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_reset(self.h))
+
+    def run(self, d_in, in_is_iq, stride, nwindows, mode=0, in_offset=0):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_run(self.h, d_in.at(in_offset), int(in_is_iq), stride, nwindows, mode))
+
+    def plots(self):
+        f = np.empty(self.flen, np.float64)
+        l = np.empty(self.llen, np.float64)
+        calls = C.c_uint64()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_plots(self.h, f.ctypes.data, l.ctypes.data, C.byref(calls)))
+        return f, l, calls.value
+
+    def device_plots(self):
+        p, n = vp(), C.c_int64()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_device_plots(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def finalize_sums(self, total_windows):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_finalize_sums(self.h, total_windows))
+
+    def argmax(self):
+        a, b = C.c_int32(), C.c_int32()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_argmax(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def last_corr(self):
+        p, n = vp(), C.c_uint32()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_last_corr(self.h, C.byref(p), C.byref(n)))
+        out = np.empty(2 * n.value, np.float32)
+        self.ctx._ck(self.ctx.lib.tsdrgpu_download(self.ctx.h, out.ctypes.data, p.value, out.nbytes))
+        self.ctx.sync()
+        return out
