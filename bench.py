@@ -184,7 +184,7 @@ def main():
     pp = gpu.PostProcess(g)
     ac = gpu.Autocorr(g, fs)
     nwin = nsamples // ac.capture
-    max_pix = int(nsamples * (up / down)) + 64
+    max_pix = int(nsamples * (up / down)) + 64 + P  # + a carried partial frame
     pix = torch.empty(max_pix, dtype=torch.float32, device=dev)
     frames_cap = max_pix // P + 1
     out = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
