@@ -1,0 +1,119 @@
+"""ctypes driver of libTSDRLibrary.so (the tsdr_* drop-in) for the host tests.
+Replays the call sequence the Java GUI issues through its JNI shim
+(SURVEY.md §3.6)."""
+import ctypes as C
+import os
+import subprocess
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tempestsdr_amd", "libTSDRLibrary.so")
+PLUGIN_SRC = os.path.join(ROOT, "tests", "plugins", "tsdr_test_plugin.c")
+PLUGIN = os.path.join(ROOT, "tests", "plugins", "libtsdr_test_plugin.so")
+
+FRAME_CB = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p)
+VALUE_CB = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_double, C.c_void_p)
+PLOT_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_uint32, C.c_void_p)
+
+TSDR_SYMBOLS = ["tsdr_free", "tsdr_getctx", "tsdr_getlasterrortext", "tsdr_getsamplerate", "tsdr_init",
+                "tsdr_isrunning", "tsdr_loadplugin", "tsdr_motionblur", "tsdr_readasync", "tsdr_reset",
+                "tsdr_setbasefreq", "tsdr_setgain", "tsdr_setparameter_double", "tsdr_setparameter_int",
+                "tsdr_setresolution", "tsdr_stop", "tsdr_sync", "tsdr_unloadplugin"]
+
+
+def build_test_plugin():
+    if not os.path.exists(PLUGIN) or os.path.getmtime(PLUGIN) < os.path.getmtime(PLUGIN_SRC):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-o", PLUGIN, PLUGIN_SRC],
+                       check=True)
+    return PLUGIN
+
+
+def load():
+    lib = C.CDLL(LIB)
+    vp = C.c_void_p
+    lib.tsdr_init.argtypes = [C.POINTER(vp), VALUE_CB, PLOT_CB, vp]
+    lib.tsdr_init.restype = None
+    lib.tsdr_free.argtypes = [C.POINTER(vp)]
+    lib.tsdr_free.restype = None
+    lib.tsdr_getctx.argtypes = [vp]
+    lib.tsdr_getctx.restype = vp
+    lib.tsdr_getlasterrortext.argtypes = [vp]
+    lib.tsdr_getlasterrortext.restype = C.c_char_p
+    lib.tsdr_loadplugin.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.tsdr_unloadplugin.argtypes = [vp]
+    lib.tsdr_setresolution.argtypes = [vp, C.c_int, C.c_double]
+    lib.tsdr_setbasefreq.argtypes = [vp, C.c_uint32]
+    lib.tsdr_setgain.argtypes = [vp, C.c_float]
+    lib.tsdr_motionblur.argtypes = [vp, C.c_float]
+    lib.tsdr_sync.argtypes = [vp, C.c_int, C.c_int]
+    lib.tsdr_setparameter_int.argtypes = [vp, C.c_int, C.c_uint32]
+    lib.tsdr_setparameter_double.argtypes = [vp, C.c_int, C.c_double]
+    lib.tsdr_readasync.argtypes = [vp, FRAME_CB, vp]
+    lib.tsdr_stop.argtypes = [vp]
+    lib.tsdr_isrunning.argtypes = [vp]
+    lib.tsdr_getsamplerate.argtypes = [vp]
+    lib.tsdr_reset.argtypes = [vp]
+    lib.tsdr_reset.restype = None
+    return lib
+
+
+class Session:
+    """One tsdr_lib_t plus the three callbacks, collecting what they deliver."""
+
+    def __init__(self):
+        self.lib = load()
+        self.frames, self.plots, self.values = [], [], []
+        self.lock = threading.Lock()
+
+        def on_frame(buf, w, h, ctx):
+            a = np.ctypeslib.as_array(buf, shape=(w * h,)).copy()
+            with self.lock:
+                self.frames.append((w, h, a))
+
+        def on_value(vid, a0, a1, ctx):
+            with self.lock:
+                self.values.append((vid, a0, a1))
+
+        def on_plot(pid, offset, vals, size, rate, ctx):
+            a = np.ctypeslib.as_array(vals, shape=(size,)).copy()
+            with self.lock:
+                self.plots.append((pid, offset, a, rate))
+
+        self._cbs = (FRAME_CB(on_frame), VALUE_CB(on_value), PLOT_CB(on_plot))
+        self.h = C.c_void_p()
+        self.lib.tsdr_init(C.byref(self.h), self._cbs[1], self._cbs[2], None)
+        self.thread = None
+        self.status = None
+
+    def err(self):
+        e = self.lib.tsdr_getlasterrortext(self.h)
+        return e.decode() if e else None
+
+    def start(self):
+        def run():
+            self.status = self.lib.tsdr_readasync(self.h, self._cbs[0], None)
+        self.thread = threading.Thread(target=run)
+        self.thread.start()
+
+    def wait_frames(self, n, timeout=30.0):
+        t0 = time.time()
+        while time.time() - t0 < timeout:
+            with self.lock:
+                if len(self.frames) >= n:
+                    return True
+            if self.thread is not None and not self.thread.is_alive():
+                return False
+            time.sleep(0.01)
+        return False
+
+    def stop(self):
+        rc = self.lib.tsdr_stop(self.h)
+        if self.thread is not None:
+            self.thread.join(30)
+        return rc
+
+    def close(self):
+        self.lib.tsdr_free(C.byref(self.h))

@@ -1,0 +1,219 @@
+"""The tsdr_* drop-in end to end on a GPU: plugin -> libTSDRLibrary.so ->
+libtsdrgpu.so -> callbacks, replaying the call sequence of the Java GUI's JNI
+shim.  The reference's threaded pipeline is timing dependent;
+ours is deterministic as long as no block is dropped, so delivered frames are
+compared bit-for-bit with the oracle's single-threaded driver.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import host_util as hu
+from tempestsdr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+FS, H, FV = 8_000_000, 525, 60.0
+BLOCK = 524288  # floats per plugin callback, like RawFile (TSDRPlugin_RawFile.c:39)
+
+
+@pytest.fixture(scope="module")
+def iq_file(tmp_path_factory):
+    n = 16 * (BLOCK // 2)  # 0.52 s
+    iq = synth.synth_iq(FS, "640x480", 60.0, n, seed=0x5EED0001)
+    p = tmp_path_factory.mktemp("iq") / "cfg1.f32"
+    iq.tofile(p)
+    return str(p), iq
+
+
+def oracle_frames(orc, mag_stream_iq, geo, cfg=(0.0, 0, 0, 0, 0), first_pixel=0):
+    pix, _ = orc.demod_resample_stream(mag_stream_iq, geo)
+    pix = pix[first_pixel:]
+    P = geo.width * geo.height
+    pp = orc.PostProcess(geo)
+    mb, lbs, aap, ash, pll = cfg
+    out = []
+    for k in range(pix.size // P):
+        out.append(pp.run(pix[k * P:(k + 1) * P].copy(), mb, 0.1, lbs, aap, ash, pll, 0))
+    return out
+
+
+def match_in_order(got, want):
+    """every delivered frame equals an oracle frame, in increasing order (the
+    video queue may drop frames when the Python callback is slow)"""
+    k = 0
+    hits = []
+    for (_, _, a) in got:
+        while k < len(want) and not np.array_equal(a, want[k]):
+            k += 1
+        assert k < len(want), f"frame after oracle frame {hits[-1] if hits else -1} matches no oracle frame"
+        hits.append(k)
+        k += 1
+    return hits
+
+
+def run_session(plugin, params, setup=None, nframes=8, during=None, timeout=40):
+    s = hu.Session()
+    assert s.lib.tsdr_loadplugin(s.h, plugin.encode(), params.encode()) == 0, s.err()
+    assert s.lib.tsdr_setbasefreq(s.h, 400_000_000) == 0
+    assert s.lib.tsdr_setgain(s.h, 0.5) == 0
+    assert s.lib.tsdr_setresolution(s.h, H, FV) == 0
+    if setup:
+        setup(s)
+    s.start()
+    ok = s.wait_frames(nframes, timeout)
+    if during:
+        during(s)
+    assert s.lib.tsdr_isrunning(s.h) == 1 or not ok
+    rc = s.stop()
+    assert s.thread is not None and not s.thread.is_alive()
+    assert s.lib.tsdr_isrunning(s.h) == 0
+    return s, ok, rc
+
+
+@pytest.mark.parametrize("cfg", [(0.0, 0, 0, 0, 0), (0.5, 1, 0, 1, 0)])
+def test_pipeline_matches_oracle(orc, iq_file, cfg):
+    path, iq = iq_file
+    plugin = hu.build_test_plugin()
+    mb, lbs, aap, ash, pll = cfg
+
+    def setup(s):
+        s.lib.tsdr_motionblur(s.h, mb)
+        s.lib.tsdr_setparameter_int(s.h, 6, lbs)
+        s.lib.tsdr_setparameter_int(s.h, 7, aap)
+        s.lib.tsdr_setparameter_int(s.h, 0, ash)
+
+    geo = orc.geometry(FS, H, FV)
+    want = oracle_frames(orc, iq, geo, cfg)
+    s, ok, rc = run_session(plugin, f"{path} {FS} {BLOCK} 8000", setup, nframes=len(want))
+    assert rc == 0 and s.status == 0, s.err()
+    assert len(s.frames) >= len(want) - 4
+    assert all((w, h) == (geo.width, H) for (w, h, _) in s.frames)
+    hits = match_in_order(s.frames, want)
+    assert hits[0] == 0
+    # plots: first one == the oracle's first capture window
+    frame_plots = [p for p in s.plots if p[0] == 0]
+    line_plots = [p for p in s.plots if p[0] == 1]
+    assert frame_plots and line_plots
+    ac = orc.Autocorr(FS)
+    ac.run(orc.am_demod(iq)[:orc.capture_size(FS)])
+    pid, off, vals, rate = frame_plots[0]
+    assert (off, vals.size, rate) == (ac.flo, ac.flen, FS)
+    assert np.max(np.abs(vals - ac.frame)) <= 1e-4 * np.max(ac.frame)
+    assert int(np.argmax(vals)) == int(np.argmax(ac.frame))
+    assert (line_plots[0][1], line_plots[0][2].size) == (ac.llo, ac.llen)
+    counts = [v for v in s.values if v[0] == 2]
+    assert counts and counts[0][2] == 1.0  # VALUE_ID_AUTOCORRECT_FRAMES_COUNT, first window
+    assert any(v[0] == 3 for v in s.values) or len(s.frames) < 7  # autogain report every 7th frame
+    s.close()
+
+
+def test_dropped_samples_keep_alignment(orc, iq_file):
+    """A plugin-reported drop: the library skips whole `block`s' worth so the
+    raster stays aligned (dsp.c:313-368).  Expected frames are built by applying
+    the oracle's bookkeeping to the same block sequence."""
+    path, iq = iq_file
+    plugin = hu.build_test_plugin()
+    geo = orc.geometry(FS, H, FV)
+    drop_at, drop_n = 3, 100_000
+    s, ok, rc = run_session(plugin, f"{path} {FS} {BLOCK} 8000 {drop_at} {drop_n}", nframes=20)
+    assert rc == 0
+    # what the pipeline forwards to the resampler
+    per = BLOCK // 2
+    block = int(round(((geo.width * geo.height) << 1) * geo.pixeltimeoversampletime))
+    diff = 0
+    pos = 0
+    fwd = []
+    nblocks = (iq.size // 2 - drop_n) // per
+    for b in range(nblocks):
+        dropped = drop_n if b == drop_at + 1 else 0
+        seg = iq[2 * pos:2 * (pos + per)]
+        pos += per
+        if b == drop_at:
+            pos += drop_n
+        diff = orc.lib.orc_dropped_shift_with(diff, block, dropped)
+        if per <= diff:
+            diff -= per
+        else:
+            fwd.append(seg[2 * diff:])
+            diff = 0
+    want = oracle_frames(orc, np.concatenate(fwd), geo)
+    hits = match_in_order(s.frames, want)
+    assert len(hits) >= 10 and hits[-1] > 12
+    s.close()
+
+
+def test_runtime_setters_and_pll(orc, iq_file):
+    path, iq = iq_file
+    plugin = hu.build_test_plugin()
+
+    def setup(s):
+        s.lib.tsdr_setparameter_int(s.h, 1, 1)  # PLL
+        s.lib.tsdr_motionblur(s.h, 0.25)
+
+    def during(s):
+        assert s.lib.tsdr_loadplugin(s.h, plugin.encode(), b"x 1 2 3") == 3  # TSDR_ALREADY_RUNNING
+        assert s.lib.tsdr_unloadplugin(s.h) == 3
+        assert s.lib.tsdr_sync(s.h, 10, 3) == 0
+        assert s.lib.tsdr_sync(s.h, 5, 1) == 0
+        assert s.lib.tsdr_setresolution(s.h, 600, 60.0) == 0
+        s.wait_frames(len(s.frames) + 3, 10)
+
+    s, ok, rc = run_session(plugin, f"{path} {FS} {BLOCK} 8000", setup, nframes=6, during=during)
+    assert rc == 0
+    dims = {(w, h) for (w, h, _) in s.frames}
+    assert (507, 525) in dims
+    assert any(h == 600 for (_, h) in dims), dims  # the new resolution took effect mid-run
+    for (w, h, a) in s.frames:
+        assert a.size == w * h and np.isfinite(a).all()
+    s.close()
+
+
+def test_reference_rawfile_plugin_end_to_end(orc, iq_file):
+    """The reference's own RawFile plugin binary (compiled unchanged into
+    oracle/_ref) drives our library: real-time pacing, looping at EOF."""
+    raw = os.path.join(hu.ROOT, "oracle", "_ref", "libTSDRPlugin_RawFile.so")
+    if not os.path.exists(raw):
+        pytest.skip("oracle/_ref not shipped")
+    path, iq = iq_file
+    geo = orc.geometry(FS, H, FV)
+    want = oracle_frames(orc, iq, geo)
+    t0 = time.time()
+    s, ok, rc = run_session(raw, f"{path} {FS} float", nframes=25, timeout=20)
+    dt = time.time() - t0
+    assert ok and rc == 0 and s.status == 0
+    assert all((w, h) == (geo.width, H) for (w, h, _) in s.frames)
+    assert len(s.frames) / dt > 30  # paced at 60 fps by the plugin
+    # the first pass over the file is the deterministic stream
+    first = [f for f in s.frames[:len(want) - 2]]
+    hits = match_in_order(first[:10], want)
+    assert hits[0] == 0
+    assert any(p[0] == 0 for p in s.plots) and any(p[0] == 1 for p in s.plots)
+    s.close()
+
+
+def test_superresolution_mode(orc, tmp_path):
+    """PARAM_AUTOCORR_SUPERRESOLUTION: 4 hops x 10 frames, 0.5 s pauses, stitch,
+    then frames at 4x the sample rate (superbandwidth.c:179-254)."""
+    fs, h, fv = 2_000_000, 131, 60.0
+    mode = (200, 131, 160, 120)
+    n = int(5.2 * fs)
+    iq = synth.synth_iq(fs, mode, fv, n, seed=5)
+    p = tmp_path / "super.f32"
+    iq.tofile(p)
+    plugin = hu.build_test_plugin()
+    s = hu.Session()
+    assert s.lib.tsdr_loadplugin(s.h, plugin.encode(), f"{p} {fs} 65536 100".encode()) == 0
+    assert s.lib.tsdr_setresolution(s.h, h, fv) == 0
+    s.lib.tsdr_setparameter_int(s.h, 4, 1)
+    s.start()
+    ok = s.wait_frames(5, 60)
+    rc = s.stop()
+    assert ok and rc == 0, (len(s.frames), s.err())
+    w4 = orc.geometry(4 * fs, h, fv).width
+    assert all((w, hh) == (w4, h) for (w, hh, _) in s.frames), {(w, hh) for (w, hh, _) in s.frames}
+    for (_, _, a) in s.frames:
+        assert np.isfinite(a).all()
+    s.close()
