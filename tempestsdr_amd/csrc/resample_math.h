@@ -24,6 +24,7 @@
 // All functions are host+device so the CPU-only test-suite can exercise the
 // same code (tests/emu/) that the HIP kernels run.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -46,54 +47,57 @@ struct RsGeom {
     unsigned size;
 };
 
-TSDR_HD double rs_lo(const RsGeom &g, long long id) { return (double)id * g.r + g.o; }
-TSDR_HD double rs_hi(const RsGeom &g, long long id) { return rs_lo(g, id) + g.r; }
-TSDR_HD double rs_him1(const RsGeom &g, long long id) { return rs_lo(g, id) + g.r - 1.0; }
+// sample indices fit 32 bits (chunk sizes are uint32_t in the reference and far
+// below 2^31 in practice): int -> double conversions are single instructions
+TSDR_HD double rs_lo(const RsGeom &g, int id) { return (double)id * g.r + g.o; }
+TSDR_HD double rs_hi(const RsGeom &g, int id) { return rs_lo(g, id) + g.r; }
+TSDR_HD double rs_him1(const RsGeom &g, int id) { return rs_lo(g, id) + g.r - 1.0; }
 
 // smallest integer q >= 0 with q >= x  (q compared as double, like `pid < idcheck2`)
-TSDR_HD double rs_first_not_below(double x)
-{
-    if (!(x > 0.0)) return 0.0;
-    double c = (double)(long long)x;  // trunc; x > 0
-    if (c < x) c += 1.0;
-    return c;
-}
+TSDR_HD double rs_first_not_below(double x) { return (x > 0.0) ? ceil(x) : 0.0; }
 
-TSDR_HD double rs_pix_in(const RsGeom &g, long long id)
+TSDR_HD double rs_pix_in(const RsGeom &g, int id)
 {
     return (id <= 0) ? 0.0 : rs_first_not_below(rs_him1(g, id - 1));
 }
 
 // did sample `id` take the straddling-pixel branch (dsp.c:288)?
-TSDR_HD bool rs_fired(const RsGeom &g, long long id)
+TSDR_HD bool rs_fired(const RsGeom &g, int id)
 {
     const double pin = rs_pix_in(g, id);
     return pin < rs_lo(g, id) && pin < rs_him1(g, id);
 }
 
-// E(p); returns g.size when no sample of this chunk stores p
-TSDR_HD long long rs_owner(const RsGeom &g, double p)
+// E(p) searched from a starting guess; returns g.size when no sample of this chunk stores p
+TSDR_HD int rs_owner_from(const RsGeom &g, double p, int id)
 {
-    long long id = (long long)((p + 1.0 - g.r - g.o) / g.r) + 1;
+    const int size = (int)g.size;
     if (id < 0) id = 0;
-    if (id > (long long)g.size) id = g.size;
+    if (id > size) id = size;
     while (id > 0 && p < rs_him1(g, id - 1)) id--;
-    while (id < (long long)g.size && !(p < rs_him1(g, id))) id++;
+    while (id < size && !(p < rs_him1(g, id))) id++;
     return id;
+}
+
+TSDR_HD int rs_owner(const RsGeom &g, double p)
+{
+    const double guess = (p + 1.0 - g.r - g.o) / g.r;
+    int id = (guess < 0.0) ? 0 : ((guess >= 2147483000.0) ? (int)g.size : (int)guess + 1);
+    return rs_owner_from(g, p, id);
 }
 
 // `contrib` as the reference holds it when sample `id` begins (id may be
 // g.size: the value carried out of the chunk).  in(j) returns sample j as float.
 // *used_in (optional) tells whether the chunk's incoming contrib took part.
 template <class In>
-TSDR_HD double rs_contrib_before(const RsGeom &g, long long id, double contrib_in, In in,
+TSDR_HD double rs_contrib_before(const RsGeom &g, int id, double contrib_in, In in,
                                  bool *used_in = nullptr)
 {
-    long long j0 = id - 1;
+    int j0 = id - 1;
     while (j0 >= 0 && !rs_fired(g, j0)) j0--;
     if (used_in) *used_in = (j0 < 0);
     double contrib = (j0 >= 0) ? 0.0 : contrib_in;
-    for (long long j = (j0 >= 0 ? j0 : 0); j < id; j++) {
+    for (int j = (j0 >= 0 ? j0 : 0); j < id; j++) {
         const double v = (double)in(j);
         const double pix = rs_pix_in(g, j + 1);
         const double lo = rs_lo(g, j), hi = lo + g.r;
@@ -107,20 +111,23 @@ TSDR_HD double rs_contrib_before(const RsGeom &g, long long id, double contrib_i
 
 // Value of output pixel p of the chunk; returns false when the reference's
 // loop never stores it (aligned edge case) — the caller then writes 0.0f.
+// `*owner` carries the search position from one pixel to the next (pass a
+// negative value for "no hint").
 template <class In>
-TSDR_HD bool rs_area_pixel(const RsGeom &g, unsigned p, double contrib_in, In in, float *out)
+TSDR_HD bool rs_area_pixel(const RsGeom &g, unsigned p, double contrib_in, In in, float *out, int *owner = nullptr)
 {
     const double pd = (double)p;
-    const long long id = rs_owner(g, pd);
-    if (id >= (long long)g.size) return false;
-    const double v = (double)in(id);
+    const int id = (owner && *owner >= 0) ? rs_owner_from(g, pd, *owner) : rs_owner(g, pd);
+    if (owner) *owner = id;
+    if (id >= (int)g.size) return false;
+    const float vf = in(id);
     const double lo = rs_lo(g, id);
     const bool first = (id == 0) ? (p == 0) : (p == 0 || (pd - 1.0) < rs_him1(g, id - 1));
     if (first && pd < lo) {
         const double contrib = rs_contrib_before(g, id, contrib_in, in);
-        *out = (float)(contrib + v * (1.0 - lo + pd));
+        *out = (float)(contrib + (double)vf * (1.0 - lo + pd));
     } else {
-        *out = (float)v;
+        *out = vf;  // (float)(double)vf
     }
     return true;
 }

@@ -323,7 +323,7 @@ struct tsdrgpu_resampler {
 template <bool IQ>
 struct SampleLoad {
     const float *base;
-    __device__ __forceinline__ float operator()(long long j) const
+    __device__ __forceinline__ float operator()(int j) const
     {
         if (IQ) {
             const float2 s = ((const float2 *)base)[j];
@@ -347,18 +347,30 @@ __global__ void k_rs_tail(const RsChunk *__restrict__ chunks, int nchunks, doubl
     g.size = ch.size;
     SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
     bool used = false;
-    tail[c] = rs_contrib_before(g, (long long)ch.size, 0.0, ld, &used);
+    tail[c] = rs_contrib_before(g, (int)ch.size, 0.0, ld, &used);
     need[c] = used ? 1 : 0;
 }
 
-// phase 2: chain them (a scalar recurrence; chunks that need their incoming
-// contrib — no pixel finished inside the chunk — are replayed here)
+// phase 2: chain them.  Normally every chunk finishes at least one pixel, so
+// its outgoing contrib does not depend on the incoming one and the chain is a
+// shift; chunks that do depend on it (need[c]) force the scalar replay.
 template <bool IQ>
-__global__ void k_rs_chain(const RsChunk *__restrict__ chunks, int nchunks, double r, const float *__restrict__ in,
-                           const double *__restrict__ tail, const unsigned char *__restrict__ need,
-                           double *__restrict__ cin, double *__restrict__ contrib_state)
+__global__ __launch_bounds__(256) void k_rs_chain(const RsChunk *__restrict__ chunks, int nchunks, double r,
+                                                  const float *__restrict__ in, const double *__restrict__ tail,
+                                                  const unsigned char *__restrict__ need, double *__restrict__ cin,
+                                                  double *__restrict__ contrib_state)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int any = 0;
+    for (int c = threadIdx.x; c < nchunks; c += blockDim.x) any |= need[c];
+    any = __syncthreads_or(any);
+    if (!any) {
+        const double first = *contrib_state;
+        for (int c = threadIdx.x; c < nchunks; c += blockDim.x) cin[c] = c ? tail[c - 1] : first;
+        __syncthreads();
+        if (threadIdx.x == 0) *contrib_state = tail[nchunks - 1];
+        return;
+    }
+    if (threadIdx.x != 0) return;
     double c_in = *contrib_state;
     for (int c = 0; c < nchunks; c++) {
         cin[c] = c_in;
@@ -369,7 +381,7 @@ __global__ void k_rs_chain(const RsChunk *__restrict__ chunks, int nchunks, doub
             g.o = ch.o;
             g.size = ch.size;
             SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
-            c_in = rs_contrib_before(g, (long long)ch.size, c_in, ld);
+            c_in = rs_contrib_before(g, (int)ch.size, c_in, ld);
         } else {
             c_in = tail[c];
         }
@@ -377,6 +389,9 @@ __global__ void k_rs_chain(const RsChunk *__restrict__ chunks, int nchunks, doub
     *contrib_state = c_in;
 }
 
+// Each thread produces the four pixels of one 16-byte-aligned group of the
+// output stream (one dwordx4 store); the owner search of the first pixel seeds
+// the next three.  Groups cut by the chunk's ends fall back to dword stores.
 template <bool IQ>
 __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chunks, double r, const float *__restrict__ in,
                                                  const double *__restrict__ cin, float *__restrict__ out)
@@ -389,9 +404,29 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
     SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
     const double c_in = cin[blockIdx.y];
     float *dst = out + ch.out_off;
-    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < ch.n_out; p += gridDim.x * blockDim.x) {
-        float v;
-        dst[p] = rs_area_pixel(g, p, c_in, ld, &v) ? v : 0.0f;
+    const int mis = (int)((((uintptr_t)dst) >> 2) & 3);  // dst's offset inside its 16-byte group
+    const int n_out = (int)ch.n_out;
+    const int ngroups = (n_out + mis + 3) >> 2;
+    for (int grp = blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += gridDim.x * blockDim.x) {
+        const int p0 = 4 * grp - mis;
+        float v[4];
+        int owner = -1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p = p0 + k;
+            v[k] = 0.0f;
+            if (p >= 0 && p < n_out) {
+                float t;
+                if (rs_area_pixel(g, (unsigned)p, c_in, ld, &t, &owner)) v[k] = t;
+            }
+        }
+        if (p0 >= 0 && p0 + 3 < n_out) {
+            *reinterpret_cast<float4 *>(dst + p0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (p0 + k >= 0 && p0 + k < n_out) dst[p0 + k] = v[k];
+        }
     }
 }
 
@@ -403,7 +438,7 @@ __global__ __launch_bounds__(256) void k_rs_nearest(const RsChunk *__restrict__ 
     SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
     float *dst = out + ch.out_off;
     for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < ch.n_out; p += gridDim.x * blockDim.x)
-        dst[p] = ld(rs_nearest_src(ch.size, ch.n_out, p));
+        dst[p] = ld((int)rs_nearest_src(ch.size, ch.n_out, p));
 }
 
 extern "C" int tsdrgpu_resampler_create(tsdrgpu_t *g, tsdrgpu_resampler_t **out)
@@ -523,7 +558,8 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
 
     const double r = up / down;
     const unsigned bx = ceil_div_u(max_out ? max_out : 1, 256);
-    dim3 grid(bx, (unsigned)nchunks);
+    dim3 grid(bx, (unsigned)nchunks);                                   // one pixel per thread (nearest)
+    dim3 grid4(ceil_div_u((max_out ? max_out : 1) + 6, 1024), (unsigned)nchunks);  // one 4-pixel group per thread
     if (nearest) {
         // dsp.c:274-276: contrib is untouched in this mode
         if (max_out) {
@@ -538,16 +574,16 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
             ProfScope prof(g, PROF_RS_CARRY);
             if (in_is_iq) {
                 k_rs_tail<true><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need);
-                k_rs_chain<true><<<1, 64, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+                k_rs_chain<true><<<1, 256, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
             } else {
                 k_rs_tail<false><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need);
-                k_rs_chain<false><<<1, 64, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+                k_rs_chain<false><<<1, 256, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
             }
         }
         if (max_out) {
             ProfScope prof(g, PROF_RS_AREA);
-            if (in_is_iq) k_rs_area<true><<<grid, 256, 0, g->stream>>>(d_tab, r, d_in, rs->d_cin, d_out);
-            else k_rs_area<false><<<grid, 256, 0, g->stream>>>(d_tab, r, d_in, rs->d_cin, d_out);
+            if (in_is_iq) k_rs_area<true><<<grid4, 256, 0, g->stream>>>(d_tab, r, d_in, rs->d_cin, d_out);
+            else k_rs_area<false><<<grid4, 256, 0, g->stream>>>(d_tab, r, d_in, rs->d_cin, d_out);
         }
         KERNEL_CHECK(g, "k_rs_area");
     }

@@ -23,6 +23,8 @@ struct tsdrgpu_autocorr {
     float2 *d_last;    // where the last window's correlation lives
     int *d_arg;
     int *h_arg;
+    double *d_pval;  // argmax partials
+    int *d_pidx;
 };
 
 // ---------------------------------------------------------------------------
@@ -54,6 +56,8 @@ __device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 
 template <int R>
 __device__ __forceinline__ void dft_reg(float2 (&v)[R]);
 
+template <>
+__device__ __forceinline__ void dft_reg<1>(float2 (&v)[1]) {}
 template <>
 __device__ __forceinline__ void dft_reg<2>(float2 (&v)[2]) { dft2(v[0], v[1]); }
 template <>
@@ -173,6 +177,121 @@ __global__ __launch_bounds__(256) void k_fft_pass(const void *__restrict__ xin, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// LDS pass: one Stockham pass of radix R = 16*R1 (16..256) where the R-point
+// DFT is done on chip as DFT-R1 (registers) -> LDS exchange -> DFT-16
+// (registers).  A workgroup of 256 threads owns a tile of C = 256/R1
+// neighbouring columns j (4096 points, 32 KiB of LDS), so every global access is
+// a run of C*8 >= 128 contiguous bytes.  With it a 2^22-point transform takes 3
+// trips over memory instead of 6.
+//   n = t0 + 16*i (t0 < 16, i < R1), k = k1 + R1*k2 (k1 < R1, k2 < 16):
+//   X[k] = sum_t0 w16^{t0 k2} [ w_R^{t0 k1} sum_i x[t0+16 i] w_R1^{i k1} ]
+// ---------------------------------------------------------------------------
+template <int R1, int IN_MODE, bool OUT_MAG>
+__global__ __launch_bounds__(256) void k_fft_lds(const void *__restrict__ xin, long long in_stride, float2 *__restrict__ y,
+                                                 unsigned n, unsigned Ns, int conj_in, int conj_out, float scale)
+{
+    constexpr int R = 16 * R1;
+    constexpr int C = 256 / R1;
+    constexpr int G = 16 / R1;  // DFT-R1's per thread in stage 1
+    __shared__ float2 lds[4096 + 256];
+    __shared__ float2 tw[256];
+    const unsigned T = n / R;
+    const unsigned tid = threadIdx.x;
+    const unsigned c = tid % C, q = tid / C;
+    const unsigned j = blockIdx.x * C + c;
+    const unsigned b = blockIdx.y;
+    {
+        float sn, cs;
+        sincospif(-(float)tid * (1.0f / 128.0f), &sn, &cs);
+        tw[tid] = make_float2(cs, sn);
+    }
+    float2 v[16];
+#pragma unroll
+    for (int a = 0; a < G; a++) {
+#pragma unroll
+        for (int i = 0; i < R1; i++) {
+            const unsigned nidx = q * G + a + 16 * i;
+            const long long at = (long long)j + (long long)nidx * T;
+            float2 val;
+            if (IN_MODE == 0) val = ((const float2 *)xin + (long long)b * in_stride)[at];
+            else if (IN_MODE == 1) val = make_float2(((const float *)xin + (long long)b * in_stride)[at], 0.f);
+            else {
+                const float2 sq = ((const float2 *)xin + (long long)b * in_stride)[at];
+                val = make_float2(sqrtf(sq.x * sq.x + sq.y * sq.y), 0.f);
+            }
+            if (conj_in) val.y = -val.y;
+            v[a * R1 + i] = val;
+        }
+    }
+    const unsigned k = j & (Ns - 1);
+    if (Ns > 1) {
+        const unsigned span = Ns * R;
+        const float inv = -2.0f / (float)span;
+#pragma unroll
+        for (int a = 0; a < G; a++) {
+#pragma unroll
+            for (int i = 0; i < R1; i++) {
+                const unsigned nidx = q * G + a + 16 * i;
+                const unsigned m = (nidx * k) & (span - 1);
+                float sn, cs;
+                sincospif((float)m * inv, &sn, &cs);
+                v[a * R1 + i] = cmul(v[a * R1 + i], make_float2(cs, sn));
+            }
+        }
+    }
+    __syncthreads();  // tw[] ready
+#pragma unroll
+    for (int a = 0; a < G; a++) {
+        dft_reg<R1>(*reinterpret_cast<float2(*)[R1]>(&v[a * R1]));
+        const unsigned t0 = q * G + a;
+#pragma unroll
+        for (int k1 = 0; k1 < R1; k1++) {
+            float2 val = v[a * R1 + k1];
+            if (R1 > 1 && k1 > 0) val = cmul(val, tw[(t0 * k1 * (256 / R)) & 255]);
+            lds[(k1 * 16 + t0) * C + c] = val;
+        }
+    }
+    __syncthreads();
+    // stage 2: this thread is (k1 = q, column c)
+    float2 w[16];
+#pragma unroll
+    for (int t0 = 0; t0 < 16; t0++) w[t0] = lds[(q * 16 + t0) * C + c];
+    dft_reg<16>(w);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) {
+        float2 o = w[k2];
+        if (OUT_MAG) {
+            o.x *= scale;
+            o.y *= scale;
+            o = make_float2(sqrtf(o.x * o.x + o.y * o.y), 0.f);
+        } else {
+            if (conj_out) o.y = -o.y;
+            o.x *= scale;
+            o.y *= scale;
+        }
+        w[k2] = o;
+    }
+    float2 *yb = y + (long long)b * n;
+    if (Ns == 1) {
+        // outputs of the tile are the contiguous block [jb*R, jb*R + 4096): stage through LDS
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++) lds[c * (R + 1) + q + R1 * k2] = w[k2];
+        __syncthreads();
+        float2 *dst = yb + (long long)blockIdx.x * C * R;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const unsigned idx = tid + 256 * it;
+            dst[idx] = lds[(idx / R) * (R + 1) + (idx % R)];
+        }
+    } else {
+        float2 *yo = yb + ((long long)(j - k) * R + k);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++) yo[(long long)(q + R1 * k2) * Ns] = w[k2];
+    }
+}
+
 struct PassPlan {
     int radix[32];
     int count;
@@ -184,7 +303,15 @@ static PassPlan plan_passes(uint32_t n)
     p.count = 0;
     int m = 0;
     while ((1u << m) < n) m++;
-    // small remainder first (its writes are the least coalesced while Ns is small anyway)
+    if (m >= 12) {
+        // LDS passes: split log2(n) into ceil(m/8) radices of 2^4..2^8, smallest first (the
+        // first pass reads the narrowest elements, so it gets the widest tile)
+        const int parts = (m + 7) / 8;
+        const int base = m / parts, rem = m % parts;
+        for (int i = 0; i < parts; i++) p.radix[p.count++] = 1 << (base + (i >= parts - rem ? 1 : 0));
+        return p;
+    }
+    // small transforms: register-only radix 16/8/4/2 passes
     int rem = m % 4;
     if (rem) p.radix[p.count++] = 1 << rem;
     for (int i = 0; i < m / 4; i++) p.radix[p.count++] = 16;
@@ -196,6 +323,18 @@ template <int IN_MODE, bool OUT_MAG>
 static void launch_pass(hipStream_t st, int R, const void *x, long long in_stride, float2 *y, unsigned n, unsigned Ns, int batch,
                         int conj_in, int conj_out, float scale)
 {
+    if (n >= 4096) {
+        const int R1 = R / 16;
+        dim3 grid(n / 4096, batch);  // (n/R)/C tiles, R*C = 4096
+        switch (R1) {
+            case 1: k_fft_lds<1, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            case 2: k_fft_lds<2, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            case 4: k_fft_lds<4, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            case 8: k_fft_lds<8, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            default: k_fft_lds<16, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+        }
+        return;
+    }
     const unsigned T = n / R;
     dim3 grid((T + 255) / 256, batch);
     switch (R) {
@@ -295,19 +434,23 @@ __global__ void k_scale_plots(double *plots, int count, double divisor)
     if (i < count) plots[i] = plots[i] / divisor;
 }
 
-// argmax with lowest-index tie-break; one workgroup per plot
-__global__ __launch_bounds__(1024) void k_argmax(const double *__restrict__ plots, int frame_len, int line_len, int *__restrict__ out)
+// argmax with lowest-index tie-break (PlotVisualizer.java:233-236), two stages:
+// ARGMAX_BLOCKS workgroups per plot, then one wave per plot
+#define ARGMAX_BLOCKS 64
+__global__ __launch_bounds__(256) void k_argmax_partial(const double *__restrict__ plots, int frame_len, int line_len,
+                                                        double *__restrict__ pval, int *__restrict__ pidx)
 {
-    const double *p = blockIdx.x == 0 ? plots : plots + frame_len;
-    const int len = blockIdx.x == 0 ? frame_len : line_len;
+    const int plot = blockIdx.y;
+    const double *p = plot == 0 ? plots : plots + frame_len;
+    const int len = plot == 0 ? frame_len : line_len;
     double best = -1.0;
     int at = 0x7fffffff;
-    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
         const double v = p[i];
-        if (v > best) { best = v; at = i; }
+        if (v > best) { best = v; at = i; }  // i ascending per thread
     }
-    __shared__ double sb[16];
-    __shared__ int si[16];
+    __shared__ double sb[4];
+    __shared__ int si[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const double ob = __shfl_down(best, o, 64);
@@ -317,10 +460,26 @@ __global__ __launch_bounds__(1024) void k_argmax(const double *__restrict__ plot
     if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = at; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; w++)
+        for (int w = 1; w < 4; w++)
             if (sb[w] > best || (sb[w] == best && si[w] < at)) { best = sb[w]; at = si[w]; }
-        out[blockIdx.x] = (len > 0) ? at : -1;
+        pval[plot * ARGMAX_BLOCKS + blockIdx.x] = best;
+        pidx[plot * ARGMAX_BLOCKS + blockIdx.x] = at;
     }
+}
+
+__global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ pval, const int *__restrict__ pidx, int frame_len,
+                                                     int line_len, int *__restrict__ out)
+{
+    const int plot = blockIdx.x;
+    double best = pval[plot * ARGMAX_BLOCKS + threadIdx.x];
+    int at = pidx[plot * ARGMAX_BLOCKS + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(at, o, 64);
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+    if (threadIdx.x == 0) out[plot] = ((plot == 0 ? frame_len : line_len) > 0) ? at : -1;
 }
 
 extern "C" int tsdrgpu_autocorr_create(tsdrgpu_t *g, tsdrgpu_autocorr_t **out, uint32_t samplerate)
@@ -349,6 +508,8 @@ extern "C" int tsdrgpu_autocorr_create(tsdrgpu_t *g, tsdrgpu_autocorr_t **out, u
         return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_create", "sample rate too low for the lag windows");
     }
     if (hipMalloc(&ac->d_plots, sizeof(double) * L) != hipSuccess || hipMalloc(&ac->d_arg, 2 * sizeof(int)) != hipSuccess ||
+        hipMalloc(&ac->d_pval, 2 * ARGMAX_BLOCKS * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ac->d_pidx, 2 * ARGMAX_BLOCKS * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&ac->h_arg, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         free(ac);
         return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_create", "plots");
@@ -365,6 +526,8 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
     (void)hipFree(ac->d_a);
     (void)hipFree(ac->d_b);
     (void)hipFree(ac->d_arg);
+    (void)hipFree(ac->d_pval);
+    (void)hipFree(ac->d_pidx);
     (void)hipHostFree(ac->h_arg);
     free(ac);
 }
@@ -457,7 +620,8 @@ extern "C" int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_id
 {
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
-    k_argmax<<<2, 1024, 0, g->stream>>>(ac->d_plots, ac->frame_len, ac->line_len, ac->d_arg);
+    k_argmax_partial<<<dim3(ARGMAX_BLOCKS, 2), 256, 0, g->stream>>>(ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_pidx);
+    k_argmax_final<<<2, 64, 0, g->stream>>>(ac->d_pval, ac->d_pidx, ac->frame_len, ac->line_len, ac->d_arg);
     KERNEL_CHECK(g, "k_argmax");
     HIP_TRY(g, hipMemcpyAsync(ac->h_arg, ac->d_arg, 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(g, hipStreamSynchronize(g->stream));

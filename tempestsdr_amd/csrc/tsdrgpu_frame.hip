@@ -61,6 +61,8 @@ struct tsdrgpu_postproc {
     size_t cap_chain;
     int width, height;
     int lowpass_before_sync;
+    int chain_has_autogain;  // within one tsdrgpu_postproc_run: the autogain record of d_chain is valid
+    int last_F;
     float taps[5];
 };
 
@@ -165,8 +167,9 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
 }
 
 // ---------------------------------------------------------------------------
-// k_frame_reduce: grid (F, 3): y=0 min/max of the frame, y=1 column strips,
-// y=2 row strips (f64 sums over the tile partials).
+// k_frame_reduce: grid (blocks over the strip, 3, F): y=0 min/max of the frame
+// (block x=0 only), y=1 column strips, y=2 row strips (f64 sums over the tile
+// partials, one thread per strip element).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x, int tiles_y, const float *__restrict__ bmin,
                                                       const float *__restrict__ bmax, const float *__restrict__ colp,
@@ -174,8 +177,9 @@ __global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x,
                                                       float *__restrict__ fmax_, double *__restrict__ strip_x,
                                                       double *__restrict__ strip_y, int want_strips)
 {
-    const int f = blockIdx.x;
+    const int f = blockIdx.z;
     if (blockIdx.y == 0) {
+        if (blockIdx.x != 0) return;
         const int nblk = tiles_x * tiles_y;
         float lo = INFINITY, hi = -INFINITY;
         for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
@@ -194,25 +198,37 @@ __global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x,
     } else if (want_strips) {
         const bool cols = blockIdx.y == 1;
         const int n = cols ? W : H;
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n) return;
         const int parts = cols ? tiles_y : tiles_x;
         const float *src = (cols ? colp : rowp) + (long long)f * parts * 3 * n;
         double *dst = (cols ? strip_x : strip_y) + (long long)f * 3 * n;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                double acc = 0.0;
-                for (int p = 0; p < parts; p++) acc += (double)src[((long long)p * 3 + q) * n + i];
-                dst[q * n + i] = acc;
-            }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int p = 0; p < parts; p++) {
+            const float *s3 = src + (long long)p * 3 * n + i;
+            a0 += (double)s3[0];
+            a1 += (double)s3[n];
+            a2 += (double)s3[2 * n];
         }
+        dst[i] = a0;
+        dst[n + i] = a1;
+        dst[2 * n + i] = a2;
     }
 }
 
 // ---------------------------------------------------------------------------
-// k_chain: the sequential part.  Workgroup 0: autogain + x strip + PLL;
-// workgroup 1: autogain (recomputed, it is a scalar recurrence) + y strip.
+// The frame-to-frame recurrences.
+//   k_autogain_chain  scalar IIR of min/max over the F frames (dsp.c:50-66)
+//   k_strip_prepare   per frame and axis, in parallel: strip of the (autogained)
+//                     frame, circular 5-tap blur (gaussian.c:18-79), f64 prefix
+//                     sums and total — none of it depends on the sync state
+//   k_sync_chain      2 workgroups (x, y): sliding-window best fit for the up to
+//                     five strip sizes (syncdetector.c:26-119), dx low-pass, PLL
+//                     (syncdetector.c:133-153) — sequential over the frames, but
+//                     only O(n) prefix look-ups + one reduction per frame
 // ---------------------------------------------------------------------------
 #define CHAIN_T 1024
+#define STRIP_MAX 16384
 
 __device__ __forceinline__ double wave_incl_scan(double v, int lane)
 {
@@ -235,37 +251,90 @@ __device__ __forceinline__ FitBest better(FitBest a, FitBest b)
     return a;
 }
 
-struct ChainShared {
-    double wsum[16];
-    FitBest wbest[5][16];
-    double total;
-    FitBest best[5];
-    int sizes[5];
-    int cur;
+__global__ __launch_bounds__(64) void k_autogain_chain(int F, const float *__restrict__ frames, long long fstride,
+                                                       const float *__restrict__ fmin_, const float *__restrict__ fmax_,
+                                                       PpState *__restrict__ state, ChainOut *__restrict__ out,
+                                                       int do_autogain, float norm)
+{
+    // stage the per-frame inputs in LDS in parallel, then one lane walks the recurrence
+    __shared__ float sv0[256], slo[256], shi[256];
+    float lastmax = state->lastmax, lastmin = state->lastmin;
+    for (int base = 0; base < F; base += 256) {
+        const int cnt = (F - base < 256) ? (F - base) : 256;
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            sv0[i] = do_autogain ? frames[(long long)(base + i) * fstride] : 0.f;
+            slo[i] = do_autogain ? fmin_[base + i] : 0.f;
+            shi[i] = do_autogain ? fmax_[base + i] : 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < cnt; i++) {
+                if (do_autogain) {
+                    // dsp.c:50-66: min/max start from v[0] even when it is a sentinel
+                    const float hi = fmaxf(sv0[i], shi[i]);
+                    const float lo = fminf(sv0[i], slo[i]);
+                    const float keep = 1.0f - norm;
+                    lastmax = keep * lastmax + norm * hi;
+                    lastmin = keep * lastmin + norm * lo;
+                }
+                ChainOut *o = &out[base + i];
+                o->lastmin = lastmin;
+                o->lastmax = lastmax;
+                o->span = (lastmax == lastmin) ? 1.0f : (lastmax - lastmin);
+            }
+        }
+    }
+    if (threadIdx.x == 0 && do_autogain) {
+        state->lastmax = lastmax;
+        state->lastmin = lastmin;
+    }
+}
+
+// scratch layout per (frame, axis): blur[n] floats, prefix[n+1] doubles, total
+struct StripScratch {
+    float *blur;     // [F][2][nmax]
+    double *prefix;  // [F][2][nmax+1]
+    double *total;   // [F][2]
+    int nmax;
 };
 
-// One findthesweetspot call (syncdetector.c:71-119) executed by the whole
-// workgroup.  `data` holds the collapsed strip (n floats, global scratch),
-// `blur` receives the blurred strip (+ the two markers), `prefix` n+1 doubles.
-__device__ void chain_sweetspot(ChainShared &S, const float *__restrict__ data, float *__restrict__ blur,
-                                double *__restrict__ prefix, int n, int minsize, double lowpass, const float *taps,
-                                int &dx, int &vx, int &cur_strip)
+__global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const double *__restrict__ strip_x,
+                                                           const double *__restrict__ strip_y,
+                                                           const ChainOut *__restrict__ chain, StripScratch sc,
+                                                           int strips_normalised, float t0, float t1, float t2, float t3,
+                                                           float t4)
 {
+    __shared__ float data[STRIP_MAX];
+    __shared__ float blur[STRIP_MAX];
+    __shared__ double wsum[16];
+    const int axis = blockIdx.x, f = blockIdx.y;
+    const int n = axis == 0 ? W : H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (minsize < 1) minsize = 1;
-    const int half = n >> 1;
-    int cur = cur_strip;
-    if (cur < minsize) cur = minsize; else if (cur > half) cur = half;
-
-    // gaussianblur (gaussian.c:18-79): out[(i+2)%n] = sum_k taps[k]*in[(i+k)%n], left to right in f32
+    const double *sp = (axis == 0 ? strip_x : strip_y) + (long long)f * 3 * n;
+    const double cnt_all = (double)(axis == 0 ? H : W);
+    const float lastmin = chain[f].lastmin, span = chain[f].span;
+    for (int i = tid; i < n; i += CHAIN_T) {
+        const double ns = sp[i], s = sp[n + i], c = sp[2 * n + i];
+        double v;
+        if (strips_normalised)  // strip of the autogained frame, from the raw frame's sums
+            v = (ns - (cnt_all - c) * (double)lastmin) / (double)span + s;
+        else
+            v = ns + s;
+        data[i] = (float)v;
+    }
+    __syncthreads();
+    // gaussianblur: out[(i+2)%n] = sum_k taps[k]*in[(i+k)%n], left to right in f32
+    float *gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
     for (int i = tid; i < n; i += CHAIN_T) {
         const float a = data[i % n], b = data[(i + 1) % n], c = data[(i + 2) % n];
         const float d = data[(i + 3) % n], e = data[(i + 4) % n];
-        blur[(i + 2) % n] = a * taps[0] + b * taps[1] + c * taps[2] + d * taps[3] + e * taps[4];
+        const float v = a * t0 + b * t1 + c * t2 + d * t3 + e * t4;
+        blur[(i + 2) % n] = v;
+        gblur[(i + 2) % n] = v;
     }
     __syncthreads();
-
-    // prefix sums in f64 (block scan): thread t owns [t*per, (t+1)*per)
+    // f64 prefix sums: thread t owns [t*per, (t+1)*per)
     const int per = (n + CHAIN_T - 1) / CHAIN_T;
     const int b0 = tid * per;
     double local = 0.0;
@@ -273,191 +342,152 @@ __device__ void chain_sweetspot(ChainShared &S, const float *__restrict__ data, 
     const double incl = wave_incl_scan(local, lane);
     double excl = __shfl_up(incl, 1, 64);
     if (lane == 0) excl = 0.0;
-    if (lane == 63) S.wsum[wave] = incl;
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     if (wave == 0) {
-        double w = (lane < 16) ? S.wsum[lane] : 0.0;
+        double w = (lane < 16) ? wsum[lane] : 0.0;
         w = wave_incl_scan(w, lane);
-        if (lane < 16) S.wsum[lane] = w;
+        if (lane < 16) wsum[lane] = w;
     }
     __syncthreads();
-    {
-        double run = excl + (wave ? S.wsum[wave - 1] : 0.0);
-        for (int i = b0; i < b0 + per && i < n; i++) {
-            prefix[i] = run;
-            run += (double)blur[i];
-        }
-        if (tid == 0) {
-            S.total = S.wsum[15];
-            prefix[n] = S.wsum[15];
-            S.sizes[0] = cur;
-            const int trial[4] = {cur - 4, cur + 4, cur >> 1, cur << 1};
-            for (int t = 0; t < 4; t++) {
-                const int s = trial[t];
-                S.sizes[t + 1] = (s >= minsize && s < half && s != cur) ? s : 0;
-            }
-        }
+    double *gprefix = sc.prefix + ((long long)f * 2 + axis) * (sc.nmax + 1);
+    double run = excl + (wave ? wsum[wave - 1] : 0.0);
+    for (int i = b0; i < b0 + per && i < n; i++) {
+        gprefix[i] = run;
+        run += (double)blur[i];
     }
-    __syncthreads();
-
-    // findbestfit (syncdetector.c:26-58) for the (up to) five strip sizes at once.
-    const float totalf = (float)S.total;  // narrowed to float by the callee's parameter type
-    FitBest mine[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) { mine[k].fit = -1.0; mine[k].q = 0x7fffffff; }
-    for (int q = tid; q < n; q += CHAIN_T) {
-        const double pq = prefix[q];
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int s = S.sizes[k];
-            if (s > 0) {
-                const int e = q + s;
-                const double sum = (e <= n) ? (prefix[e] - pq) : (prefix[n] - pq + prefix[e - n]);
-                const double d = ((double)totalf - sum) / (double)(n - s) - sum / (double)s;
-                const double fit = d * d;
-                if (fit > mine[k].fit) { mine[k].fit = fit; mine[k].q = q; }  // q ascending per thread
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        FitBest b = mine[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            FitBest other;
-            other.fit = __shfl_down(b.fit, o, 64);
-            other.q = __shfl_down(b.q, o, 64);
-            b = better(b, other);
-        }
-        if (lane == 0) S.wbest[k][wave] = b;
-    }
-    __syncthreads();
     if (tid == 0) {
-        for (int k = 0; k < 5; k++) {
-            FitBest b = S.wbest[k][0];
-            for (int w = 1; w < 16; w++) b = better(b, S.wbest[k][w]);
-            S.best[k] = b;
-        }
-        // choose among sizes in the reference's order with its strict `>`
-        double bestfit = S.best[0].fit;
-        int bestq = S.best[0].q, bestsize = S.sizes[0];
-        for (int k = 1; k < 5; k++)
-            if (S.sizes[k] > 0 && S.best[k].fit > bestfit) {
-                bestfit = S.best[k].fit;
-                bestq = S.best[k].q;
-                bestsize = S.sizes[k];
-            }
-        // window start q is labelled with the index just removed (q-1), start 0 with 0
-        const int beststart = bestq > 0 ? bestq - 1 : 0;
-        blur[beststart] = PIX_B;
-        blur[(beststart + bestsize) % n] = PIX_B;
-
-        const int h2 = n / 2;
-        int centre = (beststart + bestsize / 2) % n;
-        const int rawdiff = centre - dx;
-        if (rawdiff > h2) dx += n;
-        else if (rawdiff < -h2) centre += n;
-        const int last = dx;
-        dx = (int)(((long long)round(centre * lowpass + (1.0 - lowpass) * dx)) % ((long long)n));
-        const int rawvx = dx - last;
-        vx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
-        S.cur = bestsize;
-        S.sizes[0] = dx;
-        S.sizes[1] = vx;
+        gprefix[n] = wsum[15];
+        sc.total[f * 2 + axis] = wsum[15];
     }
-    __syncthreads();
-    cur_strip = S.cur;
-    dx = S.sizes[0];
-    vx = S.sizes[1];
-    __syncthreads();
 }
 
-__global__ __launch_bounds__(CHAIN_T) void k_chain(int F, int W, int H, const float *__restrict__ frames, long long fstride,
-                                                   const float *__restrict__ fmin_, const float *__restrict__ fmax_,
-                                                   const double *__restrict__ strip_x, const double *__restrict__ strip_y,
-                                                   float *__restrict__ work, PpState *__restrict__ state,
-                                                   ChainOut *__restrict__ out, int do_autogain, int do_sync,
-                                                   int strips_normalised, int pll_enabled, float norm, float t0, float t1,
-                                                   float t2, float t3, float t4)
-{
-    __shared__ ChainShared S;
-    const bool xblock = blockIdx.x == 0;
-    const int n = xblock ? W : H;
-    const float taps[5] = {t0, t1, t2, t3, t4};
-    // scratch: [data n][blur n] floats then prefix (n+1) doubles, per workgroup
-    const size_t per_block = (size_t)((2 * n + 2 + 1) / 2 * 2) * sizeof(float) + (size_t)(n + 1) * sizeof(double);
-    const int nmax = W > H ? W : H;
-    const size_t stride_block = (size_t)((2 * nmax + 2 + 1) / 2 * 2) * sizeof(float) + (size_t)(nmax + 1) * sizeof(double);
-    (void)per_block;
-    char *base = (char *)work + (size_t)blockIdx.x * stride_block;
-    float *data = (float *)base;
-    float *blur = data + n;
-    double *prefix = (double *)(base + (size_t)((2 * nmax + 2 + 1) / 2 * 2) * sizeof(float));
+struct SyncShared {
+    FitBest wbest[5][16];
+    int sizes[5];
+    int cur, dx, vx;
+};
 
-    PpState st = *state;  // every thread carries the scalar state in registers
-    int dx = xblock ? st.dx_x : st.dx_y;
-    int vx = xblock ? st.vx_x : st.vx_y;
-    int cur = xblock ? st.strip_x : st.strip_y;
-    float lastmax = st.lastmax, lastmin = st.lastmin;
-    double avg_speed = st.avg_speed;
-    int locked = st.locked;
+__global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, StripScratch sc, PpState *__restrict__ state,
+                                                        ChainOut *__restrict__ out, int pll_enabled)
+{
+    __shared__ SyncShared S;
+    const bool xblock = blockIdx.x == 0;
+    const int axis = blockIdx.x;
+    const int n = xblock ? W : H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int minsize = xblock ? (int)(W * 0.05f) : (int)(H * 0.01f);  // syncdetector.c:178-179
+    if (minsize < 1) minsize = 1;
+    const double lowpass = xblock ? 0.9 : 0.1;
+    const int half = n >> 1;
+
+    int dx = xblock ? state->dx_x : state->dx_y;
+    int vx = xblock ? state->vx_x : state->vx_y;
+    int cur = xblock ? state->strip_x : state->strip_y;
+    double avg_speed = state->avg_speed;
+    int locked = state->locked;
 
     for (int f = 0; f < F; f++) {
-        float span = (lastmax == lastmin) ? 1.0f : (lastmax - lastmin);
-        if (do_autogain) {
-            // dsp.c:50-66: min/max start from v[0] even when it is a sentinel
-            const float v0 = frames[(long long)f * fstride];
-            const float hi = fmaxf(v0, fmax_[f]);
-            const float lo = fminf(v0, fmin_[f]);
-            const float keep = 1.0f - norm;
-            lastmax = keep * lastmax + norm * hi;
-            lastmin = keep * lastmin + norm * lo;
-            span = (lastmax == lastmin) ? 1.0f : (lastmax - lastmin);
+        const double *prefix = sc.prefix + ((long long)f * 2 + axis) * (sc.nmax + 1);
+        const float totalf = (float)sc.total[f * 2 + axis];  // narrowed by findbestfit's float parameter
+        if (cur < minsize) cur = minsize; else if (cur > half) cur = half;  // syncdetector.c:76-77
+        int sizes[5];
+        sizes[0] = cur;
+        {
+            const int trial[4] = {cur - 4, cur + 4, cur >> 1, cur << 1};
+#pragma unroll
+            for (int t = 0; t < 4; t++) sizes[t + 1] = (trial[t] >= minsize && trial[t] < half && trial[t] != cur) ? trial[t] : 0;
         }
-        int fired = 0;
-        double diff = 0.0;
-        if (do_sync) {
-            const double *sp = (xblock ? strip_x : strip_y) + (long long)f * 3 * n;
-            const double cnt_all = (double)(xblock ? H : W);
-            for (int i = threadIdx.x; i < n; i += CHAIN_T) {
-                const double ns = sp[i], s = sp[n + i], c = sp[2 * n + i];
-                double v;
-                if (strips_normalised)  // strip of the autogained frame from the raw frame's sums
-                    v = (ns - (cnt_all - c) * (double)lastmin) / (double)span + s;
-                else
-                    v = ns + s;
-                data[i] = (float)v;
+        // findbestfit (syncdetector.c:26-58) for the candidate sizes at once
+        FitBest mine[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { mine[k].fit = -1.0; mine[k].q = 0x7fffffff; }
+        const double pn = prefix[n];
+        for (int q = tid; q < n; q += CHAIN_T) {
+            const double pq = prefix[q];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int s = sizes[k];
+                if (s > 0) {
+                    const int e = q + s;
+                    const double sum = (e <= n) ? (prefix[e] - pq) : (pn - pq + prefix[e - n]);
+                    const double d = ((double)totalf - sum) / (double)(n - s) - sum / (double)s;
+                    const double fit = d * d;
+                    if (fit > mine[k].fit) { mine[k].fit = fit; mine[k].q = q; }  // q ascending per thread
+                }
             }
-            __syncthreads();
-            if (xblock)
-                chain_sweetspot(S, data, blur, prefix, n, (int)(W * 0.05f), 0.9, taps, dx, vx, cur);
-            else
-                chain_sweetspot(S, data, blur, prefix, n, (int)(H * 0.01f), 0.1, taps, dx, vx, cur);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (sizes[k] > 0) {
+                FitBest b = mine[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    FitBest other;
+                    other.fit = __shfl_down(b.fit, o, 64);
+                    other.q = __shfl_down(b.q, o, 64);
+                    b = better(b, other);
+                }
+                if (lane == 0) S.wbest[k][wave] = b;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double bestfit = -1.0;
+            int bestq = 0, bestsize = cur;
+            for (int k = 0; k < 5; k++) {
+                if (sizes[k] <= 0) continue;
+                FitBest b = S.wbest[k][0];
+                for (int w = 1; w < 16; w++) b = better(b, S.wbest[k][w]);
+                // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
+                if (k == 0 || b.fit > bestfit) { bestfit = b.fit; bestq = b.q; bestsize = sizes[k]; }
+            }
+            // window start q carries the label of the index just removed (q-1); start 0 is labelled 0
+            const int beststart = bestq > 0 ? bestq - 1 : 0;
+            float *gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
+            gblur[beststart] = PIX_B;  // syncdetector.c:98-99
+            gblur[(beststart + bestsize) % n] = PIX_B;
+
+            const int h2 = n / 2;
+            int centre = (beststart + bestsize / 2) % n;
+            int ndx = dx;
+            const int rawdiff = centre - ndx;
+            if (rawdiff > h2) ndx += n;
+            else if (rawdiff < -h2) centre += n;
+            const int last = ndx;
+            ndx = (int)(((long long)round(centre * lowpass + (1.0 - lowpass) * ndx)) % ((long long)n));
+            const int rawvx = ndx - last;
+            S.vx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
+            S.dx = ndx;
+            S.cur = bestsize;
+        }
+        __syncthreads();
+        cur = S.cur;
+        dx = S.dx;
+        vx = S.vx;
+        if (tid == 0) {
+            ChainOut *o = &out[f];
             if (xblock) {
                 // frameratepll, syncdetector.c:133-153
                 avg_speed = avg_speed * 0.99 + 0.01 * vx;
                 locked = (avg_speed < 0.5 && avg_speed > -0.5) ? 1 : 0;
+                int fired = 0;
+                double diff = 0.0;
                 if (pll_enabled && vx != 0) {
                     diff = locked ? (avg_speed * 0.000001) : (vx * 0.00001);
                     fired = 1;
                 }
-            }
-        }
-        if (threadIdx.x == 0) {
-            ChainOut *o = &out[f];
-            // each launch fills only the fields of the recurrences it ran
-            if (xblock && do_autogain) { o->lastmin = lastmin; o->lastmax = lastmax; o->span = span; }
-            if (xblock && do_sync) {
                 o->dx = dx; o->vx = vx; o->stripx = cur;
                 o->locked = locked; o->pll_fired = fired;
                 o->avg_speed = avg_speed; o->frameratediff = diff;
+            } else {
+                o->dy = dx; o->vy = vx; o->stripy = cur;
             }
-            if (!xblock && do_sync) { o->dy = dx; o->vy = vx; o->stripy = cur; }
         }
+        __syncthreads();  // S is rewritten by the next frame
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         if (xblock) {
-            state->lastmax = lastmax; state->lastmin = lastmin;
             state->dx_x = dx; state->vx_x = vx; state->strip_x = cur;
             state->locked = locked; state->avg_speed = avg_speed;
         } else {
@@ -609,7 +639,7 @@ static int launch_stats(tsdrgpu_postproc_t *pp, const float *frames, long long f
     }
     KERNEL_CHECK(g, "k_frame_stats");
     ProfScope prof(g, PROF_FRAME_REDUCE);
-    k_frame_reduce<<<dim3(F, 3), 256, 0, g->stream>>>(W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
+    k_frame_reduce<<<dim3(((W > H ? W : H) + 255) / 256, 3, F), 256, 0, g->stream>>>(W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
                                                       pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, want_strips);
     KERNEL_CHECK(g, "k_frame_reduce");
     return TSDRGPU_OK;
@@ -620,11 +650,28 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
 {
     tsdrgpu_t *g = pp->g;
     ProfScope prof(g, PROF_CHAIN);
-    k_chain<<<2, CHAIN_T, 0, g->stream>>>(F, W, H, frames, fstride, pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y,
-                                          pp->d_work, pp->d_state, pp->d_chain, do_autogain, do_sync, strips_normalised,
-                                          prm->pll, prm->lowpasscoeff, pp->taps[0], pp->taps[1], pp->taps[2], pp->taps[3],
-                                          pp->taps[4]);
-    KERNEL_CHECK(g, "k_chain");
+    // the autogain record (lastmin/lastmax/span per frame) is (re)written by every call: a sync-only
+    // call repeats the carried state, which no later launch of that order reads
+    if (do_autogain || !pp->chain_has_autogain) {
+        k_autogain_chain<<<1, 64, 0, g->stream>>>(F, frames, fstride, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain,
+                                                  do_autogain, prm->lowpasscoeff);
+        KERNEL_CHECK(g, "k_autogain_chain");
+        pp->chain_has_autogain = 1;
+    }
+    if (do_sync) {
+        const int nmax = W > H ? W : H;
+        StripScratch sc;
+        sc.nmax = nmax;
+        sc.blur = pp->d_work;
+        sc.prefix = (double *)(pp->d_work + (((size_t)F * 2 * nmax + 1) & ~(size_t)1));
+        sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
+        k_strip_prepare<<<dim3(2, F), CHAIN_T, 0, g->stream>>>(W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
+                                                               strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2],
+                                                               pp->taps[3], pp->taps[4]);
+        KERNEL_CHECK(g, "k_strip_prepare");
+        k_sync_chain<<<2, CHAIN_T, 0, g->stream>>>(F, W, H, sc, pp->d_state, pp->d_chain, prm->pll);
+        KERNEL_CHECK(g, "k_sync_chain");
+    }
     return TSDRGPU_OK;
 }
 
@@ -680,10 +727,14 @@ extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frame
     if ((rc = ensure(g, &pp->d_strip_x, &pp->cap_sx, (size_t)F * 3 * W))) return rc;
     if ((rc = ensure(g, &pp->d_strip_y, &pp->cap_sy, (size_t)F * 3 * H))) return rc;
     {
-        const int nmax = W > H ? W : H;
-        const size_t per = (size_t)((2 * nmax + 2 + 1) / 2 * 2) * sizeof(float) + (size_t)(nmax + 1) * sizeof(double);
-        if ((rc = ensure(g, &pp->d_work, &pp->cap_work, (2 * per + 64) / sizeof(float)))) return rc;
+        const size_t nmax = (size_t)(W > H ? W : H);
+        // [F][2][nmax] floats + [F][2][nmax+1] doubles + [F][2] doubles
+        const size_t floats = (((size_t)F * 2 * nmax + 1) & ~(size_t)1) + 2 * ((size_t)F * 2 * (nmax + 1) + (size_t)F * 2) + 16;
+        if ((rc = ensure(g, &pp->d_work, &pp->cap_work, floats))) return rc;
     }
+    if (W > STRIP_MAX || H > STRIP_MAX) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "width/height above 16384");
+    pp->chain_has_autogain = 0;
+    pp->last_F = F;
     if ((size_t)F > pp->cap_chain) {
         if (pp->d_chain) { (void)hipStreamSynchronize(g->stream); (void)hipFree(pp->d_chain); (void)hipHostFree(pp->h_chain); }
         pp->d_chain = nullptr; pp->h_chain = nullptr; pp->cap_chain = 0;
@@ -752,14 +803,13 @@ extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frame
 
 extern "C" int tsdrgpu_postproc_strips(tsdrgpu_postproc_t *pp, float *h_colsum, float *h_rowsum)
 {
-    if (!pp || !pp->d_work || pp->width <= 0) return TSDRGPU_ESTATE;
+    if (!pp || !pp->d_work || pp->width <= 0 || pp->last_F <= 0) return TSDRGPU_ESTATE;
     tsdrgpu_t *g = pp->g;
     const int W = pp->width, H = pp->height;
-    const int nmax = W > H ? W : H;
-    const size_t stride_block = (size_t)((2 * nmax + 2 + 1) / 2 * 2) * sizeof(float) + (size_t)(nmax + 1) * sizeof(double);
-    const char *base = (const char *)pp->d_work;
-    if (h_colsum) HIP_TRY(g, hipMemcpyAsync(h_colsum, (const float *)base + W, sizeof(float) * W, hipMemcpyDeviceToHost, g->stream));
-    if (h_rowsum) HIP_TRY(g, hipMemcpyAsync(h_rowsum, (const float *)(base + stride_block) + H, sizeof(float) * H, hipMemcpyDeviceToHost, g->stream));
+    const size_t nmax = (size_t)(W > H ? W : H);
+    const float *last = pp->d_work + (size_t)(pp->last_F - 1) * 2 * nmax;  // blurred strips (+markers) of the last frame
+    if (h_colsum) HIP_TRY(g, hipMemcpyAsync(h_colsum, last, sizeof(float) * W, hipMemcpyDeviceToHost, g->stream));
+    if (h_rowsum) HIP_TRY(g, hipMemcpyAsync(h_rowsum, last + nmax, sizeof(float) * H, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(g, hipStreamSynchronize(g->stream));
     return TSDRGPU_OK;
 }

@@ -15,12 +15,15 @@ unsigned emu_resample_chunk(const float *in, unsigned size, double up, double do
     g.size = size;
     g.o = -offset_in * g.r;
     const unsigned n_out = (unsigned)(int)(((double)size - offset_in) * g.r);
-    auto load = [&](long long j) { return in[j]; };
-    for (unsigned p = 0; p < n_out; p++) {
-        float v;
-        out[p] = rs_area_pixel(g, p, contrib_in, load, &v) ? v : 0.0f;
+    auto load = [&](int j) { return in[j]; };
+    for (unsigned p = 0; p < n_out; p += 4) {  // groups of four share the owner search, like the kernel
+        int owner = -1;
+        for (unsigned k = p; k < p + 4 && k < n_out; k++) {
+            float v;
+            out[k] = rs_area_pixel(g, k, contrib_in, load, &v, &owner) ? v : 0.0f;
+        }
     }
-    *contrib_out = rs_contrib_before(g, (long long)size, contrib_in, load);
+    *contrib_out = rs_contrib_before(g, (int)size, contrib_in, load);
     *offset_out = offset_in + (n_out * (down / up) - size);
     return n_out;
 }

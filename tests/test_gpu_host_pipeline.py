@@ -102,7 +102,13 @@ def test_pipeline_matches_oracle(orc, iq_file, cfg):
     pid, off, vals, rate = frame_plots[0]
     assert (off, vals.size, rate) == (ac.flo, ac.flen, FS)
     assert np.max(np.abs(vals - ac.frame)) <= 1e-4 * np.max(ac.frame)
-    assert int(np.argmax(vals)) == int(np.argmax(ac.frame))
+    # the frame window of this config straddles N/2 and a circular autocorrelation is
+    # symmetric (R[j] == R[N-j] mathematically), so the peak and its mirror twin tie up to
+    # rounding: the delivered plot's peak must be a peak of the oracle's plot within tolerance
+    assert ac.frame[int(np.argmax(vals))] >= np.max(ac.frame) * (1 - 2e-4)
+    lag = ac.flo + int(np.argmax(vals))
+    n = orc.lib.orc_fft_getrealsize(orc.capture_size(FS))
+    assert min(abs(lag - FS / 60.0), abs((n - lag) - FS / 60.0)) <= 1.0
     assert (line_plots[0][1], line_plots[0][2].size) == (ac.llo, ac.llen)
     counts = [v for v in s.values if v[0] == 2]
     assert counts and counts[0][2] == 1.0  # VALUE_ID_AUTOCORRECT_FRAMES_COUNT, first window
