@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=1.0, help="signal seconds per batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="autocorrelation on the main stream (serial)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,8 +196,15 @@ def main():
     carry = 0  # pixels left over from the previous step (a frame straddling two batches)
     frames_done = 0
 
+    ac.set_async(not args.no_overlap)  # FFT autocorrelation on the side stream, beside the frame path
+
     def step():
         nonlocal carry, frames_done
+        if world == 1:
+            ac.run(d_iq, 1, ac.capture, nwin, mode=0)  # queued first: overlaps everything below
+        else:
+            ac.reset()
+            ac.run(d_iq, 1, ac.capture, nwin, mode=1)
         # a1+a2: the new pixels are appended behind the carried remainder
         n = rs.process(d_iq, 1, chunk, nchunks, up, down, 0, d_pix, out_offset=carry)
         avail = carry + n
@@ -208,17 +216,17 @@ def main():
         carry = rem
         frames_done += F
         if world > 1:
-            ac.reset()
-            ac.run(d_iq, 1, ac.capture, nwin, mode=1)
+            g.sync()  # both streams
             g._ck(g.lib.tsdrgpu_copy(g.h, red.data_ptr(), plots_ptr, plots_n * 8))
             g.sync()
             dist.all_reduce(red)  # RCCL over xGMI: per-lag |R| sums of all ranks' windows
             torch.cuda.synchronize()
             g._ck(g.lib.tsdrgpu_copy(g.h, plots_ptr, red.data_ptr(), plots_n * 8))
+            g.sync()
             ac.finalize_sums(nwin * world)
-        else:
-            ac.run(d_iq, 1, ac.capture, nwin, mode=0)
-        return ac.argmax()
+        fi_li = ac.argmax()  # waits for the side stream
+        g.sync()             # and the frames of this step
+        return fi_li
 
     def barrier():
         g.sync()

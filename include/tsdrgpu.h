@@ -163,6 +163,10 @@ int tsdrgpu_autocorr_geometry(tsdrgpu_autocorr_t *ac, int32_t *frame_lo, int32_t
  * the sums, then tsdrgpu_autocorr_finalize_sums). */
 int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, int64_t stride,
                          int nwindows, int mode);
+/* on != 0: this object's work is queued on the context's side stream, so it
+ * overlaps the frame path; each run still waits for everything queued on the
+ * main stream before it.  tsdrgpu_sync() waits for both streams. */
+int tsdrgpu_autocorr_set_async(tsdrgpu_autocorr_t *ac, int on);
 int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line,
                            uint64_t *h_calls); /* syncs */
 /* device plots: frame_len + line_len doubles, contiguous (frame first) */

@@ -19,6 +19,8 @@ extern "C" int tsdrgpu_create(tsdrgpu_t **out, int device)
     g->device = device;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&g->prop, device) != hipSuccess ||
         hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&g->t0) != hipSuccess || hipEventCreate(&g->t1) != hipSuccess) {
         free(g);
         return TSDRGPU_EHIP;
@@ -32,6 +34,9 @@ extern "C" void tsdrgpu_destroy(tsdrgpu_t *g)
     if (!g) return;
     hipSetDevice(g->device);
     hipStreamSynchronize(g->stream);
+    hipStreamSynchronize(g->stream2);
+    hipStreamDestroy(g->stream2);
+    hipEventDestroy(g->fork);
     for (int i = 0; i < g->cap_spans; i++) {
         if (g->spans[i].a) hipEventDestroy(g->spans[i].a);
         if (g->spans[i].b) hipEventDestroy(g->spans[i].b);
@@ -50,6 +55,7 @@ extern "C" int tsdrgpu_sync(tsdrgpu_t *g)
 {
     if (!g) return TSDRGPU_EINVAL;
     HIP_TRY(g, hipStreamSynchronize(g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream2));
     return TSDRGPU_OK;
 }
 
@@ -132,9 +138,10 @@ static const char *const kStageNames[PROF_COUNT] = {"k_demod", "k_rs_tail+k_rs_c
                                                     "k_frame_stats", "k_frame_reduce", "k_chain", "k_frame_pass",
                                                     "k_fft_pass", "k_accumulate", "superb_misc"};
 
-ProfScope::ProfScope(tsdrgpu_t *g_, int stage) : g(g_), idx(-1)
+ProfScope::ProfScope(tsdrgpu_t *g_, int stage, hipStream_t stream) : g(g_), st(stream), idx(-1)
 {
     if (!g || !g->prof_on) return;
+    if (!st) st = g->stream;
     if (g->nspans == g->cap_spans) {
         const int cap = g->cap_spans ? g->cap_spans * 2 : 1024;
         ProfSpan *n = (ProfSpan *)realloc(g->spans, sizeof(ProfSpan) * cap);
@@ -146,18 +153,19 @@ ProfScope::ProfScope(tsdrgpu_t *g_, int stage) : g(g_), idx(-1)
     ProfSpan &sp = g->spans[g->nspans];
     if (!sp.a && (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess)) return;
     sp.stage = stage;
-    if (hipEventRecord(sp.a, g->stream) != hipSuccess) return;
+    if (hipEventRecord(sp.a, st) != hipSuccess) return;
     idx = g->nspans++;
 }
 ProfScope::~ProfScope()
 {
-    if (idx >= 0) (void)hipEventRecord(g->spans[idx].b, g->stream);
+    if (idx >= 0) (void)hipEventRecord(g->spans[idx].b, st);
 }
 
 extern "C" int tsdrgpu_profile_begin(tsdrgpu_t *g)
 {
     if (!g) return TSDRGPU_EINVAL;
     HIP_TRY(g, hipStreamSynchronize(g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream2));
     g->nspans = 0;
     g->prof_on = 1;
     return TSDRGPU_OK;
@@ -168,6 +176,7 @@ extern "C" int tsdrgpu_profile_end(tsdrgpu_t *g, tsdrgpu_profile_entry_t *h_entr
     if (!g) return TSDRGPU_EINVAL;
     g->prof_on = 0;
     HIP_TRY(g, hipStreamSynchronize(g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream2));
     double total[PROF_COUNT] = {0};
     int launches[PROF_COUNT] = {0};
     for (int i = 0; i < g->nspans; i++) {
@@ -389,9 +398,11 @@ __global__ __launch_bounds__(256) void k_rs_chain(const RsChunk *__restrict__ ch
     *contrib_state = c_in;
 }
 
-// Each thread produces the four pixels of one 16-byte-aligned group of the
-// output stream (one dwordx4 store); the owner search of the first pixel seeds
-// the next three.  Groups cut by the chunk's ends fall back to dword stores.
+// Each thread produces eight consecutive pixels that start on a 16-byte boundary
+// of the output stream (two dwordx4 stores) by replaying the reference loop over
+// the few samples that touch them (rs_area_group).  Groups cut by the chunk's
+// ends fall back to dword stores.
+#define RS_NPIX 8
 template <bool IQ>
 __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chunks, double r, const float *__restrict__ in,
                                                  const double *__restrict__ cin, float *__restrict__ out)
@@ -406,25 +417,19 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
     float *dst = out + ch.out_off;
     const int mis = (int)((((uintptr_t)dst) >> 2) & 3);  // dst's offset inside its 16-byte group
     const int n_out = (int)ch.n_out;
-    const int ngroups = (n_out + mis + 3) >> 2;
+    const int ngroups = (n_out + mis + RS_NPIX - 1) / RS_NPIX;
     for (int grp = blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += gridDim.x * blockDim.x) {
-        const int p0 = 4 * grp - mis;
-        float v[4];
-        int owner = -1;
+        const int p0 = RS_NPIX * grp - mis;
+        float v[RS_NPIX];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int p = p0 + k;
-            v[k] = 0.0f;
-            if (p >= 0 && p < n_out) {
-                float t;
-                if (rs_area_pixel(g, (unsigned)p, c_in, ld, &t, &owner)) v[k] = t;
-            }
-        }
-        if (p0 >= 0 && p0 + 3 < n_out) {
+        for (int k = 0; k < RS_NPIX; k++) v[k] = 0.0f;
+        rs_area_group<RS_NPIX>(g, p0, n_out, c_in, ld, v);
+        if (p0 >= 0 && p0 + RS_NPIX <= n_out) {
             *reinterpret_cast<float4 *>(dst + p0) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(dst + p0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < RS_NPIX; k++)
                 if (p0 + k >= 0 && p0 + k < n_out) dst[p0 + k] = v[k];
         }
     }
@@ -559,7 +564,7 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
     const double r = up / down;
     const unsigned bx = ceil_div_u(max_out ? max_out : 1, 256);
     dim3 grid(bx, (unsigned)nchunks);                                   // one pixel per thread (nearest)
-    dim3 grid4(ceil_div_u((max_out ? max_out : 1) + 6, 1024), (unsigned)nchunks);  // one 4-pixel group per thread
+    dim3 grid4(ceil_div_u((max_out ? max_out : 1) + 2 * RS_NPIX, 256 * RS_NPIX), (unsigned)nchunks);  // one pixel group per thread
     if (nearest) {
         // dsp.c:274-276: contrib is untouched in this mode
         if (max_out) {

@@ -25,6 +25,7 @@ struct tsdrgpu_autocorr {
     int *h_arg;
     double *d_pval;  // argmax partials
     int *d_pidx;
+    hipStream_t st;  // g->stream, or g->stream2 when set asynchronous
 };
 
 // ---------------------------------------------------------------------------
@@ -349,8 +350,9 @@ static void launch_pass(hipStream_t st, int R, const void *x, long long in_strid
 // in_mode, window b at in + b*in_stride elements).  Work buffers a, b (batch*n
 // float2 each).  Returns the buffer that holds the result.
 static float2 *run_fft(tsdrgpu_t *g, const void *in, int in_mode, long long in_stride, float2 *a, float2 *b, uint32_t n, int batch,
-                       int inverse, bool mag_out, float scale)
+                       int inverse, bool mag_out, float scale, hipStream_t st = nullptr)
 {
+    if (!st) st = g->stream;
     const PassPlan p = plan_passes(n);
     unsigned Ns = 1;
     const void *src = in;
@@ -362,17 +364,17 @@ static float2 *run_fft(tsdrgpu_t *g, const void *in, int in_mode, long long in_s
         const bool first = i == 0, last = i == p.count - 1;
         const int cin = (inverse && first) ? 1 : 0, cout = (inverse && last) ? 1 : 0;
         const float sc = last ? scale : 1.0f;
-        ProfScope prof(g, PROF_FFT_PASS);
+        ProfScope prof(g, PROF_FFT_PASS, st);
         if (R == 1) {  // n == 1: copy
-            (void)hipMemcpyAsync(dst, src, sizeof(float2) * batch, hipMemcpyDeviceToDevice, g->stream);
+            (void)hipMemcpyAsync(dst, src, sizeof(float2) * batch, hipMemcpyDeviceToDevice, st);
         } else if (last && mag_out) {
-            if (smode == 0) launch_pass<0, true>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
-            else if (smode == 1) launch_pass<1, true>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
-            else launch_pass<2, true>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            if (smode == 0) launch_pass<0, true>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else if (smode == 1) launch_pass<1, true>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else launch_pass<2, true>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
         } else {
-            if (smode == 0) launch_pass<0, false>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
-            else if (smode == 1) launch_pass<1, false>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
-            else launch_pass<2, false>(g->stream, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            if (smode == 0) launch_pass<0, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else if (smode == 1) launch_pass<1, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else launch_pass<2, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
         }
         Ns *= R;
         src = dst;
@@ -514,6 +516,7 @@ extern "C" int tsdrgpu_autocorr_create(tsdrgpu_t *g, tsdrgpu_autocorr_t **out, u
         free(ac);
         return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_create", "plots");
     }
+    ac->st = g->stream;
     *out = ac;
     return tsdrgpu_autocorr_reset(ac);
 }
@@ -522,6 +525,7 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
 {
     if (!ac) return;
     (void)hipStreamSynchronize(ac->g->stream);
+    (void)hipStreamSynchronize(ac->g->stream2);
     (void)hipFree(ac->d_plots);
     (void)hipFree(ac->d_a);
     (void)hipFree(ac->d_b);
@@ -537,7 +541,7 @@ extern "C" int tsdrgpu_autocorr_reset(tsdrgpu_autocorr_t *ac)
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     ac->calls = 0;  // extbuffer "cleartozero" semantics, extbuffer.c:68-81
-    HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len), g->stream));
+    HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len), ac->st));
     return TSDRGPU_OK;
 }
 
@@ -562,6 +566,7 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     if (nwindows > 65535) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "too many windows in one call");
     if (ac->cap_windows < nwindows) {
         (void)hipStreamSynchronize(g->stream);
+        (void)hipStreamSynchronize(g->stream2);
         (void)hipFree(ac->d_a);
         (void)hipFree(ac->d_b);
         ac->d_a = ac->d_b = nullptr;
@@ -571,14 +576,19 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
             return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_run", "work buffers");
         ac->cap_windows = nwindows;
     }
+    if (ac->st != g->stream) {
+        // side stream: everything already queued on the main stream (e.g. the producer of d_in) comes first
+        HIP_TRY(g, hipEventRecord(g->fork, g->stream));
+        HIP_TRY(g, hipStreamWaitEvent(ac->st, g->fork, 0));
+    }
     // forward FFT scaled by 1/n, magnitude fused into its last pass (fft.c:57-60) ...
-    float2 *spec = run_fft(g, d_in, in_is_iq ? 2 : 1, stride, ac->d_a, ac->d_b, ac->n, nwindows, 0, true, 1.0f / (float)ac->n);
+    float2 *spec = run_fft(g, d_in, in_is_iq ? 2 : 1, stride, ac->d_a, ac->d_b, ac->n, nwindows, 0, true, 1.0f / (float)ac->n, ac->st);
     // ... unscaled inverse FFT (fft.c:63)
-    float2 *corr = run_fft(g, spec, 0, ac->n, ac->d_a, ac->d_b, ac->n, nwindows, 1, false, 1.0f);
+    float2 *corr = run_fft(g, spec, 0, ac->n, ac->d_a, ac->d_b, ac->n, nwindows, 1, false, 1.0f, ac->st);
     KERNEL_CHECK(g, "fft passes");
     const int L = ac->frame_len + ac->line_len;
-    ProfScope prof(g, PROF_ACCUMULATE);
-    k_accumulate<<<(L + 255) / 256, 256, 0, g->stream>>>(corr, ac->n, nwindows, ac->frame_lo, ac->frame_len, ac->line_lo,
+    ProfScope prof(g, PROF_ACCUMULATE, ac->st);
+    k_accumulate<<<(L + 255) / 256, 256, 0, ac->st>>>(corr, ac->n, nwindows, ac->frame_lo, ac->frame_len, ac->line_lo,
                                                          ac->line_len, ac->d_plots, (unsigned long long)ac->calls, mode);
     KERNEL_CHECK(g, "k_accumulate");
     ac->calls += (uint64_t)nwindows;
@@ -590,9 +600,9 @@ extern "C" int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, d
 {
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
-    if (h_frame) HIP_TRY(g, hipMemcpyAsync(h_frame, ac->d_plots, sizeof(double) * ac->frame_len, hipMemcpyDeviceToHost, g->stream));
-    if (h_line) HIP_TRY(g, hipMemcpyAsync(h_line, ac->d_plots + ac->frame_len, sizeof(double) * ac->line_len, hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (h_frame) HIP_TRY(g, hipMemcpyAsync(h_frame, ac->d_plots, sizeof(double) * ac->frame_len, hipMemcpyDeviceToHost, ac->st));
+    if (h_line) HIP_TRY(g, hipMemcpyAsync(h_line, ac->d_plots + ac->frame_len, sizeof(double) * ac->line_len, hipMemcpyDeviceToHost, ac->st));
+    HIP_TRY(g, hipStreamSynchronize(ac->st));
     if (h_calls) *h_calls = ac->calls;
     return TSDRGPU_OK;
 }
@@ -610,7 +620,7 @@ extern "C" int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t t
     if (!ac || total_windows == 0) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     const int L = ac->frame_len + ac->line_len;
-    k_scale_plots<<<(L + 255) / 256, 256, 0, g->stream>>>(ac->d_plots, L, (double)total_windows);
+    k_scale_plots<<<(L + 255) / 256, 256, 0, ac->st>>>(ac->d_plots, L, (double)total_windows);
     KERNEL_CHECK(g, "k_scale_plots");
     ac->calls = total_windows;
     return TSDRGPU_OK;
@@ -620,11 +630,11 @@ extern "C" int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_id
 {
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
-    k_argmax_partial<<<dim3(ARGMAX_BLOCKS, 2), 256, 0, g->stream>>>(ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_pidx);
-    k_argmax_final<<<2, 64, 0, g->stream>>>(ac->d_pval, ac->d_pidx, ac->frame_len, ac->line_len, ac->d_arg);
+    k_argmax_partial<<<dim3(ARGMAX_BLOCKS, 2), 256, 0, ac->st>>>(ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_pidx);
+    k_argmax_final<<<2, 64, 0, ac->st>>>(ac->d_pval, ac->d_pidx, ac->frame_len, ac->line_len, ac->d_arg);
     KERNEL_CHECK(g, "k_argmax");
-    HIP_TRY(g, hipMemcpyAsync(ac->h_arg, ac->d_arg, 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    HIP_TRY(g, hipMemcpyAsync(ac->h_arg, ac->d_arg, 2 * sizeof(int), hipMemcpyDeviceToHost, ac->st));
+    HIP_TRY(g, hipStreamSynchronize(ac->st));
     if (frame_idx) *frame_idx = ac->h_arg[0];
     if (line_idx) *line_idx = ac->h_arg[1];
     return TSDRGPU_OK;
@@ -635,6 +645,16 @@ extern "C" int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **
     if (!ac || !ac->d_last) return TSDRGPU_ESTATE;
     if (d_corr) *d_corr = (const float *)ac->d_last;
     if (n) *n = ac->n;
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int tsdrgpu_autocorr_set_async(tsdrgpu_autocorr_t *ac, int on)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    HIP_TRY(g, hipStreamSynchronize(ac->st));
+    ac->st = on ? g->stream2 : g->stream;
     return TSDRGPU_OK;
 }
 

@@ -364,14 +364,16 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
 
 struct SyncShared {
     FitBest wbest[5][16];
-    int sizes[5];
     int cur, dx, vx;
 };
+
+#define SYNC_PER ((STRIP_MAX + 1 + CHAIN_T - 1) / CHAIN_T)
 
 __global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, StripScratch sc, PpState *__restrict__ state,
                                                         ChainOut *__restrict__ out, int pll_enabled)
 {
     __shared__ SyncShared S;
+    __shared__ double spre[STRIP_MAX + 1];  // this frame's prefix sums
     const bool xblock = blockIdx.x == 0;
     const int axis = blockIdx.x;
     const int n = xblock ? W : H;
@@ -387,9 +389,28 @@ __global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, Str
     double avg_speed = state->avg_speed;
     int locked = state->locked;
 
+    // frame f+1's prefix sums travel global -> registers while frame f is being searched
+    double nxt[SYNC_PER];
+    {
+        const double *p0 = sc.prefix + (long long)axis * (sc.nmax + 1);
+#pragma unroll
+        for (int i = 0; i < SYNC_PER; i++) {
+            const int idx = tid + CHAIN_T * i;
+            if (idx <= n) spre[idx] = p0[idx];
+        }
+    }
+    __syncthreads();
+
     for (int f = 0; f < F; f++) {
-        const double *prefix = sc.prefix + ((long long)f * 2 + axis) * (sc.nmax + 1);
-        const float totalf = (float)sc.total[f * 2 + axis];  // narrowed by findbestfit's float parameter
+        if (f + 1 < F) {
+            const double *pn = sc.prefix + ((long long)(f + 1) * 2 + axis) * (sc.nmax + 1);
+#pragma unroll
+            for (int i = 0; i < SYNC_PER; i++) {
+                const int idx = tid + CHAIN_T * i;
+                nxt[i] = (idx <= n) ? pn[idx] : 0.0;
+            }
+        }
+        const float totalf = (float)spre[n];  // narrowed by findbestfit's float parameter
         if (cur < minsize) cur = minsize; else if (cur > half) cur = half;  // syncdetector.c:76-77
         int sizes[5];
         sizes[0] = cur;
@@ -402,15 +423,15 @@ __global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, Str
         FitBest mine[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) { mine[k].fit = -1.0; mine[k].q = 0x7fffffff; }
-        const double pn = prefix[n];
+        const double pn_ = spre[n];
         for (int q = tid; q < n; q += CHAIN_T) {
-            const double pq = prefix[q];
+            const double pq = spre[q];
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 const int s = sizes[k];
                 if (s > 0) {
                     const int e = q + s;
-                    const double sum = (e <= n) ? (prefix[e] - pq) : (pn - pq + prefix[e - n]);
+                    const double sum = (e <= n) ? (spre[e] - pq) : (pn_ - pq + spre[e - n]);
                     const double d = ((double)totalf - sum) / (double)(n - s) - sum / (double)s;
                     const double fit = d * d;
                     if (fit > mine[k].fit) { mine[k].fit = fit; mine[k].q = q; }  // q ascending per thread
@@ -431,60 +452,76 @@ __global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, Str
                 if (lane == 0) S.wbest[k][wave] = b;
             }
         }
-        __syncthreads();
-        if (tid == 0) {
+        __syncthreads();  // all reads of spre for frame f are done; wbest is complete
+        if (f + 1 < F) {
+#pragma unroll
+            for (int i = 0; i < SYNC_PER; i++) {
+                const int idx = tid + CHAIN_T * i;
+                if (idx <= n) spre[idx] = nxt[i];
+            }
+        }
+        if (wave == 0) {
             double bestfit = -1.0;
             int bestq = 0, bestsize = cur;
+#pragma unroll
             for (int k = 0; k < 5; k++) {
                 if (sizes[k] <= 0) continue;
-                FitBest b = S.wbest[k][0];
-                for (int w = 1; w < 16; w++) b = better(b, S.wbest[k][w]);
+                FitBest b;
+                b.fit = (lane < 16) ? S.wbest[k][lane & 15].fit : -2.0;
+                b.q = (lane < 16) ? S.wbest[k][lane & 15].q : 0x7fffffff;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    FitBest other;
+                    other.fit = __shfl_down(b.fit, o, 64);
+                    other.q = __shfl_down(b.q, o, 64);
+                    b = better(b, other);
+                }
                 // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
                 if (k == 0 || b.fit > bestfit) { bestfit = b.fit; bestq = b.q; bestsize = sizes[k]; }
             }
-            // window start q carries the label of the index just removed (q-1); start 0 is labelled 0
-            const int beststart = bestq > 0 ? bestq - 1 : 0;
-            float *gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
-            gblur[beststart] = PIX_B;  // syncdetector.c:98-99
-            gblur[(beststart + bestsize) % n] = PIX_B;
+            if (lane == 0) {
+                // window start q carries the label of the index just removed (q-1); start 0 is labelled 0
+                const int beststart = bestq > 0 ? bestq - 1 : 0;
+                float *gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
+                gblur[beststart] = PIX_B;  // syncdetector.c:98-99
+                gblur[(beststart + bestsize) % n] = PIX_B;
 
-            const int h2 = n / 2;
-            int centre = (beststart + bestsize / 2) % n;
-            int ndx = dx;
-            const int rawdiff = centre - ndx;
-            if (rawdiff > h2) ndx += n;
-            else if (rawdiff < -h2) centre += n;
-            const int last = ndx;
-            ndx = (int)(((long long)round(centre * lowpass + (1.0 - lowpass) * ndx)) % ((long long)n));
-            const int rawvx = ndx - last;
-            S.vx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
-            S.dx = ndx;
-            S.cur = bestsize;
+                const int h2 = n / 2;
+                int centre = (beststart + bestsize / 2) % n;
+                int ndx = dx;
+                const int rawdiff = centre - ndx;
+                if (rawdiff > h2) ndx += n;
+                else if (rawdiff < -h2) centre += n;
+                const int last = ndx;
+                ndx = (int)(((long long)round(centre * lowpass + (1.0 - lowpass) * ndx)) % ((long long)n));
+                const int rawvx = ndx - last;
+                const int nvx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
+                S.vx = nvx;
+                S.dx = ndx;
+                S.cur = bestsize;
+                ChainOut *o = &out[f];
+                if (xblock) {
+                    // frameratepll, syncdetector.c:133-153
+                    avg_speed = avg_speed * 0.99 + 0.01 * nvx;
+                    locked = (avg_speed < 0.5 && avg_speed > -0.5) ? 1 : 0;
+                    int fired = 0;
+                    double diff = 0.0;
+                    if (pll_enabled && nvx != 0) {
+                        diff = locked ? (avg_speed * 0.000001) : (nvx * 0.00001);
+                        fired = 1;
+                    }
+                    o->dx = ndx; o->vx = nvx; o->stripx = bestsize;
+                    o->locked = locked; o->pll_fired = fired;
+                    o->avg_speed = avg_speed; o->frameratediff = diff;
+                } else {
+                    o->dy = ndx; o->vy = nvx; o->stripy = bestsize;
+                }
+            }
         }
-        __syncthreads();
+        __syncthreads();  // S.cur/dx/vx and the next frame's spre are visible
         cur = S.cur;
         dx = S.dx;
         vx = S.vx;
-        if (tid == 0) {
-            ChainOut *o = &out[f];
-            if (xblock) {
-                // frameratepll, syncdetector.c:133-153
-                avg_speed = avg_speed * 0.99 + 0.01 * vx;
-                locked = (avg_speed < 0.5 && avg_speed > -0.5) ? 1 : 0;
-                int fired = 0;
-                double diff = 0.0;
-                if (pll_enabled && vx != 0) {
-                    diff = locked ? (avg_speed * 0.000001) : (vx * 0.00001);
-                    fired = 1;
-                }
-                o->dx = dx; o->vx = vx; o->stripx = cur;
-                o->locked = locked; o->pll_fired = fired;
-                o->avg_speed = avg_speed; o->frameratediff = diff;
-            } else {
-                o->dy = dx; o->vy = vx; o->stripy = cur;
-            }
-        }
-        __syncthreads();  // S is rewritten by the next frame
     }
     if (tid == 0) {
         if (xblock) {

@@ -33,6 +33,8 @@ struct ProfSpan {
 struct tsdrgpu {
     int device;
     hipStream_t stream;
+    hipStream_t stream2;  // side stream: the autocorrelation can run beside the frame path
+    hipEvent_t fork;      // orders stream2 behind what is already queued on `stream`
     hipEvent_t t0, t1;
     char err[512];
     hipDeviceProp_t prop;
@@ -45,8 +47,9 @@ struct tsdrgpu {
 // RAII span: records an event pair around the launches issued in its scope
 struct ProfScope {
     tsdrgpu_t *g;
+    hipStream_t st;
     int idx;
-    ProfScope(tsdrgpu_t *g_, int stage);
+    ProfScope(tsdrgpu_t *g_, int stage, hipStream_t stream = nullptr);
     ~ProfScope();
 };
 

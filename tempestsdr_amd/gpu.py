@@ -77,6 +77,7 @@ _SIGS = {
     "tsdrgpu_autocorr_reset": (C.c_int, [vp]),
     "tsdrgpu_autocorr_geometry": (C.c_int, [vp] + [C.POINTER(C.c_int32)] * 4 + [C.POINTER(C.c_uint32)] * 2),
     "tsdrgpu_autocorr_run": (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "tsdrgpu_autocorr_set_async": (C.c_int, [vp, C.c_int]),
     "tsdrgpu_autocorr_plots": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
@@ -360,6 +361,10 @@ class Autocorr:
 
     def reset(self):
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_reset(self.h))
+
+    def set_async(self, on=True):
+        """queue this object's work on the context's side stream (overlaps the frame path)"""
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_set_async(self.h, int(on)))
 
     def run(self, d_in, in_is_iq, stride, nwindows, mode=0, in_offset=0):
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_run(self.h, d_in.at(in_offset), int(in_is_iq), stride, nwindows, mode))

@@ -16,12 +16,19 @@ unsigned emu_resample_chunk(const float *in, unsigned size, double up, double do
     g.o = -offset_in * g.r;
     const unsigned n_out = (unsigned)(int)(((double)size - offset_in) * g.r);
     auto load = [&](int j) { return in[j]; };
-    for (unsigned p = 0; p < n_out; p += 4) {  // groups of four share the owner search, like the kernel
-        int owner = -1;
-        for (unsigned k = p; k < p + 4 && k < n_out; k++) {
-            float v;
-            out[k] = rs_area_pixel(g, k, contrib_in, load, &v, &owner) ? v : 0.0f;
-        }
+    // like the kernel: groups of 8 pixels, the first group misaligned by `mis` (here: size % 4)
+    const int mis = (int)(size & 3);
+    for (int p0 = -mis; p0 < (int)n_out; p0 += 8) {
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        rs_area_group<8>(g, p0, (int)n_out, contrib_in, load, v);
+        for (int k = 0; k < 8; k++)
+            if (p0 + k >= 0 && p0 + k < (int)n_out) {
+                out[p0 + k] = v[k];
+                // the per-pixel form must agree with the group form
+                float s;
+                const float want = rs_area_pixel(g, (unsigned)(p0 + k), contrib_in, load, &s) ? s : 0.0f;
+                if (want != v[k]) out[p0 + k] = -12345.0f;
+            }
     }
     *contrib_out = rs_contrib_before(g, (int)size, contrib_in, load);
     *offset_out = offset_in + (n_out * (down / up) - size);
