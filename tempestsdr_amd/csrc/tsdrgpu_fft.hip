@@ -18,9 +18,10 @@ struct tsdrgpu_autocorr {
     uint32_t capture, n;
     uint64_t calls;
     double *d_plots;   // frame_len + line_len
-    float2 *d_a, *d_b; // ping-pong work buffers, cap_windows * n each
+    float2 *d_a, *d_b; // ping-pong work buffers, cap_windows * n/2 complex each (packed real transform)
     int cap_windows;
-    float2 *d_last;    // where the last window's correlation lives
+    float2 *d_last;    // packed correlation of the last window run (n/2 complex = n reals)
+    float2 *d_expand;  // the same unpacked to n complex values, made on demand
     int *d_arg;
     int *h_arg;
     double *d_pval;  // argmax partials
@@ -31,6 +32,24 @@ struct tsdrgpu_autocorr {
 // ---------------------------------------------------------------------------
 // small DFTs in registers (forward, e^{-2 pi i/R})
 // ---------------------------------------------------------------------------
+template <int IN_MODE>
+__device__ __forceinline__ float2 fft_load(const void *__restrict__ xin, long long base, long long at)
+{
+    if (IN_MODE == 0) return ((const float2 *)xin + base)[at];
+    if (IN_MODE == 1) return make_float2(((const float *)xin + base)[at], 0.f);
+    if (IN_MODE == 2) {
+        const float2 s = ((const float2 *)xin + base)[at];
+        return make_float2(sqrtf(s.x * s.x + s.y * s.y), 0.f);
+    }
+    if (IN_MODE == 3) {
+        const float *x = (const float *)xin + base;
+        return make_float2(x[2 * at], x[2 * at + 1]);
+    }
+    const float2 *x = (const float2 *)xin + base;
+    const float2 a = x[2 * at], b = x[2 * at + 1];
+    return make_float2(sqrtf(a.x * a.x + a.y * a.y), sqrtf(b.x * b.x + b.y * b.y));
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -116,7 +135,9 @@ __device__ __forceinline__ void dft_reg<16>(float2 (&v)[16])
 //   thread j (< n/R): k = j mod Ns; reads x[j + t*n/R], multiplies by
 //   w_{Ns*R}^{t*k}, R-point DFT, writes y[(j-k)*R + k + u*Ns]
 // IN_MODE 0: complex input; 1: real float input (imag = 0); 2: interleaved IQ,
-// magnitude taken on the fly (am_demod fused, TSDRLibrary.c:244-262)
+// magnitude taken on the fly (am_demod fused, TSDRLibrary.c:244-262);
+// 3: real input packed two samples per complex point, z[m] = x[2m] + i x[2m+1];
+// 4: the same packing with the samples demodulated from interleaved IQ
 // OUT_MAG: store (|v|*scale, 0) — fft_complex_to_absolute_complex, fft.c:34-45
 // ---------------------------------------------------------------------------
 template <int R, int IN_MODE, bool OUT_MAG>
@@ -128,22 +149,8 @@ __global__ __launch_bounds__(256) void k_fft_pass(const void *__restrict__ xin, 
     if (j >= T) return;
     const unsigned b = blockIdx.y;
     float2 v[R];
-    if (IN_MODE == 0) {
-        const float2 *x = (const float2 *)xin + (long long)b * in_stride;
 #pragma unroll
-        for (int t = 0; t < R; t++) v[t] = x[j + t * T];
-    } else if (IN_MODE == 1) {
-        const float *x = (const float *)xin + (long long)b * in_stride;
-#pragma unroll
-        for (int t = 0; t < R; t++) v[t] = make_float2(x[j + t * T], 0.f);
-    } else {
-        const float2 *x = (const float2 *)xin + (long long)b * in_stride;
-#pragma unroll
-        for (int t = 0; t < R; t++) {
-            const float2 s = x[j + t * T];
-            v[t] = make_float2(sqrtf(s.x * s.x + s.y * s.y), 0.f);
-        }
-    }
+    for (int t = 0; t < R; t++) v[t] = fft_load<IN_MODE>(xin, (long long)b * in_stride, (long long)j + (long long)t * T);
     if (conj_in) {
 #pragma unroll
         for (int t = 0; t < R; t++) v[t].y = -v[t].y;
@@ -214,13 +221,7 @@ __global__ __launch_bounds__(256) void k_fft_lds(const void *__restrict__ xin, l
         for (int i = 0; i < R1; i++) {
             const unsigned nidx = q * G + a + 16 * i;
             const long long at = (long long)j + (long long)nidx * T;
-            float2 val;
-            if (IN_MODE == 0) val = ((const float2 *)xin + (long long)b * in_stride)[at];
-            else if (IN_MODE == 1) val = make_float2(((const float *)xin + (long long)b * in_stride)[at], 0.f);
-            else {
-                const float2 sq = ((const float2 *)xin + (long long)b * in_stride)[at];
-                val = make_float2(sqrtf(sq.x * sq.x + sq.y * sq.y), 0.f);
-            }
+            float2 val = fft_load<IN_MODE>(xin, (long long)b * in_stride, at);
             if (conj_in) val.y = -val.y;
             v[a * R1 + i] = val;
         }
@@ -372,9 +373,13 @@ static float2 *run_fft(tsdrgpu_t *g, const void *in, int in_mode, long long in_s
             else if (smode == 1) launch_pass<1, true>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
             else launch_pass<2, true>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
         } else {
-            if (smode == 0) launch_pass<0, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
-            else if (smode == 1) launch_pass<1, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
-            else launch_pass<2, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            switch (smode) {
+                case 0: launch_pass<0, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                case 1: launch_pass<1, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                case 2: launch_pass<2, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                case 3: launch_pass<3, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                default: launch_pass<4, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+            }
         }
         Ns *= R;
         src = dst;
@@ -405,10 +410,72 @@ extern "C" int tsdrgpu_fft(tsdrgpu_t *g, float *d_iq, uint32_t n, int inverse)
 }
 
 // ---------------------------------------------------------------------------
+// Real-input trick for the autocorrelation.  The capture window is real, so it is
+// transformed as nh = n/2 complex points z[m] = x[2m] + i x[2m+1]; with
+// Z = FFT_nh(z) (unscaled) and w = exp(-2 pi i / n):
+//     X[k]   = (A + B)/2 - (i/2) w^k (A - B),   A = Z[k], B = conj(Z[nh-k])
+//     M[k]   = |X[k]| / n          (fft.c:167-175 scale, fft.c:34-45 magnitude; M is real and even)
+// and the unscaled inverse r = IFFT_n(M) comes out of one nh-point inverse FFT of
+//     Zin[k] = (M[k] + M[nh-k]) + i w^-k (M[k] - M[nh-k])
+// packed as zout[m] = r[2m] + i r[2m+1].  k_ac_split does the Z -> Zin step in
+// place, one thread per (k, nh-k) pair.  Memory traffic per window drops from
+// 96 n to 56 n bytes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ac_split(float2 *__restrict__ z, unsigned nh)
+{
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nh / 2) return;
+    float2 *zb = z + (long long)blockIdx.y * nh;
+    const float inv_n = 1.0f / (float)(2 * nh);
+    if (k == 0) {
+        const float2 z0 = zb[0];
+        const float m0 = fabsf(z0.x + z0.y) * inv_n;   // X[0]  = Re Z0 + Im Z0
+        const float mh = fabsf(z0.x - z0.y) * inv_n;   // X[nh] = Re Z0 - Im Z0
+        zb[0] = make_float2(m0 + mh, m0 - mh);
+        return;
+    }
+    const unsigned km = nh - k;
+    const float2 a = zb[k];
+    const float2 bm = zb[km];
+    const float2 b = make_float2(bm.x, -bm.y);
+    float sn, cs;
+    sincospif(-(float)k / (float)nh, &sn, &cs);  // w^k, w = exp(-2 pi i / n), n = 2 nh
+    const float2 wk = make_float2(cs, sn);
+    // X[k] = (A+B)/2 - (i/2) w^k (A-B)
+    const float2 sum = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+    const float2 dif = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+    const float2 t = cmul(wk, dif);                  // w^k (A-B)/2
+    const float2 xk = make_float2(sum.x + t.y, sum.y - t.x);  // sum - i t
+    // X[nh-k] = conj( (A+B)/2 + (i/2) w^k (A-B) )   (Hermitian partner, w^{nh-k} = -conj(w^k))
+    const float2 xm = make_float2(sum.x - t.y, -(sum.y + t.x));
+    const float mk = sqrtf(xk.x * xk.x + xk.y * xk.y) * inv_n;
+    const float mm = sqrtf(xm.x * xm.x + xm.y * xm.y) * inv_n;
+    // Zin[k] = (M[k]+M[nh-k]) + i w^-k (M[k]-M[nh-k]),  w^-k = conj(w^k)
+    const float s = mk + mm, d = mk - mm;
+    // i * conj(wk) * d = i (cs - i sn) d = (sn d) + i (cs d)
+    zb[k] = make_float2(s + sn * d, cs * d);
+    if (km != k) {
+        // Zin[nh-k] = (M[nh-k]+M[k]) + i w^-(nh-k) (M[nh-k]-M[k]); w^-(nh-k) = -w^k
+        // i * (-wk) * (-d) = i wk d = i (cs + i sn) d = (-sn d) + i (cs d)
+        zb[km] = make_float2(s - sn * d, cs * d);
+    }
+}
+
+// unpack zout (r[2m] + i r[2m+1]) into the reference's layout: complex, imaginary part 0
+__global__ __launch_bounds__(256) void k_ac_expand(const float2 *__restrict__ zout, float2 *__restrict__ corr, unsigned nh)
+{
+    const unsigned m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nh) return;
+    const float2 v = zout[m];
+    corr[2 * m] = make_float2(v.x, 0.f);
+    corr[2 * m + 1] = make_float2(v.y, 0.f);
+}
+
+// ---------------------------------------------------------------------------
 // accummulate (frameratedetector.c:34-62) over a batch of windows, in window
 // order, so the running mean's f64 rounding matches the reference's recurrence.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_accumulate(const float2 *__restrict__ corr, unsigned n, int nwindows, int frame_lo,
+__global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ corr, unsigned n, int nwindows, int frame_lo,
                                                     int frame_len, int line_lo, int line_len, double *__restrict__ plots,
                                                     unsigned long long calls_before, int mode)
 {
@@ -417,9 +484,9 @@ __global__ __launch_bounds__(256) void k_accumulate(const float2 *__restrict__ c
     const int lag = (i < frame_len) ? (frame_lo + i) : (line_lo + (i - frame_len));
     double acc = plots[i];
     for (int w = 0; w < nwindows; w++) {
-        const float2 c = corr[(long long)w * n + lag];
-        const double re = c.x, im = c.y;
-        const double now = sqrt(re * re + im * im);
+        // r[lag] of window w (real: the packed inverse transform has no imaginary residue)
+        const double re = corr[(long long)w * n + lag];
+        const double now = sqrt(re * re);
         if (mode == 0) {
             const unsigned long long calls = calls_before + w + 1;
             acc = (acc * (double)(calls - 1) + now) / (double)calls;
@@ -529,6 +596,7 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
     (void)hipFree(ac->d_plots);
     (void)hipFree(ac->d_a);
     (void)hipFree(ac->d_b);
+    (void)hipFree(ac->d_expand);
     (void)hipFree(ac->d_arg);
     (void)hipFree(ac->d_pval);
     (void)hipFree(ac->d_pidx);
@@ -571,8 +639,8 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
         (void)hipFree(ac->d_b);
         ac->d_a = ac->d_b = nullptr;
         ac->cap_windows = 0;
-        if (hipMalloc(&ac->d_a, sizeof(float2) * (size_t)ac->n * nwindows) != hipSuccess ||
-            hipMalloc(&ac->d_b, sizeof(float2) * (size_t)ac->n * nwindows) != hipSuccess)
+        if (hipMalloc(&ac->d_a, sizeof(float2) * (size_t)(ac->n / 2) * nwindows) != hipSuccess ||
+            hipMalloc(&ac->d_b, sizeof(float2) * (size_t)(ac->n / 2) * nwindows) != hipSuccess)
             return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_run", "work buffers");
         ac->cap_windows = nwindows;
     }
@@ -581,18 +649,25 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
         HIP_TRY(g, hipEventRecord(g->fork, g->stream));
         HIP_TRY(g, hipStreamWaitEvent(ac->st, g->fork, 0));
     }
-    // forward FFT scaled by 1/n, magnitude fused into its last pass (fft.c:57-60) ...
-    float2 *spec = run_fft(g, d_in, in_is_iq ? 2 : 1, stride, ac->d_a, ac->d_b, ac->n, nwindows, 0, true, 1.0f / (float)ac->n, ac->st);
-    // ... unscaled inverse FFT (fft.c:63)
-    float2 *corr = run_fft(g, spec, 0, ac->n, ac->d_a, ac->d_b, ac->n, nwindows, 1, false, 1.0f, ac->st);
+    const uint32_t nh = ac->n / 2;
+    // fft_autocorrelation (fft.c:49-64) on the real window, packed two samples per complex point:
+    // forward FFT of nh points ...
+    float2 *zf = run_fft(g, d_in, in_is_iq ? 4 : 3, stride, ac->d_a, ac->d_b, nh, nwindows, 0, false, 1.0f, ac->st);
+    // ... spectrum split, 1/n scale and magnitude, re-packing for the inverse (in place) ...
+    {
+        ProfScope prof(g, PROF_AC_SPLIT, ac->st);
+        k_ac_split<<<dim3((nh / 2 + 1 + 255) / 256, nwindows), 256, 0, ac->st>>>(zf, nh);
+    }
+    // ... unscaled inverse FFT of nh points: zout[m] = r[2m] + i r[2m+1]
+    float2 *corr = run_fft(g, zf, 0, nh, ac->d_a, ac->d_b, nh, nwindows, 1, false, 1.0f, ac->st);
     KERNEL_CHECK(g, "fft passes");
     const int L = ac->frame_len + ac->line_len;
     ProfScope prof(g, PROF_ACCUMULATE, ac->st);
-    k_accumulate<<<(L + 255) / 256, 256, 0, ac->st>>>(corr, ac->n, nwindows, ac->frame_lo, ac->frame_len, ac->line_lo,
-                                                         ac->line_len, ac->d_plots, (unsigned long long)ac->calls, mode);
+    k_accumulate<<<(L + 255) / 256, 256, 0, ac->st>>>((const float *)corr, ac->n, nwindows, ac->frame_lo, ac->frame_len, ac->line_lo,
+                                                      ac->line_len, ac->d_plots, (unsigned long long)ac->calls, mode);
     KERNEL_CHECK(g, "k_accumulate");
     ac->calls += (uint64_t)nwindows;
-    ac->d_last = corr + (size_t)(nwindows - 1) * ac->n;
+    ac->d_last = corr + (size_t)(nwindows - 1) * nh;
     return TSDRGPU_OK;
 }
 
@@ -643,12 +718,18 @@ extern "C" int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_id
 extern "C" int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **d_corr, uint32_t *n)
 {
     if (!ac || !ac->d_last) return TSDRGPU_ESTATE;
-    if (d_corr) *d_corr = (const float *)ac->d_last;
+    tsdrgpu_t *g = ac->g;
+    if (!ac->d_expand && hipMalloc(&ac->d_expand, sizeof(float2) * (size_t)ac->n) != hipSuccess)
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_last_corr", "buffer");
+    const uint32_t nh = ac->n / 2;
+    k_ac_expand<<<(nh + 255) / 256, 256, 0, ac->st>>>(ac->d_last, ac->d_expand, nh);
+    KERNEL_CHECK(g, "k_ac_expand");
+    HIP_TRY(g, hipStreamSynchronize(ac->st));
+    if (d_corr) *d_corr = (const float *)ac->d_expand;
     if (n) *n = ac->n;
     return TSDRGPU_OK;
 }
 
-// ---------------------------------------------------------------------------
 extern "C" int tsdrgpu_autocorr_set_async(tsdrgpu_autocorr_t *ac, int on)
 {
     if (!ac) return TSDRGPU_EINVAL;

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
 
 struct SyncShared {
     FitBest wbest[5][16];
+    double wmin[5][16], wmax[5][16];
     int cur, dx, vx;
 };
 
@@ -419,11 +420,17 @@ __global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, Str
 #pragma unroll
             for (int t = 0; t < 4; t++) sizes[t + 1] = (trial[t] >= minsize && trial[t] < half && trial[t] != cur) ? trial[t] : 0;
         }
-        // findbestfit (syncdetector.c:26-58) for the candidate sizes at once
-        FitBest mine[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) { mine[k].fit = -1.0; mine[k].q = 0x7fffffff; }
+        // findbestfit (syncdetector.c:26-58) for the candidate sizes at once.
+        // fit(q) = ((total-S_q)/(n-s) - S_q/s)^2 is, with every rounding kept, a monotone
+        // function of the window sum S_q on either side of its zero, so its maximum sits at the
+        // smallest or the largest S_q.  Step 1 finds those two extremes (adds and compares
+        // only); step 2 evaluates the reference's exact f64 expression — two divisions — only
+        // for windows whose sum lies within a 1e-9 band of an extreme (rounding plateaus are
+        // ~1e-16 wide), which keeps the first-maximum tie-break exact at a fraction of the cost.
         const double pn_ = spre[n];
+        double smin[5], smax[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { smin[k] = INFINITY; smax[k] = -INFINITY; }
         for (int q = tid; q < n; q += CHAIN_T) {
             const double pq = spre[q];
 #pragma unroll
@@ -432,9 +439,54 @@ __global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, Str
                 if (s > 0) {
                     const int e = q + s;
                     const double sum = (e <= n) ? (spre[e] - pq) : (pn_ - pq + spre[e - n]);
-                    const double d = ((double)totalf - sum) / (double)(n - s) - sum / (double)s;
-                    const double fit = d * d;
-                    if (fit > mine[k].fit) { mine[k].fit = fit; mine[k].q = q; }  // q ascending per thread
+                    smin[k] = fmin(smin[k], sum);
+                    smax[k] = fmax(smax[k], sum);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (sizes[k] > 0) {
+                double lo = smin[k], hi = smax[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    lo = fmin(lo, __shfl_xor(lo, o, 64));
+                    hi = fmax(hi, __shfl_xor(hi, o, 64));
+                }
+                if (lane == 0) { S.wmin[k][wave] = lo; S.wmax[k][wave] = hi; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (sizes[k] > 0) {
+                double lo = S.wmin[k][lane & 15], hi = S.wmax[k][lane & 15];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    lo = fmin(lo, __shfl_xor(lo, o, 64));
+                    hi = fmax(hi, __shfl_xor(hi, o, 64));
+                }
+                smin[k] = lo;
+                smax[k] = hi;
+            }
+        }
+        FitBest mine[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { mine[k].fit = -1.0; mine[k].q = 0x7fffffff; }
+        for (int q = tid; q < n; q += CHAIN_T) {
+            const double pq = spre[q];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int s = sizes[k];
+                if (s > 0) {
+                    const int e = q + s;
+                    const double sum = (e <= n) ? (spre[e] - pq) : (pn_ - pq + spre[e - n]);
+                    const double band = 1e-9 * (fabs(smin[k]) + fabs(smax[k])) + 1e-300;
+                    if (sum <= smin[k] + band || sum >= smax[k] - band) {
+                        const double d = ((double)totalf - sum) / (double)(n - s) - sum / (double)s;
+                        const double fit = d * d;
+                        if (fit > mine[k].fit) { mine[k].fit = fit; mine[k].q = q; }  // q ascending per thread
+                    }
                 }
             }
         }

@@ -20,6 +20,7 @@ enum ProfStage {
     PROF_CHAIN,
     PROF_FRAME_PASS,
     PROF_FFT_PASS,
+    PROF_AC_SPLIT,
     PROF_ACCUMULATE,
     PROF_SUPERB_MISC,
     PROF_COUNT
