@@ -362,24 +362,166 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
     }
 }
 
-struct SyncShared {
-    FitBest wbest[5][16];
-    double wmin[5][16], wmax[5][16];
-    int cur, dx, vx;
+#define SYNC_T 256
+
+struct SearchShared {
+    FitBest wbest[5][SYNC_T / 64];
+    double wlo[5][SYNC_T / 64], whi[5][SYNC_T / 64];
+    FitBest best[5];  // result: per candidate size the first window start with the largest fit
 };
 
-#define SYNC_PER ((STRIP_MAX + 1 + CHAIN_T - 1) / CHAIN_T)
-
-__global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, StripScratch sc, PpState *__restrict__ state,
-                                                        ChainOut *__restrict__ out, int pll_enabled)
+// candidate strip sizes around `cur` (RUNWITH_SIZE, syncdetector.c:60-69,90-93); 0 = not tried
+__device__ __forceinline__ int sync_sizes(int cur, int minsize, int half, int sizes[5])
 {
-    __shared__ SyncShared S;
-    __shared__ double spre[STRIP_MAX + 1];  // this frame's prefix sums
+    if (cur < minsize) cur = minsize; else if (cur > half) cur = half;  // syncdetector.c:76-77
+    sizes[0] = cur;
+    const int trial[4] = {cur - 4, cur + 4, cur >> 1, cur << 1};
+#pragma unroll
+    for (int t = 0; t < 4; t++) sizes[t + 1] = (trial[t] >= minsize && trial[t] < half && trial[t] != cur) ? trial[t] : 0;
+    return cur;
+}
+
+// findbestfit (syncdetector.c:26-58) for the candidate sizes at once, by the whole workgroup.
+// P = prefix sums of the blurred strip (n+1 doubles).  fit(q) = ((total-S_q)/(n-s) - S_q/s)^2 is,
+// with every rounding kept, a monotone function of the window sum S_q on either side of its
+// zero, so its maximum over q sits at the smallest or the largest S_q.  Step 1 finds those
+// extremes with adds and compares only; step 2 evaluates the reference's exact f64 expression
+// (two divisions) just for the windows within a 1e-9 band of them (rounding plateaus are ~1e-16
+// wide); the (fit, q) reduction applies the reference's first-maximum rule.  Result: S.best[].
+__device__ void strip_search(SearchShared &S, const double *__restrict__ P, int n, const int sizes[5])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double pn_ = P[n];
+    const float totalf = (float)pn_;  // narrowed by findbestfit's float parameter
+    int sz[5];
+    double c1[5], c2[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        sz[k] = sizes[k] > 0 ? sizes[k] : sizes[0];  // untried sizes alias the current one (results ignored)
+        c1[k] = (double)(n - sz[k]);
+        c2[k] = (double)sz[k];
+    }
+    double lo[5], hi[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+#pragma unroll 4
+    for (int q = tid; q < n; q += SYNC_T) {
+        const double pq = P[q];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int e = q + sz[k];
+            const double pe = P[e <= n ? e : e - n];
+            const double sum = (e <= n) ? (pe - pq) : (pn_ - pq + pe);
+            lo[k] = (sum < lo[k]) ? sum : lo[k];
+            hi[k] = (sum > hi[k]) ? sum : hi[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double l2 = __shfl_xor(lo[k], o, 64), h2 = __shfl_xor(hi[k], o, 64);
+            lo[k] = (l2 < lo[k]) ? l2 : lo[k];
+            hi[k] = (h2 > hi[k]) ? h2 : hi[k];
+        }
+        if (lane == 0) { S.wlo[k][wave] = lo[k]; S.whi[k][wave] = hi[k]; }
+    }
+    __syncthreads();
+    FitBest mine[5];
+    double lo_b[5], hi_b[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        double l = S.wlo[k][0], h = S.whi[k][0];
+#pragma unroll
+        for (int w = 1; w < SYNC_T / 64; w++) {
+            l = (S.wlo[k][w] < l) ? S.wlo[k][w] : l;
+            h = (S.whi[k][w] > h) ? S.whi[k][w] : h;
+        }
+        const double band = 1e-9 * (fabs(l) + fabs(h)) + 1e-300;
+        lo_b[k] = l + band;
+        hi_b[k] = h - band;
+        mine[k].fit = -1.0;
+        mine[k].q = 0x7fffffff;
+    }
+#pragma unroll 4
+    for (int q = tid; q < n; q += SYNC_T) {
+        const double pq = P[q];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int e = q + sz[k];
+            const double pe = P[e <= n ? e : e - n];
+            const double sum = (e <= n) ? (pe - pq) : (pn_ - pq + pe);
+            if (sum <= lo_b[k] || sum >= hi_b[k]) {
+                const double d = ((double)totalf - sum) / c1[k] - sum / c2[k];
+                const double fit = d * d;
+                if (fit > mine[k].fit) { mine[k].fit = fit; mine[k].q = q; }  // q ascending per thread
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        FitBest b = mine[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            FitBest other;
+            other.fit = __shfl_down(b.fit, o, 64);
+            other.q = __shfl_down(b.q, o, 64);
+            b = better(b, other);
+        }
+        if (lane == 0) S.wbest[k][wave] = b;
+    }
+    __syncthreads();
+    if (tid < 5) {
+        FitBest b = S.wbest[tid][0];
+#pragma unroll
+        for (int w = 1; w < SYNC_T / 64; w++) b = better(b, S.wbest[tid][w]);
+        S.best[tid] = b;
+    }
+    __syncthreads();
+}
+
+struct SpecEntry {
+    FitBest best[5];
+};
+
+// Speculative, fully parallel part of the sync detector: the strip size a frame starts from is
+// the previous frame's result, but it settles within a few frames and then stays — so search
+// every frame of the batch for the candidate sizes around the size the batch STARTS with.
+// k_sync_chain consumes these results while the prediction holds and searches on its own
+// where it does not.
+__global__ __launch_bounds__(SYNC_T) void k_sync_search(int W, int H, StripScratch sc, const PpState *__restrict__ state,
+                                                        SpecEntry *__restrict__ spec)
+{
+    __shared__ SearchShared S;
+    const int axis = blockIdx.x, f = blockIdx.y;
+    const int n = axis == 0 ? W : H;
+    int minsize = axis == 0 ? (int)(W * 0.05f) : (int)(H * 0.01f);  // syncdetector.c:178-179
+    if (minsize < 1) minsize = 1;
+    int sizes[5];
+    sync_sizes(axis == 0 ? state->strip_x : state->strip_y, minsize, n >> 1, sizes);
+    strip_search(S, sc.prefix + ((long long)f * 2 + axis) * (sc.nmax + 1), n, sizes);
+    if (threadIdx.x < 5) spec[f * 2 + axis].best[threadIdx.x] = S.best[threadIdx.x];
+}
+
+// The sequential part (syncdetector.c:95-119,133-153): pick the winning size, move dx with its
+// low-pass, run the framerate PLL — a scalar recurrence that lane 0 walks frame by frame using
+// the speculative search results; a frame whose starting size differs from the prediction is
+// searched here by the whole workgroup.
+struct ChainShared {
+    int f, cur, dx, vx;
+};
+
+__global__ __launch_bounds__(SYNC_T) void k_sync_chain(int F, int W, int H, StripScratch sc, PpState *__restrict__ state,
+                                                       ChainOut *__restrict__ out, const SpecEntry *__restrict__ spec,
+                                                       int pll_enabled)
+{
+    __shared__ SearchShared S;
+    __shared__ ChainShared C;
     const bool xblock = blockIdx.x == 0;
     const int axis = blockIdx.x;
     const int n = xblock ? W : H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int minsize = xblock ? (int)(W * 0.05f) : (int)(H * 0.01f);  // syncdetector.c:178-179
+    const int tid = threadIdx.x;
+    int minsize = xblock ? (int)(W * 0.05f) : (int)(H * 0.01f);
     if (minsize < 1) minsize = 1;
     const double lowpass = xblock ? 0.9 : 0.1;
     const int half = n >> 1;
@@ -389,149 +531,27 @@ __global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, Str
     int cur = xblock ? state->strip_x : state->strip_y;
     double avg_speed = state->avg_speed;
     int locked = state->locked;
+    int pred[5];
+    const int cur0 = sync_sizes(cur, minsize, half, pred);  // what k_sync_search assumed
 
-    // frame f+1's prefix sums travel global -> registers while frame f is being searched
-    double nxt[SYNC_PER];
-    {
-        const double *p0 = sc.prefix + (long long)axis * (sc.nmax + 1);
+    int f = 0;
+    bool have_search = false;  // S.best holds this frame's own search
+    while (f < F) {
+        if (tid == 0) {
+            for (; f < F; f++) {
+                int sizes[5];
+                const int cc = sync_sizes(cur, minsize, half, sizes);
+                if (!have_search && cc != cur0) break;  // misprediction: the workgroup searches frame f
+                const FitBest *res = have_search ? S.best : spec[f * 2 + axis].best;
+                have_search = false;
+                double bestfit = -1.0;
+                int bestq = 0, bestsize = cc;
 #pragma unroll
-        for (int i = 0; i < SYNC_PER; i++) {
-            const int idx = tid + CHAIN_T * i;
-            if (idx <= n) spre[idx] = p0[idx];
-        }
-    }
-    __syncthreads();
-
-    for (int f = 0; f < F; f++) {
-        if (f + 1 < F) {
-            const double *pn = sc.prefix + ((long long)(f + 1) * 2 + axis) * (sc.nmax + 1);
-#pragma unroll
-            for (int i = 0; i < SYNC_PER; i++) {
-                const int idx = tid + CHAIN_T * i;
-                nxt[i] = (idx <= n) ? pn[idx] : 0.0;
-            }
-        }
-        const float totalf = (float)spre[n];  // narrowed by findbestfit's float parameter
-        if (cur < minsize) cur = minsize; else if (cur > half) cur = half;  // syncdetector.c:76-77
-        int sizes[5];
-        sizes[0] = cur;
-        {
-            const int trial[4] = {cur - 4, cur + 4, cur >> 1, cur << 1};
-#pragma unroll
-            for (int t = 0; t < 4; t++) sizes[t + 1] = (trial[t] >= minsize && trial[t] < half && trial[t] != cur) ? trial[t] : 0;
-        }
-        // findbestfit (syncdetector.c:26-58) for the candidate sizes at once.
-        // fit(q) = ((total-S_q)/(n-s) - S_q/s)^2 is, with every rounding kept, a monotone
-        // function of the window sum S_q on either side of its zero, so its maximum sits at the
-        // smallest or the largest S_q.  Step 1 finds those two extremes (adds and compares
-        // only); step 2 evaluates the reference's exact f64 expression — two divisions — only
-        // for windows whose sum lies within a 1e-9 band of an extreme (rounding plateaus are
-        // ~1e-16 wide), which keeps the first-maximum tie-break exact at a fraction of the cost.
-        const double pn_ = spre[n];
-        double smin[5], smax[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) { smin[k] = INFINITY; smax[k] = -INFINITY; }
-        for (int q = tid; q < n; q += CHAIN_T) {
-            const double pq = spre[q];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int s = sizes[k];
-                if (s > 0) {
-                    const int e = q + s;
-                    const double sum = (e <= n) ? (spre[e] - pq) : (pn_ - pq + spre[e - n]);
-                    smin[k] = fmin(smin[k], sum);
-                    smax[k] = fmax(smax[k], sum);
+                for (int k = 0; k < 5; k++) {
+                    if (sizes[k] <= 0) continue;
+                    // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
+                    if (k == 0 || res[k].fit > bestfit) { bestfit = res[k].fit; bestq = res[k].q; bestsize = sizes[k]; }
                 }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            if (sizes[k] > 0) {
-                double lo = smin[k], hi = smax[k];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    lo = fmin(lo, __shfl_xor(lo, o, 64));
-                    hi = fmax(hi, __shfl_xor(hi, o, 64));
-                }
-                if (lane == 0) { S.wmin[k][wave] = lo; S.wmax[k][wave] = hi; }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            if (sizes[k] > 0) {
-                double lo = S.wmin[k][lane & 15], hi = S.wmax[k][lane & 15];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    lo = fmin(lo, __shfl_xor(lo, o, 64));
-                    hi = fmax(hi, __shfl_xor(hi, o, 64));
-                }
-                smin[k] = lo;
-                smax[k] = hi;
-            }
-        }
-        FitBest mine[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) { mine[k].fit = -1.0; mine[k].q = 0x7fffffff; }
-        for (int q = tid; q < n; q += CHAIN_T) {
-            const double pq = spre[q];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int s = sizes[k];
-                if (s > 0) {
-                    const int e = q + s;
-                    const double sum = (e <= n) ? (spre[e] - pq) : (pn_ - pq + spre[e - n]);
-                    const double band = 1e-9 * (fabs(smin[k]) + fabs(smax[k])) + 1e-300;
-                    if (sum <= smin[k] + band || sum >= smax[k] - band) {
-                        const double d = ((double)totalf - sum) / (double)(n - s) - sum / (double)s;
-                        const double fit = d * d;
-                        if (fit > mine[k].fit) { mine[k].fit = fit; mine[k].q = q; }  // q ascending per thread
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            if (sizes[k] > 0) {
-                FitBest b = mine[k];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    FitBest other;
-                    other.fit = __shfl_down(b.fit, o, 64);
-                    other.q = __shfl_down(b.q, o, 64);
-                    b = better(b, other);
-                }
-                if (lane == 0) S.wbest[k][wave] = b;
-            }
-        }
-        __syncthreads();  // all reads of spre for frame f are done; wbest is complete
-        if (f + 1 < F) {
-#pragma unroll
-            for (int i = 0; i < SYNC_PER; i++) {
-                const int idx = tid + CHAIN_T * i;
-                if (idx <= n) spre[idx] = nxt[i];
-            }
-        }
-        if (wave == 0) {
-            double bestfit = -1.0;
-            int bestq = 0, bestsize = cur;
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                if (sizes[k] <= 0) continue;
-                FitBest b;
-                b.fit = (lane < 16) ? S.wbest[k][lane & 15].fit : -2.0;
-                b.q = (lane < 16) ? S.wbest[k][lane & 15].q : 0x7fffffff;
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    FitBest other;
-                    other.fit = __shfl_down(b.fit, o, 64);
-                    other.q = __shfl_down(b.q, o, 64);
-                    b = better(b, other);
-                }
-                // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
-                if (k == 0 || b.fit > bestfit) { bestfit = b.fit; bestq = b.q; bestsize = sizes[k]; }
-            }
-            if (lane == 0) {
                 // window start q carries the label of the index just removed (q-1); start 0 is labelled 0
                 const int beststart = bestq > 0 ? bestq - 1 : 0;
                 float *gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
@@ -545,35 +565,41 @@ __global__ __launch_bounds__(CHAIN_T) void k_sync_chain(int F, int W, int H, Str
                 if (rawdiff > h2) ndx += n;
                 else if (rawdiff < -h2) centre += n;
                 const int last = ndx;
-                ndx = (int)(((long long)round(centre * lowpass + (1.0 - lowpass) * ndx)) % ((long long)n));
+                // operands are far below 2^31: the reference's int64 round-and-modulo in 32 bits
+                ndx = ((int)round(centre * lowpass + (1.0 - lowpass) * ndx)) % n;
                 const int rawvx = ndx - last;
-                const int nvx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
-                S.vx = nvx;
-                S.dx = ndx;
-                S.cur = bestsize;
+                vx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
+                dx = ndx;
+                cur = bestsize;
                 ChainOut *o = &out[f];
                 if (xblock) {
                     // frameratepll, syncdetector.c:133-153
-                    avg_speed = avg_speed * 0.99 + 0.01 * nvx;
+                    avg_speed = avg_speed * 0.99 + 0.01 * vx;
                     locked = (avg_speed < 0.5 && avg_speed > -0.5) ? 1 : 0;
                     int fired = 0;
                     double diff = 0.0;
-                    if (pll_enabled && nvx != 0) {
-                        diff = locked ? (avg_speed * 0.000001) : (nvx * 0.00001);
+                    if (pll_enabled && vx != 0) {
+                        diff = locked ? (avg_speed * 0.000001) : (vx * 0.00001);
                         fired = 1;
                     }
-                    o->dx = ndx; o->vx = nvx; o->stripx = bestsize;
+                    o->dx = dx; o->vx = vx; o->stripx = cur;
                     o->locked = locked; o->pll_fired = fired;
                     o->avg_speed = avg_speed; o->frameratediff = diff;
                 } else {
-                    o->dy = ndx; o->vy = nvx; o->stripy = bestsize;
+                    o->dy = dx; o->vy = vx; o->stripy = cur;
                 }
             }
+            C.f = f;
+            C.cur = cur;
         }
-        __syncthreads();  // S.cur/dx/vx and the next frame's spre are visible
-        cur = S.cur;
-        dx = S.dx;
-        vx = S.vx;
+        __syncthreads();
+        f = C.f;
+        if (f >= F) break;
+        // frame f starts from a size the speculation did not cover
+        int sizes[5];
+        sync_sizes(C.cur, minsize, half, sizes);
+        strip_search(S, sc.prefix + ((long long)f * 2 + axis) * (sc.nmax + 1), n, sizes);
+        have_search = true;  // only lane 0's copy matters
     }
     if (tid == 0) {
         if (xblock) {
@@ -758,7 +784,10 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
                                                                strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2],
                                                                pp->taps[3], pp->taps[4]);
         KERNEL_CHECK(g, "k_strip_prepare");
-        k_sync_chain<<<2, CHAIN_T, 0, g->stream>>>(F, W, H, sc, pp->d_state, pp->d_chain, prm->pll);
+        SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
+        k_sync_search<<<dim3(2, F), SYNC_T, 0, g->stream>>>(W, H, sc, pp->d_state, spec);
+        KERNEL_CHECK(g, "k_sync_search");
+        k_sync_chain<<<2, SYNC_T, 0, g->stream>>>(F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll);
         KERNEL_CHECK(g, "k_sync_chain");
     }
     return TSDRGPU_OK;
@@ -817,8 +846,9 @@ extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frame
     if ((rc = ensure(g, &pp->d_strip_y, &pp->cap_sy, (size_t)F * 3 * H))) return rc;
     {
         const size_t nmax = (size_t)(W > H ? W : H);
-        // [F][2][nmax] floats + [F][2][nmax+1] doubles + [F][2] doubles
-        const size_t floats = (((size_t)F * 2 * nmax + 1) & ~(size_t)1) + 2 * ((size_t)F * 2 * (nmax + 1) + (size_t)F * 2) + 16;
+        // [F][2][nmax] floats + [F][2][nmax+1] doubles + [F][2] doubles + [F][2] speculative search results
+        const size_t floats = (((size_t)F * 2 * nmax + 1) & ~(size_t)1) + 2 * ((size_t)F * 2 * (nmax + 1) + (size_t)F * 2) +
+                              (size_t)F * 2 * (sizeof(SpecEntry) / sizeof(float)) + 16;
         if ((rc = ensure(g, &pp->d_work, &pp->cap_work, floats))) return rc;
     }
     if (W > STRIP_MAX || H > STRIP_MAX) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "width/height above 16384");
