@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: its HIP runtime is the one the process uses)
 
-from tempestsdr_amd import gpu, synth  # noqa: E402
+from tempestsdr_amd import gpu, shard, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -218,14 +218,15 @@ def main():
         carry = rem
         frames_done += F
         if world > 1:
-            g.sync()  # both streams
+            g.sync()  # both streams: this rank's per-lag sums are complete
             g._ck(g.lib.tsdrgpu_copy(g.h, red.data_ptr(), plots_ptr, plots_n * 8))
             g.sync()
-            dist.all_reduce(red)  # RCCL over xGMI: per-lag |R| sums of all ranks' windows
+            # RCCL all-reduce over xGMI of the per-lag |R| sums of every rank's windows
+            _, total = shard.allreduce_plots(red, nwin, dist, mean=False)
             torch.cuda.synchronize()
             g._ck(g.lib.tsdrgpu_copy(g.h, plots_ptr, red.data_ptr(), plots_n * 8))
             g.sync()
-            ac.finalize_sums(nwin * world)
+            ac.finalize_sums(total)
         fi_li = ac.argmax()  # waits for the side stream
         g.sync()             # and the frames of this step
         return fi_li
