@@ -154,6 +154,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=1.0, help="signal seconds per batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="split the frame path of a step into sub-batches of about this many frames (0 = one batch)")
+    ap.add_argument("--pmc-calibrate", action="store_true",
+                    help="also launch k_demod_vec4 over the batch (known 8 B read + 4 B written per sample) so that "
+                         "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE readings can be calibrated (scripts/pmc_summarize.py)")
     ap.add_argument("--overlap", action="store_true",
                     help="queue the autocorrelation on the side stream so it overlaps the frame path (higher "
                          "throughput; per-kernel durations then include contention, so the default keeps one stream)")
@@ -207,16 +212,24 @@ def main():
         else:
             ac.reset()
             ac.run(d_iq, 1, ac.capture, nwin, mode=1)
-        # a1+a2: the new pixels are appended behind the carried remainder
-        n = rs.process(d_iq, 1, chunk, nchunks, up, down, 0, d_pix, out_offset=carry)
-        avail = carry + n
-        F = avail // P
-        pp.run(d_pix, F, W, h, d_out, motionblur=0.0, want_info=False)
-        rem = avail - F * P
-        if rem:
-            g._ck(g.lib.tsdrgpu_copy(g.h, d_pix.at(0), d_pix.at(F * P), rem * 4))
-        carry = rem
-        frames_done += F
+        # a1+a2: the new pixels are appended behind the carried remainder; a3..a8 on the whole frames.
+        # Optionally in sub-batches so that the raw pixels of a sub-batch are still in the Infinity
+        # Cache when the statistics and the normalise/IIR pass read them back.
+        cps = nchunks if args.frames_per_launch <= 0 else max(1, args.frames_per_launch * 10)
+        done_chunks = 0
+        while done_chunks < nchunks:
+            k = min(cps, nchunks - done_chunks)
+            n = rs.process(d_iq, 1, chunk, k, up, down, 0, d_pix, in_offset=2 * done_chunks * chunk, out_offset=carry)
+            done_chunks += k
+            avail = carry + n
+            F = avail // P
+            if F:
+                pp.run(d_pix, F, W, h, d_out, motionblur=0.0, want_info=False)
+            rem = avail - F * P
+            if rem and F:
+                g._ck(g.lib.tsdrgpu_copy(g.h, d_pix.at(0), d_pix.at(F * P), rem * 4))
+            carry = rem
+            frames_done += F
         if world > 1:
             g.sync()  # both streams: this rank's per-lag sums are complete
             g._ck(g.lib.tsdrgpu_copy(g.h, red.data_ptr(), plots_ptr, plots_n * 8))
@@ -238,6 +251,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pmc_calibrate:
+        cal = torch.empty(nsamples, dtype=torch.float32, device=dev)
+        g.am_demod(d_iq, DevPtr(cal), nsamples)
+        g.sync()
+        del cal
     for _ in range(args.warmup):
         step()
     barrier()
@@ -266,10 +284,10 @@ def main():
         # ---- roofline of the dominant kernel (live HIP-event timings of the timed region)
         N, L = ac.n, ac.flen + ac.llen
         S = fs / fv
-        fft_launches = prof.get("k_fft_pass", (0, 1))[1] / max(1, args.steps)
+        fft_launches = prof.get("k_fft_lds", (0, 1))[1] / max(1, args.steps)
         alg_bytes = {
             # autocorrelation 28N+16L per window, spread over the FFT pass launches
-            "k_fft_pass": (28.0 * N + 16.0 * L) * nwin / max(1.0, fft_launches),
+            "k_fft_lds": (28.0 * N + 16.0 * L) * nwin / max(1.0, fft_launches),
             # frame path 8S+16P per frame = resample (8S+4P) + stats (4P) + normalise/IIR pass (8P)
             "k_rs_area": (8.0 * S + 4.0 * P) * (nsamples / S),
             "k_frame_stats": 4.0 * P * (frames_total / world / args.steps),

@@ -136,7 +136,7 @@ extern "C" int tsdrgpu_timer_stop_ms(tsdrgpu_t *g, float *ms)
 // ---------------------------------------------------------------------------
 static const char *const kStageNames[PROF_COUNT] = {"k_demod", "k_rs_tail+k_rs_chain", "k_rs_area", "k_rs_nearest",
                                                     "k_frame_stats", "k_frame_reduce", "k_chain", "k_frame_pass",
-                                                    "k_fft_pass", "k_ac_split", "k_accumulate", "superb_misc"};
+                                                    "k_fft_lds", "k_ac_split", "k_accumulate", "superb_misc"};
 
 ProfScope::ProfScope(tsdrgpu_t *g_, int stage, hipStream_t stream) : g(g_), st(stream), idx(-1)
 {

@@ -103,17 +103,31 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
     float cns[4] = {0, 0, 0, 0}, cs[4] = {0, 0, 0, 0}, cc[4] = {0, 0, 0, 0};
     float lo = INFINITY, hi = -INFINITY;
 
-    for (int yy = wave; yy < TILE_H; yy += 4) {
-        const int y = y0 + yy;
-        if (y >= H) break;
-        const float *row = src + (long long)y * W;
-        float rns = 0.f, rs = 0.f, rc = 0.f;
+    // phase 1: issue all of this wave's loads (8 rows x 4 columns per lane) before touching them,
+    // so that 32 requests per lane are in flight
+    constexpr int ROWS = TILE_H / 4;
+    float val[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int y = y0 + wave + 4 * r;
+        const float *row = src + (long long)(y < H ? y : 0) * W;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int x = x0 + lane + 64 * j;
-            if (x < W) {
-                const float v = row[x];
-                const bool sent = (v > 250.0f) || (v < -250.0f);  // dsp.c:57
+            val[r][j] = (y < H && x < W) ? row[x] : NAN;  // NaN = outside the frame (neither branch below takes it)
+        }
+    }
+    // phase 2
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int y = y0 + wave + 4 * r;
+        float rns = 0.f, rs = 0.f, rc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float v = val[r][j];
+            const bool sent = (v > 250.0f) || (v < -250.0f);  // dsp.c:57
+            const bool inside = (y < H) && (x0 + lane + 64 * j < W);
+            if (inside) {
                 if (sent) {
                     cs[j] += v; cc[j] += 1.f; rs += v; rc += 1.f;
                 } else {
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
                 }
             }
         }
-        if (want_strips) {
+        if (want_strips && y < H) {  // y is wave-uniform
             rns = wave_sum(rns);
             const bool any_sent = __any(rc != 0.f);
             if (any_sent) { rs = wave_sum(rs); rc = wave_sum(rc); }
@@ -625,54 +639,110 @@ __global__ __launch_bounds__(SYNC_T) void k_sync_chain(int F, int W, int H, Stri
 #define PASS_LINES 4
 #define PASS_IIR 8
 
-template <int FLAGS>
+template <int VW> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<2> { typedef float2 type; };
+template <> struct VecT<4> { typedef float4 type; };
+
+__device__ __forceinline__ float pass_one(int flags, float v, float &s, float a, double one_minus_a, float lastmin, float span,
+                                          bool on_line)
+{
+    if (flags & PASS_NORMALISE) v = (v > 250.0f || v < -250.0f) ? v : ((v - lastmin) / span);
+    if ((flags & PASS_LINES) && on_line) v = PIX_G;
+    if (flags & PASS_IIR) {
+        s = (float)((double)(s * a) + (double)v * one_minus_a);
+        v = s;
+    }
+    return v;
+}
+
+// VW consecutive pixels per thread (one VW*4-byte load/store per frame when the layout allows it),
+// two frames per loop trip so that several loads are in flight per lane.
+template <int FLAGS, int VW>
 __global__ __launch_bounds__(256) void k_frame_pass(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
                                                     long long dstride, int F, int W, int H,
                                                     const ChainOut *__restrict__ chain, float *__restrict__ screen, float a)
 {
+    typedef typename VecT<VW>::type vec_t;
     const int P = W * H;
     const double one_minus_a = 1.0 - a;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const int y = p / W, x = p - y * W;
-        float s = (FLAGS & PASS_IIR) ? screen[p] : 0.f;
+    const int ngroups = (P + VW - 1) / VW;
+    for (int grp = blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += gridDim.x * blockDim.x) {
+        const int p0 = grp * VW;
+        int x[VW], y[VW];
+        float s[VW];
+#pragma unroll
+        for (int k = 0; k < VW; k++) {
+            const int p = p0 + k;
+            y[k] = p / W;
+            x[k] = p - y[k] * W;
+            s[k] = ((FLAGS & PASS_IIR) && p < P) ? screen[p] : 0.f;
+        }
+        const bool full = (p0 + VW <= P);
+#pragma unroll 2
         for (int f = 0; f < F; f++) {
             const float *in = src + (long long)f * sstride;
-            int sp = p;
+            float *outp = dst + (long long)f * dstride;
             int dx = 0, dy = 0;
+            float lastmin = 0.f, span = 1.f;
             if (FLAGS & (PASS_ROLL | PASS_LINES)) { dx = chain[f].dx; dy = chain[f].dy; }
-            if (FLAGS & PASS_ROLL) {
-                int sx = x + dx; if (sx >= W) sx -= W;
-                int sy = y + dy; if (sy >= H) sy -= H;
-                sp = sy * W + sx;
+            if (FLAGS & PASS_NORMALISE) { lastmin = chain[f].lastmin; span = chain[f].span; }
+            float v[VW];
+            if (!(FLAGS & PASS_ROLL) && VW > 1 && full) {
+                const vec_t t = *reinterpret_cast<const vec_t *>(in + p0);
+                const float *tp = reinterpret_cast<const float *>(&t);
+#pragma unroll
+                for (int k = 0; k < VW; k++) v[k] = tp[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < VW; k++) {
+                    int sp = p0 + k;
+                    if (FLAGS & PASS_ROLL) {
+                        int sx = x[k] + dx; if (sx >= W) sx -= W;
+                        int sy = y[k] + dy; if (sy >= H) sy -= H;
+                        sp = sy * W + sx;
+                    }
+                    v[k] = (p0 + k < P) ? in[sp] : 0.f;
+                }
             }
-            float v = in[sp];
-            if (FLAGS & PASS_NORMALISE) {
-                const float lastmin = chain[f].lastmin, span = chain[f].span;
-                v = (v > 250.0f || v < -250.0f) ? v : ((v - lastmin) / span);
+#pragma unroll
+            for (int k = 0; k < VW; k++) v[k] = pass_one(FLAGS, v[k], s[k], a, one_minus_a, lastmin, span, x[k] == dx || y[k] == dy);
+            if (VW > 1 && full) {
+                vec_t t;
+                float *tp = reinterpret_cast<float *>(&t);
+#pragma unroll
+                for (int k = 0; k < VW; k++) tp[k] = v[k];
+                *reinterpret_cast<vec_t *>(outp + p0) = t;
+            } else {
+#pragma unroll
+                for (int k = 0; k < VW; k++)
+                    if (p0 + k < P) outp[p0 + k] = v[k];
             }
-            if (FLAGS & PASS_LINES) {
-                if (x == dx || y == dy) v = PIX_G;
-            }
-            if (FLAGS & PASS_IIR) {
-                s = (float)((double)(s * a) + (double)v * one_minus_a);
-                v = s;
-            }
-            dst[(long long)f * dstride + p] = v;
         }
-        if (FLAGS & PASS_IIR) screen[p] = s;
+        if (FLAGS & PASS_IIR) {
+#pragma unroll
+            for (int k = 0; k < VW; k++)
+                if (p0 + k < P) screen[p0 + k] = s[k];
+        }
     }
 }
 
 typedef void (*pass_fn)(const float *, long long, float *, long long, int, int, int, const ChainOut *, float *, float);
 
-static pass_fn pick_pass(int flags)
+template <int VW>
+static pass_fn pick_pass_vw(int flags)
 {
     switch (flags) {
-#define CASE(f) case f: return k_frame_pass<f>;
+#define CASE(f) case f: return k_frame_pass<f, VW>;
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
 #undef CASE
     }
     return nullptr;
+}
+
+static pass_fn pick_pass(int flags, int vw)
+{
+    return vw == 4 ? pick_pass_vw<4>(flags) : (vw == 2 ? pick_pass_vw<2>(flags) : pick_pass_vw<1>(flags));
 }
 
 // ---------------------------------------------------------------------------
@@ -797,12 +867,18 @@ static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long
                        int F, int W, int H, float a)
 {
     tsdrgpu_t *g = pp->g;
-    pass_fn fn = pick_pass(flags);
+    // widest vector access every frame of both buffers is aligned for
+    int vw = 4;
+    while (vw > 1 && ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)pp->d_screen)) % (vw * sizeof(float)) != 0 ||
+                      (F > 1 && (sstride % vw != 0 || dstride % vw != 0))))
+        vw >>= 1;
+    pass_fn fn = pick_pass(flags, vw);
     if (!fn) return tsdr_fail(g, TSDRGPU_EINVAL, "k_frame_pass", "unsupported flag combination");
     const long long P = (long long)W * H;
-    long long blocks = (P + 255) / 256;
-    const long long cap = (long long)g->prop.multiProcessorCount * 8;
+    long long blocks = (P / vw + 255) / 256;
+    const long long cap = (long long)g->prop.multiProcessorCount * 16;
     if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
     ProfScope prof(g, PROF_FRAME_PASS);
     fn<<<(unsigned)blocks, 256, 0, g->stream>>>(src, sstride, dst, dstride, F, W, H, pp->d_chain, pp->d_screen, a);
     KERNEL_CHECK(g, "k_frame_pass");
