@@ -187,6 +187,40 @@ int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nhops, int gat
                           int samples_in_frame, float *d_out, int32_t *h_offsets,
                           uint32_t *h_total);
 
+/* ---- the components next to the hot path ------------------------- */
+/* f1: the RawFile plugin's sample formats decoded on the device
+ * (TSDRPlugin_RawFile/src/TSDRPlugin_RawFile.c:241-261): type 0 float32 (copy), 1 int8 (/128.0),
+ * 2 int16 (/32767.0), 3 uint8 ((v-128)/128.0), 4 uint16 ((v-32767)/32767.0); n = number of values
+ * (2 per IQ sample).  Bit-exact with the plugin's double division + float store. */
+int tsdrgpu_decode_samples(tsdrgpu_t *g, const void *d_raw, int type, float *d_out, int64_t n);
+
+/* f3: frame -> packed 0x00RRGGBB exactly like the JNI shim (JavaGUI/jni/TSDRLibraryNDK.c:222-276):
+ * gray = (int)(v*255) for 0 < v <= 1, black/white outside, the PIXEL_SPECIAL_VALUE_* debug colours,
+ * TRANSPARENT keeps the pixel d_rgb already holds; `inverted` as the GUI's invert option. */
+int tsdrgpu_frame_to_rgb(tsdrgpu_t *g, const float *d_frame, int32_t *d_rgb, int64_t npixels, int inverted);
+
+/* f2: mode detection from the two plots' argmax (the GUI's logic, PlotVisualizer.java:200-247,
+ * Main.java:1233-1277,1301-1303,1346-1350, VideoMode.java:163-190): feed one (frame, line) argmax pair
+ * per plot update; `accepted` becomes 1 once the same (fps, height) was seen 3 times before. */
+typedef struct tsdrgpu_modedetect tsdrgpu_modedetect_t;
+typedef struct tsdrgpu_detection {
+    int frame_lag, line_lag;   /* offset + argmax index, in samples */
+    double framerate;          /* samplerate / frame_lag */
+    double linerate;           /* samplerate / line_lag */
+    int height;                /* round(frame_lag / line_lag): total lines */
+    double pixelrate;          /* width*height*framerate as tsdr_setresolution would derive it */
+    int seen, accepted;
+    int mode_id;               /* closest pre-registered video mode, -1 if none */
+    char mode_name[48];
+    int mode_width, mode_height;
+    double mode_refresh;
+} tsdrgpu_detection_t;
+int tsdrgpu_modedetect_create(tsdrgpu_modedetect_t **out);
+void tsdrgpu_modedetect_destroy(tsdrgpu_modedetect_t *d);
+void tsdrgpu_modedetect_reset(tsdrgpu_modedetect_t *d);
+int tsdrgpu_modedetect_feed(tsdrgpu_modedetect_t *d, int frame_offset, int frame_idx, int line_offset,
+                            int line_idx, uint32_t samplerate, tsdrgpu_detection_t *out);
+
 #ifdef __cplusplus
 }
 #endif

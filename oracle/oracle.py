@@ -95,6 +95,8 @@ _sig(lib.orc_complex_to_abs_diff, None, f32p, C.c_int)
 _sig(lib.orc_superb_bestfit, C.c_int, f32p, f32p, C.c_int, C.c_int)
 _sig(lib.orc_superb_stitch, C.c_uint32, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, f32p,
      i32p)
+_sig(lib.orc_decode_samples, None, C.c_void_p, C.c_int, f32p, C.c_int64)
+_sig(lib.orc_frame_to_rgb, None, f32p, i32p, C.c_int64, C.c_int)
 _sig(lib.orc_dropped_shift_with, C.c_int64, C.c_int64, C.c_uint32, C.c_int64)
 _sig(lib.orc_dropped_add, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, C.c_int,
      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))

@@ -797,3 +797,45 @@ ORC_API int64_t orc_dropped_add(int64_t difference, uint32_t size, uint32_t bloc
     if (difference < 0) difference = (int64_t)orc_drop_comp((int)block, (int)-difference);
     return difference;
 }
+
+/* ------------------------------------------------------------------------ */
+/* §8(f) rows — adjacent components                                          */
+/* ------------------------------------------------------------------------ */
+
+/* RawFile sample formats -> float, TSDRPlugin_RawFile/src/TSDRPlugin_RawFile.c:241-261.
+   type: 0 float, 1 int8, 2 int16, 3 uint8, 4 uint16 (the plugin's TYPE_* ids, :29-33). */
+ORC_API void orc_decode_samples(const void *raw, int type, float *out, int64_t n)
+{
+    switch (type) {
+        case 0: memcpy(out, raw, sizeof(float) * (size_t)n); break;
+        case 1: for (int64_t i = 0; i < n; i++) out[i] = ((const int8_t *)raw)[i] / 128.0; break;
+        case 2: for (int64_t i = 0; i < n; i++) out[i] = ((const int16_t *)raw)[i] / 32767.0; break;
+        case 3: for (int64_t i = 0; i < n; i++) out[i] = (((const uint8_t *)raw)[i] - 128) / 128.0; break;
+        case 4: for (int64_t i = 0; i < n; i++) out[i] = (((const uint16_t *)raw)[i] - 32767) / 32767.0; break;
+    }
+}
+
+/* frame -> packed 0x00RRGGBB, JavaGUI/jni/TSDRLibraryNDK.c:222-276.  Pixels equal
+   to PIXEL_SPECIAL_VALUE_TRANSPARENT keep what `rgb` already holds. */
+ORC_API void orc_frame_to_rgb(const float *frame, int32_t *rgb, int64_t n, int inverted)
+{
+    for (int64_t i = 0; i < n; i++) {
+        const float val = frame[i];
+        if (val > 0.0f && val <= 1.0f) {
+            const int col = inverted ? (255 - (int)(val * 255.0f)) : ((int)(val * 255.0f));
+            rgb[i] = col | (col << 8) | (col << 16);
+        } else if (val <= 0.0f) {
+            rgb[i] = inverted ? (255 | (255 << 8) | (255 << 16)) : 0;
+        } else if (val == 256.0f) {
+            rgb[i] = 255 << 16;
+        } else if (val == 512.0f) {
+            rgb[i] = 255 << 8;
+        } else if (val == 1024.0f) {
+            rgb[i] = 255;
+        } else if (val == 2048.0f) {
+            /* transparent: left as is */
+        } else {
+            rgb[i] = inverted ? 0 : (255 | (255 << 8) | (255 << 16));
+        }
+    }
+}

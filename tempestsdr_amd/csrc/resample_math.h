@@ -42,7 +42,8 @@ struct RsChunk {
 };
 
 struct RsGeom {
-    double r;  // upsample_by/downsample_by
+    double r;     // upsample_by/downsample_by
+    double rinv;  // ~1/r, used only to seed searches
     double o;
     unsigned size;
 };
@@ -81,7 +82,8 @@ TSDR_HD int rs_owner_from(const RsGeom &g, double p, int id)
 
 TSDR_HD int rs_owner(const RsGeom &g, double p)
 {
-    const double guess = (p + 1.0 - g.r - g.o) / g.r;
+    // only a starting point for the exact search below, so a reciprocal multiply is as good as the division
+    const double guess = (p + 1.0 - g.r - g.o) * g.rinv;
     int id = (guess < 0.0) ? 0 : ((guess >= 2147483000.0) ? (int)g.size : (int)guess + 1);
     return rs_owner_from(g, p, id);
 }

@@ -344,7 +344,7 @@ struct SampleLoad {
 
 // phase 1: every chunk's outgoing contrib, in parallel
 template <bool IQ>
-__global__ void k_rs_tail(const RsChunk *__restrict__ chunks, int nchunks, double r, const float *__restrict__ in,
+__global__ void k_rs_tail(const RsChunk *__restrict__ chunks, int nchunks, double r, double rinv, const float *__restrict__ in,
                           double *__restrict__ tail, unsigned char *__restrict__ need)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,6 +352,7 @@ __global__ void k_rs_tail(const RsChunk *__restrict__ chunks, int nchunks, doubl
     const RsChunk ch = chunks[c];
     RsGeom g;
     g.r = r;
+    g.rinv = rinv;
     g.o = ch.o;
     g.size = ch.size;
     SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
@@ -364,7 +365,7 @@ __global__ void k_rs_tail(const RsChunk *__restrict__ chunks, int nchunks, doubl
 // its outgoing contrib does not depend on the incoming one and the chain is a
 // shift; chunks that do depend on it (need[c]) force the scalar replay.
 template <bool IQ>
-__global__ __launch_bounds__(256) void k_rs_chain(const RsChunk *__restrict__ chunks, int nchunks, double r,
+__global__ __launch_bounds__(256) void k_rs_chain(const RsChunk *__restrict__ chunks, int nchunks, double r, double rinv,
                                                   const float *__restrict__ in, const double *__restrict__ tail,
                                                   const unsigned char *__restrict__ need, double *__restrict__ cin,
                                                   double *__restrict__ contrib_state)
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(256) void k_rs_chain(const RsChunk *__restrict__ ch
             const RsChunk ch = chunks[c];
             RsGeom g;
             g.r = r;
+    g.rinv = rinv;
             g.o = ch.o;
             g.size = ch.size;
             SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
@@ -404,12 +406,13 @@ __global__ __launch_bounds__(256) void k_rs_chain(const RsChunk *__restrict__ ch
 // ends fall back to dword stores.
 #define RS_NPIX 8
 template <bool IQ>
-__global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chunks, double r, const float *__restrict__ in,
+__global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chunks, double r, double rinv, const float *__restrict__ in,
                                                  const double *__restrict__ cin, float *__restrict__ out)
 {
     const RsChunk ch = chunks[blockIdx.y];
     RsGeom g;
     g.r = r;
+    g.rinv = rinv;
     g.o = ch.o;
     g.size = ch.size;
     SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
@@ -578,17 +581,17 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
         {
             ProfScope prof(g, PROF_RS_CARRY);
             if (in_is_iq) {
-                k_rs_tail<true><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need);
-                k_rs_chain<true><<<1, 256, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+                k_rs_tail<true><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need);
+                k_rs_chain<true><<<1, 256, 0, g->stream>>>(d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
             } else {
-                k_rs_tail<false><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need);
-                k_rs_chain<false><<<1, 256, 0, g->stream>>>(d_tab, nchunks, r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+                k_rs_tail<false><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need);
+                k_rs_chain<false><<<1, 256, 0, g->stream>>>(d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
             }
         }
         if (max_out) {
             ProfScope prof(g, PROF_RS_AREA);
-            if (in_is_iq) k_rs_area<true><<<grid4, 256, 0, g->stream>>>(d_tab, r, d_in, rs->d_cin, d_out);
-            else k_rs_area<false><<<grid4, 256, 0, g->stream>>>(d_tab, r, d_in, rs->d_cin, d_out);
+            if (in_is_iq) k_rs_area<true><<<grid4, 256, 0, g->stream>>>(d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out);
+            else k_rs_area<false><<<grid4, 256, 0, g->stream>>>(d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out);
         }
         KERNEL_CHECK(g, "k_rs_area");
     }

@@ -1,0 +1,209 @@
+// tsdrgpu_extras.hip — the components right next to the hot path:
+//   f1  sample-format decode of the RawFile plugin on the device
+//       (TSDRPlugin_RawFile/src/TSDRPlugin_RawFile.c:241-261): int8/uint8/int16/uint16 raw IQ cross
+//       PCIe at 1/4..1/2 of the float32 volume
+//   f2  native mode detection: argmax of the two plots -> frame rate / line count, the
+//       "seen 3 times" acceptance rule and the video-mode table lookup that live in the Java GUI
+//       (PlotVisualizer.java:200-247, Main.java:82,1233-1277,1301-1303,1346-1350, VideoMode.java:25-190)
+//   f3  frame -> packed RGB with the debug colours and inversion of the JNI shim
+//       (JavaGUI/jni/TSDRLibraryNDK.c:222-276), so that 4 bytes/pixel of final image leave the GPU
+#include "tsdrgpu_internal.h"
+#include <math.h>
+
+// ---------------------------------------------------------------------------
+// f1  decode.  The plugin divides in double and stores a float; the same here.
+// ---------------------------------------------------------------------------
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_decode(const void *__restrict__ raw, float *__restrict__ out, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v;
+        if (TYPE == 1) v = (double)((const signed char *)raw)[i] / 128.0;
+        else if (TYPE == 2) v = (double)((const short *)raw)[i] / 32767.0;
+        else if (TYPE == 3) v = (double)((int)((const unsigned char *)raw)[i] - 128) / 128.0;
+        else v = (double)((int)((const unsigned short *)raw)[i] - 32767) / 32767.0;
+        out[i] = (float)v;
+    }
+}
+
+extern "C" int tsdrgpu_decode_samples(tsdrgpu_t *g, const void *d_raw, int type, float *d_out, int64_t n)
+{
+    if (!g || !d_raw || !d_out || n < 0 || type < 0 || type > 4) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_decode_samples", "bad argument") : TSDRGPU_EINVAL;
+    if (n == 0) return TSDRGPU_OK;
+    if (type == 0) {
+        HIP_TRY(g, hipMemcpyAsync(d_out, d_raw, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, g->stream));
+        return TSDRGPU_OK;
+    }
+    long long blocks = (n + 255) / 256;
+    const long long cap = (long long)g->prop.multiProcessorCount * 16;
+    if (blocks > cap) blocks = cap;
+    switch (type) {
+        case 1: k_decode<1><<<(unsigned)blocks, 256, 0, g->stream>>>(d_raw, d_out, n); break;
+        case 2: k_decode<2><<<(unsigned)blocks, 256, 0, g->stream>>>(d_raw, d_out, n); break;
+        case 3: k_decode<3><<<(unsigned)blocks, 256, 0, g->stream>>>(d_raw, d_out, n); break;
+        default: k_decode<4><<<(unsigned)blocks, 256, 0, g->stream>>>(d_raw, d_out, n); break;
+    }
+    KERNEL_CHECK(g, "k_decode");
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// f3  frame -> 0x00RRGGBB
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_frame_to_rgb(const float *__restrict__ frame, int *__restrict__ rgb, long long n, int inverted)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float val = frame[i];
+        if (val > 0.0f && val <= 1.0f) {
+            const int col = inverted ? (255 - (int)(val * 255.0f)) : ((int)(val * 255.0f));
+            rgb[i] = col | (col << 8) | (col << 16);
+        } else if (val <= 0.0f) {
+            rgb[i] = inverted ? 0xFFFFFF : 0;
+        } else if (val == 256.0f) {   // PIXEL_SPECIAL_VALUE_R
+            rgb[i] = 255 << 16;
+        } else if (val == 512.0f) {   // PIXEL_SPECIAL_VALUE_G
+            rgb[i] = 255 << 8;
+        } else if (val == 1024.0f) {  // PIXEL_SPECIAL_VALUE_B
+            rgb[i] = 255;
+        } else if (val == 2048.0f) {  // PIXEL_SPECIAL_VALUE_TRANSPARENT: the previous pixel stays
+        } else {
+            rgb[i] = inverted ? 0 : 0xFFFFFF;
+        }
+    }
+}
+
+extern "C" int tsdrgpu_frame_to_rgb(tsdrgpu_t *g, const float *d_frame, int32_t *d_rgb, int64_t npixels, int inverted)
+{
+    if (!g || !d_frame || !d_rgb || npixels < 0) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_frame_to_rgb", "bad argument") : TSDRGPU_EINVAL;
+    if (npixels == 0) return TSDRGPU_OK;
+    long long blocks = (npixels + 255) / 256;
+    const long long cap = (long long)g->prop.multiProcessorCount * 16;
+    if (blocks > cap) blocks = cap;
+    k_frame_to_rgb<<<(unsigned)blocks, 256, 0, g->stream>>>(d_frame, (int *)d_rgb, npixels, inverted);
+    KERNEL_CHECK(g, "k_frame_to_rgb");
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// f2  mode detection (host-side arithmetic on the two argmax indices)
+// ---------------------------------------------------------------------------
+struct VideoModeRow {
+    const char *name;
+    int width, height;  // TOTAL pixels per line / lines per frame, blanking included
+    double refresh;
+};
+
+// the GUI's pre-registered modes, JavaGUI/src/martin/tempest/gui/VideoMode.java:25-106 (data)
+static const VideoModeRow kModes[] = {
+    {"PAL TV", 576, 625, 25}, {"640x400 @ 85Hz", 832, 445, 85}, {"720x400 @ 85Hz", 936, 446, 85},
+    {"640x480 @ 60Hz", 800, 525, 60}, {"640x480 @ 100Hz", 848, 509, 100}, {"640x480 @ 72Hz", 832, 520, 72},
+    {"640x480 @ 75Hz", 840, 500, 75}, {"640x480 @ 85Hz", 832, 509, 85}, {"768x576 @ 60 Hz", 976, 597, 60},
+    {"768x576 @ 72 Hz", 992, 601, 72}, {"768x576 @ 75 Hz", 1008, 602, 75}, {"768x576 @ 85 Hz", 1008, 605, 85},
+    {"768x576 @ 100 Hz", 1024, 611, 100}, {"800x600 @ 56Hz", 1024, 625, 56}, {"800x600 @ 60Hz", 1056, 628, 60},
+    {"800x600 @ 72Hz", 1040, 666, 72}, {"800x600 @ 75Hz", 1056, 625, 75}, {"800x600 @ 85Hz", 1048, 631, 85},
+    {"800x600 @ 100Hz", 1072, 636, 100}, {"1024x600 @ 60 Hz", 1312, 622, 60}, {"1024x768i @ 43Hz", 1264, 817, 43},
+    {"1024x768 @ 60Hz", 1344, 806, 60}, {"1024x768 @ 70Hz", 1328, 806, 70}, {"1024x768 @ 75Hz", 1312, 800, 75},
+    {"1024x768 @ 85Hz", 1376, 808, 85}, {"1024x768 @ 100Hz", 1392, 814, 100}, {"1024x768 @ 120Hz", 1408, 823, 120},
+    {"1152x864 @ 60Hz", 1520, 895, 60}, {"1152x864 @ 75Hz", 1600, 900, 75}, {"1152x864 @ 85Hz", 1552, 907, 85},
+    {"1152x864 @ 100Hz", 1568, 915, 100}, {"1280x768 @ 60 Hz", 1680, 795, 60}, {"1280x800 @ 60 Hz", 1680, 828, 60},
+    {"1280x960 @ 60Hz", 1800, 1000, 60}, {"1280x960 @ 75Hz", 1728, 1002, 75}, {"1280x960 @ 85Hz", 1728, 1011, 85},
+    {"1280x960 @ 100Hz", 1760, 1017, 100}, {"1280x1024 @ 60Hz", 1688, 1066, 60}, {"1280x1024 @ 75Hz", 1688, 1066, 75},
+    {"1280x1024 @ 85Hz", 1728, 1072, 85}, {"1280x1024 @ 100Hz", 1760, 1085, 100}, {"1280x1024 @ 120Hz", 1776, 1097, 120},
+    {"1368x768 @ 60 Hz", 1800, 795, 60}, {"1400x1050 @ 60Hz", 1880, 1082, 60}, {"1400x1050 @ 72 Hz", 1896, 1094, 72},
+    {"1400x1050 @ 75 Hz", 1896, 1096, 75}, {"1400x1050 @ 85 Hz", 1912, 1103, 85}, {"1400x1050 @ 100 Hz", 1928, 1112, 100},
+    {"1440x900 @ 60 Hz", 1904, 932, 60}, {"1440x1050 @ 60 Hz", 1936, 1087, 60}, {"1600x1000 @ 60Hz", 2144, 1035, 60},
+    {"1600x1000 @ 75Hz", 2160, 1044, 75}, {"1600x1000 @ 85Hz", 2176, 1050, 85}, {"1600x1000 @ 100Hz", 2192, 1059, 100},
+    {"1600x1024 @ 60Hz", 2144, 1060, 60}, {"1600x1024 @ 75Hz", 2176, 1069, 75}, {"1600x1024 @ 76Hz", 2096, 1070, 76},
+    {"1600x1024 @ 85Hz", 2176, 1075, 85}, {"1600x1200 @ 60Hz", 2160, 1250, 60}, {"1600x1200 @ 65Hz", 2160, 1250, 65},
+    {"1600x1200 @ 70Hz", 2160, 1250, 70}, {"1600x1200 @ 75Hz", 2160, 1250, 75}, {"1600x1200 @ 85Hz", 2160, 1250, 85},
+    {"1600x1200 @ 100 Hz", 2208, 1271, 100}, {"1680x1050 @ 60Hz (reduced blanking)", 1840, 1080, 60},
+    {"1680x1050 @ 60Hz (non-interlaced)", 2240, 1089, 60}, {"1680x1050 @ 60 Hz", 2256, 1087, 60},
+    {"1792x1344 @ 60Hz", 2448, 1394, 60}, {"1792x1344 @ 75Hz", 2456, 1417, 75}, {"1856x1392 @ 60Hz", 2528, 1439, 60},
+    {"1856x1392 @ 75Hz", 2560, 1500, 75}, {"1920x1080 @ 60Hz", 2576, 1125, 60}, {"1920x1080 @ 75Hz", 2608, 1126, 75},
+    {"1920x1200 @ 60Hz", 2592, 1242, 60}, {"1920x1200 @ 75Hz", 2624, 1253, 75}, {"1920x1440 @ 60Hz", 2600, 1500, 60},
+    {"1920x1440 @ 75Hz", 2640, 1500, 75}, {"1920x2400 @ 25Hz", 2048, 2434, 25}, {"1920x2400 @ 30Hz", 2044, 2434, 30},
+    {"2048x1536 @ 60Hz", 2800, 1589, 60},
+};
+static const int kModeCount = (int)(sizeof(kModes) / sizeof(kModes[0]));
+
+// VideoMode.findClosestVideoModeId(framerate, height, modes), VideoMode.java:163-190
+static int closest_mode(double framerate, int height)
+{
+    int mode = -1;
+    double diff = 5000.0;
+    for (int i = 0; i < kModeCount; i++)
+        if (kModes[i].height == height) {
+            const double delta = fabs(kModes[i].refresh - framerate);
+            if (delta < diff) { diff = delta; mode = i; }
+        }
+    if (mode == -1) {
+        int idiff = 5000;
+        for (int i = 0; i < kModeCount; i++) {
+            const int delta = abs(kModes[i].height - height);
+            if (delta < idiff) { idiff = delta; mode = i; }
+        }
+    }
+    return mode;
+}
+
+#define DETECT_SLOTS 256
+struct tsdrgpu_modedetect {
+    long long key[DETECT_SLOTS];
+    int count[DETECT_SLOTS];
+    int used;
+};
+
+extern "C" int tsdrgpu_modedetect_create(tsdrgpu_modedetect_t **out)
+{
+    if (!out) return TSDRGPU_EINVAL;
+    *out = (tsdrgpu_modedetect_t *)calloc(1, sizeof(tsdrgpu_modedetect_t));
+    return *out ? TSDRGPU_OK : TSDRGPU_ENOMEM;
+}
+extern "C" void tsdrgpu_modedetect_destroy(tsdrgpu_modedetect_t *d) { free(d); }
+extern "C" void tsdrgpu_modedetect_reset(tsdrgpu_modedetect_t *d) { if (d) d->used = 0; }
+
+// One (frame plot, line plot) pair, as Main.onIncommingPlot handles it (Main.java:1233-1277).
+extern "C" int tsdrgpu_modedetect_feed(tsdrgpu_modedetect_t *d, int frame_offset, int frame_idx, int line_offset, int line_idx,
+                                       uint32_t samplerate, tsdrgpu_detection_t *out)
+{
+    if (!d || !out || frame_offset + frame_idx <= 0 || line_offset + line_idx <= 0) return TSDRGPU_EINVAL;
+    memset(out, 0, sizeof(*out));
+    const int frame_lag = frame_offset + frame_idx, line_lag = line_offset + line_idx;
+    const double fps = samplerate / (double)frame_lag;                         // Main.java:1301-1303
+    const double h = (double)frame_lag / (double)line_lag;                     // Main.java:1346-1350
+    const int height = (int)floor(h + 0.5);                                    // Math.round
+    const long long key = (long long)(fps * height);                           // hashHeightAndFPS, Main.java:1229-1231
+    out->frame_lag = frame_lag;
+    out->line_lag = line_lag;
+    out->framerate = fps;
+    out->linerate = samplerate / (double)line_lag;
+    out->height = height;
+    int slot = -1;
+    for (int i = 0; i < d->used; i++)
+        if (d->key[i] == key) { slot = i; break; }
+    // accepted once the same (fps, height) has already been seen 3 times (Main.java:82,1257-1268)
+    if (slot >= 0 && d->count[slot] == 3) {
+        out->accepted = 1;
+    } else {
+        if (slot < 0) {
+            slot = d->used < DETECT_SLOTS ? d->used++ : (DETECT_SLOTS - 1);
+            d->key[slot] = key;
+            d->count[slot] = 0;
+        }
+        d->count[slot]++;
+    }
+    out->seen = d->count[slot];
+    const int m = closest_mode(fps, height);
+    out->mode_id = m;
+    if (m >= 0) {
+        snprintf(out->mode_name, sizeof(out->mode_name), "%s", kModes[m].name);
+        out->mode_width = kModes[m].width;
+        out->mode_height = kModes[m].height;
+        out->mode_refresh = kModes[m].refresh;
+    }
+    // what tsdr_setresolution(height, fps) would derive (TSDRLibrary.c:543-546)
+    out->pixelrate = (double)((int)(2 * (samplerate / (fps * height)))) * height * fps;
+    return TSDRGPU_OK;
+}

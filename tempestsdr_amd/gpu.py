@@ -29,6 +29,13 @@ class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int)]
 
 
+class Detection(C.Structure):
+    _fields_ = [("frame_lag", C.c_int), ("line_lag", C.c_int), ("framerate", C.c_double), ("linerate", C.c_double),
+                ("height", C.c_int), ("pixelrate", C.c_double), ("seen", C.c_int), ("accepted", C.c_int),
+                ("mode_id", C.c_int), ("mode_name", C.c_char * 48), ("mode_width", C.c_int),
+                ("mode_height", C.c_int), ("mode_refresh", C.c_double)]
+
+
 class PPFrameInfo(C.Structure):
     _fields_ = [("lastmin", C.c_float), ("lastmax", C.c_float),
                 ("dx", C.c_int), ("vx", C.c_int), ("stripx", C.c_int),
@@ -85,6 +92,12 @@ _SIGS = {
     "tsdrgpu_autocorr_last_corr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]),
     "tsdrgpu_superb_stitch": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
+    "tsdrgpu_decode_samples": (C.c_int, [vp, vp, C.c_int, vp, C.c_int64]),
+    "tsdrgpu_frame_to_rgb": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int]),
+    "tsdrgpu_modedetect_create": (C.c_int, [C.POINTER(vp)]),
+    "tsdrgpu_modedetect_destroy": (None, [vp]),
+    "tsdrgpu_modedetect_reset": (None, [vp]),
+    "tsdrgpu_modedetect_feed": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(Detection)]),
 }
 
 _lib = None
@@ -236,6 +249,15 @@ class TsdrGpu:
     # ---- a1 ----------------------------------------------------------------
     def am_demod(self, d_iq, d_out, nsamples, iq_offset=0, out_offset=0):
         self._ck(self.lib.tsdrgpu_am_demod(self.h, d_iq.at(iq_offset), d_out.at(out_offset), nsamples))
+
+    # ---- §8(f) ---------------------------------------------------------------
+    SAMPLE_TYPES = {"float": 0, "int8": 1, "int16": 2, "uint8": 3, "uint16": 4}
+
+    def decode_samples(self, d_raw, sample_type, d_out, n):
+        self._ck(self.lib.tsdrgpu_decode_samples(self.h, d_raw.ptr, self.SAMPLE_TYPES[sample_type], d_out.ptr, n))
+
+    def frame_to_rgb(self, d_frame, d_rgb, npixels, inverted=False, frame_offset=0):
+        self._ck(self.lib.tsdrgpu_frame_to_rgb(self.h, d_frame.at(frame_offset), d_rgb.ptr, npixels, int(inverted)))
 
     # ---- a13/a14 -------------------------------------------------------------
     def fft_perform(self, d_iq, n, inverse, offset=0):
@@ -396,3 +418,29 @@ class Autocorr:
         self.ctx._ck(self.ctx.lib.tsdrgpu_download(self.ctx.h, out.ctypes.data, p.value, out.nbytes))
         self.ctx.sync()
         return out
+
+
+class ModeDetect:
+    """The GUI's auto-resolution logic (Main.onIncommingPlot) as a library object; CPU only."""
+
+    def __init__(self):
+        self.lib = load_library()
+        h = vp()
+        if self.lib.tsdrgpu_modedetect_create(C.byref(h)) != 0:
+            raise TsdrGpuError("tsdrgpu_modedetect_create failed")
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.tsdrgpu_modedetect_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.lib.tsdrgpu_modedetect_reset(self.h)
+
+    def feed(self, frame_offset, frame_idx, line_offset, line_idx, samplerate):
+        d = Detection()
+        rc = self.lib.tsdrgpu_modedetect_feed(self.h, frame_offset, frame_idx, line_offset, line_idx, samplerate, C.byref(d))
+        if rc != 0:
+            raise TsdrGpuError(f"tsdrgpu_modedetect_feed failed with {rc}")
+        return d

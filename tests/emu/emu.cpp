@@ -12,6 +12,7 @@ unsigned emu_resample_chunk(const float *in, unsigned size, double up, double do
 {
     RsGeom g;
     g.r = up / down;
+    g.rinv = down / up;
     g.size = size;
     g.o = -offset_in * g.r;
     const unsigned n_out = (unsigned)(int)(((double)size - offset_in) * g.r);

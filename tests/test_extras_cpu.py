@@ -1,0 +1,89 @@
+"""SURVEY §8(f) rows, CPU side: the oracle's sample decode pinned against the
+reference's RawFile plugin binary, and the mode-detection object against a
+restatement of the Java GUI's logic."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tempestsdr_amd import build, gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAW = os.path.join(ROOT, "oracle", "_ref", "libTSDRPlugin_RawFile_bench.so")
+CB = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_uint64, C.c_void_p, C.c_int64)
+
+
+@pytest.mark.parametrize("fmt,dtype,tid", [("int8", np.int8, 1), ("int16", np.int16, 2), ("uint8", np.uint8, 3),
+                                            ("uint16", np.uint16, 4), ("float", np.float32, 0)])
+def test_oracle_decode_equals_rawfile_plugin(orc, tmp_path, fmt, dtype, tid):
+    """TSDRPlugin_RawFile.c:241-261 through the compiled plugin itself (free-running build)."""
+    if not os.path.exists(RAW):
+        pytest.skip("oracle/_ref not built")
+    n = 512 * 1024  # one plugin block (SAMPLES_TO_READ_AT_ONCE)
+    rng = np.random.default_rng(3)
+    if dtype == np.float32:
+        raw = rng.standard_normal(n).astype(np.float32)
+    else:
+        info = np.iinfo(dtype)
+        raw = rng.integers(info.min, info.max + 1, n).astype(dtype)
+        raw[:4] = [info.min, info.max, 0 if info.min < 0 else 128, 1]
+    path = tmp_path / f"s.{fmt}"
+    raw.tofile(path)
+    plug = C.CDLL(RAW)
+    plug.tsdrplugin_init.argtypes = [C.c_char_p]
+    plug.tsdrplugin_readasync.argtypes = [CB, C.c_void_p]
+    params = C.create_string_buffer(f"{path} 8000000 {fmt}".encode())  # the plugin tokenises in place
+    assert plug.tsdrplugin_init(params) == 0
+    got = []
+
+    def cb(buf, items, ctx, dropped):
+        if not got:
+            got.append(np.ctypeslib.as_array(buf, shape=(items,)).copy())
+        plug.tsdrplugin_stop()
+
+    assert plug.tsdrplugin_readasync(CB(cb), None) == 0
+    want = np.empty(n, np.float32)
+    orc.lib.orc_decode_samples(raw.ctypes.data, tid, want, n)
+    assert np.array_equal(got[0], want)
+
+
+def java_round(x):
+    return int(math.floor(x + 0.5))
+
+
+def test_modedetect_follows_the_gui_logic():
+    build.build(verbose=False)
+    md = gpu.ModeDetect()
+    fs = 100_000_000
+    flo, llo = 1149425, 766
+    # Main.onIncommingPlot: fps = fs/(offset+idx); height = round(frame_lag/line_lag); accepted when the same
+    # (long)(fps*height) key has already been counted AUTO_FRAMERATE_CONVERGANCE_ITERATIONS = 3 times
+    seq = [(517242, 715), (517242, 715), (517240, 715), (517242, 715), (517242, 715), (517242, 715)]
+    counts = {}
+    for (fi, li) in seq:
+        d = md.feed(flo, fi, llo, li, fs)
+        frame_lag, line_lag = flo + fi, llo + li
+        fps = fs / frame_lag
+        height = java_round(frame_lag / line_lag)
+        key = int(fps * height)
+        accepted = counts.get(key) == 3
+        if not accepted:
+            counts[key] = counts.get(key, 0) + 1
+        assert (d.frame_lag, d.line_lag, d.height) == (frame_lag, line_lag, height)
+        assert d.framerate == fps and d.linerate == fs / line_lag
+        assert d.accepted == int(accepted) and d.seen == counts[key]
+    assert d.accepted == 1
+    assert (d.height, round(d.framerate, 3)) == (1125, 60.0)
+    assert d.mode_name == b"1920x1080 @ 60Hz" and (d.mode_width, d.mode_height) == (2576, 1125)
+    w = int(2 * (fs / (d.framerate * d.height)))  # TSDRLibrary.c:543-546
+    assert d.pixelrate == w * d.height * d.framerate
+    # no mode with that height: the closest height wins (VideoMode.java:177-187)
+    md.reset()
+    d = md.feed(0, 1_000_000, 0, 1000, fs)  # height 1000 exists (1280x960 @ 60Hz); fps 100
+    assert d.mode_name == b"1280x960 @ 60Hz"
+    d = md.feed(0, 2_000_000, 0, 1999, fs)  # height 1001 -> closest height 1000 / 1002
+    assert d.mode_height in (1000, 1002)
+    with pytest.raises(gpu.TsdrGpuError):
+        md.feed(0, 0, 0, 0, fs)
