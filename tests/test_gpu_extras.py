@@ -52,7 +52,8 @@ def test_frame_to_rgb(orc, inverted):
     g.frame_to_rgb(d_fr, d_rgb, n, inverted)
     got = d_rgb.download()
     assert np.array_equal(got, want)
-    assert np.array_equal(got[3::97], prev[3::97])
+    keep = fr == 2048.0
+    assert keep.sum() > 1000 and np.array_equal(got[keep], prev[keep])
 
 
 def test_decode_then_pipeline_matches_float_path(orc):
