@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="also launch k_demod_vec4 over the batch (known 8 B read + 4 B written per sample) so that "
                          "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE readings can be calibrated (scripts/pmc_summarize.py)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (sums + all-reduce + finalize) even with one rank; used to "
+                         "exercise the RCCL path on a 1-GPU box")
     ap.add_argument("--overlap", action="store_true",
                     help="queue the autocorrelation on the side stream so it overlaps the frame path (higher "
                          "throughput; per-kernel durations then include contention, so the default keeps one stream)")
@@ -168,9 +171,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    sharded = dist is not None  # autocorrelation as per-lag sums + all-reduce
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -198,7 +207,7 @@ def main():
     out = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
     d_pix, d_out = DevPtr(pix), DevPtr(out)
     plots_ptr, plots_n = ac.device_plots()
-    red = torch.zeros(plots_n, dtype=torch.float64, device=dev) if world > 1 else None
+    red = torch.zeros(plots_n, dtype=torch.float64, device=dev) if sharded else None
 
     carry = 0  # pixels left over from the previous step (a frame straddling two batches)
     frames_done = 0
@@ -207,7 +216,7 @@ def main():
 
     def step():
         nonlocal carry, frames_done
-        if world == 1:
+        if not sharded:
             ac.run(d_iq, 1, ac.capture, nwin, mode=0)  # queued first: overlaps everything below
         else:
             ac.reset()
@@ -230,7 +239,7 @@ def main():
                 g._ck(g.lib.tsdrgpu_copy(g.h, d_pix.at(0), d_pix.at(F * P), rem * 4))
             carry = rem
             frames_done += F
-        if world > 1:
+        if sharded:
             g.sync()  # both streams: this rank's per-lag sums are complete
             g._ck(g.lib.tsdrgpu_copy(g.h, red.data_ptr(), plots_ptr, plots_n * 8))
             g.sync()
@@ -333,7 +342,7 @@ def main():
                          "height": int(round(flag / llag)), "linerate": round(fs / llag, 2)},
             "device": g.device_name(),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.force_dist:
             try:
                 half = min(nsamples, 50_000_000)
                 host = iq[:2 * half].cpu().numpy()

@@ -1,0 +1,175 @@
+"""Edge cases through the C ABI: empty and ragged inputs, odd geometries, size
+changes between calls, maximum sizes, many-frame batches."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tempestsdr_amd import gpu
+from gpu_util import ctx
+import cases
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(21)
+
+
+def test_empty_calls_are_noops(orc):
+    g = ctx()
+    d = g.empty(16)
+    g.am_demod(d, d, 0)
+    rs = gpu.Resampler(g)
+    assert rs.process(d, 0, 7, 0, 2.0, 1.0, 0, d) == 0
+    assert rs.state() == (0.0, 0.0)
+    pp = gpu.PostProcess(g)
+    assert pp.run(d, 0, 4, 4, d) == []
+    ac = gpu.Autocorr(g, 300_000)
+    ac.run(d, 0, ac.capture, 0)
+    f, l, calls = ac.plots()
+    assert calls == 0 and not f.any() and not l.any()
+    g.decode_samples(d, "int16", d, 0)
+    g.frame_to_rgb(d, g.empty(16, np.int32), 0)
+
+
+def test_bad_arguments_are_rejected(orc):
+    g = ctx()
+    d = g.empty(64)
+    with pytest.raises(gpu.TsdrGpuError):
+        g.fft_perform(d, 24, 0)  # not a power of two
+    rs = gpu.Resampler(g)
+    with pytest.raises(gpu.TsdrGpuError):
+        rs.process(d, 0, 16, 2, 4.0, 1.0, 0, d)  # output buffer too small (needs 128)
+    with pytest.raises(gpu.TsdrGpuError):
+        rs.process(d, 0, 0, 1, 2.0, 1.0, 0, d)  # chunk of zero samples
+    with pytest.raises(gpu.TsdrGpuError):
+        gpu.Autocorr(g, 100)  # lag windows empty at this rate
+    pp = gpu.PostProcess(g)
+    with pytest.raises(gpu.TsdrGpuError):
+        pp.run(d, 1, 0, 4, d)
+
+
+@pytest.mark.parametrize("w,h", [(5, 3), (7, 129), (257, 33), (1033, 806), (64, 64), (4000, 11)])
+@pytest.mark.parametrize("cfg", [(0, 0, 0, 0.5), (1, 0, 1, 0.0), (0, 1, 0, 0.25)])
+def test_ragged_frame_geometries(orc, w, h, cfg):
+    """widths/heights that are not multiples of any tile, vector width or wave size"""
+    g = ctx()
+    lbs, aap, ash, mb = cfg
+    rng = np.random.default_rng(w * 1000 + h)
+    frames = [cases.frame_pattern(w, h, k, rng) for k in range(5)]
+    geo = orc.geometry(1, h, 1.0)  # only width/height are used by the post-processing oracle
+    geo.width = w
+    opp = orc.PostProcess(geo)
+    pp = gpu.PostProcess(g)
+    d_in = g.to_device(np.concatenate(frames))
+    d_out = g.empty(5 * w * h)
+    infos = pp.run(d_in, 5, w, h, d_out, mb, 0.1, lbs, aap, ash, 0, 0)
+    got = d_out.download().reshape(5, -1)
+    for k, fr in enumerate(frames):
+        want = opp.run(fr.copy(), mb, 0.1, lbs, aap, ash, 0, 0)
+        si, sd = opp.state()
+        assert (infos[k].dx, infos[k].stripx, infos[k].dy, infos[k].stripy) == (si[0], si[2], si[3], si[5]), (k, w, h)
+        assert np.array_equal(got[k], want), (k, w, h)
+
+
+def test_resolution_change_between_calls(orc):
+    """dsp_post_process keeps autogain/sync state across a size change and zeroes the screen
+    buffer only when it has to grow (dsp.c:152-173)."""
+    g = ctx()
+    geo = orc.geometry(1, 1, 1.0)
+    opp = orc.PostProcess(geo)
+    pp = gpu.PostProcess(g)
+    rng = np.random.default_rng(5)
+    for (w, h) in [(200, 131), (120, 90), (260, 140), (200, 131)]:
+        geo.width, geo.height = w, h
+        for k in range(3):
+            fr = cases.frame_pattern(w, h, k, rng)
+            want = opp.run(fr.copy(), 0.5, 0.1, 0, 0, 0, 0, 0)
+            d_in = g.to_device(fr)
+            d_out = g.empty(w * h)
+            info = pp.run(d_in, 1, w, h, d_out, 0.5)[0]
+            si, sd = opp.state()
+            assert (info.dx, info.dy) == (si[0], si[3])
+            assert np.array_equal(d_out.download(), want), (w, h, k)
+
+
+def test_many_frames_one_batch(orc):
+    g = ctx()
+    fs, h, fv = 2_000_000, 131, 60.0
+    geo = orc.geometry(fs, h, fv)
+    w = geo.width
+    rng = np.random.default_rng(8)
+    F = 150
+    frames = [cases.frame_pattern(w, h, k, rng) for k in range(F)]
+    opp = orc.PostProcess(geo)
+    pp = gpu.PostProcess(g)
+    d_in = g.to_device(np.concatenate(frames))
+    d_out = g.empty(F * w * h)
+    infos = pp.run(d_in, F, w, h, d_out, 0.9375)
+    got = d_out.download().reshape(F, -1)
+    for k in range(F):
+        want = opp.run(frames[k].copy(), 0.9375)
+        if k % 10 == 0 or k == F - 1:
+            assert np.array_equal(got[k], want), k
+    si, sd = opp.state()
+    assert (infos[-1].dx, infos[-1].dy, infos[-1].stripx, infos[-1].stripy) == (si[0], si[3], si[2], si[5])
+
+
+def test_maximum_frame_size(orc):
+    """MAX_ARR_SIZE = 4000*4000 pixels (TSDRLibrary.c:31): one frame through the default order."""
+    g = ctx()
+    w, h = 4000, 4000
+    rng = np.random.default_rng(9)
+    fr = cases.frame_pattern(w, h, 3, rng)
+    geo = orc.geometry(1, h, 1.0)
+    geo.width = w
+    want = orc.PostProcess(geo).run(fr.copy(), 0.0)
+    pp = gpu.PostProcess(g)
+    d_in = g.to_device(fr)
+    d_out = g.empty(w * h)
+    pp.run(d_in, 1, w, h, d_out, 0.0)
+    assert np.array_equal(d_out.download(), want)
+
+
+@pytest.mark.parametrize("fs", [100_000, 1_000_000, 8_000_000, 25_000_000, 200_000_000])
+def test_autocorr_geometry_all_rates(orc, fs):
+    g = ctx()
+    ac = gpu.Autocorr(g, fs)
+    assert (ac.flo, ac.flen, ac.llo, ac.llen) == orc.lag_windows(fs)
+    assert ac.capture == orc.capture_size(fs)
+    assert ac.n == orc.lib.orc_fft_getrealsize(ac.capture)
+
+
+def test_autocorr_200Msps_window(orc):
+    """BASELINE config 5's window: N = 2^23."""
+    g = ctx()
+    fs = 200_000_000
+    ac = gpu.Autocorr(g, fs)
+    assert ac.n == 1 << 23
+    period = fs // 60
+    x = RNG.random(ac.capture).astype(np.float32) * np.float32(0.3)
+    x += (np.arange(ac.capture) % period < period // 10).astype(np.float32)
+    ac.run(g.to_device(x), 0, ac.capture, 1)
+    f, l, _ = ac.plots()
+    fi, li = ac.argmax()
+    assert abs((ac.flo + fi) - period) <= 16  # a noisy pulse train: the triangle's top is a few lags wide
+    oac = orc.Autocorr(fs)
+    oac.run(x)
+    assert np.max(np.abs(f - oac.frame)) <= 1e-4 * np.max(oac.frame)
+    assert oac.frame[fi] >= np.max(oac.frame) * (1 - 2e-4)
+
+
+def test_resampler_tiny_and_huge_chunks(orc):
+    g = ctx()
+    for chunk, nch, r in [(1, 50, 2.0), (2, 33, 1.999), (3, 1000, 0.7), (700_001, 2, 1.99935)]:
+        mag = RNG.random(chunk * nch).astype(np.float32)
+        ref_rs = orc.Resampler()
+        want = []
+        for c in range(nch):
+            o = ref_rs.process(mag[c * chunk:(c + 1) * chunk], r, 1.0)
+            o[min(ref_rs.last_emitted, o.size):] = 0.0
+            want.append(o)
+        want = np.concatenate(want)
+        rs = gpu.Resampler(g)
+        d_out = g.empty(want.size + 8)
+        n = rs.process(g.to_device(mag), 0, chunk, nch, r, 1.0, 0, d_out)
+        assert n == want.size and np.array_equal(d_out.download(n), want), (chunk, nch, r)
+        assert rs.state() == (ref_rs.st.contrib, ref_rs.st.offset)
