@@ -207,7 +207,12 @@ def main():
     out = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
     d_pix, d_out = DevPtr(pix), DevPtr(out)
     plots_ptr, plots_n = ac.device_plots()
-    red = torch.zeros(plots_n, dtype=torch.float64, device=dev) if sharded else None
+    red = ext = None
+    if sharded:
+        # the library's plot buffer seen as a torch tensor (zero copy) and its stream as a torch stream, so
+        # the RCCL all-reduce is ordered on the same stream as the kernels: no host synchronisation
+        red = shard.as_tensor(plots_ptr, plots_n, dev)
+        ext = torch.cuda.ExternalStream(g.stream(), device=dev)
 
     carry = 0  # pixels left over from the previous step (a frame straddling two batches)
     frames_done = 0
@@ -240,15 +245,14 @@ def main():
             carry = rem
             frames_done += F
         if sharded:
-            g.sync()  # both streams: this rank's per-lag sums are complete
-            g._ck(g.lib.tsdrgpu_copy(g.h, red.data_ptr(), plots_ptr, plots_n * 8))
-            g.sync()
-            # RCCL all-reduce over xGMI of the per-lag |R| sums of every rank's windows
-            _, total = shard.allreduce_plots(red, nwin, dist, mean=False)
-            torch.cuda.synchronize()
-            g._ck(g.lib.tsdrgpu_copy(g.h, plots_ptr, red.data_ptr(), plots_n * 8))
-            g.sync()
-            ac.finalize_sums(total)
+            if args.overlap:
+                g.sync()  # the sums were accumulated on the side stream
+            with torch.cuda.stream(ext):
+                # RCCL all-reduce over xGMI of the per-lag |R| sums of every rank's windows, in place
+                shard.allreduce_plots(red, nwin, dist, mean=False, total_windows=nwin * world)
+            if args.overlap:
+                ext.synchronize()
+            ac.finalize_sums(nwin * world)
         fi_li = ac.argmax()  # waits for the side stream
         g.sync()             # and the frames of this step
         return fi_li

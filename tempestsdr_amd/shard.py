@@ -21,22 +21,39 @@ def windows_for_rank(total_windows, rank, world):
     return list(range(rank, total_windows, world))
 
 
-def allreduce_plots(sums, local_windows, dist=None, mean=True):
+class DeviceView:
+    """Zero-copy torch view of library-owned device memory (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr, count, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def as_tensor(ptr, count, device):
+    import torch
+    return torch.as_tensor(DeviceView(ptr, count), device=device)
+
+
+def allreduce_plots(sums, local_windows, dist=None, mean=True, total_windows=None):
     """sums: 1-D float64 torch tensor (device or CPU) or numpy array with this
     rank's per-lag sums of |R| (frame lags then line lags).  Returns (plots as
     the same type, total window count); plots are the global means, or the
     global sums when mean=False (the caller then divides on the device,
     tsdrgpu_autocorr_finalize_sums).  `dist` = torch.distributed or None for a
-    single process."""
+    single process.  total_windows: the global window count when the caller knows
+    it (skips the second all-reduce and its host synchronisation)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         total = int(local_windows)
         return ((sums / max(total, 1)) if mean else sums), total
     import torch
     t = sums if isinstance(sums, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sums, np.float64))
-    cnt = torch.tensor([float(local_windows)], dtype=torch.float64, device=t.device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)    # per-lag energies of every rank's windows
-    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)  # ranks may hold different numbers of windows
-    total = int(round(float(cnt.item())))
+    if total_windows is None:                   # ranks may hold different numbers of windows
+        cnt = torch.tensor([float(local_windows)], dtype=torch.float64, device=t.device)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total = int(round(float(cnt.item())))   # (host sync; pass total_windows to avoid it)
+    else:
+        total = int(total_windows)
     out = (t / max(total, 1)) if mean else t
     return (out if isinstance(sums, torch.Tensor) else out.numpy()), total
 
