@@ -136,12 +136,12 @@ extern "C" int tsdrgpu_timer_stop_ms(tsdrgpu_t *g, float *ms)
 // ---------------------------------------------------------------------------
 static const char *const kStageNames[PROF_COUNT] = {"k_demod", "k_rs_tail+k_rs_chain", "k_rs_area", "k_rs_nearest",
                                                     "k_frame_stats", "k_frame_reduce", "k_chain", "k_frame_pass",
-                                                    "k_fft_lds", "k_ac_split", "k_accumulate", "superb_misc"};
+                                                    "k_fft_lds", "k_ac_split", "k_accumulate", "superb_misc", "k_argmax", "extras"};
 
-ProfScope::ProfScope(tsdrgpu_t *g_, int stage, hipStream_t stream) : g(g_), st(stream), idx(-1)
+void prof_pair(tsdrgpu_t *g, int stage, hipEvent_t *a, hipEvent_t *b)
 {
+    *a = *b = nullptr;
     if (!g || !g->prof_on) return;
-    if (!st) st = g->stream;
     if (g->nspans == g->cap_spans) {
         const int cap = g->cap_spans ? g->cap_spans * 2 : 1024;
         ProfSpan *n = (ProfSpan *)realloc(g->spans, sizeof(ProfSpan) * cap);
@@ -153,12 +153,9 @@ ProfScope::ProfScope(tsdrgpu_t *g_, int stage, hipStream_t stream) : g(g_), st(s
     ProfSpan &sp = g->spans[g->nspans];
     if (!sp.a && (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess)) return;
     sp.stage = stage;
-    if (hipEventRecord(sp.a, st) != hipSuccess) return;
-    idx = g->nspans++;
-}
-ProfScope::~ProfScope()
-{
-    if (idx >= 0) (void)hipEventRecord(g->spans[idx].b, st);
+    *a = sp.a;
+    *b = sp.b;
+    g->nspans++;
 }
 
 extern "C" int tsdrgpu_profile_begin(tsdrgpu_t *g)
@@ -296,16 +293,15 @@ extern "C" int tsdrgpu_am_demod(tsdrgpu_t *g, const float *d_iq, float *d_out, i
 {
     if (!g || !d_iq || !d_out || n < 0) return TSDRGPU_EINVAL;
     if (n == 0) return TSDRGPU_OK;
-    ProfScope prof(g, PROF_DEMOD);
     long long done = 0;
     if ((((uintptr_t)d_iq) & 15) == 0 && (((uintptr_t)d_out) & 15) == 0 && n >= 4) {
         const long long nquads = n / 4;
-        k_demod_vec4<<<stream_grid(nquads, 256, g), 256, 0, g->stream>>>((const float4 *)d_iq, (float4 *)d_out, nquads);
+        TSDR_LAUNCH(g, PROF_DEMOD, g->stream, k_demod_vec4, stream_grid(nquads, 256, g), 256, (const float4 *)d_iq, (float4 *)d_out, nquads);
         KERNEL_CHECK(g, "k_demod_vec4");
         done = nquads * 4;
     }
     if (done < n) {
-        k_demod_scalar<<<stream_grid(n - done, 256, g), 256, 0, g->stream>>>((const float2 *)d_iq, d_out, done, n);
+        TSDR_LAUNCH(g, PROF_DEMOD, g->stream, k_demod_scalar, stream_grid(n - done, 256, g), 256, (const float2 *)d_iq, d_out, done, n);
         KERNEL_CHECK(g, "k_demod_scalar");
     }
     return TSDRGPU_OK;
@@ -571,27 +567,24 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
     if (nearest) {
         // dsp.c:274-276: contrib is untouched in this mode
         if (max_out) {
-            ProfScope prof(g, PROF_RS_NEAREST);
-            if (in_is_iq) k_rs_nearest<true><<<grid, 256, 0, g->stream>>>(d_tab, d_in, d_out);
-            else k_rs_nearest<false><<<grid, 256, 0, g->stream>>>(d_tab, d_in, d_out);
+            if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_NEAREST, g->stream, (k_rs_nearest<true>), grid, 256, d_tab, d_in, d_out);
+            else TSDR_LAUNCH(g, PROF_RS_NEAREST, g->stream, (k_rs_nearest<false>), grid, 256, d_tab, d_in, d_out);
             KERNEL_CHECK(g, "k_rs_nearest");
         }
     } else {
         const unsigned tb = ceil_div_u((unsigned)nchunks, 128);
         {
-            ProfScope prof(g, PROF_RS_CARRY);
             if (in_is_iq) {
-                k_rs_tail<true><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need);
-                k_rs_chain<true><<<1, 256, 0, g->stream>>>(d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+                TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, (k_rs_tail<true>), tb, 128, d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need);
+                TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, (k_rs_chain<true>), 1, 256, d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
             } else {
-                k_rs_tail<false><<<tb, 128, 0, g->stream>>>(d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need);
-                k_rs_chain<false><<<1, 256, 0, g->stream>>>(d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+                TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, (k_rs_tail<false>), tb, 128, d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need);
+                TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, (k_rs_chain<false>), 1, 256, d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
             }
         }
         if (max_out) {
-            ProfScope prof(g, PROF_RS_AREA);
-            if (in_is_iq) k_rs_area<true><<<grid4, 256, 0, g->stream>>>(d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out);
-            else k_rs_area<false><<<grid4, 256, 0, g->stream>>>(d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out);
+            if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<true>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out);
+            else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<false>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out);
         }
         KERNEL_CHECK(g, "k_rs_area");
     }

@@ -39,10 +39,10 @@ extern "C" int tsdrgpu_decode_samples(tsdrgpu_t *g, const void *d_raw, int type,
     const long long cap = (long long)g->prop.multiProcessorCount * 16;
     if (blocks > cap) blocks = cap;
     switch (type) {
-        case 1: k_decode<1><<<(unsigned)blocks, 256, 0, g->stream>>>(d_raw, d_out, n); break;
-        case 2: k_decode<2><<<(unsigned)blocks, 256, 0, g->stream>>>(d_raw, d_out, n); break;
-        case 3: k_decode<3><<<(unsigned)blocks, 256, 0, g->stream>>>(d_raw, d_out, n); break;
-        default: k_decode<4><<<(unsigned)blocks, 256, 0, g->stream>>>(d_raw, d_out, n); break;
+        case 1: TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, (k_decode<1>), (unsigned)blocks, 256, d_raw, d_out, n); break;
+        case 2: TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, (k_decode<2>), (unsigned)blocks, 256, d_raw, d_out, n); break;
+        case 3: TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, (k_decode<3>), (unsigned)blocks, 256, d_raw, d_out, n); break;
+        default: TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, (k_decode<4>), (unsigned)blocks, 256, d_raw, d_out, n); break;
     }
     KERNEL_CHECK(g, "k_decode");
     return TSDRGPU_OK;
@@ -81,7 +81,7 @@ extern "C" int tsdrgpu_frame_to_rgb(tsdrgpu_t *g, const float *d_frame, int32_t 
     long long blocks = (npixels + 255) / 256;
     const long long cap = (long long)g->prop.multiProcessorCount * 16;
     if (blocks > cap) blocks = cap;
-    k_frame_to_rgb<<<(unsigned)blocks, 256, 0, g->stream>>>(d_frame, (int *)d_rgb, npixels, inverted);
+    TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_frame_to_rgb, (unsigned)blocks, 256, d_frame, (int *)d_rgb, npixels, inverted);
     KERNEL_CHECK(g, "k_frame_to_rgb");
     return TSDRGPU_OK;
 }

@@ -324,28 +324,28 @@ static PassPlan plan_passes(uint32_t n)
 }
 
 template <int IN_MODE, bool OUT_MAG>
-static void launch_pass(hipStream_t st, int R, const void *x, long long in_stride, float2 *y, unsigned n, unsigned Ns, int batch,
+static void launch_pass(tsdrgpu_t *g, hipStream_t st, int R, const void *x, long long in_stride, float2 *y, unsigned n, unsigned Ns, int batch,
                         int conj_in, int conj_out, float scale)
 {
     if (n >= 4096) {
         const int R1 = R / 16;
         dim3 grid(n / 4096, batch);  // (n/R)/C tiles, R*C = 4096
         switch (R1) {
-            case 1: k_fft_lds<1, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-            case 2: k_fft_lds<2, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-            case 4: k_fft_lds<4, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-            case 8: k_fft_lds<8, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-            default: k_fft_lds<16, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            case 1: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<1, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            case 2: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<2, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            case 4: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<4, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<8, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            default: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<16, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
         }
         return;
     }
     const unsigned T = n / R;
     dim3 grid((T + 255) / 256, batch);
     switch (R) {
-        case 2: k_fft_pass<2, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-        case 4: k_fft_pass<4, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-        case 8: k_fft_pass<8, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-        default: k_fft_pass<16, IN_MODE, OUT_MAG><<<grid, 256, 0, st>>>(x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+        case 2: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<2, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+        case 4: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<4, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+        case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<8, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+        default: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<16, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
     }
 }
 
@@ -367,20 +367,19 @@ static float2 *run_fft(tsdrgpu_t *g, const void *in, int in_mode, long long in_s
         const bool first = i == 0, last = i == p.count - 1;
         const int cin = (inverse && first) ? 1 : 0, cout = (inverse && last) ? 1 : 0;
         const float sc = last ? scale : 1.0f;
-        ProfScope prof(g, PROF_FFT_PASS, st);
         if (R == 1) {  // n == 1: copy
             (void)hipMemcpyAsync(dst, src, sizeof(float2) * batch, hipMemcpyDeviceToDevice, st);
         } else if (last && mag_out) {
-            if (smode == 0) launch_pass<0, true>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
-            else if (smode == 1) launch_pass<1, true>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
-            else launch_pass<2, true>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            if (smode == 0) launch_pass<0, true>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else if (smode == 1) launch_pass<1, true>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
+            else launch_pass<2, true>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
         } else {
             switch (smode) {
-                case 0: launch_pass<0, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
-                case 1: launch_pass<1, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
-                case 2: launch_pass<2, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
-                case 3: launch_pass<3, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
-                default: launch_pass<4, false>(st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                case 0: launch_pass<0, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                case 1: launch_pass<1, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                case 2: launch_pass<2, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                case 3: launch_pass<3, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                default: launch_pass<4, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
             }
         }
         Ns *= R;
@@ -658,22 +657,22 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     const int L = ac->frame_len + ac->line_len;
     float2 *corr = nullptr;
     int last_count = 0;
-    for (int w0 = 0; w0 < nwindows; w0 += AC_SUBBATCH) {
-        const int cnt = (nwindows - w0 < AC_SUBBATCH) ? (nwindows - w0) : AC_SUBBATCH;
+    const int parts = (nwindows + AC_SUBBATCH - 1) / AC_SUBBATCH;
+    const int per_part = (nwindows + parts - 1) / parts;  // equal sub-batches (17 -> 6,6,5)
+    for (int w0 = 0; w0 < nwindows; w0 += per_part) {
+        const int cnt = (nwindows - w0 < per_part) ? (nwindows - w0) : per_part;
         const float *src = d_in + (size_t)w0 * (size_t)stride * (in_is_iq ? 2 : 1);
         // fft_autocorrelation (fft.c:49-64) on the real window, packed two samples per complex point:
         // forward FFT of nh points ...
         float2 *zf = run_fft(g, src, in_is_iq ? 4 : 3, stride, ac->d_a, ac->d_b, nh, cnt, 0, false, 1.0f, ac->st);
         // ... spectrum split, 1/n scale and magnitude, re-packing for the inverse (in place) ...
         {
-            ProfScope prof(g, PROF_AC_SPLIT, ac->st);
-            k_ac_split<<<dim3((nh / 2 + 1 + 255) / 256, cnt), 256, 0, ac->st>>>(zf, nh);
+            TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, k_ac_split, dim3((nh / 2 + 1 + 255) / 256, cnt), 256, zf, nh);
         }
         // ... unscaled inverse FFT of nh points: zout[m] = r[2m] + i r[2m+1]
         corr = run_fft(g, zf, 0, nh, ac->d_a, ac->d_b, nh, cnt, 1, false, 1.0f, ac->st);
         KERNEL_CHECK(g, "fft passes");
-        ProfScope prof(g, PROF_ACCUMULATE, ac->st);
-        k_accumulate<<<(L + 255) / 256, 256, 0, ac->st>>>((const float *)corr, ac->n, cnt, ac->frame_lo, ac->frame_len, ac->line_lo,
+        TSDR_LAUNCH(g, PROF_ACCUMULATE, ac->st, k_accumulate, (L + 255) / 256, 256, (const float *)corr, ac->n, cnt, ac->frame_lo, ac->frame_len, ac->line_lo,
                                                           ac->line_len, ac->d_plots, (unsigned long long)(ac->calls + w0), mode);
         KERNEL_CHECK(g, "k_accumulate");
         last_count = cnt;
@@ -708,7 +707,7 @@ extern "C" int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t t
     if (!ac || total_windows == 0) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     const int L = ac->frame_len + ac->line_len;
-    k_scale_plots<<<(L + 255) / 256, 256, 0, ac->st>>>(ac->d_plots, L, (double)total_windows);
+    TSDR_LAUNCH(g, PROF_ACCUMULATE, ac->st, k_scale_plots, (L + 255) / 256, 256, ac->d_plots, L, (double)total_windows);
     KERNEL_CHECK(g, "k_scale_plots");
     ac->calls = total_windows;
     return TSDRGPU_OK;
@@ -718,8 +717,8 @@ extern "C" int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_id
 {
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
-    k_argmax_partial<<<dim3(ARGMAX_BLOCKS, 2), 256, 0, ac->st>>>(ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_pidx);
-    k_argmax_final<<<2, 64, 0, ac->st>>>(ac->d_pval, ac->d_pidx, ac->frame_len, ac->line_len, ac->d_arg);
+    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_partial, dim3(ARGMAX_BLOCKS, 2), 256, ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_pidx);
+    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_final, 2, 64, ac->d_pval, ac->d_pidx, ac->frame_len, ac->line_len, ac->d_arg);
     KERNEL_CHECK(g, "k_argmax");
     HIP_TRY(g, hipMemcpyAsync(ac->h_arg, ac->d_arg, 2 * sizeof(int), hipMemcpyDeviceToHost, ac->st));
     HIP_TRY(g, hipStreamSynchronize(ac->st));
@@ -735,7 +734,7 @@ extern "C" int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **
     if (!ac->d_expand && hipMalloc(&ac->d_expand, sizeof(float2) * (size_t)ac->n) != hipSuccess)
         return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_last_corr", "buffer");
     const uint32_t nh = ac->n / 2;
-    k_ac_expand<<<(nh + 255) / 256, 256, 0, ac->st>>>(ac->d_last, ac->d_expand, nh);
+    TSDR_LAUNCH(g, PROF_SUPERB_MISC, ac->st, k_ac_expand, (nh + 255) / 256, 256, ac->d_last, ac->d_expand, nh);
     KERNEL_CHECK(g, "k_ac_expand");
     HIP_TRY(g, hipStreamSynchronize(ac->st));
     if (d_corr) *d_corr = (const float *)ac->d_expand;
@@ -853,16 +852,16 @@ extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nho
 
     float2 *spec0 = nullptr;
     for (int i = 1; i < nhops; i++) {
-        k_abs_diff<<<(bn + 255) / 256, 256, 0, st>>>((const float2 *)d_hops[0], A, bn);
-        k_abs_diff<<<(bn + 255) / 256, 256, 0, st>>>((const float2 *)d_hops[i], B, bn);
+        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_hops[0], A, bn);
+        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_hops[i], B, bn);
         float2 *fa = run_fft(g, A, 0, bn, T1, T2, bn, 1, 0, false, 1.0f / (float)bn);
         float2 *fb = run_fft(g, B, 0, bn, T3, T4, bn, 1, 0, false, 1.0f / (float)bn);
-        k_mul_conj<<<(bn + 255) / 256, 256, 0, st>>>(fa, fb, bn);
+        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_mul_conj, (bn + 255) / 256, 256, fa, fb, bn);
         float2 *other = (fa == T1) ? T2 : T1;
         float2 *xc = run_fft(g, fa, 0, bn, fa, other, bn, 1, 1, false, 1.0f);
-        k_argmax_abs<<<1, 1024, 0, st>>>(xc, bn, d_off + i);
+        TSDR_LAUNCH(g, PROF_ARGMAX, st, k_argmax_abs, 1, 1024, xc, bn, d_off + i);
         // rotate hop i, then forward FFT of `per` points back into the hop buffer
-        k_rotate<<<(nfl + 255) / 256, 256, 0, st>>>(d_hops[i], (float *)T1, nfl, d_off + i);
+        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_rotate, (nfl + 255) / 256, 256, d_hops[i], (float *)T1, nfl, d_off + i);
         float2 *sp = run_fft(g, T1, 0, per, T1, T2, per, 1, 0, false, 1.0f / (float)per);
         (void)hipMemcpyAsync(d_hops[i], sp, sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
     }

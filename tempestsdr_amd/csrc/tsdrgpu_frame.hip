@@ -818,13 +818,11 @@ static int launch_stats(tsdrgpu_postproc_t *pp, const float *frames, long long f
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
     dim3 grid(tiles_x, tiles_y, F);
     {
-        ProfScope prof(g, PROF_FRAME_STATS);
-        k_frame_stats<<<grid, 256, 0, g->stream>>>(frames, fstride, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp,
+        TSDR_LAUNCH(g, PROF_FRAME_STATS, g->stream, k_frame_stats, grid, 256, frames, fstride, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp,
                                                pp->d_rowp, want_strips);
     }
     KERNEL_CHECK(g, "k_frame_stats");
-    ProfScope prof(g, PROF_FRAME_REDUCE);
-    k_frame_reduce<<<dim3(((W > H ? W : H) + 255) / 256, 3, F), 256, 0, g->stream>>>(W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, g->stream, k_frame_reduce, dim3(((W > H ? W : H) + 255) / 256, 3, F), 256, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
                                                       pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, want_strips);
     KERNEL_CHECK(g, "k_frame_reduce");
     return TSDRGPU_OK;
@@ -834,11 +832,10 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
                         int do_sync, int strips_normalised, const tsdrgpu_pp_params_t *prm)
 {
     tsdrgpu_t *g = pp->g;
-    ProfScope prof(g, PROF_CHAIN);
     // the autogain record (lastmin/lastmax/span per frame) is (re)written by every call: a sync-only
     // call repeats the carried state, which no later launch of that order reads
     if (do_autogain || !pp->chain_has_autogain) {
-        k_autogain_chain<<<1, 64, 0, g->stream>>>(F, frames, fstride, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain,
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_autogain_chain, 1, 64, F, frames, fstride, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain,
                                                   do_autogain, prm->lowpasscoeff);
         KERNEL_CHECK(g, "k_autogain_chain");
         pp->chain_has_autogain = 1;
@@ -850,14 +847,14 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         sc.blur = pp->d_work;
         sc.prefix = (double *)(pp->d_work + (((size_t)F * 2 * nmax + 1) & ~(size_t)1));
         sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
-        k_strip_prepare<<<dim3(2, F), CHAIN_T, 0, g->stream>>>(W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
                                                                strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2],
                                                                pp->taps[3], pp->taps[4]);
         KERNEL_CHECK(g, "k_strip_prepare");
         SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
-        k_sync_search<<<dim3(2, F), SYNC_T, 0, g->stream>>>(W, H, sc, pp->d_state, spec);
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, pp->d_state, spec);
         KERNEL_CHECK(g, "k_sync_search");
-        k_sync_chain<<<2, SYNC_T, 0, g->stream>>>(F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll);
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_sync_chain, 2, SYNC_T, F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll);
         KERNEL_CHECK(g, "k_sync_chain");
     }
     return TSDRGPU_OK;
@@ -879,8 +876,7 @@ static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long
     const long long cap = (long long)g->prop.multiProcessorCount * 16;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    ProfScope prof(g, PROF_FRAME_PASS);
-    fn<<<(unsigned)blocks, 256, 0, g->stream>>>(src, sstride, dst, dstride, F, W, H, pp->d_chain, pp->d_screen, a);
+    TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, fn, (unsigned)blocks, 256, src, sstride, dst, dstride, F, W, H, pp->d_chain, pp->d_screen, a);
     KERNEL_CHECK(g, "k_frame_pass");
     return TSDRGPU_OK;
 }

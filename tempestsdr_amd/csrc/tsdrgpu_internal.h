@@ -1,6 +1,7 @@
 // tsdrgpu_internal.h — shared by the .hip translation units of libtsdrgpu.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,6 +24,8 @@ enum ProfStage {
     PROF_AC_SPLIT,
     PROF_ACCUMULATE,
     PROF_SUPERB_MISC,
+    PROF_ARGMAX,
+    PROF_EXTRAS,
     PROF_COUNT
 };
 
@@ -45,14 +48,16 @@ struct tsdrgpu {
     int nspans, cap_spans;
 };
 
-// RAII span: records an event pair around the launches issued in its scope
-struct ProfScope {
-    tsdrgpu_t *g;
-    hipStream_t st;
-    int idx;
-    ProfScope(tsdrgpu_t *g_, int stage, hipStream_t stream = nullptr);
-    ~ProfScope();
-};
+// Profiling-aware launch: with the profiler on, the kernel's own dispatch carries a start and a
+// stop event (hipExtLaunchKernelGGL), so per-kernel durations are measured without extra barrier
+// packets between launches; with it off this is a plain launch.
+void prof_pair(tsdrgpu_t *g, int stage, hipEvent_t *a, hipEvent_t *b);
+#define TSDR_LAUNCH(g_, stage_, stream_, kernel_, grid_, block_, ...)                                        \
+    do {                                                                                                    \
+        hipEvent_t pa_ = nullptr, pb_ = nullptr;                                                            \
+        prof_pair((g_), (stage_), &pa_, &pb_);                                                              \
+        hipExtLaunchKernelGGL(kernel_, dim3(grid_), dim3(block_), 0, (stream_), pa_, pb_, 0, __VA_ARGS__);  \
+    } while (0)
 
 static inline int tsdr_fail(tsdrgpu_t *g, int code, const char *what, const char *detail)
 {
