@@ -12,6 +12,11 @@
  * libTSDRLibrary.so in this repository — the drop-in for the tsdr_* API — is
  * built on.
  *
+ * Threading: a context and the objects created from it belong to one host thread at a time (the
+ * library takes no locks); use one context per thread / per GPU.  Limits: frame width and height
+ * <= 16384 each (the reference allows width*height <= 4000*4000), <= 65535 resampler chunks or
+ * autocorrelation windows per call.
+ *
  * Return value: 0 (TSDRGPU_OK) or a negative TSDRGPU_E* code;
  * tsdrgpu_last_error() gives the text.  There is no CPU fallback: without a
  * HIP device tsdrgpu_create() fails.
@@ -143,7 +148,7 @@ int tsdrgpu_postproc_strips(tsdrgpu_postproc_t *pp, float *h_colsum, float *h_ro
 
 /* ---- a9..a12: FFT autocorrelation ---------------------------------------------- */
 /* fft_perform, fft.c:96-176: in-place complex FFT of n = 2^m points on
- * interleaved float32 (forward scaled by 1/n, inverse unscaled). */
+ * interleaved float32 (forward scaled by 1/n, inverse unscaled).  Asynchronous like the rest. */
 int tsdrgpu_fft(tsdrgpu_t *g, float *d_iq, uint32_t n, int inverse);
 
 /* frameratedetector_runontodata numerics (frameratedetector.c:87-126):

@@ -141,20 +141,17 @@ TSDR_HD bool rs_area_pixel(const RsGeom &g, unsigned p, double contrib_in, In in
 // (dsp.c:280-303) literally over the handful of samples that touch the group.
 // lo/hi/him1 and the demodulated sample are computed once per sample.
 // v[] must be pre-filled with 0 (pixels the reference never stores).
-// v[idx] = val without dynamic register indexing (which would spill v[] to scratch on the GPU)
-template <int NPIX>
-TSDR_HD void rs_put(float *v, int idx, float val)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int k = 0; k < NPIX; k++) v[k] = (k == idx) ? val : v[k];
-#else
-    v[idx] = val;
-#endif
-}
-
-template <int NPIX, class In>
-TSDR_HD void rs_area_group(const RsGeom &g, int p0, int n_out, double contrib_in, In in, float *v)
+// A thread's share of the work: pixels [p0, p0+NPIX) of the chunk (clipped to
+// [0, n_out)).  Instead of evaluating each pixel on its own, jump into the
+// reference's loop at the sample that stores the first pixel — its state there
+// (`pid`, `contrib`) is known in closed form — and replay the loop body
+// (dsp.c:280-303) literally over the handful of samples that touch the group.
+// lo/hi/him1 and the demodulated sample are computed once per sample.
+// put(k, value) receives pixel p0+k; pixels the reference never stores are not
+// reported (the caller pre-fills zeros).  `ipix` shadows the double `pix` so
+// that the group-window tests are integer compares.
+template <int NPIX, class In, class Put>
+TSDR_HD void rs_area_group(const RsGeom &g, int p0, int n_out, double contrib_in, In in, Put put)
 {
     const int pfirst = p0 < 0 ? 0 : p0;
     const int pend = (p0 + NPIX < n_out) ? (p0 + NPIX) : n_out;
@@ -163,8 +160,8 @@ TSDR_HD void rs_area_group(const RsGeom &g, int p0, int n_out, double contrib_in
     int id = rs_owner(g, (double)pfirst);
     if (id >= size) return;
     double pix = rs_pix_in(g, id);
+    int ipix = (int)pix;
     double contrib = rs_contrib_before(g, id, contrib_in, in);
-    const double first = (double)pfirst, end = (double)pend;
     for (; id < size; id++) {
         const double lo = (double)id * g.r + g.o;
         const double hi = lo + g.r;
@@ -172,15 +169,15 @@ TSDR_HD void rs_area_group(const RsGeom &g, int p0, int n_out, double contrib_in
         const float vf = in(id);
         const double val = (double)vf;
         if (pix < lo && pix < him1) {
-            if (pix >= first) rs_put<NPIX>(v, (int)pix - p0, (float)(contrib + val * (1.0 - lo + pix)));
+            if (ipix >= pfirst) put(ipix - p0, (float)(contrib + val * (1.0 - lo + pix)));
             contrib = 0;
             pix += 1.0;
-            if (pix >= end) return;
+            if (++ipix >= pend) return;
         }
         while (pix < him1) {
-            if (pix >= first) rs_put<NPIX>(v, (int)pix - p0, vf);
+            if (ipix >= pfirst) put(ipix - p0, vf);
             pix += 1.0;
-            if (pix >= end) return;
+            if (++ipix >= pend) return;
         }
         if (pix < hi && pix > lo)
             contrib += (hi - pix) * val;

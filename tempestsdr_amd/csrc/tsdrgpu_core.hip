@@ -42,6 +42,7 @@ extern "C" void tsdrgpu_destroy(tsdrgpu_t *g)
         if (g->spans[i].b) hipEventDestroy(g->spans[i].b);
     }
     free(g->spans);
+    if (g->fft_ws) hipFree(g->fft_ws);
     hipEventDestroy(g->t0);
     hipEventDestroy(g->t1);
     hipStreamDestroy(g->stream);
@@ -417,12 +418,18 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
     const int mis = (int)((((uintptr_t)dst) >> 2) & 3);  // dst's offset inside its 16-byte group
     const int n_out = (int)ch.n_out;
     const int ngroups = (n_out + mis + RS_NPIX - 1) / RS_NPIX;
+    // emitted pixels are staged in LDS as [k][thread] (a lane only ever touches its own column, so no
+    // barrier is needed and equal k across lanes is conflict free); a dynamic register index would
+    // cost a compare+select per register instead of one ds_write
+    __shared__ float stage[RS_NPIX][256];
     for (int grp = blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += gridDim.x * blockDim.x) {
         const int p0 = RS_NPIX * grp - mis;
+#pragma unroll
+        for (int k = 0; k < RS_NPIX; k++) stage[k][threadIdx.x] = 0.0f;
+        rs_area_group<RS_NPIX>(g, p0, n_out, c_in, ld, [&](int k, float val) { stage[k][threadIdx.x] = val; });
         float v[RS_NPIX];
 #pragma unroll
-        for (int k = 0; k < RS_NPIX; k++) v[k] = 0.0f;
-        rs_area_group<RS_NPIX>(g, p0, n_out, c_in, ld, v);
+        for (int k = 0; k < RS_NPIX; k++) v[k] = stage[k][threadIdx.x];
         if (p0 >= 0 && p0 + RS_NPIX <= n_out) {
             *reinterpret_cast<float4 *>(dst + p0) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4 *>(dst + p0 + 4) = make_float4(v[4], v[5], v[6], v[7]);

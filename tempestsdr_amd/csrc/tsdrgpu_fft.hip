@@ -398,15 +398,20 @@ extern "C" int tsdrgpu_fft(tsdrgpu_t *g, float *d_iq, uint32_t n, int inverse)
 {
     if (!g || !d_iq || n == 0 || (n & (n - 1))) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_fft", "n must be a power of two") : TSDRGPU_EINVAL;
     if (n == 1) return TSDRGPU_OK;
-    float2 *tmp = nullptr;
-    if (hipMalloc(&tmp, sizeof(float2) * (size_t)n * 2) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_fft", "work buffer");
-    // pass 1 reads the caller's buffer, the rest ping-pongs inside tmp
+    const size_t need = sizeof(float2) * (size_t)n * 2;
+    if (g->fft_ws_bytes < need) {  // the context keeps the ping-pong scratch between calls
+        HIP_TRY(g, hipStreamSynchronize(g->stream));
+        if (g->fft_ws) (void)hipFree(g->fft_ws);
+        g->fft_ws = nullptr;
+        g->fft_ws_bytes = 0;
+        if (hipMalloc(&g->fft_ws, need) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_fft", "work buffer");
+        g->fft_ws_bytes = need;
+    }
+    float2 *tmp = (float2 *)g->fft_ws;
+    // pass 1 reads the caller's buffer, the rest ping-pongs inside the scratch
     float2 *res = run_fft(g, d_iq, 0, n, tmp, tmp + n, n, 1, inverse, false, inverse ? 1.0f : 1.0f / (float)n);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(d_iq, res, sizeof(float2) * (size_t)n, hipMemcpyDeviceToDevice, g->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_fft", hipGetErrorString(e));
+    KERNEL_CHECK(g, "fft passes");
+    HIP_TRY(g, hipMemcpyAsync(d_iq, res, sizeof(float2) * (size_t)n, hipMemcpyDeviceToDevice, g->stream));
     return TSDRGPU_OK;
 }
 

@@ -42,6 +42,9 @@ struct tsdrgpu {
     hipEvent_t t0, t1;
     char err[512];
     hipDeviceProp_t prop;
+    // scratch kept between calls of tsdrgpu_fft (grown on demand)
+    void *fft_ws;
+    size_t fft_ws_bytes;
     // profiler
     int prof_on;
     ProfSpan *spans;

@@ -21,7 +21,7 @@ unsigned emu_resample_chunk(const float *in, unsigned size, double up, double do
     const int mis = (int)(size & 3);
     for (int p0 = -mis; p0 < (int)n_out; p0 += 8) {
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        rs_area_group<8>(g, p0, (int)n_out, contrib_in, load, v);
+        rs_area_group<8>(g, p0, (int)n_out, contrib_in, load, [&](int k, float val) { v[k] = val; });
         for (int k = 0; k < 8; k++)
             if (p0 + k >= 0 && p0 + k < (int)n_out) {
                 out[p0 + k] = v[k];
