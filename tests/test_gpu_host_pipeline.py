@@ -223,3 +223,86 @@ def test_superresolution_mode(orc, tmp_path):
     for (_, _, a) in s.frames:
         assert np.isfinite(a).all()
     s.close()
+
+
+def simulate_superb(orc, iq, fs, fv, block_floats):
+    """superb_run (superbandwidth.c:179-254) replayed on the plugin's block sequence with the oracle's
+    numerics: returns the list of stitched magnitude buffers (one per completed 4-hop cycle)."""
+    sif = int(fs / fv)
+    to_gather = 10 * sif
+    to_pause = int(0.5 * fs)
+    STARTING, GATHERING, PAUSE = 1, 2, 3
+    state, hop, gathered = STARTING, 0, 0
+    hops = [np.zeros(2 * to_gather, np.float32) for _ in range(4)]
+    outs = []
+    nblocks = iq.size // block_floats
+    for b in range(nblocks):
+        blk = iq[b * block_floats:(b + 1) * block_floats]
+        if state == STARTING:
+            hop, gathered = 0, 0
+            state = GATHERING
+        if state == PAUSE:
+            gathered += blk.size // 2
+            if gathered > to_pause:
+                gathered = 0
+                state = GATHERING
+        if state == GATHERING:
+            now = blk.size // 2
+            if gathered + now < to_gather:
+                hops[hop][2 * gathered:2 * gathered + blk.size] = blk
+                gathered += now
+            else:
+                remain = to_gather - gathered
+                hops[hop][2 * gathered:2 * to_gather] = blk[:2 * remain]
+                hop += 1
+                gathered = 0
+                if hop >= 4:
+                    stitched, _ = orc.superb_stitch([h.copy() for h in hops], sif)
+                    outs.append(orc.am_demod(stitched))
+                    state = STARTING
+                else:
+                    state = PAUSE
+    return outs
+
+
+def test_superresolution_frames_match_oracle(orc, tmp_path):
+    """a13/a14 end to end: the frames delivered in super-resolution mode against the oracle's stitch +
+    demod + resample + post-process of the same hop data.  Tolerance: the stitched signal carries the
+    FFT tolerance (1e-4 of its maximum), so frames (0..1 after autogain) are compared to 2e-3."""
+    fs, h, fv = 2_000_000, 131, 60.0
+    mode = (200, 131, 160, 120)
+    block = 65536
+    n = int(5.2 * fs)
+    iq = synth.synth_iq(fs, mode, fv, n, seed=5)
+    p = tmp_path / "super.f32"
+    iq.tofile(p)
+    plugin = hu.build_test_plugin()
+    s = hu.Session()
+    assert s.lib.tsdr_loadplugin(s.h, plugin.encode(), f"{p} {fs} {block} 200".encode()) == 0
+    assert s.lib.tsdr_setresolution(s.h, h, fv) == 0
+    s.lib.tsdr_motionblur(s.h, 0.5)
+    s.lib.tsdr_setparameter_int(s.h, 4, 1)
+    s.start()
+    ok = s.wait_frames(8, 90)
+    rc = s.stop()
+    assert ok and rc == 0
+    mags = simulate_superb(orc, iq, fs, fv, block)
+    assert mags
+    geo = orc.geometry(4 * fs, h, fv)
+    chunk = orc.chunk_size(4 * fs, fv)
+    up, down = geo.width * geo.height * geo.refreshrate, float(4 * fs)
+    rs = orc.Resampler()
+    pix = []
+    stream = mags[0]
+    for c in range(stream.size // chunk):
+        pix.append(rs.process(stream[c * chunk:(c + 1) * chunk], up, down))
+    pix = np.concatenate(pix)
+    P = geo.width * h
+    pp = orc.PostProcess(geo)
+    want = [pp.run(pix[k * P:(k + 1) * P].copy(), 0.5, 0.1, 0, 0, 0, 0, 1) for k in range(pix.size // P)]
+    got = [a for (w, hh, a) in s.frames if (w, hh) == (geo.width, h)]
+    m = min(len(got), len(want), 6)
+    assert m >= 4
+    for k in range(m):
+        assert np.max(np.abs(got[k] - want[k])) <= 2e-3, k
+    s.close()
