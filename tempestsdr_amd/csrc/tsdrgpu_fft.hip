@@ -352,20 +352,22 @@ static void launch_pass(tsdrgpu_t *g, hipStream_t st, int R, const void *x, long
 // Runs all passes of `batch` n-point transforms.  Input: `in` (mode per
 // in_mode, window b at in + b*in_stride elements).  Work buffers a, b (batch*n
 // float2 each).  Returns the buffer that holds the result.
-static float2 *run_fft(tsdrgpu_t *g, const void *in, int in_mode, long long in_stride, float2 *a, float2 *b, uint32_t n, int batch,
-                       int inverse, bool mag_out, float scale, hipStream_t st = nullptr)
+// Runs passes [pbegin, pend) of the plan `radix[0..count)`; Ns0 = product of the radices before
+// pbegin.  conj_first / conj_last: conjugate the input of pass 0 / the output of pass count-1 (the
+// inverse transform as conj(FFT(conj(x)))); scale / mag_out apply to pass count-1.
+static float2 *run_fft_range(tsdrgpu_t *g, const void *in, int in_mode, long long in_stride, float2 *a, float2 *b, uint32_t n,
+                             int batch, const int *radix, int count, int pbegin, int pend, unsigned Ns0, int conj_first,
+                             int conj_last, bool mag_out, float scale, hipStream_t st)
 {
-    if (!st) st = g->stream;
-    const PassPlan p = plan_passes(n);
-    unsigned Ns = 1;
+    unsigned Ns = Ns0;
     const void *src = in;
     long long sstride = in_stride;
     int smode = in_mode;
     float2 *dst = (in == (const void *)a) ? b : a;
-    for (int i = 0; i < p.count; i++) {
-        const int R = p.radix[i];
-        const bool first = i == 0, last = i == p.count - 1;
-        const int cin = (inverse && first) ? 1 : 0, cout = (inverse && last) ? 1 : 0;
+    for (int i = pbegin; i < pend; i++) {
+        const int R = radix[i];
+        const bool first = i == 0, last = i == count - 1;
+        const int cin = (conj_first && first) ? 1 : 0, cout = (conj_last && last) ? 1 : 0;
         const float sc = last ? scale : 1.0f;
         if (R == 1) {  // n == 1: copy
             (void)hipMemcpyAsync(dst, src, sizeof(float2) * batch, hipMemcpyDeviceToDevice, st);
@@ -389,6 +391,15 @@ static float2 *run_fft(tsdrgpu_t *g, const void *in, int in_mode, long long in_s
         dst = (dst == a) ? b : a;
     }
     return (float2 *)src;
+}
+
+static float2 *run_fft(tsdrgpu_t *g, const void *in, int in_mode, long long in_stride, float2 *a, float2 *b, uint32_t n, int batch,
+                       int inverse, bool mag_out, float scale, hipStream_t st = nullptr)
+{
+    if (!st) st = g->stream;
+    const PassPlan p = plan_passes(n);
+    return run_fft_range(g, in, in_mode, in_stride, a, b, n, batch, p.radix, p.count, 0, p.count, 1, inverse, inverse, mag_out,
+                         scale, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -465,6 +476,200 @@ __global__ __launch_bounds__(256) void k_ac_split(float2 *__restrict__ z, unsign
         // i * (-wk) * (-d) = i wk d = i (cs + i sn) d = (-sn d) + i (cs d)
         zb[km] = make_float2(s - sn * d, cs * d);
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_ac_mid: the middle of the autocorrelation in one trip over memory.
+// The last forward pass (radix R, Ns = nh/R) produces, for a tile of C columns k, the spectrum
+// entries Z[k + u*Ns]; the split needs Z[idx] together with Z[nh-idx], which lies in the mirrored
+// column Ns-k at row R-1-u; and the first inverse pass (same radix, Ns = 1) consumes exactly the
+// entries of one tile again.  So a workgroup takes a tile A = columns [1+C*b, 1+C*b+C) and its
+// mirror B = columns [Ns-C-C*b, Ns-C*b) (C = 128/R1 columns each), runs the forward pass for both into LDS, does the split
+// in LDS, runs the first inverse pass from LDS and stores the two contiguous output blocks.
+// Column 0 mirrors onto itself and is handled by k_ac_mid_col0.  Saves writing the spectrum,
+// the k_ac_split round trip and re-reading it: 64 of 224 MB per 2^22-sample window.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, unsigned k, unsigned nh, float2 *zk, float2 *zkm)
+{
+    // see k_ac_split: A = Z[k], B = conj(Z[nh-k]); returns Zin[k], Zin[nh-k]
+    const float inv_n = 1.0f / (float)(2 * nh);
+    const float2 b = make_float2(bm.x, -bm.y);
+    float sn, cs;
+    sincospif(-(float)k / (float)nh, &sn, &cs);
+    const float2 sum = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+    const float2 dif = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+    const float2 t = cmul(make_float2(cs, sn), dif);
+    const float2 xk = make_float2(sum.x + t.y, sum.y - t.x);
+    const float2 xm = make_float2(sum.x - t.y, -(sum.y + t.x));
+    const float mk = sqrtf(xk.x * xk.x + xk.y * xk.y) * inv_n;
+    const float mm = sqrtf(xm.x * xm.x + xm.y * xm.y) * inv_n;
+    const float s = mk + mm, d = mk - mm;
+    *zk = make_float2(s + sn * d, cs * d);
+    *zkm = make_float2(s - sn * d, cs * d);
+}
+
+template <int R1>
+__global__ __launch_bounds__(256) void k_ac_mid(const float2 *__restrict__ x, float2 *__restrict__ y, unsigned nh)
+{
+    // 128 threads per tile (tile A: threads 0..127, its mirror B: 128..255); a tile is C2 = 128/R1
+    // columns x R rows = 2048 points, so the LDS footprint and the per-thread work equal k_fft_lds's
+    constexpr int R = 16 * R1;
+    constexpr int C2 = 128 / R1;
+    constexpr int G = 16 / R1;
+    constexpr int TILE = 2048 + 128;  // + room for the padded [c][R+1] staging of the stores
+    __shared__ float2 spec[2][TILE];
+    __shared__ float2 tw[256];
+    const unsigned Ns = nh / R;  // columns; also the T of both passes
+    const unsigned tid = threadIdx.x;
+    const unsigned tile = tid >> 7, t = tid & 127;
+    const unsigned c = t % C2, q = t / C2;
+    const float2 *xb = x + (long long)blockIdx.y * nh;
+    float2 *yb = y + (long long)blockIdx.y * nh;
+    const unsigned colA = 1u + C2 * blockIdx.x, colB = Ns - C2 - C2 * blockIdx.x;
+    const unsigned col0 = tile ? colB : colA;
+    float2 *L = spec[tile];
+    {
+        float sn, cs;
+        sincospif(-(float)tid * (1.0f / 128.0f), &sn, &cs);
+        tw[tid] = make_float2(cs, sn);
+    }
+    // ---- last forward pass -> L[u*C2 + c]
+    const unsigned j = col0 + c;
+    float2 v[16];
+#pragma unroll
+    for (int a = 0; a < G; a++)
+#pragma unroll
+        for (int i = 0; i < R1; i++) {
+            const unsigned nidx = q * G + a + 16 * i;
+            const float2 val = xb[(long long)j + (long long)nidx * Ns];
+            const unsigned m = (nidx * j) & (nh - 1);  // w_nh^(nidx*k), k = j
+            float sn, cs;
+            sincospif((float)m * (-2.0f / (float)nh), &sn, &cs);
+            v[a * R1 + i] = cmul(val, make_float2(cs, sn));
+        }
+    __syncthreads();  // tw[] ready
+#pragma unroll
+    for (int a = 0; a < G; a++) {
+        dft_reg<R1>(*reinterpret_cast<float2(*)[R1]>(&v[a * R1]));
+        const unsigned t0 = q * G + a;
+#pragma unroll
+        for (int k1 = 0; k1 < R1; k1++) {
+            float2 val = v[a * R1 + k1];
+            if (R1 > 1 && k1 > 0) val = cmul(val, tw[(t0 * k1 * (256 / R)) & 255]);
+            L[(k1 * 16 + t0) * C2 + c] = val;
+        }
+    }
+    __syncthreads();
+    float2 w[16];
+#pragma unroll
+    for (int t0 = 0; t0 < 16; t0++) w[t0] = L[(q * 16 + t0) * C2 + c];
+    dft_reg<16>(w);
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) L[(q + R1 * k2) * C2 + c] = w[k2];  // row u = q + R1*k2
+    __syncthreads();
+    // ---- split: element (u, c) of A pairs with (R-1-u, C2-1-c) of B; 2048 pairs, 8 per thread
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const unsigned e = tid + 256 * it;
+        const unsigned u = e / C2, cc = e % C2;
+        const unsigned pa = u * C2 + cc, pb = (R - 1 - u) * C2 + (C2 - 1 - cc);
+        const unsigned k = (colA + cc) + u * Ns;
+        float2 zk, zkm;
+        ac_split_pair(spec[0][pa], spec[1][pb], k, nh, &zk, &zkm);
+        spec[0][pa] = zk;
+        spec[1][pb] = zkm;
+    }
+    __syncthreads();
+    // ---- first inverse pass (Ns = 1: no outer twiddles; input conjugated)
+#pragma unroll
+    for (int a = 0; a < G; a++)
+#pragma unroll
+        for (int i = 0; i < R1; i++) {
+            const unsigned nidx = q * G + a + 16 * i;
+            float2 val = L[nidx * C2 + c];
+            val.y = -val.y;
+            v[a * R1 + i] = val;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < G; a++) {
+        dft_reg<R1>(*reinterpret_cast<float2(*)[R1]>(&v[a * R1]));
+        const unsigned t0 = q * G + a;
+#pragma unroll
+        for (int k1 = 0; k1 < R1; k1++) {
+            float2 val = v[a * R1 + k1];
+            if (R1 > 1 && k1 > 0) val = cmul(val, tw[(t0 * k1 * (256 / R)) & 255]);
+            L[(k1 * 16 + t0) * C2 + c] = val;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t0 = 0; t0 < 16; t0++) w[t0] = L[(q * 16 + t0) * C2 + c];
+    dft_reg<16>(w);
+    __syncthreads();
+    // outputs of a tile: y[(col0+c)*R + u], a contiguous block of 2048: stage as [c][R+1] and copy out
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) L[c * (R + 1) + q + R1 * k2] = w[k2];
+    __syncthreads();
+#pragma unroll
+    for (int tl = 0; tl < 2; tl++) {
+        float2 *dst = yb + (long long)(tl ? colB : colA) * R;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const unsigned idx = tid + 256 * it;
+            dst[idx] = spec[tl][(idx / R) * (R + 1) + (idx % R)];
+        }
+    }
+}
+
+// column 0 of the same step: Z[u*Ns] <-> Z[(R-u)*Ns]; one workgroup of R threads per window
+template <int R>
+__global__ void k_ac_mid_col0(const float2 *__restrict__ x, float2 *__restrict__ y, unsigned nh)
+{
+    __shared__ float2 col[R];
+    __shared__ float2 tw[R];
+    const unsigned Ns = nh / R;
+    const unsigned u = threadIdx.x;
+    const float2 *xb = x + (long long)blockIdx.y * nh;
+    float2 *yb = y + (long long)blockIdx.y * nh;
+    {
+        float sn, cs;
+        sincospif(-2.0f * (float)u / (float)R, &sn, &cs);
+        tw[u] = make_float2(cs, sn);
+        col[u] = xb[(long long)u * Ns];  // k = 0: no outer twiddle
+    }
+    __syncthreads();
+    float2 acc = make_float2(0.f, 0.f);
+    for (unsigned t = 0; t < R; t++) {  // direct DFT: X[u*Ns] = sum_t x[t*Ns] w_R^(t u)
+        const float2 p = cmul(col[t], tw[(t * u) & (R - 1)]);
+        acc.x += p.x;
+        acc.y += p.y;
+    }
+    __syncthreads();
+    col[u] = acc;
+    __syncthreads();
+    float2 zin;
+    if (u == 0) {
+        const float inv_n = 1.0f / (float)(2 * nh);
+        const float2 z0 = col[0];
+        const float m0 = fabsf(z0.x + z0.y) * inv_n, mh = fabsf(z0.x - z0.y) * inv_n;
+        zin = make_float2(m0 + mh, m0 - mh);
+    } else {
+        float2 zk, zkm;
+        ac_split_pair(col[u], col[R - u], u * Ns, nh, &zk, &zkm);
+        zin = zk;
+    }
+    __syncthreads();
+    col[u] = make_float2(zin.x, -zin.y);  // conjugated input of the inverse transform
+    __syncthreads();
+    acc = make_float2(0.f, 0.f);
+    for (unsigned t = 0; t < R; t++) {
+        const float2 p = cmul(col[t], tw[(t * u) & (R - 1)]);
+        acc.x += p.x;
+        acc.y += p.y;
+    }
+    yb[u] = acc;  // y[0*R + u]
 }
 
 // unpack zout (r[2m] + i r[2m+1]) into the reference's layout: complex, imaginary part 0
@@ -667,15 +872,42 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     for (int w0 = 0; w0 < nwindows; w0 += per_part) {
         const int cnt = (nwindows - w0 < per_part) ? (nwindows - w0) : per_part;
         const float *src = d_in + (size_t)w0 * (size_t)stride * (in_is_iq ? 2 : 1);
-        // fft_autocorrelation (fft.c:49-64) on the real window, packed two samples per complex point:
-        // forward FFT of nh points ...
-        float2 *zf = run_fft(g, src, in_is_iq ? 4 : 3, stride, ac->d_a, ac->d_b, nh, cnt, 0, false, 1.0f, ac->st);
-        // ... spectrum split, 1/n scale and magnitude, re-packing for the inverse (in place) ...
-        {
+        // fft_autocorrelation (fft.c:49-64) on the real window, packed two samples per complex point
+        const PassPlan plan = plan_passes(nh);
+        const int R_last = plan.radix[plan.count - 1];
+        const unsigned Ns_last = nh / R_last;
+        const bool fused = nh >= 4096 && plan.count >= 2 && Ns_last >= 2u * (2048u / R_last);
+        float2 *corr_;
+        if (fused) {
+            // forward passes but the last ...
+            float2 *z = run_fft_range(g, src, in_is_iq ? 4 : 3, stride, ac->d_a, ac->d_b, nh, cnt, plan.radix, plan.count, 0,
+                                      plan.count - 1, 1, 0, 0, false, 1.0f, ac->st);
+            // ... last forward pass + split + first inverse pass in one kernel ...
+            float2 *mid = (z == ac->d_a) ? ac->d_b : ac->d_a;
+            const dim3 grid(Ns_last / (2 * (2048 / R_last)), cnt);
+            switch (R_last / 16) {
+                case 1: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<1>), grid, 256, z, mid, nh);
+                        TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<16>), dim3(1, cnt), 16, z, mid, nh); break;
+                case 2: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<2>), grid, 256, z, mid, nh);
+                        TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<32>), dim3(1, cnt), 32, z, mid, nh); break;
+                case 4: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<4>), grid, 256, z, mid, nh);
+                        TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<64>), dim3(1, cnt), 64, z, mid, nh); break;
+                case 8: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<8>), grid, 256, z, mid, nh);
+                        TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<128>), dim3(1, cnt), 128, z, mid, nh); break;
+                default: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<16>), grid, 256, z, mid, nh);
+                         TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<256>), dim3(1, cnt), 256, z, mid, nh); break;
+            }
+            // ... the remaining inverse passes, radices in reverse order (the fused kernel did radix R_last, Ns = 1)
+            int rev[32];
+            for (int i = 0; i < plan.count; i++) rev[i] = plan.radix[plan.count - 1 - i];
+            corr_ = run_fft_range(g, mid, 0, nh, ac->d_a, ac->d_b, nh, cnt, rev, plan.count, 1, plan.count, (unsigned)R_last, 1, 1,
+                                  false, 1.0f, ac->st);
+        } else {
+            float2 *zf = run_fft(g, src, in_is_iq ? 4 : 3, stride, ac->d_a, ac->d_b, nh, cnt, 0, false, 1.0f, ac->st);
             TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, k_ac_split, dim3((nh / 2 + 1 + 255) / 256, cnt), 256, zf, nh);
+            corr_ = run_fft(g, zf, 0, nh, ac->d_a, ac->d_b, nh, cnt, 1, false, 1.0f, ac->st);
         }
-        // ... unscaled inverse FFT of nh points: zout[m] = r[2m] + i r[2m+1]
-        corr = run_fft(g, zf, 0, nh, ac->d_a, ac->d_b, nh, cnt, 1, false, 1.0f, ac->st);
+        corr = corr_;
         KERNEL_CHECK(g, "fft passes");
         TSDR_LAUNCH(g, PROF_ACCUMULATE, ac->st, k_accumulate, (L + 255) / 256, 256, (const float *)corr, ac->n, cnt, ac->frame_lo, ac->frame_len, ac->line_lo,
                                                           ac->line_len, ac->d_plots, (unsigned long long)(ac->calls + w0), mode);
