@@ -197,9 +197,60 @@ __global__ __launch_bounds__(256) void k_fft_pass(const void *__restrict__ xin, 
 //   n = t0 + 16*i (t0 < 16, i < R1), k = k1 + R1*k2 (k1 < R1, k2 < 16):
 //   X[k] = sum_t0 w16^{t0 k2} [ w_R^{t0 k1} sum_i x[t0+16 i] w_R1^{i k1} ]
 // ---------------------------------------------------------------------------
+// Outer twiddles of an LDS pass, w_span^(nidx*k) for the 16 elements nidx = q*G + a + 16*i of a thread.
+// The exponent factors as (q*G)*k + a*k + (16*i)*k, so 1 + log2(G) + log2(R1) = 5 accurately evaluated
+// sincospif's (powers of two of each factor) and a few complex products replace 16 evaluations; a
+// product chain is at most 4 deep, i.e. a few f32 ulps.  (The passes were VALU-bound on sincospif.)
+__device__ __forceinline__ float2 tw_exact(unsigned e, unsigned mask, float inv)
+{
+    float sn, cs;
+    sincospif((float)(e & mask) * inv, &sn, &cs);
+    return make_float2(cs, sn);
+}
+
+template <int M>
+__device__ __forceinline__ void tw_powers(float2 (&pw)[M], unsigned e1, unsigned mask, float inv)
+{
+    pw[0] = make_float2(1.f, 0.f);
+#pragma unroll
+    for (int bit = 1; bit < M; bit <<= 1) {
+        pw[bit] = tw_exact(e1 * (unsigned)bit, mask, inv);
+#pragma unroll
+        for (int i = bit + 1; i < 2 * bit; i++) pw[i] = cmul(pw[bit], pw[i - bit]);
+    }
+}
+
+template <int R1>
+__device__ __forceinline__ void outer_twiddles(float2 (&v)[16], unsigned q, unsigned k, unsigned span)
+{
+    constexpr int G = 16 / R1;
+    const unsigned mask = span - 1;
+    const float inv = -2.0f / (float)span;
+    float2 pw[R1], pa[G];
+    tw_powers<R1>(pw, 16u * k, mask, inv);
+    tw_powers<G>(pa, k, mask, inv);
+    const float2 bq = tw_exact(q * G * k, mask, inv);
+#pragma unroll
+    for (int a = 0; a < G; a++) {
+        const float2 ba = a ? cmul(bq, pa[a]) : bq;
+#pragma unroll
+        for (int i = 0; i < R1; i++) v[a * R1 + i] = cmul(v[a * R1 + i], i ? cmul(ba, pw[i]) : ba);
+    }
+}
+
+// Output filter of a transform's last pass: when `on`, only outputs whose index lies in one of two
+// ranges are stored (the autocorrelation reads nothing but its two lag windows, frameratedetector.c:
+// 115-118), except for transform `full_b` of the batch, which is stored whole.
+struct FftKeep {
+    int on;
+    int full_b;
+    unsigned lo0, hi0, lo1, hi1;
+};
+static const FftKeep KEEP_ALL = {0, -1, 0u, 0u, 0u, 0u};
+
 template <int R1, int IN_MODE, bool OUT_MAG>
 __global__ __launch_bounds__(256) void k_fft_lds(const void *__restrict__ xin, long long in_stride, float2 *__restrict__ y,
-                                                 unsigned n, unsigned Ns, int conj_in, int conj_out, float scale)
+                                                 unsigned n, unsigned Ns, int conj_in, int conj_out, float scale, FftKeep keep)
 {
     constexpr int R = 16 * R1;
     constexpr int C = 256 / R1;
@@ -229,21 +280,7 @@ __global__ __launch_bounds__(256) void k_fft_lds(const void *__restrict__ xin, l
         }
     }
     const unsigned k = j & (Ns - 1);
-    if (Ns > 1) {
-        const unsigned span = Ns * R;
-        const float inv = -2.0f / (float)span;
-#pragma unroll
-        for (int a = 0; a < G; a++) {
-#pragma unroll
-            for (int i = 0; i < R1; i++) {
-                const unsigned nidx = q * G + a + 16 * i;
-                const unsigned m = (nidx * k) & (span - 1);
-                float sn, cs;
-                sincospif((float)m * inv, &sn, &cs);
-                v[a * R1 + i] = cmul(v[a * R1 + i], make_float2(cs, sn));
-            }
-        }
-    }
+    if (Ns > 1) outer_twiddles<R1>(v, q, k, Ns * R);
     __syncthreads();  // tw[] ready
 #pragma unroll
     for (int a = 0; a < G; a++) {
@@ -290,9 +327,18 @@ __global__ __launch_bounds__(256) void k_fft_lds(const void *__restrict__ xin, l
             dst[idx] = lds[(idx / R) * (R + 1) + (idx % R)];
         }
     } else {
-        float2 *yo = yb + ((long long)(j - k) * R + k);
+        const unsigned o0 = (j - k) * R + k;
+        float2 *yo = yb + o0;
+        if (keep.on && (int)b != keep.full_b) {
 #pragma unroll
-        for (int k2 = 0; k2 < 16; k2++) yo[(long long)(q + R1 * k2) * Ns] = w[k2];
+            for (int k2 = 0; k2 < 16; k2++) {
+                const unsigned o = o0 + (q + R1 * k2) * Ns;
+                if ((o >= keep.lo0 && o < keep.hi0) || (o >= keep.lo1 && o < keep.hi1)) yo[(long long)(q + R1 * k2) * Ns] = w[k2];
+            }
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < 16; k2++) yo[(long long)(q + R1 * k2) * Ns] = w[k2];
+        }
     }
 }
 
@@ -325,17 +371,17 @@ static PassPlan plan_passes(uint32_t n)
 
 template <int IN_MODE, bool OUT_MAG>
 static void launch_pass(tsdrgpu_t *g, hipStream_t st, int R, const void *x, long long in_stride, float2 *y, unsigned n, unsigned Ns, int batch,
-                        int conj_in, int conj_out, float scale)
+                        int conj_in, int conj_out, float scale, const FftKeep &keep = KEEP_ALL)
 {
     if (n >= 4096) {
         const int R1 = R / 16;
         dim3 grid(n / 4096, batch);  // (n/R)/C tiles, R*C = 4096
         switch (R1) {
-            case 1: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<1, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-            case 2: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<2, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-            case 4: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<4, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-            case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<8, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-            default: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<16, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+            case 1: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<1, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
+            case 2: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<2, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
+            case 4: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<4, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
+            case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<8, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
+            default: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<16, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
         }
         return;
     }
@@ -357,7 +403,7 @@ static void launch_pass(tsdrgpu_t *g, hipStream_t st, int R, const void *x, long
 // inverse transform as conj(FFT(conj(x)))); scale / mag_out apply to pass count-1.
 static float2 *run_fft_range(tsdrgpu_t *g, const void *in, int in_mode, long long in_stride, float2 *a, float2 *b, uint32_t n,
                              int batch, const int *radix, int count, int pbegin, int pend, unsigned Ns0, int conj_first,
-                             int conj_last, bool mag_out, float scale, hipStream_t st)
+                             int conj_last, bool mag_out, float scale, hipStream_t st, const FftKeep &keep = KEEP_ALL)
 {
     unsigned Ns = Ns0;
     const void *src = in;
@@ -377,7 +423,7 @@ static float2 *run_fft_range(tsdrgpu_t *g, const void *in, int in_mode, long lon
             else launch_pass<2, true>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc);
         } else {
             switch (smode) {
-                case 0: launch_pass<0, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                case 0: launch_pass<0, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc, last ? keep : KEEP_ALL); break;
                 case 1: launch_pass<1, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
                 case 2: launch_pass<2, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
                 case 3: launch_pass<3, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
@@ -456,7 +502,7 @@ __global__ __launch_bounds__(256) void k_ac_split(float2 *__restrict__ z, unsign
     const float2 bm = zb[km];
     const float2 b = make_float2(bm.x, -bm.y);
     float sn, cs;
-    sincospif(-(float)k / (float)nh, &sn, &cs);  // w^k, w = exp(-2 pi i / n), n = 2 nh
+    sincospif(-(float)k * (1.0f / (float)nh), &sn, &cs);  // w^k, w = exp(-2 pi i / n), n = 2 nh (nh = 2^m: exact)
     const float2 wk = make_float2(cs, sn);
     // X[k] = (A+B)/2 - (i/2) w^k (A-B)
     const float2 sum = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
@@ -489,13 +535,12 @@ __global__ __launch_bounds__(256) void k_ac_split(float2 *__restrict__ z, unsign
 // Column 0 mirrors onto itself and is handled by k_ac_mid_col0.  Saves writing the spectrum,
 // the k_ac_split round trip and re-reading it: 64 of 224 MB per 2^22-sample window.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, unsigned k, unsigned nh, float2 *zk, float2 *zkm)
+__device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, unsigned nh, float2 *zk, float2 *zkm)
 {
-    // see k_ac_split: A = Z[k], B = conj(Z[nh-k]); returns Zin[k], Zin[nh-k]
+    // see k_ac_split: A = Z[k], B = conj(Z[nh-k]), wk = exp(-i pi k/nh); returns Zin[k], Zin[nh-k]
     const float inv_n = 1.0f / (float)(2 * nh);
     const float2 b = make_float2(bm.x, -bm.y);
-    float sn, cs;
-    sincospif(-(float)k / (float)nh, &sn, &cs);
+    const float cs = wk.x, sn = wk.y;
     const float2 sum = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
     const float2 dif = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
     const float2 t = cmul(make_float2(cs, sn), dif);
@@ -541,12 +586,9 @@ __global__ __launch_bounds__(256) void k_ac_mid(const float2 *__restrict__ x, fl
 #pragma unroll
         for (int i = 0; i < R1; i++) {
             const unsigned nidx = q * G + a + 16 * i;
-            const float2 val = xb[(long long)j + (long long)nidx * Ns];
-            const unsigned m = (nidx * j) & (nh - 1);  // w_nh^(nidx*k), k = j
-            float sn, cs;
-            sincospif((float)m * (-2.0f / (float)nh), &sn, &cs);
-            v[a * R1 + i] = cmul(val, make_float2(cs, sn));
+            v[a * R1 + i] = xb[(long long)j + (long long)nidx * Ns];
         }
+    outer_twiddles<R1>(v, q, j, nh);  // w_nh^(nidx*k), k = j
     __syncthreads();  // tw[] ready
 #pragma unroll
     for (int a = 0; a < G; a++) {
@@ -569,16 +611,23 @@ __global__ __launch_bounds__(256) void k_ac_mid(const float2 *__restrict__ x, fl
     for (int k2 = 0; k2 < 16; k2++) L[(q + R1 * k2) * C2 + c] = w[k2];  // row u = q + R1*k2
     __syncthreads();
     // ---- split: element (u, c) of A pairs with (R-1-u, C2-1-c) of B; 2048 pairs, 8 per thread
+    // pair `it` of a thread sits 256/C2 rows = (256/C2)*Ns spectrum entries after pair it-1, so its
+    // twiddle exp(-i pi k/nh) is the first one times exp(-i pi it/8) = tw[16 it] (C2*R = 2048)
+    {
+        const unsigned u0 = tid / C2, cc = tid % C2;
+        float sn0, cs0;
+        sincospif(-(float)((colA + cc) + u0 * Ns) * (1.0f / (float)nh), &sn0, &cs0);
+        const float2 w0 = make_float2(cs0, sn0);
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const unsigned e = tid + 256 * it;
-        const unsigned u = e / C2, cc = e % C2;
-        const unsigned pa = u * C2 + cc, pb = (R - 1 - u) * C2 + (C2 - 1 - cc);
-        const unsigned k = (colA + cc) + u * Ns;
-        float2 zk, zkm;
-        ac_split_pair(spec[0][pa], spec[1][pb], k, nh, &zk, &zkm);
-        spec[0][pa] = zk;
-        spec[1][pb] = zkm;
+        for (int it = 0; it < 8; it++) {
+            const unsigned u = u0 + (256 / C2) * it;
+            const unsigned pa = u * C2 + cc, pb = (R - 1 - u) * C2 + (C2 - 1 - cc);
+            const float2 wk = it ? cmul(w0, tw[16 * it]) : w0;
+            float2 zk, zkm;
+            ac_split_pair(spec[0][pa], spec[1][pb], wk, nh, &zk, &zkm);
+            spec[0][pa] = zk;
+            spec[1][pb] = zkm;
+        }
     }
     __syncthreads();
     // ---- first inverse pass (Ns = 1: no outer twiddles; input conjugated)
@@ -615,9 +664,13 @@ __global__ __launch_bounds__(256) void k_ac_mid(const float2 *__restrict__ x, fl
 #pragma unroll
     for (int tl = 0; tl < 2; tl++) {
         float2 *dst = yb + (long long)(tl ? colB : colA) * R;
+        // the self-mirrored column Ns/2 is the last of tile A and the first of tile B in the last
+        // workgroup; both copies are complete, A's is the one stored
+        const bool dup = tl == 1 && colB == Ns / 2;
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const unsigned idx = tid + 256 * it;
+            if (dup && idx < R) continue;
             dst[idx] = spec[tl][(idx / R) * (R + 1) + (idx % R)];
         }
     }
@@ -657,7 +710,9 @@ __global__ void k_ac_mid_col0(const float2 *__restrict__ x, float2 *__restrict__
         zin = make_float2(m0 + mh, m0 - mh);
     } else {
         float2 zk, zkm;
-        ac_split_pair(col[u], col[R - u], u * Ns, nh, &zk, &zkm);
+        float sn, cs;
+        sincospif(-(float)u * (1.0f / (float)R), &sn, &cs);  // k = u*Ns: exp(-i pi k/nh) = exp(-i pi u/R)
+        ac_split_pair(col[u], col[R - u], make_float2(cs, sn), nh, &zk, &zkm);
         zin = zk;
     }
     __syncthreads();
@@ -900,8 +955,17 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
             // ... the remaining inverse passes, radices in reverse order (the fused kernel did radix R_last, Ns = 1)
             int rev[32];
             for (int i = 0; i < plan.count; i++) rev[i] = plan.radix[plan.count - 1 - i];
+            // the last pass stores only the two lag windows (complex point m holds lags 2m, 2m+1), plus the
+            // whole correlation of the call's final window for tsdrgpu_autocorr_last_corr
+            FftKeep keep;
+            keep.on = plan.count >= 2 ? 1 : 0;  // with 2 passes the "last" one is pass 1 of rev[], still Ns > 1
+            keep.full_b = (w0 + cnt == nwindows) ? cnt - 1 : -1;
+            keep.lo0 = (unsigned)ac->frame_lo / 2;
+            keep.hi0 = (unsigned)(ac->frame_lo + ac->frame_len + 1) / 2;
+            keep.lo1 = (unsigned)ac->line_lo / 2;
+            keep.hi1 = (unsigned)(ac->line_lo + ac->line_len + 1) / 2;
             corr_ = run_fft_range(g, mid, 0, nh, ac->d_a, ac->d_b, nh, cnt, rev, plan.count, 1, plan.count, (unsigned)R_last, 1, 1,
-                                  false, 1.0f, ac->st);
+                                  false, 1.0f, ac->st, keep);
         } else {
             float2 *zf = run_fft(g, src, in_is_iq ? 4 : 3, stride, ac->d_a, ac->d_b, nh, cnt, 0, false, 1.0f, ac->st);
             TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, k_ac_split, dim3((nh / 2 + 1 + 255) / 256, cnt), 256, zf, nh);
