@@ -226,6 +226,23 @@ void tsdrgpu_modedetect_reset(tsdrgpu_modedetect_t *d);
 int tsdrgpu_modedetect_feed(tsdrgpu_modedetect_t *d, int frame_offset, int frame_idx, int line_offset,
                             int line_idx, uint32_t samplerate, tsdrgpu_detection_t *out);
 
+/* f4: plot decimation for display — what PlotVisualizer.populateData
+ * (JavaGUI/src/martin/tempest/gui/PlotVisualizer.java:200-247) computes from a plot of `size` doubles for a
+ * widget `nwidth` pixels wide: h_visdata[px] = maximum of the lags drawn in pixel column px (columns no lag
+ * maps to repeat the previous column), before the y scaling of :245-246; lowest/highest = the pair handed to
+ * scale_y (:243); max_index = getMaxIndex() (:226-229).  `scale` is the state of the widget's
+ * ZoomableXScale (gui/scale/ZoomableXScale.java:133-149: value_to_pixel_absolute(v) =
+ * (int)((v-min_value)*one_val_in_pixels) - offset_px, pixels_to_value_absolute(px) =
+ * px*one_px_in_values + offset_val + min_value); NULL = the unzoomed scale (tsdrgpu_plotscale_default).
+ * d_data is a device pointer, e.g. from tsdrgpu_autocorr_device_plots; only nwidth doubles cross PCIe. */
+typedef struct tsdrgpu_plotscale {
+    double one_val_in_pixels, one_px_in_values, offset_val, min_value;
+    int offset_px;
+} tsdrgpu_plotscale_t;
+void tsdrgpu_plotscale_default(int size, int nwidth, tsdrgpu_plotscale_t *s);
+int tsdrgpu_plot_columns(tsdrgpu_t *g, const double *d_data, int size, int nwidth, const tsdrgpu_plotscale_t *scale,
+                         double *h_visdata, double *h_lowest, double *h_highest, int *h_max_index);
+
 #ifdef __cplusplus
 }
 #endif

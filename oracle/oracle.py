@@ -97,6 +97,16 @@ _sig(lib.orc_superb_stitch, C.c_uint32, C.POINTER(C.c_void_p), C.c_int, C.c_int,
      i32p)
 _sig(lib.orc_decode_samples, None, C.c_void_p, C.c_int, f32p, C.c_int64)
 _sig(lib.orc_frame_to_rgb, None, f32p, i32p, C.c_int64, C.c_int)
+
+
+class PlotScale(C.Structure):
+    _fields_ = [("one_val_in_pixels", C.c_double), ("one_px_in_values", C.c_double), ("offset_val", C.c_double),
+                ("min_value", C.c_double), ("offset_px", C.c_int)]
+
+
+_sig(lib.orc_plotscale_default, None, C.c_int, C.c_int, C.POINTER(PlotScale))
+_sig(lib.orc_plot_populate, None, f64p, C.c_int, C.c_int, C.POINTER(PlotScale), f64p, C.POINTER(C.c_double),
+     C.POINTER(C.c_double), C.POINTER(C.c_int))
 _sig(lib.orc_dropped_shift_with, C.c_int64, C.c_int64, C.c_uint32, C.c_int64)
 _sig(lib.orc_dropped_add, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, C.c_int,
      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
@@ -306,3 +316,15 @@ def ref():
     _sig(r.dsp_dropped_compensation_shift_with, None, C.POINTER(C.c_int64), C.c_uint32, C.c_int64)
     _ref = r
     return r
+
+
+def plot_populate(data, nwidth, scale=None):
+    """PlotVisualizer.populateData: (visdata, lowest, highest, max_index); scale=None = unzoomed."""
+    data = np.ascontiguousarray(data, np.float64)
+    if scale is None:
+        scale = PlotScale()
+        lib.orc_plotscale_default(data.size, nwidth, C.byref(scale))
+    vis = np.empty(nwidth, np.float64)
+    lo, hi, mi = C.c_double(), C.c_double(), C.c_int()
+    lib.orc_plot_populate(data, data.size, nwidth, C.byref(scale), vis, C.byref(lo), C.byref(hi), C.byref(mi))
+    return vis, lo.value, hi.value, mi.value

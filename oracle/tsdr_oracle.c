@@ -839,3 +839,82 @@ ORC_API void orc_frame_to_rgb(const float *frame, int32_t *rgb, int64_t n, int i
         }
     }
 }
+
+/* ---------------------------------------------------------------------------
+   Plot decimation for display, JavaGUI/src/martin/tempest/gui/PlotVisualizer.java:200-247
+   (populateData) with the x mapping of gui/scale/ZoomableXScale.java:133-149:
+       pixels_to_value_absolute(px) = px*one_px_in_values + offset_val + min_value
+       value_to_pixel_absolute(v)   = (int)((v - min_value)*one_val_in_pixels) - offset_px
+   visdata[] holds, per pixel column, the maximum of the lags that map to it (columns no lag maps
+   to repeat the previous column's value), before the y scaling of PlotVisualizer.java:245-246.
+   lowest/highest are what scale_y.setLowestHighestValue receives (:243); max_index is the
+   argmax the GUI reads back through getMaxIndex() (:226-229).
+   PARITY UNPINNED: the reference for this function is Java and no JDK exists in the build image,
+   so this restatement could not be run against it.
+   --------------------------------------------------------------------------- */
+typedef struct {
+    double one_val_in_pixels, one_px_in_values, offset_val, min_value;
+    int offset_px;
+} orc_plotscale_t;
+
+/* ZoomableXScale after reset() + setMinMaxValue(0, size) + setMaxPixels(nwidth), zoom 1
+   (PlotVisualizer.java:259-264,296; ZoomableXScale.java:177-188 with max_zoom_val = 10) */
+ORC_API void orc_plotscale_default(int size, int nwidth, orc_plotscale_t *s)
+{
+    const double min_value = 0.0, max_value = (double)size, max_zoom_val = 10.0;
+    double scale = 1.0;
+    s->one_val_in_pixels = nwidth / ((max_value - min_value) * scale);
+    s->one_px_in_values = ((max_value - min_value) * scale) / nwidth;
+    const double values_in_screen = nwidth * s->one_px_in_values;
+    if (values_in_screen < max_zoom_val) {
+        scale = max_zoom_val / (max_value - min_value);
+        s->one_val_in_pixels = nwidth / ((max_value - min_value) * scale);
+        s->one_px_in_values = ((max_value - min_value) * scale) / nwidth;
+    }
+    s->offset_val = 0.0;
+    s->min_value = min_value;
+    s->offset_px = 0;
+}
+
+static double orc_px_to_val(const orc_plotscale_t *s, int px) { return px * s->one_px_in_values + s->offset_val + s->min_value; }
+static int orc_val_to_px(const orc_plotscale_t *s, double v) { return (int)((v - s->min_value) * s->one_val_in_pixels) - s->offset_px; }
+
+ORC_API void orc_plot_populate(const double *data, int size, int nwidth, const orc_plotscale_t *s, double *visdata,
+                               double *lowest, double *highest, int *max_index)
+{
+    double highest_val = data[0];
+    double lowest_val = highest_val;
+    int maxi = 0;
+    double max_val = highest_val;
+    int prev_px = 0;
+    double t = orc_px_to_val(s, 0);
+    t = t > 0 ? t : 0;
+    const int first_id = (int)(t < size ? t : size);
+    t = orc_px_to_val(s, nwidth) + 1;
+    t = t > 0 ? t : 0;
+    const int last_id = (int)(t < size ? t : size);
+    /* Java would throw on data[size]; a scale that starts at or beyond the end shows nothing */
+    double localmax = first_id < size ? data[first_id] : data[size - 1];
+    for (int id = first_id; id < last_id; id++) {
+        const double val = data[id];
+        const int px = orc_val_to_px(s, id);
+        if (px >= 0 && px < nwidth) {
+            if (prev_px != px) {
+                if (localmax > highest_val) highest_val = localmax;
+                else if (localmax < lowest_val) lowest_val = localmax;
+                for (int i = prev_px; i < px; i++) visdata[i] = localmax;
+                localmax = val;
+                prev_px = px;
+            } else if (val > localmax)
+                localmax = val;
+        }
+        if (val > max_val) {
+            max_val = val;
+            maxi = id;
+        }
+    }
+    for (int i = prev_px; i < nwidth; i++) visdata[i] = localmax;
+    *lowest = lowest_val;
+    *highest = highest_val;
+    *max_index = maxi;
+}

@@ -7,6 +7,9 @@
 //       (PlotVisualizer.java:200-247, Main.java:82,1233-1277,1301-1303,1346-1350, VideoMode.java:25-190)
 //   f3  frame -> packed RGB with the debug colours and inversion of the JNI shim
 //       (JavaGUI/jni/TSDRLibraryNDK.c:222-276), so that 4 bytes/pixel of final image leave the GPU
+//   f4  plot decimation for display: per pixel column the maximum of the lags drawn in it
+//       (PlotVisualizer.java:200-247, gui/scale/ZoomableXScale.java:133-149), so that `nwidth`
+//       doubles instead of 0.67 M per plot go to the host
 #include "tsdrgpu_internal.h"
 #include <math.h>
 
@@ -206,4 +209,196 @@ extern "C" int tsdrgpu_modedetect_feed(tsdrgpu_modedetect_t *d, int frame_offset
     // what tsdr_setresolution(height, fps) would derive (TSDRLibrary.c:543-546)
     out->pixelrate = (double)((int)(2 * (samplerate / (fps * height)))) * height * fps;
     return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// f4  plot decimation (PlotVisualizer.populateData).  value_to_pixel_absolute is monotone in the lag
+// index, so the lags of pixel column c form one contiguous range, found by bisection; one wave per
+// column takes its maximum.  max_index (first lag holding the largest value of the visible range) is a
+// two-stage argmax.  The O(nwidth) tail of populateData — repeating the previous column where no lag
+// maps to a column, lowest/highest — runs on the host from the column maxima.
+// ---------------------------------------------------------------------------
+struct PlotScale {
+    double one_val_in_pixels, one_px_in_values, offset_val, min_value;
+    int offset_px;
+};
+__host__ __device__ static inline int plot_px(const PlotScale &s, int id)
+{
+    return (int)(((double)id - s.min_value) * s.one_val_in_pixels) - s.offset_px;
+}
+// first id in [lo, hi) whose pixel is >= c
+__device__ static int plot_lower_bound(const PlotScale &s, int lo, int hi, int c)
+{
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (plot_px(s, mid) >= c) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+#define PLOT_ARG_BLOCKS 256
+__global__ __launch_bounds__(64) void k_plot_columns(const double *__restrict__ data, int first_id, int last_id, int nwidth,
+                                                     PlotScale s, double *__restrict__ colmax, int *__restrict__ colcount)
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int a = plot_lower_bound(s, first_id, last_id, c), b = plot_lower_bound(s, a, last_id, c + 1);
+    double m = -INFINITY;
+    for (int id = a + lane; id < b; id += 64) m = fmax(m, data[id]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+    if (lane == 0) { colmax[c] = m; colcount[c] = b - a; }
+}
+
+__global__ __launch_bounds__(256) void k_plot_argmax(const double *__restrict__ data, int first_id, int last_id,
+                                                     double *__restrict__ pval, int *__restrict__ pidx, int *__restrict__ done,
+                                                     int *__restrict__ out)
+{
+    double best = -INFINITY;
+    int at = 0x7fffffff;
+    for (int i = first_id + blockIdx.x * blockDim.x + threadIdx.x; i < last_id; i += gridDim.x * blockDim.x) {
+        const double v = data[i];
+        if (v > best) { best = v; at = i; }
+    }
+    __shared__ double sb[4];
+    __shared__ int si[4];
+    __shared__ int last_block;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(at, o, 64);
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = at; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (sb[w] > best || (sb[w] == best && si[w] < at)) { best = sb[w]; at = si[w]; }
+        pval[blockIdx.x] = best;
+        pidx[blockIdx.x] = at;
+        __threadfence();
+        last_block = atomicAdd(done, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_block) return;
+    // the last workgroup to finish folds the partials (any order: the comparison is a total order)
+    __threadfence();
+    best = -INFINITY;
+    at = 0x7fffffff;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+        const double ob = ((volatile double *)pval)[b];
+        const int oi = ((volatile int *)pidx)[b];
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(at, o, 64);
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = at; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (sb[w] > best || (sb[w] == best && si[w] < at)) { best = sb[w]; at = si[w]; }
+        out[0] = at;
+        *done = 0;
+    }
+}
+
+extern "C" void tsdrgpu_plotscale_default(int size, int nwidth, tsdrgpu_plotscale_t *s)
+{
+    // ZoomableXScale after reset(), setMinMaxValue(0, size), setMaxPixels(nwidth): zoom 1, max_zoom_val 10
+    // (PlotVisualizer.java:64,259-264,296; ZoomableXScale.java:177-188)
+    if (!s) return;
+    const double span = (double)size;
+    double scale = 1.0;
+    s->one_val_in_pixels = nwidth / (span * scale);
+    s->one_px_in_values = (span * scale) / nwidth;
+    if (nwidth * s->one_px_in_values < 10.0) {
+        scale = 10.0 / span;
+        s->one_val_in_pixels = nwidth / (span * scale);
+        s->one_px_in_values = (span * scale) / nwidth;
+    }
+    s->offset_val = 0.0;
+    s->min_value = 0.0;
+    s->offset_px = 0;
+}
+
+extern "C" int tsdrgpu_plot_columns(tsdrgpu_t *g, const double *d_data, int size, int nwidth, const tsdrgpu_plotscale_t *scale,
+                                    double *h_visdata, double *h_lowest, double *h_highest, int *h_max_index)
+{
+    if (!g || !d_data || size <= 0 || nwidth <= 0 || nwidth > 65535 || !h_visdata)
+        return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_plot_columns", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_plotscale_t def;
+    if (!scale) { tsdrgpu_plotscale_default(size, nwidth, &def); scale = &def; }
+    PlotScale s = {scale->one_val_in_pixels, scale->one_px_in_values, scale->offset_val, scale->min_value, scale->offset_px};
+    if (!(s.one_val_in_pixels > 0.0)) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_plot_columns", "scale must be positive");
+    // visible range, PlotVisualizer.java:211-212
+    double t = 0 * s.one_px_in_values + s.offset_val + s.min_value;
+    t = t > 0 ? t : 0;
+    const int first_id = (int)(t < size ? t : size);
+    t = nwidth * s.one_px_in_values + s.offset_val + s.min_value + 1;
+    t = t > 0 ? t : 0;
+    const int last_id = (int)(t < size ? t : size);
+
+    // scratch: [nwidth] column maxima + [PLOT_ARG_BLOCKS] partial maxima (doubles), then the ints
+    const size_t nd = (size_t)nwidth + PLOT_ARG_BLOCKS + 2, ni = (size_t)nwidth + PLOT_ARG_BLOCKS + 2;
+    void *d_scratch = nullptr;
+    if (hipMalloc(&d_scratch, nd * sizeof(double) + ni * sizeof(int)) != hipSuccess)
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_plot_columns", "scratch");
+    double *d_col = (double *)d_scratch, *d_pval = d_col + nwidth;
+    int *d_cnt = (int *)(d_col + nd), *d_pidx = d_cnt + nwidth, *d_done = d_pidx + PLOT_ARG_BLOCKS, *d_out = d_done + 1;
+    int rc = TSDRGPU_OK;
+    double *hcol = (double *)malloc(sizeof(double) * (nwidth + 2));
+    int *hcnt = (int *)malloc(sizeof(int) * (nwidth + 2));
+    do {
+        if (!hcol || !hcnt) { rc = tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_plot_columns", "host scratch"); break; }
+        if (hipMemsetAsync(d_done, 0, 2 * sizeof(int), g->stream) != hipSuccess) { rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_plot_columns", "memset"); break; }
+        TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_plot_columns, nwidth, 64, d_data, first_id, last_id, nwidth, s, d_col, d_cnt);
+        if (last_id > first_id)
+            TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_plot_argmax, PLOT_ARG_BLOCKS, 256, d_data, first_id, last_id, d_pval, d_pidx, d_done, d_out);
+        if (hipGetLastError() != hipSuccess) { rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_plot_columns", "launch"); break; }
+        // data[0] (initial lowest/highest/max) and data[first_id] (initial localmax)
+        const int fid = first_id < size ? first_id : size - 1;
+        double edge[2];
+        int hmax = 0;
+        if (hipMemcpyAsync(hcol, d_col, sizeof(double) * nwidth, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+            hipMemcpyAsync(hcnt, d_cnt, sizeof(int) * nwidth, hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+            hipMemcpyAsync(&edge[0], d_data, sizeof(double), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+            hipMemcpyAsync(&edge[1], d_data + fid, sizeof(double), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+            (last_id > first_id && hipMemcpyAsync(&hmax, d_out, sizeof(int), hipMemcpyDeviceToHost, g->stream) != hipSuccess) ||
+            hipStreamSynchronize(g->stream) != hipSuccess) {
+            rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_plot_columns", "copy back");
+            break;
+        }
+        // the sequential tail of populateData over the non-empty columns
+        double highest = edge[0], lowest = edge[0], localmax = edge[1];
+        int prev_px = 0;
+        for (int px = 0; px < nwidth; px++) {
+            if (hcnt[px] <= 0) continue;
+            if (prev_px != px) {
+                if (localmax > highest) highest = localmax; else if (localmax < lowest) lowest = localmax;
+                for (int i = prev_px; i < px; i++) h_visdata[i] = localmax;
+                localmax = hcol[px];
+                prev_px = px;
+            } else if (hcol[px] > localmax) {
+                localmax = hcol[px];  // column 0 joins the initial data[first_id]
+            }
+        }
+        for (int i = prev_px; i < nwidth; i++) h_visdata[i] = localmax;
+        // max over the visible range starts from data[0] (PlotVisualizer.java:203-205,226-229)
+        int maxi = 0;
+        if (last_id > first_id) {
+            double dv;
+            if (hipMemcpy(&dv, d_data + hmax, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_plot_columns", "copy back"); break; }
+            if (dv > edge[0]) maxi = hmax;
+        }
+        if (h_lowest) *h_lowest = lowest;
+        if (h_highest) *h_highest = highest;
+        if (h_max_index) *h_max_index = maxi;
+    } while (0);
+    free(hcol);
+    free(hcnt);
+    (void)hipFree(d_scratch);
+    return rc;
 }

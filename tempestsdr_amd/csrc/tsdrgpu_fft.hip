@@ -554,7 +554,7 @@ __device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, un
 }
 
 template <int R1>
-__global__ __launch_bounds__(256) void k_ac_mid(const float2 *__restrict__ x, float2 *__restrict__ y, unsigned nh)
+__global__ __launch_bounds__(256, 4) void k_ac_mid(const float2 *__restrict__ x, float2 *__restrict__ y, unsigned nh)
 {
     // 128 threads per tile (tile A: threads 0..127, its mirror B: 128..255); a tile is C2 = 128/R1
     // columns x R rows = 2048 points, so the LDS footprint and the per-thread work equal k_fft_lds's
@@ -770,8 +770,8 @@ __global__ void k_scale_plots(double *plots, int count, double divisor)
 }
 
 // argmax with lowest-index tie-break (PlotVisualizer.java:233-236), two stages:
-// ARGMAX_BLOCKS workgroups per plot, then one wave per plot
-#define ARGMAX_BLOCKS 64
+// ARGMAX_BLOCKS workgroups per plot (enough to pull 5 MB of lags at memory speed), then one wave per plot
+#define ARGMAX_BLOCKS 512
 __global__ __launch_bounds__(256) void k_argmax_partial(const double *__restrict__ plots, int frame_len, int line_len,
                                                         double *__restrict__ pval, int *__restrict__ pidx)
 {
@@ -806,8 +806,13 @@ __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ 
                                                      int line_len, int *__restrict__ out)
 {
     const int plot = blockIdx.x;
-    double best = pval[plot * ARGMAX_BLOCKS + threadIdx.x];
-    int at = pidx[plot * ARGMAX_BLOCKS + threadIdx.x];
+    double best = -1.0;
+    int at = 0x7fffffff;
+    for (int b = threadIdx.x; b < ARGMAX_BLOCKS; b += 64) {
+        const double ob = pval[plot * ARGMAX_BLOCKS + b];
+        const int oi = pidx[plot * ARGMAX_BLOCKS + b];
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const double ob = __shfl_down(best, o, 64);

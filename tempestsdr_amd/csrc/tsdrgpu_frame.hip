@@ -49,6 +49,8 @@ struct tsdrgpu_postproc {
     size_t cap_tmp1, cap_tmp2;
     // statistics scratch
     float *d_bmin, *d_bmax;
+    int *d_tflag;  // per tile: it holds sentinel pixels (only then are the sentinel partials written / read)
+    size_t cap_tflag;
     float *d_colp, *d_rowp;
     size_t cap_bmin, cap_bmax, cap_colp, cap_rowp;
     float *d_fmin, *d_fmax;
@@ -93,7 +95,7 @@ __device__ __forceinline__ float wave_max(float v)
 __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ frames, long long fstride, int W, int H,
                                                      int tiles_x, int tiles_y, float *__restrict__ bmin,
                                                      float *__restrict__ bmax, float *__restrict__ colp,
-                                                     float *__restrict__ rowp, int want_strips)
+                                                     float *__restrict__ rowp, int *__restrict__ tflag, int want_strips)
 {
     const int tx = blockIdx.x, ty = blockIdx.y, f = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -117,7 +119,10 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
             val[r][j] = (y < H && x < W) ? row[x] : NAN;  // NaN = outside the frame (neither branch below takes it)
         }
     }
-    // phase 2
+    // phase 2.  Sentinel pixels (|v| > 250) are rare — raw resampler output has none — so their partial
+    // sums are only reduced and written when the tile holds any (tflag), which saves two thirds of the
+    // partial-sum traffic; k_frame_reduce reads them under the same flag.
+    float prs[ROWS], prc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int y = y0 + wave + 4 * r;
@@ -137,15 +142,25 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
                 }
             }
         }
+        prs[r] = rs;
+        prc[r] = rc;
         if (want_strips && y < H) {  // y is wave-uniform
             rns = wave_sum(rns);
-            const bool any_sent = __any(rc != 0.f);
-            if (any_sent) { rs = wave_sum(rs); rc = wave_sum(rc); }
-            if (lane == 0) {
-                float *rp = rowp + ((long long)(f * tiles_x + tx) * 3) * H;
-                rp[y] = rns;
-                rp[H + y] = any_sent ? rs : 0.f;
-                rp[2 * H + y] = any_sent ? rc : 0.f;
+            if (lane == 0) rowp[((long long)(f * tiles_x + tx) * 3) * H + y] = rns;
+        }
+    }
+    const int tile_sent = __syncthreads_or((cc[0] + cc[1] + cc[2] + cc[3]) != 0.f);
+    if (want_strips && tile_sent) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int y = y0 + wave + 4 * r;
+            if (y < H) {
+                const float rs = wave_sum(prs[r]), rc = wave_sum(prc[r]);
+                if (lane == 0) {
+                    float *rp = rowp + ((long long)(f * tiles_x + tx) * 3) * H;
+                    rp[H + y] = rs;
+                    rp[2 * H + y] = rc;
+                }
             }
         }
     }
@@ -156,8 +171,10 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             sh[0][wave][lane + 64 * j] = cns[j];
-            sh[1][wave][lane + 64 * j] = cs[j];
-            sh[2][wave][lane + 64 * j] = cc[j];
+            if (tile_sent) {
+                sh[1][wave][lane + 64 * j] = cs[j];
+                sh[2][wave][lane + 64 * j] = cc[j];
+            }
         }
     }
     lo = wave_min(lo);
@@ -168,8 +185,8 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
         const int x = x0 + threadIdx.x;
         if (x < W) {
             float *cp = colp + ((long long)(f * tiles_y + ty) * 3) * W;
-#pragma unroll
-            for (int q = 0; q < 3; q++)
+            const int nq = tile_sent ? 3 : 1;
+            for (int q = 0; q < nq; q++)
                 cp[q * W + x] = sh[q][0][threadIdx.x] + sh[q][1][threadIdx.x] + sh[q][2][threadIdx.x] + sh[q][3][threadIdx.x];
         }
     }
@@ -177,6 +194,7 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
         const long long b = (long long)f * tiles_x * tiles_y + (long long)ty * tiles_x + tx;
         bmin[b] = fminf(fminf(shmin[0], shmin[1]), fminf(shmin[2], shmin[3]));
         bmax[b] = fmaxf(fmaxf(shmax[0], shmax[1]), fmaxf(shmax[2], shmax[3]));
+        tflag[b] = tile_sent;
     }
 }
 
@@ -189,7 +207,8 @@ __global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x,
                                                       const float *__restrict__ bmax, const float *__restrict__ colp,
                                                       const float *__restrict__ rowp, float *__restrict__ fmin_,
                                                       float *__restrict__ fmax_, double *__restrict__ strip_x,
-                                                      double *__restrict__ strip_y, int want_strips)
+                                                      double *__restrict__ strip_y, const int *__restrict__ tflag,
+                                                      int want_strips)
 {
     const int f = blockIdx.z;
     if (blockIdx.y == 0) {
@@ -217,12 +236,17 @@ __global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x,
         const int parts = cols ? tiles_y : tiles_x;
         const float *src = (cols ? colp : rowp) + (long long)f * parts * 3 * n;
         double *dst = (cols ? strip_x : strip_y) + (long long)f * 3 * n;
+        // tile (ty, tx) that partial p of strip element i came from
+        const int *fl = tflag + (long long)f * tiles_x * tiles_y + (cols ? i / TILE_W : (i / TILE_H) * tiles_x);
+        const int fstep = cols ? tiles_x : 1;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         for (int p = 0; p < parts; p++) {
             const float *s3 = src + (long long)p * 3 * n + i;
             a0 += (double)s3[0];
-            a1 += (double)s3[n];
-            a2 += (double)s3[2 * n];
+            if (fl[p * fstep]) {
+                a1 += (double)s3[n];
+                a2 += (double)s3[2 * n];
+            }
         }
         dst[i] = a0;
         dst[n + i] = a1;
@@ -776,7 +800,7 @@ extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
 {
     if (!pp) return;
     (void)hipStreamSynchronize(pp->g->stream);
-    void *bufs[] = {pp->d_state, pp->d_screen, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
+    void *bufs[] = {pp->d_state, pp->d_screen, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
                     pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -819,11 +843,11 @@ static int launch_stats(tsdrgpu_postproc_t *pp, const float *frames, long long f
     dim3 grid(tiles_x, tiles_y, F);
     {
         TSDR_LAUNCH(g, PROF_FRAME_STATS, g->stream, k_frame_stats, grid, 256, frames, fstride, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp,
-                                               pp->d_rowp, want_strips);
+                                               pp->d_rowp, pp->d_tflag, want_strips);
     }
     KERNEL_CHECK(g, "k_frame_stats");
     TSDR_LAUNCH(g, PROF_FRAME_REDUCE, g->stream, k_frame_reduce, dim3(((W > H ? W : H) + 255) / 256, 3, F), 256, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
-                                                      pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, want_strips);
+                                                      pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_tflag, want_strips);
     KERNEL_CHECK(g, "k_frame_reduce");
     return TSDRGPU_OK;
 }
@@ -910,6 +934,7 @@ extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frame
     const size_t nblk = (size_t)F * tiles_x * tiles_y;
     if ((rc = ensure(g, &pp->d_bmin, &pp->cap_bmin, nblk))) return rc;
     if ((rc = ensure(g, &pp->d_bmax, &pp->cap_bmax, nblk))) return rc;
+    if ((rc = ensure(g, &pp->d_tflag, &pp->cap_tflag, nblk))) return rc;
     if ((rc = ensure(g, &pp->d_colp, &pp->cap_colp, (size_t)F * tiles_y * 3 * W))) return rc;
     if ((rc = ensure(g, &pp->d_rowp, &pp->cap_rowp, (size_t)F * tiles_x * 3 * H))) return rc;
     if ((rc = ensure(g, &pp->d_fmin, &pp->cap_fmin, (size_t)F))) return rc;

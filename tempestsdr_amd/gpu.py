@@ -36,6 +36,12 @@ class Detection(C.Structure):
                 ("mode_height", C.c_int), ("mode_refresh", C.c_double)]
 
 
+class PlotScale(C.Structure):
+    """State of the GUI's ZoomableXScale (gui/scale/ZoomableXScale.java:24-31)."""
+    _fields_ = [("one_val_in_pixels", C.c_double), ("one_px_in_values", C.c_double), ("offset_val", C.c_double),
+                ("min_value", C.c_double), ("offset_px", C.c_int)]
+
+
 class PPFrameInfo(C.Structure):
     _fields_ = [("lastmin", C.c_float), ("lastmax", C.c_float),
                 ("dx", C.c_int), ("vx", C.c_int), ("stripx", C.c_int),
@@ -97,6 +103,9 @@ _SIGS = {
     "tsdrgpu_modedetect_create": (C.c_int, [C.POINTER(vp)]),
     "tsdrgpu_modedetect_destroy": (None, [vp]),
     "tsdrgpu_modedetect_reset": (None, [vp]),
+    "tsdrgpu_plotscale_default": (None, [C.c_int, C.c_int, C.POINTER(PlotScale)]),
+    "tsdrgpu_plot_columns": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(PlotScale), vp, C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "tsdrgpu_modedetect_feed": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(Detection)]),
 }
 
@@ -255,6 +264,14 @@ class TsdrGpu:
 
     def decode_samples(self, d_raw, sample_type, d_out, n):
         self._ck(self.lib.tsdrgpu_decode_samples(self.h, d_raw.ptr, self.SAMPLE_TYPES[sample_type], d_out.ptr, n))
+
+    def plot_columns(self, d_ptr, size, nwidth, scale=None):
+        """PlotVisualizer.populateData on a device plot: (visdata[nwidth], lowest, highest, max_index)."""
+        vis = np.empty(nwidth, np.float64)
+        lo, hi, mi = C.c_double(), C.c_double(), C.c_int()
+        self._ck(self.lib.tsdrgpu_plot_columns(self.h, d_ptr, size, nwidth, C.byref(scale) if scale is not None else None,
+                                               vis.ctypes.data, C.byref(lo), C.byref(hi), C.byref(mi)))
+        return vis, lo.value, hi.value, mi.value
 
     def frame_to_rgb(self, d_frame, d_rgb, npixels, inverted=False, frame_offset=0):
         self._ck(self.lib.tsdrgpu_frame_to_rgb(self.h, d_frame.at(frame_offset), d_rgb.ptr, npixels, int(inverted)))

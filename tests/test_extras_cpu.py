@@ -87,3 +87,75 @@ def test_modedetect_follows_the_gui_logic():
     assert d.mode_height in (1000, 1002)
     with pytest.raises(gpu.TsdrGpuError):
         md.feed(0, 0, 0, 0, fs)
+
+
+# --------------------------------------------------------------------------
+# f4: plot decimation (PlotVisualizer.populateData).  No JDK in the image, so the oracle's C restatement
+# is cross-checked against a second, column-oriented formulation of the same Java loop.
+# --------------------------------------------------------------------------
+def _zoom_state(size, nwidth, zoom=1.0, offset_px=0):
+    """ZoomableXScale after setMinMaxValue(0,size), setMaxPixels(nwidth), zoom, setPxOffset (ZoomableXScale.java)."""
+    from oracle.oracle import PlotScale
+    s = PlotScale()
+    span = float(size) * zoom
+    s.one_val_in_pixels = nwidth / span
+    s.one_px_in_values = span / nwidth
+    s.offset_px = offset_px
+    s.offset_val = offset_px * s.one_px_in_values
+    s.min_value = 0.0
+    return s
+
+
+def _populate_by_columns(data, nwidth, s):
+    size = data.size
+    first = int(min(max(0 * s.one_px_in_values + s.offset_val + s.min_value, 0), size))
+    last = int(min(max(nwidth * s.one_px_in_values + s.offset_val + s.min_value + 1, 0), size))
+    ids = np.arange(first, last)
+    px = ((ids - s.min_value) * s.one_val_in_pixels).astype(np.int64) - s.offset_px  # (int) truncates toward zero
+    inside = (px >= 0) & (px < nwidth)
+    cols = {}
+    for i, p in zip(ids[inside], px[inside]):
+        cols[p] = max(cols.get(p, -np.inf), data[i])
+    start = data[min(first, size - 1)]
+    flushed = []
+    vis = np.empty(nwidth)
+    cur, cur_px = start, 0
+    for p in sorted(cols):
+        if p == cur_px:
+            cur = max(cur, cols[p])
+        else:
+            flushed.append(cur)
+            vis[cur_px:p] = cur
+            cur, cur_px = cols[p], p
+    vis[cur_px:] = cur
+    hi = max([data[0]] + flushed)
+    lo = min([data[0]] + flushed)
+    mi = 0
+    if last > first:
+        k = first + int(np.argmax(data[first:last]))
+        if data[k] > data[0]:
+            mi = k
+    return vis, lo, hi, mi
+
+
+@pytest.mark.parametrize("size,nwidth,zoom,offpx", [(5000, 800, 1.0, 0), (668756, 1237, 1.0, 0), (2315, 640, 1.0, 0),
+                                                     (300, 800, 1.0, 0), (5000, 800, 0.13, 411), (5000, 800, 0.01, 37000),
+                                                     (1, 16, 1.0, 0), (977, 977, 1.0, 0), (5000, 800, 1.0, -50)])
+def test_oracle_plot_populate_vs_column_formulation(orc, size, nwidth, zoom, offpx):
+    rng = np.random.default_rng(size + nwidth)
+    data = rng.random(size) + 0.2 * np.sin(np.arange(size) / 37.0)
+    data[rng.integers(0, size, 3)] = 1.5  # exact ties for the argmax
+    s = _zoom_state(size, nwidth, zoom, offpx)
+    vis, lo, hi, mi = orc.plot_populate(data, nwidth, s)
+    vis2, lo2, hi2, mi2 = _populate_by_columns(data, nwidth, s)
+    assert np.array_equal(vis, vis2)
+    assert (lo, hi, mi) == (lo2, hi2, mi2)
+
+
+def test_plotscale_default_matches_oracle(orc):
+    lib = gpu.load_library()
+    for size, nwidth in [(668756, 1237), (5, 800), (2315, 640)]:
+        a, b = gpu.PlotScale(), orc.PlotScale()
+        lib.tsdrgpu_plotscale_default(size, nwidth, C.byref(a))
+        orc.lib.orc_plotscale_default(size, nwidth, C.byref(b))
+        assert [getattr(a, f[0]) for f in a._fields_] == [getattr(b, f[0]) for f in b._fields_]

@@ -78,3 +78,53 @@ def test_decode_then_pipeline_matches_float_path(orc):
     d_out = g.empty(want.size + 8)
     n = rs.process(d_iq, 1, chunk, 4, up, down, 0, d_out)
     assert n == want.size and np.array_equal(d_out.download(n), want)
+
+
+@pytest.mark.parametrize("size,nwidth,zoom,offpx", [(668756, 1237, 1.0, 0), (2315, 640, 1.0, 0), (300, 800, 1.0, 0),
+                                                     (50000, 800, 0.13, 411), (50000, 800, 0.01, 37000), (1, 16, 1.0, 0),
+                                                     (977, 977, 1.0, 0), (50000, 800, 1.0, -50), (50000, 800, 1.0, 900)])
+def test_plot_columns_bit_exact(orc, size, nwidth, zoom, offpx):
+    """f4: PlotVisualizer.populateData on the device plot == the oracle's loop, all outputs identical."""
+    from tempestsdr_amd import gpu as G
+    g = ctx()
+    rng = np.random.default_rng(size + nwidth)
+    data = rng.random(size) + 0.2 * np.sin(np.arange(size) / 37.0)
+    data[rng.integers(0, size, 3)] = 1.5  # exact ties: the first one is the argmax
+    d = g.empty(2 * size, np.float32)  # bytes for `size` doubles
+    g._ck(g.lib.tsdrgpu_upload(g.h, d.ptr, data.ctypes.data, data.nbytes))
+    g.sync()
+    if zoom == 1.0 and offpx == 0:
+        so, sg = None, None
+    else:
+        so, sg = orc.PlotScale(), G.PlotScale()
+        for s in (so, sg):
+            span = float(size) * zoom
+            s.one_val_in_pixels = nwidth / span
+            s.one_px_in_values = span / nwidth
+            s.offset_px = offpx
+            s.offset_val = offpx * s.one_px_in_values
+            s.min_value = 0.0
+    want = orc.plot_populate(data, nwidth, so)
+    got = g.plot_columns(d.ptr, size, nwidth, sg)
+    assert np.array_equal(got[0], want[0])
+    assert got[1:] == want[1:]
+
+
+def test_plot_columns_on_autocorr_plot(orc):
+    """The frame-lag plot of an autocorrelation run, decimated on the device, vs the oracle on the downloaded plot."""
+    from tempestsdr_amd import gpu as G
+    g = ctx()
+    fs = 2_000_000
+    ac = G.Autocorr(g, fs)
+    x = (np.random.default_rng(5).random(ac.capture) + (np.arange(ac.capture) % (fs // 60) < 900)).astype(np.float32)
+    ac.run(g.to_device(x), False, ac.capture, 1)
+    f, l, _ = ac.plots()
+    p, n = ac.device_plots()
+    assert n == f.size + l.size
+    got = g.plot_columns(p, f.size, 800)
+    want = orc.plot_populate(f, 800)
+    assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+    assert got[3] == int(np.argmax(f)) or f[0] == f.max()
+    got = g.plot_columns(p + 8 * f.size, l.size, 800)
+    want = orc.plot_populate(l, 800)
+    assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
