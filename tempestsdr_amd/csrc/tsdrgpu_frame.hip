@@ -97,7 +97,13 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
                                                      float *__restrict__ bmax, float *__restrict__ colp,
                                                      float *__restrict__ rowp, int *__restrict__ tflag, int want_strips)
 {
-    const int tx = blockIdx.x, ty = blockIdx.y, f = blockIdx.z;
+    // 1-D grid, XCD-aware: a tile row is 1 KB that rarely starts on a 128-byte line (W*4 is no multiple
+    // of 128), so horizontally adjacent tiles share a cache line; workgroups go round-robin to the 8
+    // XCDs, so ids l, l+8, l+16 ... (one XCD, back to back) are mapped to consecutive tiles.
+    const unsigned total = gridDim.x;
+    const unsigned l = blockIdx.x;
+    const unsigned logical = (total % 8u == 0u) ? (l % 8u) * (total / 8u) + l / 8u : l;
+    const int tx = logical % tiles_x, ty = (logical / tiles_x) % tiles_y, f = logical / (tiles_x * tiles_y);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *src = frames + (long long)f * fstride;
     const int x0 = tx * TILE_W, y0 = ty * TILE_H;
@@ -691,7 +697,11 @@ __global__ __launch_bounds__(256) void k_frame_pass(const float *__restrict__ sr
     const int P = W * H;
     const double one_minus_a = 1.0 - a;
     const int ngroups = (P + VW - 1) / VW;
-    for (int grp = blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += gridDim.x * blockDim.x) {
+    // consecutive spans go to the same XCD (see k_frame_stats): frames are not 128-byte aligned, so
+    // neighbouring workgroups share a cache line at each end of their span
+    const unsigned gx = gridDim.x;
+    const unsigned lb = (gx % 8u == 0u) ? (blockIdx.x % 8u) * (gx / 8u) + blockIdx.x / 8u : blockIdx.x;
+    for (int grp = lb * blockDim.x + threadIdx.x; grp < ngroups; grp += gridDim.x * blockDim.x) {
         const int p0 = grp * VW;
         int x[VW], y[VW];
         float s[VW];
@@ -840,7 +850,7 @@ static int launch_stats(tsdrgpu_postproc_t *pp, const float *frames, long long f
 {
     tsdrgpu_t *g = pp->g;
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
-    dim3 grid(tiles_x, tiles_y, F);
+    const unsigned grid = (unsigned)tiles_x * tiles_y * F;
     {
         TSDR_LAUNCH(g, PROF_FRAME_STATS, g->stream, k_frame_stats, grid, 256, frames, fstride, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp,
                                                pp->d_rowp, pp->d_tflag, want_strips);
@@ -899,7 +909,7 @@ static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long
     long long blocks = (P / vw + 255) / 256;
     const long long cap = (long long)g->prop.multiProcessorCount * 16;
     if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    blocks = (blocks + 7) & ~7LL;  // a multiple of the 8 XCDs (the kernel's span order relies on it)
     TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, fn, (unsigned)blocks, 256, src, sstride, dst, dstride, F, W, H, pp->d_chain, pp->d_screen, a);
     KERNEL_CHECK(g, "k_frame_pass");
     return TSDRGPU_OK;
