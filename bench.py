@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (sums + all-reduce + finalize) even with one rank; used to "
                          "exercise the RCCL path on a 1-GPU box")
+    ap.add_argument("--no-split", action="store_true",
+                    help="one tsdrgpu_postproc_run per batch instead of _begin / autocorrelation / _finish "
+                         "(the split hides the ~0.1 ms frame-to-frame chain behind the FFT passes)")
     ap.add_argument("--overlap", action="store_true",
                     help="queue the autocorrelation on the side stream so it overlaps the frame path (higher "
                          "throughput; per-kernel durations then include contention, so the default keeps one stream)")
@@ -220,13 +223,18 @@ def main():
 
     ac.set_async(args.overlap)
 
-    def step():
-        nonlocal carry, frames_done
+    def run_autocorr():
         if not sharded:
-            ac.run(d_iq, 1, ac.capture, nwin, mode=0)  # queued first: overlaps everything below
+            ac.run(d_iq, 1, ac.capture, nwin, mode=0)
         else:
             ac.reset()
             ac.run(d_iq, 1, ac.capture, nwin, mode=1)
+
+    def step():
+        nonlocal carry, frames_done
+        split = args.frames_per_launch <= 0 and not args.no_split
+        if not split:
+            run_autocorr()  # queued first: with --overlap it runs beside everything below
         # a1+a2: the new pixels are appended behind the carried remainder; a3..a8 on the whole frames.
         # Optionally in sub-batches so that the raw pixels of a sub-batch are still in the Infinity
         # Cache when the statistics and the normalise/IIR pass read them back.
@@ -238,7 +246,13 @@ def main():
             done_chunks += k
             avail = carry + n
             F = avail // P
-            if F:
+            if split:
+                # frame statistics, then the latency-bound frame-to-frame chain on the side stream while
+                # the autocorrelation passes keep the main stream busy, then the normalise/IIR pass
+                pp.begin(d_pix, F, W, h, motionblur=0.0)
+                run_autocorr()
+                pp.finish(d_out, want_info=False)
+            elif F:
                 pp.run(d_pix, F, W, h, d_out, motionblur=0.0, want_info=False)
             rem = avail - F * P
             if rem and F:

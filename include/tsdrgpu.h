@@ -143,6 +143,17 @@ int tsdrgpu_postproc_reset(tsdrgpu_postproc_t *pp); /* dsp_post_process_init, ds
 int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width,
                          int height, const tsdrgpu_pp_params_t *params, float *d_out,
                          tsdrgpu_pp_frameinfo_t *h_info);
+/* The same run in two halves, for the default stage order (autogain, sync, low-pass): _begin queues the
+ * frame statistics on the context's stream and the short frame-to-frame chain (autogain IIR, strip blur,
+ * sync search, PLL: latency-bound, ~0.1 ms per batch during which the GPU is nearly idle) on its side
+ * stream; _finish makes the main stream wait for the chain and queues the normalise / low-pass pass.
+ * Work the caller queues on the context's stream in between (typically tsdrgpu_autocorr_run on the same
+ * samples) overlaps the chain.  d_frames must stay untouched until _finish; results are bit-identical to
+ * tsdrgpu_postproc_run.  With the other stage orders _begin only records its arguments and _finish runs
+ * everything.  tsdrgpu_postproc_run / _begin return TSDRGPU_ESTATE while a split run is open. */
+int tsdrgpu_postproc_begin(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width, int height,
+                           const tsdrgpu_pp_params_t *params);
+int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsdrgpu_pp_frameinfo_t *h_info);
 /* strips of the last frame run (after blur + markers), for stage-level tests */
 int tsdrgpu_postproc_strips(tsdrgpu_postproc_t *pp, float *h_colsum, float *h_rowsum); /* syncs */
 

@@ -66,6 +66,13 @@ struct tsdrgpu_postproc {
     int chain_has_autogain;  // within one tsdrgpu_postproc_run: the autogain record of d_chain is valid
     int last_F;
     float taps[5];
+    // split runs (tsdrgpu_postproc_begin / _finish)
+    hipStream_t chain_st;       // where launch_chain queues (the context's main stream unless split)
+    hipEvent_t ev_stats, ev_chain;
+    int pending;                // 1: begin() done, chain queued on the side stream; 2: begin() deferred everything
+    const float *p_frames;
+    int p_F, p_W, p_H;
+    tsdrgpu_pp_params_t p_prm;
 };
 
 // ---------------------------------------------------------------------------
@@ -802,6 +809,12 @@ extern "C" int tsdrgpu_postproc_create(tsdrgpu_t *g, tsdrgpu_postproc_t **out)
     pp->g = g;
     gaussian_taps(pp->taps);
     if (hipMalloc(&pp->d_state, sizeof(PpState)) != hipSuccess) { free(pp); return TSDRGPU_ENOMEM; }
+    if (hipEventCreateWithFlags(&pp->ev_stats, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&pp->ev_chain, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(pp->d_state);
+        free(pp);
+        return TSDRGPU_EHIP;
+    }
     *out = pp;
     return tsdrgpu_postproc_reset(pp);
 }
@@ -809,7 +822,10 @@ extern "C" int tsdrgpu_postproc_create(tsdrgpu_t *g, tsdrgpu_postproc_t **out)
 extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
 {
     if (!pp) return;
+    (void)hipStreamSynchronize(pp->g->stream2);
     (void)hipStreamSynchronize(pp->g->stream);
+    (void)hipEventDestroy(pp->ev_stats);
+    (void)hipEventDestroy(pp->ev_chain);
     void *bufs[] = {pp->d_state, pp->d_screen, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
                     pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain};
     for (void *b : bufs)
@@ -822,6 +838,8 @@ extern "C" int tsdrgpu_postproc_reset(tsdrgpu_postproc_t *pp)
 {
     if (!pp) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
+    if (pp->pending == 1) HIP_TRY(g, hipStreamWaitEvent(g->stream, pp->ev_chain, 0));  // an abandoned split run
+    pp->pending = 0;
     // dsp_post_process_init (dsp.c:112-132): autogain 0/0, sync detector zeroed, sizes forgotten
     HIP_TRY(g, hipMemsetAsync(pp->d_state, 0, sizeof(PpState), g->stream));
     pp->width = pp->height = 0;
@@ -866,10 +884,11 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
                         int do_sync, int strips_normalised, const tsdrgpu_pp_params_t *prm)
 {
     tsdrgpu_t *g = pp->g;
+    hipStream_t st = pp->chain_st ? pp->chain_st : g->stream;
     // the autogain record (lastmin/lastmax/span per frame) is (re)written by every call: a sync-only
     // call repeats the carried state, which no later launch of that order reads
     if (do_autogain || !pp->chain_has_autogain) {
-        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_autogain_chain, 1, 64, F, frames, fstride, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain,
+        TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, frames, fstride, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain,
                                                   do_autogain, prm->lowpasscoeff);
         KERNEL_CHECK(g, "k_autogain_chain");
         pp->chain_has_autogain = 1;
@@ -881,14 +900,14 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         sc.blur = pp->d_work;
         sc.prefix = (double *)(pp->d_work + (((size_t)F * 2 * nmax + 1) & ~(size_t)1));
         sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
-        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
+        TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
                                                                strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2],
                                                                pp->taps[3], pp->taps[4]);
         KERNEL_CHECK(g, "k_strip_prepare");
         SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
-        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, pp->d_state, spec);
+        TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, pp->d_state, spec);
         KERNEL_CHECK(g, "k_sync_search");
-        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_sync_chain, 2, SYNC_T, F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll);
+        TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll);
         KERNEL_CHECK(g, "k_sync_chain");
     }
     return TSDRGPU_OK;
@@ -915,12 +934,9 @@ static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long
     return TSDRGPU_OK;
 }
 
-extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int F, int W, int H,
-                                    const tsdrgpu_pp_params_t *prm, float *d_out, tsdrgpu_pp_frameinfo_t *h_info)
+// buffers and per-run state for F frames of W x H (everything before the first launch of a run)
+static int pp_prepare(tsdrgpu_postproc_t *pp, int F, int W, int H, const tsdrgpu_pp_params_t *prm)
 {
-    if (!pp || !d_frames || !d_out || !prm || F < 0 || W <= 0 || H <= 0)
-        return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "bad argument") : TSDRGPU_EINVAL;
-    if (F == 0) return TSDRGPU_OK;
     tsdrgpu_t *g = pp->g;
     const size_t P = (size_t)W * H;
     int rc;
@@ -968,6 +984,38 @@ extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frame
             return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "chain buffers");
         pp->cap_chain = F;
     }
+    return TSDRGPU_OK;
+}
+
+static int pp_copy_info(tsdrgpu_postproc_t *pp, int F, tsdrgpu_pp_frameinfo_t *h_info)
+{
+    tsdrgpu_t *g = pp->g;
+    // the chain record is complete after the last k_chain; convert on the host after the sync
+    HIP_TRY(g, hipMemcpyAsync(pp->h_chain, pp->d_chain, sizeof(ChainOut) * F, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    for (int f = 0; f < F; f++) {
+        const ChainOut &c = pp->h_chain[f];
+        tsdrgpu_pp_frameinfo_t &o = h_info[f];
+        o.lastmin = c.lastmin; o.lastmax = c.lastmax;
+        o.dx = c.dx; o.vx = c.vx; o.stripx = c.stripx;
+        o.dy = c.dy; o.vy = c.vy; o.stripy = c.stripy;
+        o.locked = c.locked; o.pll_fired = c.pll_fired;
+        o.avg_speed = c.avg_speed; o.frameratediff = c.frameratediff;
+    }
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int F, int W, int H,
+                                    const tsdrgpu_pp_params_t *prm, float *d_out, tsdrgpu_pp_frameinfo_t *h_info)
+{
+    if (!pp || !d_frames || !d_out || !prm || F < 0 || W <= 0 || H <= 0)
+        return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "bad argument") : TSDRGPU_EINVAL;
+    if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_run", "a split run is open: call tsdrgpu_postproc_finish first");
+    if (F == 0) return TSDRGPU_OK;
+    tsdrgpu_t *g = pp->g;
+    const size_t P = (size_t)W * H;
+    int rc;
+    if ((rc = pp_prepare(pp, F, W, H, prm))) return rc;
 
     const float a = prm->motionblur;
     const int lbs = prm->lowpass_before_sync, aap = prm->autogain_after_proc;
@@ -1010,20 +1058,63 @@ extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frame
         if ((rc = launch_pass(pp, PASS_NORMALISE, pp->d_tmp2, Ps, d_out, Ps, F, W, H, a))) return rc;
     }
 
-    if (h_info) {
-        // the chain record is complete after the last k_chain; convert on the host after the caller syncs
-        HIP_TRY(g, hipMemcpyAsync(pp->h_chain, pp->d_chain, sizeof(ChainOut) * F, hipMemcpyDeviceToHost, g->stream));
-        HIP_TRY(g, hipStreamSynchronize(g->stream));
-        for (int f = 0; f < F; f++) {
-            const ChainOut &c = pp->h_chain[f];
-            tsdrgpu_pp_frameinfo_t &o = h_info[f];
-            o.lastmin = c.lastmin; o.lastmax = c.lastmax;
-            o.dx = c.dx; o.vx = c.vx; o.stripx = c.stripx;
-            o.dy = c.dy; o.vy = c.vy; o.stripy = c.stripy;
-            o.locked = c.locked; o.pll_fired = c.pll_fired;
-            o.avg_speed = c.avg_speed; o.frameratediff = c.frameratediff;
-        }
+    if (h_info) return pp_copy_info(pp, F, h_info);
+    return TSDRGPU_OK;
+}
+
+// Split form of the default stage order.  begin(): statistics on the main stream, then the short,
+// latency-bound chain kernels (autogain IIR, strip blur, sync search, PLL: ~0.1 ms of mostly idle GPU
+// per batch) on the context's side stream; whatever the caller queues on the main stream before
+// finish() — e.g. tsdrgpu_autocorr_run on the same samples — runs meanwhile.  finish(): the main
+// stream waits for the chain, then the normalise/IIR pass.  Results are identical to
+// tsdrgpu_postproc_run; for the other three stage orders begin() only records its arguments.
+extern "C" int tsdrgpu_postproc_begin(tsdrgpu_postproc_t *pp, const float *d_frames, int F, int W, int H,
+                                      const tsdrgpu_pp_params_t *prm)
+{
+    if (!pp || !d_frames || !prm || F < 0 || W <= 0 || H <= 0)
+        return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_begin", "bad argument") : TSDRGPU_EINVAL;
+    if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_begin", "a split run is already open");
+    tsdrgpu_t *g = pp->g;
+    pp->p_frames = d_frames;
+    pp->p_F = F; pp->p_W = W; pp->p_H = H;
+    pp->p_prm = *prm;
+    if (F == 0 || prm->lowpass_before_sync || prm->autogain_after_proc) {
+        pp->pending = 2;
+        return TSDRGPU_OK;
     }
+    int rc;
+    if ((rc = pp_prepare(pp, F, W, H, prm))) return rc;
+    const long long Ps = (long long)W * H;
+    if ((rc = launch_stats(pp, d_frames, Ps, F, W, H, 1))) return rc;
+    HIP_TRY(g, hipEventRecord(pp->ev_stats, g->stream));
+    HIP_TRY(g, hipStreamWaitEvent(g->stream2, pp->ev_stats, 0));
+    pp->chain_st = g->stream2;
+    rc = launch_chain(pp, d_frames, Ps, F, W, H, 1, 1, 1, prm);
+    pp->chain_st = nullptr;
+    if (rc) return rc;
+    HIP_TRY(g, hipEventRecord(pp->ev_chain, g->stream2));
+    pp->pending = 1;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsdrgpu_pp_frameinfo_t *h_info)
+{
+    if (!pp || !d_out) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_finish", "bad argument") : TSDRGPU_EINVAL;
+    if (!pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_finish", "no split run is open");
+    tsdrgpu_t *g = pp->g;
+    const int mode = pp->pending;
+    pp->pending = 0;
+    const int F = pp->p_F, W = pp->p_W, H = pp->p_H;
+    const tsdrgpu_pp_params_t *prm = &pp->p_prm;
+    if (mode == 2) return tsdrgpu_postproc_run(pp, pp->p_frames, F, W, H, prm, d_out, h_info);
+    HIP_TRY(g, hipStreamWaitEvent(g->stream, pp->ev_chain, 0));
+    const float a = prm->motionblur;
+    const long long Ps = (long long)W * H;
+    const int map = prm->autoshift ? PASS_ROLL : 0;
+    const int lines = (!prm->autoshift && a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+    int rc;
+    if ((rc = launch_pass(pp, PASS_NORMALISE | map | lines | PASS_IIR, pp->p_frames, Ps, d_out, Ps, F, W, H, a))) return rc;
+    if (h_info) return pp_copy_info(pp, F, h_info);
     return TSDRGPU_OK;
 }
 

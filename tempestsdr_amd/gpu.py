@@ -83,6 +83,8 @@ _SIGS = {
     "tsdrgpu_postproc_reset": (C.c_int, [vp]),
     "tsdrgpu_postproc_run": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams), vp,
                                        C.POINTER(PPFrameInfo)]),
+    "tsdrgpu_postproc_begin": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams)]),
+    "tsdrgpu_postproc_finish": (C.c_int, [vp, vp, C.POINTER(PPFrameInfo)]),
     "tsdrgpu_postproc_strips": (C.c_int, [vp, vp, vp]),
     "tsdrgpu_fft": (C.c_int, [vp, vp, C.c_uint32, C.c_int]),
     "tsdrgpu_autocorr_create": (C.c_int, [vp, C.POINTER(vp), C.c_uint32]),
@@ -363,6 +365,20 @@ class PostProcess:
         info = (PPFrameInfo * nframes)() if want_info else None
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_run(self.h, d_frames.at(frames_offset), nframes, width, height,
                                                        C.byref(prm), d_out.at(out_offset), info))
+        return list(info) if want_info else None
+
+    def begin(self, d_frames, nframes, width, height, motionblur=0.0, lowpasscoeff=0.1, lowpass_before_sync=0,
+              autogain_after_proc=0, autoshift=0, pll=0, superres=0, frames_offset=0):
+        """First half of run(): statistics + the frame-to-frame chain (on the side stream)."""
+        prm = PPParams(lowpass_before_sync, autogain_after_proc, autoshift, pll, superres, motionblur, lowpasscoeff)
+        self._nframes = nframes
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_begin(self.h, d_frames.at(frames_offset), nframes, width, height,
+                                                         C.byref(prm)))
+
+    def finish(self, d_out, want_info=True, out_offset=0):
+        """Second half of run(): the normalise / low-pass pass once the chain is done."""
+        info = (PPFrameInfo * self._nframes)() if want_info else None
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_finish(self.h, d_out.at(out_offset), info))
         return list(info) if want_info else None
 
     def strips(self, width, height):

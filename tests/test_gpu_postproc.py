@@ -155,3 +155,34 @@ def test_post_process_1080p_properties(orc):
         for info, (si, sd) in zip(infos, states):
             assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy) == tuple(si[:6])
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("cfg", [(0, 0, 0, 0, 0.0), (0, 0, 1, 0, 0.75), (1, 0, 0, 0, 0.5), (1, 1, 1, 0, 0.0)])
+def test_split_run_equals_single_run(cfg):
+    """tsdrgpu_postproc_begin / _finish with an autocorrelation queued in between == tsdrgpu_postproc_run,
+    bit for bit (frames, per-frame state), for the default order (chain on the side stream) and the others."""
+    g = ctx()
+    lbs, aap, ash, pll, mb = cfg
+    w, h = 333, 131
+    n = w * h
+    rng = np.random.default_rng(7)
+    frames = [cases.frame_pattern(w, h, k, rng) for k in range(9)]
+    want, infos_a, _ = run_gpu(g, frames, w, h, cfg, 3)
+
+    pp = gpu.PostProcess(g)
+    ac = gpu.Autocorr(g, 300_000)
+    d_sig = g.to_device(rng.random(ac.capture).astype(np.float32))
+    d_in = g.to_device(np.concatenate(frames))
+    d_out = g.empty(len(frames) * n)
+    infos_b = []
+    for s in range(0, len(frames), 3):
+        pp.begin(d_in, 3, w, h, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * n)
+        with pytest.raises(gpu.TsdrGpuError):  # a split run is open
+            pp.run(d_in, 1, w, h, d_out, mb)
+        ac.run(d_sig, False, ac.capture, 1)
+        infos_b += pp.finish(d_out, out_offset=s * n)
+    assert np.array_equal(d_out.download().reshape(len(frames), n), want)
+    key = lambda i: (i.lastmin, i.lastmax, i.dx, i.vx, i.stripx, i.dy, i.vy, i.stripy, i.locked, i.avg_speed)
+    assert [key(i) for i in infos_a] == [key(i) for i in infos_b]
+    with pytest.raises(gpu.TsdrGpuError):  # nothing to finish
+        pp.finish(d_out)
