@@ -361,8 +361,12 @@ def main():
                         "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes[dom]),
                         "measured_over": f"{prof_steps} steps repeated with per-dispatch HIP events right after the timed "
                                          f"region ({dt_prof / prof_steps * 1e3:.3f} ms/step instrumented)"}
+        # with the split run the chain kernels execute on the side stream behind the FFT passes: their
+        # (contended) durations are listed in stage_ms_per_step but are not on the critical path
+        chain_hidden = args.frames_per_launch <= 0 and not args.no_split
         frame_kernels_ms = sum(prof.get(k, (0, 0))[0] for k in
-                               ("k_rs_tail+k_rs_chain", "k_rs_area", "k_frame_stats", "k_frame_reduce", "k_chain", "k_frame_pass"))
+                               ("k_rs_tail+k_rs_chain", "k_rs_area", "k_frame_stats", "k_frame_reduce", "k_frame_pass") +
+                               (() if chain_hidden else ("k_chain",)))
         frame_path_bytes = (8.0 * S + 16.0 * P) * (frames_total / world / args.steps) * max(1, prof_steps)
         stage_ms = {k: round(v[0] / max(1, prof_steps), 4) for k, v in prof.items()}
 
@@ -383,7 +387,8 @@ def main():
             "frame_path": {"kernels_ms_per_step": round(frame_kernels_ms / max(1, prof_steps), 3),
                            "achieved_GBs": round(frame_path_bytes / (frame_kernels_ms * 1e-3) / 1e9, 1) if frame_kernels_ms else None,
                            "frac": round(frame_path_bytes / (frame_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_kernels_ms else None,
-                           "alg_bytes_per_frame": int(8 * S + 16 * P)},
+                           "alg_bytes_per_frame": int(8 * S + 16 * P),
+                           "chain": "on the side stream, overlapped with the autocorrelation" if chain_hidden else "in line"},
             "autocorrelation": {"kernels_ms_per_step": round(ac_ms / max(1, prof_steps), 3),
                                 "achieved_GBs": round(ac_bytes_step / (ac_ms * 1e-3) / 1e9, 1),
                                 "frac": round(ac_bytes_step / (ac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

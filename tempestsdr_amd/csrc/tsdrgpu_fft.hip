@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_ac_split(float2 *__restrict__ z, unsign
 // entries of one tile again.  So a workgroup takes a tile A = columns [1+C*b, 1+C*b+C) and its
 // mirror B = columns [Ns-C-C*b, Ns-C*b) (C = 128/R1 columns each), runs the forward pass for both into LDS, does the split
 // in LDS, runs the first inverse pass from LDS and stores the two contiguous output blocks.
-// Column 0 mirrors onto itself and is handled by k_ac_mid_col0.  Saves writing the spectrum,
+// Column 0 mirrors onto itself and is handled by workgroup 0 (ac_mid_col0).  Saves writing the spectrum,
 // the k_ac_split round trip and re-reading it: 64 of 224 MB per 2^22-sample window.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, unsigned nh, float2 *zk, float2 *zkm)
@@ -553,6 +553,60 @@ __device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, un
     *zkm = make_float2(s - sn * d, cs * d);
 }
 
+template <int R>
+__device__ __forceinline__ void ac_mid_col0(const float2 *__restrict__ xb, float2 *__restrict__ yb, unsigned nh, float2 *col,
+                                            float2 *tw)
+{
+    // called by all 256 threads of one workgroup; threads u < R each own one row of column 0
+    const unsigned Ns = nh / R;
+    const unsigned u = threadIdx.x;
+    const bool act = u < R;
+    if (act) {
+        float sn, cs;
+        sincospif(-2.0f * (float)u / (float)R, &sn, &cs);
+        tw[u] = make_float2(cs, sn);
+        col[u] = xb[(long long)u * Ns];  // k = 0: no outer twiddle
+    }
+    __syncthreads();
+    float2 acc = make_float2(0.f, 0.f);
+    if (act)
+        for (unsigned t = 0; t < R; t++) {  // direct DFT: X[u*Ns] = sum_t x[t*Ns] w_R^(t u)
+            const float2 p = cmul(col[t], tw[(t * u) & (R - 1)]);
+            acc.x += p.x;
+            acc.y += p.y;
+        }
+    __syncthreads();
+    if (act) col[u] = acc;
+    __syncthreads();
+    float2 zin = make_float2(0.f, 0.f);
+    if (act) {
+        if (u == 0) {
+            const float inv_n = 1.0f / (float)(2 * nh);
+            const float2 z0 = col[0];
+            const float m0 = fabsf(z0.x + z0.y) * inv_n, mh = fabsf(z0.x - z0.y) * inv_n;
+            zin = make_float2(m0 + mh, m0 - mh);
+        } else {
+            float2 zk, zkm;
+            float sn, cs;
+            sincospif(-(float)u * (1.0f / (float)R), &sn, &cs);  // k = u*Ns: exp(-i pi k/nh) = exp(-i pi u/R)
+            ac_split_pair(col[u], col[R - u], make_float2(cs, sn), nh, &zk, &zkm);
+            zin = zk;
+        }
+    }
+    __syncthreads();
+    if (act) col[u] = make_float2(zin.x, -zin.y);  // conjugated input of the inverse transform
+    __syncthreads();
+    if (act) {
+        acc = make_float2(0.f, 0.f);
+        for (unsigned t = 0; t < R; t++) {
+            const float2 p = cmul(col[t], tw[(t * u) & (R - 1)]);
+            acc.x += p.x;
+            acc.y += p.y;
+        }
+        yb[u] = acc;  // y[0*R + u]
+    }
+}
+
 template <int R1>
 __global__ __launch_bounds__(256, 4) void k_ac_mid(const float2 *__restrict__ x, float2 *__restrict__ y, unsigned nh)
 {
@@ -570,12 +624,17 @@ __global__ __launch_bounds__(256, 4) void k_ac_mid(const float2 *__restrict__ x,
     const unsigned c = t % C2, q = t / C2;
     const float2 *xb = x + (long long)blockIdx.y * nh;
     float2 *yb = y + (long long)blockIdx.y * nh;
+    if (blockIdx.x == 0) {  // workgroup 0: column 0, which mirrors onto itself (a direct R-point DFT each way)
+        ac_mid_col0<R>(xb, yb, nh, spec[0], spec[1]);
+        return;
+    }
     // Tile A starts at column 1, so its 128-byte row segments straddle two cache lines, the second of
     // which is the first of the next tile: workgroups are dispatched round-robin over the 8 XCDs, so
     // consecutive tiles are given to the SAME XCD (ids x, x+8, x+16 ... are neighbours in time there)
     // and the shared line is an L2 hit instead of a second HBM fetch (PMC: 142 -> ~100 MB per launch).
-    const unsigned gx = gridDim.x;
-    const unsigned bx = (gx % 8u == 0u) ? (blockIdx.x % 8u) * (gx / 8u) + blockIdx.x / 8u : blockIdx.x;
+    // (ids with equal l mod 8 still share an XCD although workgroup 0 shifts everything by one)
+    const unsigned gx = gridDim.x - 1, l = blockIdx.x - 1;
+    const unsigned bx = (gx % 8u == 0u) ? (l % 8u) * (gx / 8u) + l / 8u : l;
     const unsigned colA = 1u + C2 * bx, colB = Ns - C2 - C2 * bx;
     const unsigned col0 = tile ? colB : colA;
     float2 *L = spec[tile];
@@ -683,55 +742,6 @@ __global__ __launch_bounds__(256, 4) void k_ac_mid(const float2 *__restrict__ x,
 }
 
 // column 0 of the same step: Z[u*Ns] <-> Z[(R-u)*Ns]; one workgroup of R threads per window
-template <int R>
-__global__ void k_ac_mid_col0(const float2 *__restrict__ x, float2 *__restrict__ y, unsigned nh)
-{
-    __shared__ float2 col[R];
-    __shared__ float2 tw[R];
-    const unsigned Ns = nh / R;
-    const unsigned u = threadIdx.x;
-    const float2 *xb = x + (long long)blockIdx.y * nh;
-    float2 *yb = y + (long long)blockIdx.y * nh;
-    {
-        float sn, cs;
-        sincospif(-2.0f * (float)u / (float)R, &sn, &cs);
-        tw[u] = make_float2(cs, sn);
-        col[u] = xb[(long long)u * Ns];  // k = 0: no outer twiddle
-    }
-    __syncthreads();
-    float2 acc = make_float2(0.f, 0.f);
-    for (unsigned t = 0; t < R; t++) {  // direct DFT: X[u*Ns] = sum_t x[t*Ns] w_R^(t u)
-        const float2 p = cmul(col[t], tw[(t * u) & (R - 1)]);
-        acc.x += p.x;
-        acc.y += p.y;
-    }
-    __syncthreads();
-    col[u] = acc;
-    __syncthreads();
-    float2 zin;
-    if (u == 0) {
-        const float inv_n = 1.0f / (float)(2 * nh);
-        const float2 z0 = col[0];
-        const float m0 = fabsf(z0.x + z0.y) * inv_n, mh = fabsf(z0.x - z0.y) * inv_n;
-        zin = make_float2(m0 + mh, m0 - mh);
-    } else {
-        float2 zk, zkm;
-        float sn, cs;
-        sincospif(-(float)u * (1.0f / (float)R), &sn, &cs);  // k = u*Ns: exp(-i pi k/nh) = exp(-i pi u/R)
-        ac_split_pair(col[u], col[R - u], make_float2(cs, sn), nh, &zk, &zkm);
-        zin = zk;
-    }
-    __syncthreads();
-    col[u] = make_float2(zin.x, -zin.y);  // conjugated input of the inverse transform
-    __syncthreads();
-    acc = make_float2(0.f, 0.f);
-    for (unsigned t = 0; t < R; t++) {
-        const float2 p = cmul(col[t], tw[(t * u) & (R - 1)]);
-        acc.x += p.x;
-        acc.y += p.y;
-    }
-    yb[u] = acc;  // y[0*R + u]
-}
 
 // unpack zout (r[2m] + i r[2m+1]) into the reference's layout: complex, imaginary part 0
 __global__ __launch_bounds__(256) void k_ac_expand(const float2 *__restrict__ zout, float2 *__restrict__ corr, unsigned nh)
@@ -950,18 +960,13 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
                                       plan.count - 1, 1, 0, 0, false, 1.0f, ac->st);
             // ... last forward pass + split + first inverse pass in one kernel ...
             float2 *mid = (z == ac->d_a) ? ac->d_b : ac->d_a;
-            const dim3 grid(Ns_last / (2 * (2048 / R_last)), cnt);
+            const dim3 grid(Ns_last / (2 * (2048 / R_last)) + 1, cnt);  // + workgroup 0 for column 0
             switch (R_last / 16) {
-                case 1: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<1>), grid, 256, z, mid, nh);
-                        TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<16>), dim3(1, cnt), 16, z, mid, nh); break;
-                case 2: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<2>), grid, 256, z, mid, nh);
-                        TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<32>), dim3(1, cnt), 32, z, mid, nh); break;
-                case 4: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<4>), grid, 256, z, mid, nh);
-                        TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<64>), dim3(1, cnt), 64, z, mid, nh); break;
-                case 8: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<8>), grid, 256, z, mid, nh);
-                        TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<128>), dim3(1, cnt), 128, z, mid, nh); break;
-                default: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<16>), grid, 256, z, mid, nh);
-                         TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid_col0<256>), dim3(1, cnt), 256, z, mid, nh); break;
+                case 1: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<1>), grid, 256, z, mid, nh); break;
+                case 2: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<2>), grid, 256, z, mid, nh); break;
+                case 4: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<4>), grid, 256, z, mid, nh); break;
+                case 8: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<8>), grid, 256, z, mid, nh); break;
+                default: TSDR_LAUNCH(g, PROF_AC_SPLIT, ac->st, (k_ac_mid<16>), grid, 256, z, mid, nh); break;
             }
             // ... the remaining inverse passes, radices in reverse order (the fused kernel did radix R_last, Ns = 1)
             int rev[32];
