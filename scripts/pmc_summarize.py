@@ -6,7 +6,7 @@ of the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is
 both are calibrated here against k_demod_vec4, whose traffic is known exactly (8 B read + 4 B written per
 sample, float4 accesses): the calibration factors are printed and applied.
 
-usage: pmc_summarize.py <dir with FETCH_SIZE/ and WRITE_SIZE/ sub-directories> [out.json]
+usage: pmc_summarize.py <dir with FETCH_SIZE/ and WRITE_SIZE/ sub-directories> [out.json [flat_for_bench.json]]
 """
 import csv
 import glob
@@ -73,6 +73,14 @@ def main():
     res = {"fetch_factor": ff, "write_factor": wf, "unit": "bytes per launch", "kernels": out}
     if len(sys.argv) > 2:
         json.dump(res, open(sys.argv[2], "w"), indent=1)
+    if len(sys.argv) > 3:
+        # the flat form bench.py reads for roofline.traffic: kernel -> HBM bytes per launch
+        flat = {k: int(round(v["hbm_bytes_per_launch"])) for k, v in out.items()}
+        flat["_note"] = (f"HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units), "
+                         f"FETCH_SIZE x{ff:.3f} and WRITE_SIZE x{wf:.3f} calibrated on k_demod_vec4 (known 8 B read + 4 B "
+                         "written per sample); bench workload: 1 s of 100 MS/s IQ per step (60 frames; 17 windows transformed "
+                         "6+6+5 per launch); scripts/pmc_collect.sh")
+        json.dump(flat, open(sys.argv[3], "w"), indent=1)
     return res
 
 
