@@ -100,6 +100,18 @@ int tsdrgpu_resampler_getstate(tsdrgpu_resampler_t *rs, double *contrib, double 
 int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int in_is_iq, uint32_t chunk,
                      int nchunks, double upsample_by, double downsample_by, int nearest,
                      float *d_out, int64_t out_capacity, int64_t *h_n_out);
+/* Frame tracking (optional, area mode).  When on, tsdrgpu_resample also reduces, for every video frame of
+ * `frame_pixels` consecutive output pixels, the minimum and maximum over the non-sentinel pixels
+ * (|v| <= 250) it emits — pass 1 of dsp_autogain_run (dsp.c:41-66) without reading the frame again.
+ * `phase` = pixels of the current, still incomplete frame that earlier calls emitted (0 on a frame
+ * boundary); from then on the frame boundaries follow the pixel count from call to call, so call this
+ * again after samples were dropped or the resolution changed.  frame_pixels = 0 switches tracking off;
+ * otherwise frame_pixels >= 4096.
+ * tsdrgpu_resampler_frame_minmax: after a tracked tsdrgpu_resample, device arrays (valid until the next
+ * call, written on the context's stream) with the min / max of the frames that call COMPLETED, in order
+ * (the first one includes the pixels earlier calls contributed), and their number. */
+int tsdrgpu_resampler_track_frames(tsdrgpu_resampler_t *rs, int64_t frame_pixels, int64_t phase);
+int tsdrgpu_resampler_frame_minmax(tsdrgpu_resampler_t *rs, const float **d_min, const float **d_max, int *nframes);
 /* Pixel count the next `nchunks` calls would produce, without running them. */
 int64_t tsdrgpu_resample_count(tsdrgpu_resampler_t *rs, uint32_t chunk, int nchunks,
                                double upsample_by, double downsample_by);

@@ -315,6 +315,47 @@ extern "C" int tsdrgpu_am_demod(tsdrgpu_t *g, const float *d_iq, float *d_out, i
 // per-chunk phase recurrence is pure f64 bookkeeping, dsp.c:262,272,306) tells
 // each block which dsp_resample_process call it belongs to.
 // ---------------------------------------------------------------------------
+// Frame tracking records.  RsChunkFrame: where a chunk's first pixel falls (frame index counted from
+// the frame the call starts in, offset inside that frame).  RsBlockMM: min/max of the non-sentinel
+// pixels one k_rs_area workgroup emitted, split over the (at most two, frames hold >= 4096 pixels)
+// frames its 2048-pixel span touches; f0 < 0 = the workgroup emitted nothing.
+struct RsChunkFrame {
+    long long rem;
+    int f;
+    int pad;
+};
+struct RsBlockMM {
+    int f0;
+    float mn0, mx0, mn1, mx1;
+};
+struct RsFrameRange {
+    int c_lo, c_hi;  // chunks that overlap the frame
+};
+
+__device__ __forceinline__ float rs_wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float rs_wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+// frame index / offset of the pixel `add` pixels after (f, rem)
+__device__ __forceinline__ void rs_frame_of(long long P, int f, long long rem, long long add, int *fo, long long *ro)
+{
+    long long pos = rem + add;
+    if (pos >= P) {
+        if (pos < 2 * P) { pos -= P; f += 1; }
+        else { const long long q = pos / P; pos -= q * P; f += (int)q; }
+    }
+    *fo = f;
+    *ro = pos;
+}
+
 struct tsdrgpu_resampler {
     tsdrgpu_t *g;
     double offset;      // dsp_resample_t.offset (host side: data independent)
@@ -324,6 +365,16 @@ struct tsdrgpu_resampler {
     unsigned char *d_need;
     int cap_chunks;
     StagingRing ring;
+    // frame tracking (tsdrgpu_resampler_track_frames): per-frame min/max of the emitted pixels
+    long long frame_pixels;  // 0 = off
+    long long phase;         // pixels of the current incomplete frame emitted by earlier calls
+    RsBlockMM *d_slots;      // one record per k_rs_area workgroup
+    size_t cap_slots;
+    float *d_fmin, *d_fmax;  // frames touched by the last call, in order
+    int cap_frames;
+    float *d_carry;          // [2][2]: min/max of the incomplete frame, double buffered by call parity
+    int parity;
+    int last_complete;       // frames completed by the last call (-1: no tracked call yet)
 };
 
 template <bool IQ>
@@ -402,9 +453,10 @@ __global__ __launch_bounds__(256) void k_rs_chain(const RsChunk *__restrict__ ch
 // the few samples that touch them (rs_area_group).  Groups cut by the chunk's
 // ends fall back to dword stores.
 #define RS_NPIX 8
-template <bool IQ>
+template <bool IQ, bool MM>
 __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chunks, double r, double rinv, const float *__restrict__ in,
-                                                 const double *__restrict__ cin, float *__restrict__ out)
+                                                 const double *__restrict__ cin, float *__restrict__ out,
+                                                 const RsChunkFrame *__restrict__ cframes, long long P, RsBlockMM *__restrict__ slots)
 {
     const RsChunk ch = chunks[blockIdx.y];
     RsGeom g;
@@ -422,6 +474,19 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
     // barrier is needed and equal k across lanes is conflict free); a dynamic register index would
     // cost a compare+select per register instead of one ds_write
     __shared__ float stage[RS_NPIX][256];
+    // frame tracking: min/max of this workgroup's pixels for the frame its first pixel lies in (fb) and
+    // the next one.  The host sizes the grid so that the loop below runs at most once per thread.
+    float mn0 = INFINITY, mx0 = -INFINITY, mn1 = INFINITY, mx1 = -INFINITY;
+    int fb = -1;
+    RsChunkFrame cf;
+    if (MM) {
+        cf = cframes[blockIdx.y];
+        const int pb = RS_NPIX * (int)(blockIdx.x * blockDim.x) - mis;
+        if (pb < n_out) {
+            long long dummy;
+            rs_frame_of(P, cf.f, cf.rem, pb < 0 ? 0 : pb, &fb, &dummy);
+        }
+    }
     for (int grp = blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += gridDim.x * blockDim.x) {
         const int p0 = RS_NPIX * grp - mis;
 #pragma unroll
@@ -430,6 +495,25 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
         float v[RS_NPIX];
 #pragma unroll
         for (int k = 0; k < RS_NPIX; k++) v[k] = stage[k][threadIdx.x];
+        if (MM) {
+            const int pf = p0 < 0 ? 0 : p0;
+            int f;
+            long long rem;
+            rs_frame_of(P, cf.f, cf.rem, pf, &f, &rem);
+#pragma unroll
+            for (int k = 0; k < RS_NPIX; k++) {
+                const int p = p0 + k;
+                if (p >= 0 && p < n_out) {
+                    const float val = v[k];
+                    const bool sent = (val > 250.0f) || (val < -250.0f);  // dsp.c:57
+                    const int fk = f + ((rem + (p - pf) >= P) ? 1 : 0);
+                    if (!sent) {
+                        if (fk == fb) { mn0 = fminf(mn0, val); mx0 = fmaxf(mx0, val); }
+                        else { mn1 = fminf(mn1, val); mx1 = fmaxf(mx1, val); }
+                    }
+                }
+            }
+        }
         if (p0 >= 0 && p0 + RS_NPIX <= n_out) {
             *reinterpret_cast<float4 *>(dst + p0) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4 *>(dst + p0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -438,6 +522,60 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
             for (int k = 0; k < RS_NPIX; k++)
                 if (p0 + k >= 0 && p0 + k < n_out) dst[p0 + k] = v[k];
         }
+    }
+    if (MM) {
+        __shared__ float red[4][4];
+        mn0 = rs_wave_min(mn0); mx0 = rs_wave_max(mx0);
+        mn1 = rs_wave_min(mn1); mx1 = rs_wave_max(mx1);
+        if ((threadIdx.x & 63) == 0) {
+            float *rw = red[threadIdx.x >> 6];
+            rw[0] = mn0; rw[1] = mx0; rw[2] = mn1; rw[3] = mx1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            RsBlockMM o;
+            o.f0 = fb;
+            o.mn0 = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+            o.mx0 = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+            o.mn1 = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
+            o.mx1 = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
+            slots[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = o;
+        }
+    }
+}
+
+// Frame tracking, second stage: one workgroup per frame touched by the call folds the records of
+// the workgroups whose span overlaps it (chunk range from the host), joins frame 0 with the
+// incomplete frame carried from the previous call and leaves the call's last, incomplete frame
+// in the other carry slot.  min/max are order independent, so this is exact.
+__global__ __launch_bounds__(256) void k_rs_minmax(const RsBlockMM *__restrict__ slots, int gx, const RsFrameRange *__restrict__ ranges,
+                                                   int ntouched, int ncomplete, const float *__restrict__ carry_in,
+                                                   float *__restrict__ carry_out, float *__restrict__ fmin_, float *__restrict__ fmax_)
+{
+    const int j = blockIdx.x;
+    const RsFrameRange rg = ranges[j];
+    float lo = INFINITY, hi = -INFINITY;
+    const long long first = (long long)rg.c_lo * gx, last = (long long)rg.c_hi * gx;
+    for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
+        const RsBlockMM b = slots[i];
+        if (b.f0 == j) { lo = fminf(lo, b.mn0); hi = fmaxf(hi, b.mx0); }
+        else if (b.f0 >= 0 && b.f0 + 1 == j) { lo = fminf(lo, b.mn1); hi = fmaxf(hi, b.mx1); }
+    }
+    __shared__ float red[4][2];
+    lo = rs_wave_min(lo);
+    hi = rs_wave_max(hi);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lo; red[threadIdx.x >> 6][1] = hi; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    lo = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+    hi = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+    if (j == 0) { lo = fminf(lo, carry_in[0]); hi = fmaxf(hi, carry_in[1]); }
+    fmin_[j] = lo;
+    fmax_[j] = hi;
+    if (j == ntouched - 1) {
+        const bool incomplete = ntouched > ncomplete;
+        carry_out[0] = incomplete ? lo : INFINITY;
+        carry_out[1] = incomplete ? hi : -INFINITY;
     }
 }
 
@@ -461,6 +599,7 @@ extern "C" int tsdrgpu_resampler_create(tsdrgpu_t *g, tsdrgpu_resampler_t **out)
     int rc = staging_init(g, &rs->ring);
     if (rc) { free(rs); return rc; }
     if (hipMalloc(&rs->d_contrib, sizeof(double)) != hipSuccess) { staging_free(&rs->ring); free(rs); return TSDRGPU_ENOMEM; }
+    rs->last_complete = -1;
     *out = rs;
     return tsdrgpu_resampler_reset(rs);
 }
@@ -474,6 +613,10 @@ extern "C" void tsdrgpu_resampler_destroy(tsdrgpu_resampler_t *rs)
     hipFree(rs->d_cin);
     hipFree(rs->d_tail);
     hipFree(rs->d_need);
+    hipFree(rs->d_slots);
+    hipFree(rs->d_fmin);
+    hipFree(rs->d_fmax);
+    hipFree(rs->d_carry);
     free(rs);
 }
 
@@ -532,6 +675,41 @@ extern "C" int64_t tsdrgpu_resample_count(tsdrgpu_resampler_t *rs, uint32_t chun
     return build_chunks(&off, chunk, nchunks, up, down, nullptr);
 }
 
+extern "C" int tsdrgpu_resampler_track_frames(tsdrgpu_resampler_t *rs, int64_t frame_pixels, int64_t phase)
+{
+    if (!rs) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = rs->g;
+    if (frame_pixels == 0) {
+        rs->frame_pixels = 0;
+        rs->last_complete = -1;
+        return TSDRGPU_OK;
+    }
+    // a workgroup's 2048-pixel span must not touch more than two frames
+    if (frame_pixels < 4096 || phase < 0 || phase >= frame_pixels)
+        return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resampler_track_frames", "frame_pixels must be >= 4096 and 0 <= phase < frame_pixels");
+    if (!rs->d_carry && hipMalloc(&rs->d_carry, 4 * sizeof(float)) != hipSuccess)
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_resampler_track_frames", "carry");
+    const float init[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+    HIP_TRY(g, hipMemcpyAsync(rs->d_carry, init, sizeof(init), hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));  // `init` is on the stack
+    rs->frame_pixels = frame_pixels;
+    rs->phase = phase;
+    rs->parity = 0;
+    rs->last_complete = -1;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_resampler_frame_minmax(tsdrgpu_resampler_t *rs, const float **d_min, const float **d_max, int *nframes)
+{
+    if (!rs) return TSDRGPU_EINVAL;
+    if (rs->frame_pixels <= 0 || rs->last_complete < 0)
+        return tsdr_fail(rs->g, TSDRGPU_ESTATE, "tsdrgpu_resampler_frame_minmax", "no tracked tsdrgpu_resample call yet");
+    if (d_min) *d_min = rs->d_fmin;
+    if (d_max) *d_max = rs->d_fmax;
+    if (nframes) *nframes = rs->last_complete;
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int in_is_iq, uint32_t chunk, int nchunks,
                                 double up, double down, int nearest, float *d_out, int64_t out_capacity,
                                 int64_t *h_n_out)
@@ -546,16 +724,46 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
     const int64_t total = build_chunks(&probe, chunk, nchunks, up, down, nullptr);
     if (total > out_capacity) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resample", "output buffer too small");
 
-    const size_t bytes = sizeof(RsChunk) * (size_t)nchunks;
+    const bool track = rs->frame_pixels > 0;
+    if (track && nearest) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resample", "frame tracking needs the area mode");
+    const long long P = rs->frame_pixels;
+    const int ntouched = (track && total > 0) ? (int)((rs->phase + total + P - 1) / P) : 0;
+    const int ncomplete = track ? (int)((rs->phase + total) / P) : 0;
+    // one staging slot: chunk table [+ per-chunk frame positions + per-frame chunk ranges]
+    const size_t tab_bytes = sizeof(RsChunk) * (size_t)nchunks;
+    const size_t cf_off = (tab_bytes + 15) & ~(size_t)15;
+    const size_t rg_off = cf_off + (track ? sizeof(RsChunkFrame) * (size_t)nchunks : 0);
+    const size_t bytes = track ? rg_off + sizeof(RsFrameRange) * (size_t)(ntouched ? ntouched : 1) : tab_bytes;
     const int slot = staging_acquire(g, &rs->ring, bytes);
     if (slot < 0) return slot;
     RsChunk *tab = (RsChunk *)rs->ring.h[slot];
     build_chunks(&rs->offset, chunk, nchunks, up, down, tab);
     unsigned max_out = 0;
     for (int c = 0; c < nchunks; c++) max_out = tab[c].n_out > max_out ? tab[c].n_out : max_out;
+    if (track) {
+        RsChunkFrame *cf = (RsChunkFrame *)((char *)rs->ring.h[slot] + cf_off);
+        for (int c = 0; c < nchunks; c++) {
+            const long long pos = rs->phase + tab[c].out_off;
+            cf[c].f = (int)(pos / P);
+            cf[c].rem = pos % P;
+            cf[c].pad = 0;
+        }
+        RsFrameRange *rg = (RsFrameRange *)((char *)rs->ring.h[slot] + rg_off);
+        int c0 = 0;
+        for (int j = 0; j < ntouched; j++) {
+            const long long lo = (long long)j * P - rs->phase, hi = lo + P;  // call-relative pixel range of frame j
+            while (c0 < nchunks && tab[c0].out_off + (long long)tab[c0].n_out <= lo) c0++;
+            int c1 = c0;
+            while (c1 < nchunks && tab[c1].out_off < hi) c1++;
+            rg[j].c_lo = c0;
+            rg[j].c_hi = c1;
+        }
+    }
     int rc = staging_push(g, &rs->ring, slot, bytes);
     if (rc) return rc;
     const RsChunk *d_tab = (const RsChunk *)rs->ring.d[slot];
+    const RsChunkFrame *d_cf = (const RsChunkFrame *)((const char *)rs->ring.d[slot] + cf_off);
+    const RsFrameRange *d_rg = (const RsFrameRange *)((const char *)rs->ring.d[slot] + rg_off);
 
     if (rs->cap_chunks < nchunks) {
         hipFree(rs->d_cin); hipFree(rs->d_tail); hipFree(rs->d_need);
@@ -589,11 +797,46 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
                 TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, (k_rs_chain<false>), 1, 256, d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
             }
         }
+        if (track) {
+            const size_t nslots = (size_t)grid4.x * (size_t)nchunks;
+            if (rs->cap_slots < nslots) {
+                (void)hipStreamSynchronize(g->stream);
+                hipFree(rs->d_slots);
+                rs->d_slots = nullptr; rs->cap_slots = 0;
+                if (hipMalloc(&rs->d_slots, sizeof(RsBlockMM) * (nslots + nslots / 8)) != hipSuccess)
+                    return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_resample", "frame tracking records");
+                rs->cap_slots = nslots + nslots / 8;
+            }
+            if (rs->cap_frames < ntouched) {
+                (void)hipStreamSynchronize(g->stream);
+                hipFree(rs->d_fmin); hipFree(rs->d_fmax);
+                rs->d_fmin = rs->d_fmax = nullptr; rs->cap_frames = 0;
+                if (hipMalloc(&rs->d_fmin, sizeof(float) * (ntouched + 16)) != hipSuccess ||
+                    hipMalloc(&rs->d_fmax, sizeof(float) * (ntouched + 16)) != hipSuccess)
+                    return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_resample", "frame min/max");
+                rs->cap_frames = ntouched + 16;
+            }
+        }
         if (max_out) {
-            if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<true>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out);
-            else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<false>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out);
+            if (track) {
+                if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<true, true>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, d_cf, P, rs->d_slots);
+                else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<false, true>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, d_cf, P, rs->d_slots);
+            } else {
+                if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<true, false>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, (const RsChunkFrame *)nullptr, 0LL, (RsBlockMM *)nullptr);
+                else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<false, false>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, (const RsChunkFrame *)nullptr, 0LL, (RsBlockMM *)nullptr);
+            }
         }
         KERNEL_CHECK(g, "k_rs_area");
+        if (track && ntouched > 0) {
+            TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, k_rs_minmax, (unsigned)ntouched, 256, rs->d_slots, (int)grid4.x, d_rg, ntouched, ncomplete,
+                        rs->d_carry + 2 * rs->parity, rs->d_carry + 2 * (1 - rs->parity), rs->d_fmin, rs->d_fmax);
+            KERNEL_CHECK(g, "k_rs_minmax");
+            rs->parity = 1 - rs->parity;
+        }
+    }
+    if (track) {
+        rs->phase = (rs->phase + total) % P;
+        rs->last_complete = ncomplete;
     }
     rc = staging_release(g, &rs->ring, slot);
     if (rc) return rc;

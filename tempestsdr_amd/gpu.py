@@ -77,6 +77,8 @@ _SIGS = {
     "tsdrgpu_resampler_getstate": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tsdrgpu_resample": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_double, C.c_double,
                                    C.c_int, vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "tsdrgpu_resampler_track_frames": (C.c_int, [vp, C.c_int64, C.c_int64]),
+    "tsdrgpu_resampler_frame_minmax": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]),
     "tsdrgpu_resample_count": (C.c_int64, [vp, C.c_uint32, C.c_int, C.c_double, C.c_double]),
     "tsdrgpu_postproc_create": (C.c_int, [vp, C.POINTER(vp)]),
     "tsdrgpu_postproc_destroy": (None, [vp]),
@@ -322,6 +324,24 @@ class Resampler:
         c, o = C.c_double(), C.c_double()
         self.ctx._ck(self.ctx.lib.tsdrgpu_resampler_getstate(self.h, C.byref(c), C.byref(o)))
         return c.value, o.value
+
+    def track_frames(self, frame_pixels, phase=0):
+        """Per-frame min/max of the emitted pixels from now on (0 = off)."""
+        self.ctx._ck(self.ctx.lib.tsdrgpu_resampler_track_frames(self.h, int(frame_pixels), int(phase)))
+
+    def frame_minmax(self, download=True):
+        """(min[], max[]) of the frames the last process() completed; device pointers with download=False."""
+        a, b, n = vp(), vp(), C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_resampler_frame_minmax(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        if not download:
+            return a.value, b.value, n.value
+        mn = np.empty(n.value, np.float32)
+        mx = np.empty(n.value, np.float32)
+        if n.value:
+            self.ctx._ck(self.ctx.lib.tsdrgpu_download(self.ctx.h, mn.ctypes.data, a.value, mn.nbytes))
+            self.ctx._ck(self.ctx.lib.tsdrgpu_download(self.ctx.h, mx.ctypes.data, b.value, mx.nbytes))
+            self.ctx.sync()
+        return mn, mx
 
     def count(self, chunk, nchunks, up, down):
         return self.ctx.lib.tsdrgpu_resample_count(self.h, chunk, nchunks, up, down)

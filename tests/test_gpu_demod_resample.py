@@ -154,3 +154,52 @@ def test_resample_full_size_properties(orc):
     ref_rs = orc.Resampler()
     want = np.concatenate([ref_rs.process(x[c * chunk:(c + 1) * chunk], up, down) for c in range(8)])
     assert np.array_equal(y1[:want.size], want)
+
+
+@pytest.mark.parametrize("from_iq", [0, 1])
+@pytest.mark.parametrize("P,phase0", [(4096, 0), (5003, 4321), (43623, 17), (100_000, 99_999)])
+def test_resampler_frame_minmax_tracking(from_iq, P, phase0):
+    """tsdrgpu_resampler_track_frames: per-frame min/max of the emitted pixel stream, carried across calls,
+    == numpy on the downloaded stream (order-independent reductions: exact), sentinels (|v| > 250) excluded."""
+    g = ctx()
+    rng = np.random.default_rng(P + from_iq)
+    rs = gpu.Resampler(g)
+    rs.track_frames(P, phase0)
+    up, down = 1.99935, 1.0
+    stream, got_mn, got_mx = [], [], []
+    for call, (chunk, nchunks) in enumerate([(3333, 7), (1000, 1), (16667, 13), (50, 3), (7777, 40)]):
+        n = chunk * nchunks
+        x = rng.random(n).astype(np.float32) * 3.0 - 0.5
+        x[rng.integers(0, n, 5)] = 700.0  # produce pixels above the sentinel threshold
+        x[rng.integers(0, n, 5)] = -900.0
+        if from_iq:
+            ph = rng.random(n) * 6.28
+            mag = np.abs(x)
+            host = np.empty(2 * n, np.float32)
+            host[0::2] = (mag * np.cos(ph)).astype(np.float32)
+            host[1::2] = (mag * np.sin(ph)).astype(np.float32)
+        else:
+            host = x
+        d_in = g.to_device(host)
+        cap = rs.count(chunk, nchunks, up, down)
+        d_out = g.empty(cap + 8)
+        npix = rs.process(d_in, from_iq, chunk, nchunks, up, down, 0, d_out)
+        assert npix == cap
+        stream.append(d_out.download()[:npix])
+        mn, mx = rs.frame_minmax()
+        got_mn += list(mn)
+        got_mx += list(mx)
+    s = np.concatenate([np.zeros(phase0, np.float32) + np.float32(1e9), np.concatenate(stream)])  # phase0 pixels came "before"
+    nfr = s.size // P
+    assert len(got_mn) == nfr
+    for f in range(nfr):
+        fr = s[f * P:(f + 1) * P]
+        if f == 0:
+            fr = fr[phase0:]  # only the tracked part of the first frame is known to the resampler
+        ok = fr[np.abs(fr) <= 250.0]
+        assert got_mn[f] == ok.min() and got_mx[f] == ok.max(), f"frame {f}"
+    with pytest.raises(gpu.TsdrGpuError):
+        rs.track_frames(1000)  # too small
+    rs.track_frames(0)
+    with pytest.raises(gpu.TsdrGpuError):
+        rs.frame_minmax()
