@@ -163,6 +163,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (sums + all-reduce + finalize) even with one rank; used to "
                          "exercise the RCCL path on a 1-GPU box")
+    ap.add_argument("--fuse", action="store_true",
+                    help="fused run: min/max from the resampler (frame tracking) and the sync detector's sums from the "
+                         "normalise/IIR pass instead of a separate statistics pass (k_frame_stats).  Moves 12P instead of "
+                         "16P bytes per frame but measured slower on MI355X (DESIGN.md section 4), so it is opt-in")
     ap.add_argument("--no-split", action="store_true",
                     help="one tsdrgpu_postproc_run per batch instead of _begin / autocorrelation / _finish "
                          "(the split hides the ~0.1 ms frame-to-frame chain behind the FFT passes)")
@@ -222,6 +226,8 @@ def main():
     frames_done = 0
 
     ac.set_async(args.overlap)
+    if args.frames_per_launch <= 0 and not args.no_split and args.fuse:
+        rs.track_frames(P, 0)  # per-frame min/max out of the resampler (the batch starts on a frame boundary)
 
     def run_autocorr():
         if not sharded:
@@ -233,6 +239,7 @@ def main():
     def step():
         nonlocal carry, frames_done
         split = args.frames_per_launch <= 0 and not args.no_split
+        fuse = split and args.fuse
         if not split:
             run_autocorr()  # queued first: with --overlap it runs beside everything below
         # a1+a2: the new pixels are appended behind the carried remainder; a3..a8 on the whole frames.
@@ -246,7 +253,15 @@ def main():
             done_chunks += k
             avail = carry + n
             F = avail // P
-            if split:
+            if split and fuse:
+                # the resampler already reduced every frame's min/max (frame tracking), so ONE trip over the
+                # raw frames normalises, low-passes and gathers the sync detector's sums; the detector itself
+                # (latency-bound) runs on the side stream while the autocorrelation keeps the main one busy
+                mn_ptr, mx_ptr, _ = rs.frame_minmax(download=False)
+                pp.begin_minmax(d_pix, F, W, h, mn_ptr, mx_ptr, d_out, motionblur=0.0)
+                run_autocorr()
+                pp.finish(d_out, want_info=False)
+            elif split:
                 # frame statistics, then the latency-bound frame-to-frame chain on the side stream while
                 # the autocorrelation passes keep the main stream busy, then the normalise/IIR pass
                 pp.begin(d_pix, F, W, h, motionblur=0.0)
@@ -364,6 +379,7 @@ def main():
         # with the split run the chain kernels execute on the side stream behind the FFT passes: their
         # (contended) durations are listed in stage_ms_per_step but are not on the critical path
         chain_hidden = args.frames_per_launch <= 0 and not args.no_split
+        fused = chain_hidden and args.fuse
         frame_kernels_ms = sum(prof.get(k, (0, 0))[0] for k in
                                ("k_rs_tail+k_rs_chain", "k_rs_area", "k_frame_stats", "k_frame_reduce", "k_frame_pass") +
                                (() if chain_hidden else ("k_chain",)))
@@ -388,7 +404,9 @@ def main():
                            "achieved_GBs": round(frame_path_bytes / (frame_kernels_ms * 1e-3) / 1e9, 1) if frame_kernels_ms else None,
                            "frac": round(frame_path_bytes / (frame_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_kernels_ms else None,
                            "alg_bytes_per_frame": int(8 * S + 16 * P),
-                           "chain": "on the side stream, overlapped with the autocorrelation" if chain_hidden else "in line"},
+                           "chain": "on the side stream, overlapped with the autocorrelation" if chain_hidden else "in line",
+                           "statistics": "min/max in k_rs_area, row/column sums in the normalise/IIR pass (12P bytes per frame "
+                                         "instead of 16P)" if fused else "k_frame_stats"},
             "autocorrelation": {"kernels_ms_per_step": round(ac_ms / max(1, prof_steps), 3),
                                 "achieved_GBs": round(ac_bytes_step / (ac_ms * 1e-3) / 1e9, 1),
                                 "frac": round(ac_bytes_step / (ac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

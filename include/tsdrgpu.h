@@ -166,6 +166,20 @@ int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int nfra
 int tsdrgpu_postproc_begin(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width, int height,
                            const tsdrgpu_pp_params_t *params);
 int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsdrgpu_pp_frameinfo_t *h_info);
+/* Fused form of _begin for a caller that already holds each frame's min / max over its non-sentinel
+ * pixels (tsdrgpu_resampler_frame_minmax; device arrays of nframes floats): with the default stage order
+ * and autoshift off, the autogain IIR runs from those values and ONE trip over the raw frames normalises,
+ * low-passes, writes d_out and gathers the row/column sums of the sync detector, which then runs (with the
+ * green lines of syncdetector.c:209-223 patched in afterwards) on the side stream — the separate
+ * statistics read of every frame (4 bytes/pixel of 16) disappears.  Results are bit-identical to
+ * tsdrgpu_postproc_run.  Everything is queued here, so d_out is given now; _finish(pp, d_out, h_info) joins
+ * the streams.  Any other parameter combination silently takes the _begin path (min/max ignored).
+ * Measured on MI355X (1080p, 60-frame batches) this form is NOT faster than _begin/_finish although it
+ * moves a quarter less data: the tile-shaped pass and the min/max reduction inside the instruction-bound
+ * resampler cost what the saved read gains — an alternative, not the default. */
+int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width, int height,
+                                  const tsdrgpu_pp_params_t *params, const float *d_fmin, const float *d_fmax,
+                                  float *d_out);
 /* strips of the last frame run (after blur + markers), for stage-level tests */
 int tsdrgpu_postproc_strips(tsdrgpu_postproc_t *pp, float *h_colsum, float *h_rowsum); /* syncs */
 

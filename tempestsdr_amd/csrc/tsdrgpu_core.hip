@@ -317,8 +317,8 @@ extern "C" int tsdrgpu_am_demod(tsdrgpu_t *g, const float *d_iq, float *d_out, i
 // ---------------------------------------------------------------------------
 // Frame tracking records.  RsChunkFrame: where a chunk's first pixel falls (frame index counted from
 // the frame the call starts in, offset inside that frame).  RsBlockMM: min/max of the non-sentinel
-// pixels one k_rs_area workgroup emitted, split over the (at most two, frames hold >= 4096 pixels)
-// frames its 2048-pixel span touches; f0 < 0 = the workgroup emitted nothing.
+// pixels one wave of a k_rs_area workgroup emitted, split over the (at most two, frames hold >= 4096
+// pixels) frames the workgroup's 2048-pixel span touches; f0 < 0 = the workgroup emitted nothing.
 struct RsChunkFrame {
     long long rem;
     int f;
@@ -332,16 +332,31 @@ struct RsFrameRange {
     int c_lo, c_hi;  // chunks that overlap the frame
 };
 
+// wave64 min/max with DPP row shifts + row broadcasts (6 VALU instructions, result in lane 63);
+// min/max are exact, so the order does not matter
+template <int CTRL>
+__device__ __forceinline__ float rs_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float rs_wave_min(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    v = fminf(v, rs_dpp<0x111>(v));  // row_shr:1
+    v = fminf(v, rs_dpp<0x112>(v));  // row_shr:2
+    v = fminf(v, rs_dpp<0x114>(v));  // row_shr:4
+    v = fminf(v, rs_dpp<0x118>(v));  // row_shr:8   -> lane 15 of each row holds the row's min
+    v = fminf(v, rs_dpp<0x142>(v));  // row_bcast:15
+    v = fminf(v, rs_dpp<0x143>(v));  // row_bcast:31 -> lane 63 holds the wave's min
     return v;
 }
 __device__ __forceinline__ float rs_wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    v = fmaxf(v, rs_dpp<0x111>(v));
+    v = fmaxf(v, rs_dpp<0x112>(v));
+    v = fmaxf(v, rs_dpp<0x114>(v));
+    v = fmaxf(v, rs_dpp<0x118>(v));
+    v = fmaxf(v, rs_dpp<0x142>(v));
+    v = fmaxf(v, rs_dpp<0x143>(v));
     return v;
 }
 // frame index / offset of the pixel `add` pixels after (f, rem)
@@ -477,16 +492,21 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
     // frame tracking: min/max of this workgroup's pixels for the frame its first pixel lies in (fb) and
     // the next one.  The host sizes the grid so that the loop below runs at most once per thread.
     float mn0 = INFINITY, mx0 = -INFINITY, mn1 = INFINITY, mx1 = -INFINITY;
-    int fb = -1;
-    RsChunkFrame cf;
+    int fb = -1;          // frame of the workgroup's first pixel
+    int pbf = 0;          // that pixel
+    int to_b = 0x3fffffff;  // pixels from it to the next frame boundary: pixel p is in frame fb iff p - pbf < to_b
     if (MM) {
-        cf = cframes[blockIdx.y];
         const int pb = RS_NPIX * (int)(blockIdx.x * blockDim.x) - mis;
+        pbf = pb < 0 ? 0 : pb;
         if (pb < n_out) {
-            long long dummy;
-            rs_frame_of(P, cf.f, cf.rem, pb < 0 ? 0 : pb, &fb, &dummy);
+            const RsChunkFrame cf = cframes[blockIdx.y];
+            long long remb;
+            rs_frame_of(P, cf.f, cf.rem, pbf, &fb, &remb);
+            const long long tb = P - remb;
+            to_b = tb > 0x3fffffffLL ? 0x3fffffff : (int)tb;
         }
     }
+    const bool crosses = MM && to_b < RS_NPIX * 256 + RS_NPIX;  // uniform: the span reaches into frame fb+1
     for (int grp = blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += gridDim.x * blockDim.x) {
         const int p0 = RS_NPIX * grp - mis;
 #pragma unroll
@@ -496,21 +516,30 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
 #pragma unroll
         for (int k = 0; k < RS_NPIX; k++) v[k] = stage[k][threadIdx.x];
         if (MM) {
-            const int pf = p0 < 0 ? 0 : p0;
-            int f;
-            long long rem;
-            rs_frame_of(P, cf.f, cf.rem, pf, &f, &rem);
+            // usual case: a whole group inside one frame and no sentinel among its pixels -> min/max of
+            // the eight values (v_min3/v_max3), no per-pixel tests
+            bool fast = !crosses && p0 >= 0 && p0 + RS_NPIX <= n_out;
+            if (fast) {
+                const float m = fminf(fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), fminf(fminf(v[4], v[5]), fminf(v[6], v[7])));
+                const float M = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+                if (M > 250.0f || m < -250.0f) {
+                    fast = false;
+                } else {
+                    mn0 = fminf(mn0, m);
+                    mx0 = fmaxf(mx0, M);
+                }
+            }
+            if (!fast) {
 #pragma unroll
-            for (int k = 0; k < RS_NPIX; k++) {
-                const int p = p0 + k;
-                if (p >= 0 && p < n_out) {
+                for (int k = 0; k < RS_NPIX; k++) {
+                    const int p = p0 + k;
                     const float val = v[k];
-                    const bool sent = (val > 250.0f) || (val < -250.0f);  // dsp.c:57
-                    const int fk = f + ((rem + (p - pf) >= P) ? 1 : 0);
-                    if (!sent) {
-                        if (fk == fb) { mn0 = fminf(mn0, val); mx0 = fmaxf(mx0, val); }
-                        else { mn1 = fminf(mn1, val); mx1 = fmaxf(mx1, val); }
-                    }
+                    const bool ok = p >= 0 && p < n_out && !((val > 250.0f) || (val < -250.0f));  // dsp.c:57
+                    const bool first = p - pbf < to_b;
+                    mn0 = fminf(mn0, (ok && first) ? val : INFINITY);
+                    mx0 = fmaxf(mx0, (ok && first) ? val : -INFINITY);
+                    mn1 = fminf(mn1, (ok && !first) ? val : INFINITY);
+                    mx1 = fmaxf(mx1, (ok && !first) ? val : -INFINITY);
                 }
             }
         }
@@ -524,22 +553,14 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
         }
     }
     if (MM) {
-        __shared__ float red[4][4];
+        // one record per wave (no workgroup barrier, no LDS): lane 63 holds the DPP reductions
         mn0 = rs_wave_min(mn0); mx0 = rs_wave_max(mx0);
-        mn1 = rs_wave_min(mn1); mx1 = rs_wave_max(mx1);
-        if ((threadIdx.x & 63) == 0) {
-            float *rw = red[threadIdx.x >> 6];
-            rw[0] = mn0; rw[1] = mx0; rw[2] = mn1; rw[3] = mx1;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
+        if (crosses) { mn1 = rs_wave_min(mn1); mx1 = rs_wave_max(mx1); }
+        if ((threadIdx.x & 63) == 63) {
             RsBlockMM o;
             o.f0 = fb;
-            o.mn0 = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
-            o.mx0 = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
-            o.mn1 = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
-            o.mx1 = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
-            slots[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = o;
+            o.mn0 = mn0; o.mx0 = mx0; o.mn1 = mn1; o.mx1 = mx1;
+            slots[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = o;
         }
     }
 }
@@ -555,7 +576,7 @@ __global__ __launch_bounds__(256) void k_rs_minmax(const RsBlockMM *__restrict__
     const int j = blockIdx.x;
     const RsFrameRange rg = ranges[j];
     float lo = INFINITY, hi = -INFINITY;
-    const long long first = (long long)rg.c_lo * gx, last = (long long)rg.c_hi * gx;
+    const long long first = (long long)rg.c_lo * gx * 4, last = (long long)rg.c_hi * gx * 4;  // 4 wave records per workgroup
     for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
         const RsBlockMM b = slots[i];
         if (b.f0 == j) { lo = fminf(lo, b.mn0); hi = fmaxf(hi, b.mx0); }
@@ -564,7 +585,7 @@ __global__ __launch_bounds__(256) void k_rs_minmax(const RsBlockMM *__restrict__
     __shared__ float red[4][2];
     lo = rs_wave_min(lo);
     hi = rs_wave_max(hi);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lo; red[threadIdx.x >> 6][1] = hi; }
+    if ((threadIdx.x & 63) == 63) { red[threadIdx.x >> 6][0] = lo; red[threadIdx.x >> 6][1] = hi; }
     __syncthreads();
     if (threadIdx.x != 0) return;
     lo = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
@@ -798,7 +819,7 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
             }
         }
         if (track) {
-            const size_t nslots = (size_t)grid4.x * (size_t)nchunks;
+            const size_t nslots = (size_t)grid4.x * (size_t)nchunks * 4;
             if (rs->cap_slots < nslots) {
                 (void)hipStreamSynchronize(g->stream);
                 hipFree(rs->d_slots);

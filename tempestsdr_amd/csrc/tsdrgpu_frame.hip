@@ -45,6 +45,10 @@ struct tsdrgpu_postproc {
     PpState *d_state;
     float *d_screen;   // dsp_postprocess_t.screenbuffer (IIR state)
     size_t cap_screen;
+    float *d_screen2;  // second IIR buffer of the fused run (read one, write the other, swap)
+    size_t cap_screen2;
+    float *d_dump;     // where the fused pass's lanes outside the frame store (never read)
+    size_t cap_dump;
     float *d_tmp1, *d_tmp2;  // intermediates for the non-default stage orders (F frames each)
     size_t cap_tmp1, cap_tmp2;
     // statistics scratch
@@ -69,8 +73,10 @@ struct tsdrgpu_postproc {
     // split runs (tsdrgpu_postproc_begin / _finish)
     hipStream_t chain_st;       // where launch_chain queues (the context's main stream unless split)
     hipEvent_t ev_stats, ev_chain;
-    int pending;                // 1: begin() done, chain queued on the side stream; 2: begin() deferred everything
+    int pending;                // 1: begin() done, chain queued on the side stream; 2: begin() deferred everything;
+                                // 3: fused run (begin_minmax) queued completely, finish() only joins the streams
     const float *p_frames;
+    const float *ext_fmin, *ext_fmax;  // per-frame min/max supplied by the caller (fused run), else null
     int p_F, p_W, p_H;
     tsdrgpu_pp_params_t p_prm;
 };
@@ -221,11 +227,11 @@ __global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x,
                                                       const float *__restrict__ rowp, float *__restrict__ fmin_,
                                                       float *__restrict__ fmax_, double *__restrict__ strip_x,
                                                       double *__restrict__ strip_y, const int *__restrict__ tflag,
-                                                      int want_strips)
+                                                      int want_strips, int want_minmax, int tile_h)
 {
     const int f = blockIdx.z;
     if (blockIdx.y == 0) {
-        if (blockIdx.x != 0) return;
+        if (blockIdx.x != 0 || !want_minmax) return;
         const int nblk = tiles_x * tiles_y;
         float lo = INFINITY, hi = -INFINITY;
         for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x,
         const float *src = (cols ? colp : rowp) + (long long)f * parts * 3 * n;
         double *dst = (cols ? strip_x : strip_y) + (long long)f * 3 * n;
         // tile (ty, tx) that partial p of strip element i came from
-        const int *fl = tflag + (long long)f * tiles_x * tiles_y + (cols ? i / TILE_W : (i / TILE_H) * tiles_x);
+        const int *fl = tflag + (long long)f * tiles_x * tiles_y + (cols ? i / TILE_W : (i / tile_h) * tiles_x);
         const int fstep = cols ? tiles_x : 1;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         for (int p = 0; p < parts; p++) {
@@ -768,6 +774,190 @@ __global__ __launch_bounds__(256) void k_frame_pass(const float *__restrict__ sr
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fused run (tsdrgpu_postproc_begin_minmax, default stage order without roll): the autogain's
+// min/max come from the resampler, so normalise + IIR can run BEFORE the sync detector, and the
+// one trip over the raw frames that does it also produces the row/column partial sums the sync
+// detector needs — k_frame_stats' read of every frame disappears (16P -> 12P bytes per frame).
+// Workgroup = one 256x32 tile for all F frames (IIR state of its 32 pixels per thread stays in
+// registers); the statistics part is k_frame_stats' code, so the strips are bit-identical.
+// The green lines (syncdetector.c:209-223) need dx/dy, which are known only afterwards:
+// k_fix_lines replays the exact per-pixel recurrence over the batch for the few pixels that lie on
+// a line in any frame (reading the pre-batch IIR state, which is why the state is double buffered).
+// ---------------------------------------------------------------------------
+// LDS-only workgroup barrier: __syncthreads() also waits for every outstanding global load/store
+// (s_waitcnt vmcnt(0)), which would serialise the prefetch of the next frame behind this frame's stores
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define TP_WAVES 8  // 512 threads per tile
+#define TP_H 16     // tile = 256 columns x 16 rows: wave w owns rows w and w+8, lane l columns l+64j
+// 8 pixels per thread keep the kernel under 64 VGPRs, so four workgroups (32 waves) fit a CU and every
+// tile of a 1080p frame is resident at once: the waves of other tiles hide a tile's load latency and
+// its two LDS barriers per frame.  Accesses are unconditional (pixels outside the frame read pixel 0
+// and store to a dump area): no divergent branches around memory operations, exact s_waitcnt counts.
+__global__ __launch_bounds__(512, 7) void k_frame_tile_pass(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
+                                                            long long dstride, int F, int W, int H, int tiles_x, int tiles_y,
+                                                            const ChainOut *__restrict__ chain, const float *__restrict__ screen_in,
+                                                            float *__restrict__ screen_out, float a, float *__restrict__ colp,
+                                                            float *__restrict__ rowp, int *__restrict__ tflag, float *__restrict__ dump)
+{
+    const unsigned total = gridDim.x;
+    const unsigned l = blockIdx.x;
+    const unsigned logical = (total % 8u == 0u) ? (l % 8u) * (total / 8u) + l / 8u : l;  // see k_frame_stats
+    const int tx = logical % tiles_x, ty = logical / tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = tx * TILE_W, y0 = ty * TP_H;
+    const double one_minus_a = 1.0 - a;
+    constexpr int ROWS = TP_H / TP_WAVES;  // 2
+    constexpr int FL = PASS_NORMALISE | PASS_IIR;
+    float *const mydump = dump + threadIdx.x;
+
+    const int base = (y0 + wave) * W + x0 + lane;
+    bool rowok[ROWS], colok[4];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) rowok[r] = (y0 + wave + TP_WAVES * r) < H;  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 4; j++) colok[j] = (x0 + lane + 64 * j) < W;
+#define TP_IN(r, j) (rowok[r] && colok[j])
+#define TP_OFF(r, j) (TP_IN(r, j) ? base + (r) * TP_WAVES * W + 64 * (j) : 0)  /* 0 for pixels outside the frame */
+    float st[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) st[r][j] = screen_in[TP_OFF(r, j)];
+    __shared__ float sh[3][TP_WAVES][TILE_W];  // 24 KiB
+    __shared__ int wsent[2][TP_WAVES];
+    for (int f = 0; f < F; f++) {
+        const float *in = src + (long long)f * sstride;
+        float *outp = dst + (long long)f * dstride;
+        const float lastmin = chain[f].lastmin, span = chain[f].span;
+        float val[ROWS][4];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) val[r][j] = in[TP_OFF(r, j)];
+        float cns[4] = {0, 0, 0, 0};
+        bool has_sent = false;
+        float *const rp = rowp + ((long long)(f * tiles_x + tx) * 3) * H;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int y = y0 + wave + TP_WAVES * r;
+            float rns = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float v = val[r][j];
+                const bool sent = (v > 250.0f) || (v < -250.0f);
+                const float vn = (TP_IN(r, j) && !sent) ? v : 0.f;
+                cns[j] += vn;
+                rns += vn;
+                has_sent |= TP_IN(r, j) && sent;
+                float *t = TP_IN(r, j) ? outp + TP_OFF(r, j) : mydump;
+                *t = pass_one(FL, v, st[r][j], a, one_minus_a, lastmin, span, false);
+            }
+            rns = wave_sum(rns);
+            float *t = (lane == 0 && y < H) ? rp + y : mydump;
+            *t = rns;
+        }
+        // sentinel pixels are rare: their sums are only formed (from the values still in registers)
+        // by waves / tiles that hold any
+        const int wave_sent = __any(has_sent) ? 1 : 0;
+        if (lane == 0) wsent[f & 1][wave] = wave_sent;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sh[0][wave][lane + 64 * j] = cns[j];
+        if (wave_sent) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float cs = 0.f, cc = 0.f;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const float v = val[r][j];
+                    const bool se = TP_IN(r, j) && ((v > 250.0f) || (v < -250.0f));
+                    cs += se ? v : 0.f;
+                    cc += se ? 1.f : 0.f;
+                }
+                sh[1][wave][lane + 64 * j] = cs;
+                sh[2][wave][lane + 64 * j] = cc;
+            }
+        }
+        lds_barrier();
+        int tile_sent = 0;
+#pragma unroll
+        for (int w = 0; w < TP_WAVES; w++) tile_sent |= wsent[f & 1][w];
+        if (tile_sent) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int y = y0 + wave + TP_WAVES * r;
+                float rs = 0.f, rc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float v = val[r][j];
+                    const bool se = TP_IN(r, j) && ((v > 250.0f) || (v < -250.0f));
+                    rs += se ? v : 0.f;
+                    rc += se ? 1.f : 0.f;
+                }
+                rs = wave_sum(rs);
+                rc = wave_sum(rc);
+                if (lane == 0 && y < H) {
+                    rp[H + y] = rs;
+                    rp[2 * H + y] = rc;
+                }
+            }
+        }
+        if (threadIdx.x < TILE_W) {
+            const int x = x0 + threadIdx.x;
+            float *cp = colp + ((long long)(f * tiles_y + ty) * 3) * W;
+            const int nq = tile_sent ? 3 : 1;
+            for (int q = 0; q < nq; q++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < TP_WAVES; w++) {
+                    // waves without sentinels did not write their q = 1, 2 rows
+                    const float t = (q == 0 || wsent[f & 1][w]) ? sh[q][w][threadIdx.x] : 0.f;
+                    acc += t;
+                }
+                float *t = (x < W) ? cp + q * W + x : mydump;
+                *t = acc;
+            }
+            if (threadIdx.x == 0) tflag[(long long)f * tiles_x * tiles_y + (long long)ty * tiles_x + tx] = tile_sent;
+        }
+        lds_barrier();  // sh[] consumed
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float *t = TP_IN(r, j) ? screen_out + TP_OFF(r, j) : mydump;
+            *t = st[r][j];
+        }
+}
+#undef TP_IN
+#undef TP_OFF
+
+// grid (ceil(max(W,H)/256), 2, F): the column (axis 0) / row (axis 1) that frame g paints, unless an
+// earlier frame of the batch paints the same one (then that frame's workgroups do the work)
+__global__ __launch_bounds__(256) void k_fix_lines(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
+                                                   long long dstride, int F, int W, int H, const ChainOut *__restrict__ chain,
+                                                   const float *__restrict__ screen_in, float *__restrict__ screen_out, float a)
+{
+    const int axis = blockIdx.y, g = blockIdx.z;
+    const int mine = axis == 0 ? chain[g].dx : chain[g].dy;
+    for (int e = 0; e < g; e++)
+        if ((axis == 0 ? chain[e].dx : chain[e].dy) == mine) return;  // uniform over the workgroup
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = axis == 0 ? mine : i, y = axis == 0 ? i : mine;
+    if (x < 0 || x >= W || y < 0 || y >= H) return;
+    const long long pix = (long long)y * W + x;
+    const double one_minus_a = 1.0 - a;
+    float s = screen_in[pix];
+    for (int f = 0; f < F; f++) {
+        const ChainOut c = chain[f];
+        const float v = src[(long long)f * sstride + pix];
+        dst[(long long)f * dstride + pix] =
+            pass_one(PASS_NORMALISE | PASS_LINES | PASS_IIR, v, s, a, one_minus_a, c.lastmin, c.span, x == c.dx || y == c.dy);
+    }
+    screen_out[pix] = s;
+}
+
 typedef void (*pass_fn)(const float *, long long, float *, long long, int, int, int, const ChainOut *, float *, float);
 
 template <int VW>
@@ -826,7 +1016,7 @@ extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
     (void)hipStreamSynchronize(pp->g->stream);
     (void)hipEventDestroy(pp->ev_stats);
     (void)hipEventDestroy(pp->ev_chain);
-    void *bufs[] = {pp->d_state, pp->d_screen, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
+    void *bufs[] = {pp->d_state, pp->d_screen, pp->d_screen2, pp->d_dump, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
                     pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -875,7 +1065,7 @@ static int launch_stats(tsdrgpu_postproc_t *pp, const float *frames, long long f
     }
     KERNEL_CHECK(g, "k_frame_stats");
     TSDR_LAUNCH(g, PROF_FRAME_REDUCE, g->stream, k_frame_reduce, dim3(((W > H ? W : H) + 255) / 256, 3, F), 256, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
-                                                      pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_tflag, want_strips);
+                                                      pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_tflag, want_strips, 1, TILE_H);
     KERNEL_CHECK(g, "k_frame_reduce");
     return TSDRGPU_OK;
 }
@@ -888,7 +1078,8 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
     // the autogain record (lastmin/lastmax/span per frame) is (re)written by every call: a sync-only
     // call repeats the carried state, which no later launch of that order reads
     if (do_autogain || !pp->chain_has_autogain) {
-        TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, frames, fstride, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain,
+        TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, frames, fstride, pp->ext_fmin ? pp->ext_fmin : pp->d_fmin,
+                    pp->ext_fmax ? pp->ext_fmax : pp->d_fmax, pp->d_state, pp->d_chain,
                                                   do_autogain, prm->lowpasscoeff);
         KERNEL_CHECK(g, "k_autogain_chain");
         pp->chain_has_autogain = 1;
@@ -1097,6 +1288,76 @@ extern "C" int tsdrgpu_postproc_begin(tsdrgpu_postproc_t *pp, const float *d_fra
     return TSDRGPU_OK;
 }
 
+// Fused run: see k_frame_tile_pass.  Everything is queued here; finish() only joins the streams.
+extern "C" int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float *d_frames, int F, int W, int H,
+                                             const tsdrgpu_pp_params_t *prm, const float *d_fmin, const float *d_fmax,
+                                             float *d_out)
+{
+    if (!pp || !d_frames || !prm || !d_fmin || !d_fmax || !d_out || F < 0 || W <= 0 || H <= 0)
+        return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_begin_minmax", "bad argument") : TSDRGPU_EINVAL;
+    if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_begin_minmax", "a split run is already open");
+    tsdrgpu_t *g = pp->g;
+    if (F == 0 || prm->lowpass_before_sync || prm->autogain_after_proc || prm->autoshift) {
+        // other stage orders take their statistics from processed frames, and the roll needs dx/dy before
+        // the pass: the plain split run handles those (it ignores the supplied min/max)
+        const int rc = tsdrgpu_postproc_begin(pp, d_frames, F, W, H, prm);
+        return rc;
+    }
+    pp->p_frames = d_frames;
+    pp->p_F = F; pp->p_W = W; pp->p_H = H;
+    pp->p_prm = *prm;
+    int rc;
+    if ((rc = pp_prepare(pp, F, W, H, prm))) return rc;
+    const size_t P = (size_t)W * H;
+    if ((rc = ensure(g, &pp->d_screen2, &pp->cap_screen2, pp->cap_screen > P ? pp->cap_screen : P, true))) return rc;
+    if ((rc = ensure(g, &pp->d_dump, &pp->cap_dump, (size_t)1024))) return rc;
+    const long long Ps = (long long)P;
+    const float a = prm->motionblur;
+    const int lines = (a == 0.0f && !prm->superresolution) ? 1 : 0;  // autoshift is off on this path
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TP_H - 1) / TP_H;  // this path's tiles are 16 rows high
+    if ((rc = ensure(g, &pp->d_tflag, &pp->cap_tflag, (size_t)F * tiles_x * tiles_y))) return rc;
+    if ((rc = ensure(g, &pp->d_colp, &pp->cap_colp, (size_t)F * tiles_y * 3 * W))) return rc;
+
+    // autogain IIR from the supplied min/max, then normalise + IIR + partial sums in one trip
+    pp->ext_fmin = d_fmin;
+    pp->ext_fmax = d_fmax;
+    rc = launch_chain(pp, d_frames, Ps, F, W, H, 1, 0, 1, prm);
+    pp->ext_fmin = pp->ext_fmax = nullptr;
+    if (rc) return rc;
+    TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, k_frame_tile_pass, (unsigned)(tiles_x * tiles_y), 512, d_frames, Ps, d_out, Ps, F, W, H, tiles_x,
+                tiles_y, pp->d_chain, pp->d_screen, pp->d_screen2, a, pp->d_colp, pp->d_rowp, pp->d_tflag, pp->d_dump);
+    KERNEL_CHECK(g, "k_frame_tile_pass");
+    {   // the state the next run reads is the buffer just written
+        float *t = pp->d_screen; pp->d_screen = pp->d_screen2; pp->d_screen2 = t;
+        const size_t c = pp->cap_screen; pp->cap_screen = pp->cap_screen2; pp->cap_screen2 = c;
+        // the reference keeps whatever lies beyond width*height in its single buffer (it matters after a later
+        // resolution change, dsp.c:152-173): carry that tail over to the buffer that is now current
+        const size_t common = pp->cap_screen < pp->cap_screen2 ? pp->cap_screen : pp->cap_screen2;
+        if (common > P)
+            HIP_TRY(g, hipMemcpyAsync(pp->d_screen + P, pp->d_screen2 + P, (common - P) * sizeof(float), hipMemcpyDeviceToDevice, g->stream));
+    }
+    // strips in line (bandwidth work: it would only fight the caller's kernels for HBM on the side stream) ...
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, g->stream, k_frame_reduce, dim3(((W > H ? W : H) + 255) / 256, 3, F), 256, W, H, tiles_x, tiles_y, pp->d_bmin,
+                pp->d_bmax, pp->d_colp, pp->d_rowp, pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_tflag, 1, 0, TP_H);
+    KERNEL_CHECK(g, "k_frame_reduce");
+    HIP_TRY(g, hipEventRecord(pp->ev_stats, g->stream));
+    // ... the latency-bound sync detector (+ the painted lines) on the side stream
+    HIP_TRY(g, hipStreamWaitEvent(g->stream2, pp->ev_stats, 0));
+    pp->chain_st = g->stream2;
+    rc = launch_chain(pp, d_frames, Ps, F, W, H, 0, 1, 1, prm);
+    pp->chain_st = nullptr;
+    if (rc) return rc;
+    if (lines) {
+        // d_screen2 now holds the pre-batch state, d_screen the post-batch one
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream2, k_fix_lines, dim3(((W > H ? W : H) + 255) / 256, 2, F), 256, d_frames, Ps, d_out, Ps, F, W, H,
+                    pp->d_chain, pp->d_screen2, pp->d_screen, a);
+        KERNEL_CHECK(g, "k_fix_lines");
+    }
+    HIP_TRY(g, hipEventRecord(pp->ev_chain, g->stream2));
+    pp->pending = 3;
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsdrgpu_pp_frameinfo_t *h_info)
 {
     if (!pp || !d_out) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_finish", "bad argument") : TSDRGPU_EINVAL;
@@ -1108,6 +1369,10 @@ extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsd
     const tsdrgpu_pp_params_t *prm = &pp->p_prm;
     if (mode == 2) return tsdrgpu_postproc_run(pp, pp->p_frames, F, W, H, prm, d_out, h_info);
     HIP_TRY(g, hipStreamWaitEvent(g->stream, pp->ev_chain, 0));
+    if (mode == 3) {  // fused run: the frames are already in the d_out given to begin_minmax
+        if (h_info) return pp_copy_info(pp, F, h_info);
+        return TSDRGPU_OK;
+    }
     const float a = prm->motionblur;
     const long long Ps = (long long)W * H;
     const int map = prm->autoshift ? PASS_ROLL : 0;

@@ -86,6 +86,7 @@ _SIGS = {
     "tsdrgpu_postproc_run": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams), vp,
                                        C.POINTER(PPFrameInfo)]),
     "tsdrgpu_postproc_begin": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams)]),
+    "tsdrgpu_postproc_begin_minmax": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams), vp, vp, vp]),
     "tsdrgpu_postproc_finish": (C.c_int, [vp, vp, C.POINTER(PPFrameInfo)]),
     "tsdrgpu_postproc_strips": (C.c_int, [vp, vp, vp]),
     "tsdrgpu_fft": (C.c_int, [vp, vp, C.c_uint32, C.c_int]),
@@ -394,6 +395,15 @@ class PostProcess:
         self._nframes = nframes
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_begin(self.h, d_frames.at(frames_offset), nframes, width, height,
                                                          C.byref(prm)))
+
+    def begin_minmax(self, d_frames, nframes, width, height, fmin_ptr, fmax_ptr, d_out, motionblur=0.0, lowpasscoeff=0.1,
+                     lowpass_before_sync=0, autogain_after_proc=0, autoshift=0, pll=0, superres=0, frames_offset=0,
+                     out_offset=0):
+        """Fused first half: per-frame min/max supplied (device pointers), one trip over the raw frames."""
+        prm = PPParams(lowpass_before_sync, autogain_after_proc, autoshift, pll, superres, motionblur, lowpasscoeff)
+        self._nframes = nframes
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_begin_minmax(self.h, d_frames.at(frames_offset), nframes, width, height,
+                                                                C.byref(prm), fmin_ptr, fmax_ptr, d_out.at(out_offset)))
 
     def finish(self, d_out, want_info=True, out_offset=0):
         """Second half of run(): the normalise / low-pass pass once the chain is done."""

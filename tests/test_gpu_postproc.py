@@ -186,3 +186,108 @@ def test_split_run_equals_single_run(cfg):
     assert [key(i) for i in infos_a] == [key(i) for i in infos_b]
     with pytest.raises(gpu.TsdrGpuError):  # nothing to finish
         pp.finish(d_out)
+
+
+def _minmax(frames):
+    """Per-frame min/max over the non-sentinel pixels, as dsp_autogain_run's first pass (dsp.c:57)."""
+    mn, mx = [], []
+    for fr in frames:
+        ok = fr[np.abs(fr) <= 250.0]
+        mn.append(ok.min() if ok.size else np.float32(np.inf))
+        mx.append(ok.max() if ok.size else np.float32(-np.inf))
+    return np.array(mn, np.float32), np.array(mx, np.float32)
+
+
+@pytest.mark.parametrize("cfg", [(0, 0, 0, 0, 0.0), (0, 0, 0, 0, 0.75), (0, 0, 0, 1, 0.0), (0, 0, 1, 0, 0.5), (1, 0, 0, 0, 0.0)])
+@pytest.mark.parametrize("w,h", [(333, 131), (700, 67), (256, 32)])
+def test_fused_run_equals_single_run(cfg, w, h):
+    """tsdrgpu_postproc_begin_minmax (autogain from supplied min/max, one trip over the raw frames, lines
+    patched in afterwards) == tsdrgpu_postproc_run: frames, IIR state carried over batches and every
+    per-frame state bit for bit.  Frames hold sentinel pixels and a drifting blanking band (moving lines)."""
+    g = ctx()
+    lbs, aap, ash, pll, mb = cfg
+    n = w * h
+    rng = np.random.default_rng(w + h)
+    frames = [cases.frame_pattern(w, h, 5 * k, rng) for k in range(10)]
+    frames[3][rng.integers(0, n, 40)] = np.float32(512.0)  # sentinels in the raw stream
+    frames[4][:] = np.float32(0.25)                         # a frame with zero dynamic range
+    frames[7][rng.integers(0, n, 3)] = np.float32(-1024.0)
+    want, infos_a, _ = run_gpu(g, frames, w, h, cfg, 5)
+
+    pp = gpu.PostProcess(g)
+    d_in = g.to_device(np.concatenate(frames))
+    d_out = g.empty(len(frames) * n)
+    mn, mx = _minmax(frames)
+    d_mn, d_mx = g.to_device(mn), g.to_device(mx)
+    infos_b = []
+    for s in range(0, len(frames), 5):
+        pp.begin_minmax(d_in, 5, w, h, d_mn.at(s), d_mx.at(s), d_out, mb, 0.1, lbs, aap, ash, pll, 0,
+                        frames_offset=s * n, out_offset=s * n)
+        infos_b += pp.finish(d_out, out_offset=s * n)
+    got = d_out.download().reshape(len(frames), n)
+    assert np.array_equal(got, want, equal_nan=True)
+    key = lambda i: (i.lastmin, i.lastmax, i.dx, i.vx, i.stripx, i.dy, i.vy, i.stripy, i.locked, i.avg_speed, i.pll_fired)
+    assert [key(i) for i in infos_a] == [key(i) for i in infos_b]
+    # and the IIR state the next (plain) run starts from is the same
+    a2 = gpu.PostProcess(g)
+    run_a = a2.run(d_in, 5, w, h, g.empty(5 * n), mb, 0.1, lbs, aap, ash, pll, 0)
+    out_b = g.empty(2 * n)
+    pp.run(d_in, 2, w, h, out_b, mb, 0.1, lbs, aap, ash, pll, 0)
+    ref_pp = gpu.PostProcess(g)
+    out_r = g.empty(len(frames) * n)
+    for s in range(0, len(frames), 5):
+        ref_pp.run(d_in, 5, w, h, out_r, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * n, out_offset=s * n)
+    out_r2 = g.empty(2 * n)
+    ref_pp.run(d_in, 2, w, h, out_r2, mb, 0.1, lbs, aap, ash, pll, 0)
+    assert np.array_equal(out_b.download(), out_r2.download(), equal_nan=True)
+
+
+def test_resampler_minmax_feeds_fused_run(orc):
+    """End of the chain: IQ -> tracked resampler -> fused post-processing == IQ -> resampler -> plain run,
+    across calls with a carried partial frame."""
+    g = ctx()
+    fs, hh, fv = 2_000_000, 131, 60.0
+    geo = orc.geometry(fs, hh, fv)
+    w, P = geo.width, geo.width * hh
+    up, down = float(P) * fv, float(fs)
+    chunk = int(0.1 * fs / fv)
+    rng = np.random.default_rng(11)
+
+    def pipeline(fused):
+        rs, pp = gpu.Resampler(g), gpu.PostProcess(g)
+        if fused:
+            rs.track_frames(P, 0)
+        d_pix = g.empty(40 * chunk * 2 + 2 * P + 64)
+        outs, carry = [], 0
+        r2 = np.random.default_rng(5)
+        for call in range(4):
+            nch = 35 + call
+            n = nch * chunk
+            t = np.arange(n)
+            iq = np.empty(2 * n, np.float32)
+            mag = (0.3 + 0.5 * ((t // 37) % 2) + 0.05 * r2.random(n)).astype(np.float32)
+            iq[0::2] = mag * np.cos(0.37 * t).astype(np.float32)
+            iq[1::2] = mag * np.sin(0.37 * t).astype(np.float32)
+            d_iq = g.to_device(iq)
+            npix = rs.process(d_iq, True, chunk, nch, up, down, 0, d_pix, out_offset=carry)
+            avail = carry + npix
+            F = avail // P
+            d_out = g.empty(max(F, 1) * P)
+            if fused:
+                a, b, nfr = rs.frame_minmax(download=False)
+                assert nfr == F
+                pp.begin_minmax(d_pix, F, w, hh, a, b, d_out)
+                pp.finish(d_out, want_info=False)
+            else:
+                pp.run(d_pix, F, w, hh, d_out, want_info=False)
+            outs.append(d_out.download()[:F * P])
+            rem = avail - F * P
+            if rem:
+                g._ck(g.lib.tsdrgpu_copy(g.h, d_pix.at(0), d_pix.at(F * P), rem * 4))
+            carry = rem
+        return np.concatenate(outs)
+
+    a = pipeline(False)
+    b = pipeline(True)
+    assert a.size == b.size and a.size > 10 * P
+    assert np.array_equal(a, b)
