@@ -291,3 +291,23 @@ def test_resampler_minmax_feeds_fused_run(orc):
     b = pipeline(True)
     assert a.size == b.size and a.size > 10 * P
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("fs,h,cfg,nfr", [(25_000_000, 806, (0, 0, 0, 0, 0.0), 4),          # BASELINE config 2
+                                          (200_000_000, 2250, (0, 0, 0, 0, 0.9375), 3),     # config 5: 4K, 16-frame IIR
+                                          (200_000_000, 2250, (1, 0, 1, 0, 0.9375), 2)])    # ... GUI order + autoshift
+def test_post_process_config2_and_config5_sizes(orc, fs, h, cfg, nfr):
+    """Full BASELINE frame sizes (1033x806 and 2962x2250): frames bit-exact, autogain and sync state
+    identical, against the oracle (seconds of CPU)."""
+    g = ctx()
+    fv = 60.0
+    geo = orc.geometry(fs, h, fv)
+    w, P = geo.width, geo.width * h
+    rng = np.random.default_rng(h)
+    frames = [cases.frame_pattern(w, h, 2 * k, rng) for k in range(nfr)]
+    want, states, _ = run_orc(orc, frames, fs, h, fv, cfg)
+    got, infos, _ = run_gpu(g, frames, w, h, cfg, nfr)
+    for info, (si, sd) in zip(infos, states):
+        assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) == tuple(si[:7])
+        assert (np.float32(info.lastmin), np.float32(info.lastmax)) == (np.float32(sd[0]), np.float32(sd[1]))
+    assert np.array_equal(got, want)
