@@ -17,6 +17,10 @@
  * /root/reference into oracle/_ref/ by oracle/Makefile (tests/test_oracle_vs_ref.py,
  * bit-exact) and against golden vectors produced by that build
  * (tests/golden/, script tests/golden/make_golden.py).
+ * PARITY UNPINNED for two restatements of Java / JNI code, which cannot be built
+ * here (no JDK): orc_plot_populate (PlotVisualizer.populateData) and
+ * orc_frame_to_rgb (TSDRLibraryNDK.c pixel conversion); both are integer / max-only
+ * loops and are cross-checked by independent formulations in tests/test_extras_cpu.py.
  *
  * Build: gcc -O3 -fPIC -shared -ffp-contract=off (no fast-math; the reference
  * is built -O3 without fast-math, TempestSDR/makefile:21).

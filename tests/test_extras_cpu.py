@@ -159,3 +159,32 @@ def test_plotscale_default_matches_oracle(orc):
         lib.tsdrgpu_plotscale_default(size, nwidth, C.byref(a))
         orc.lib.orc_plotscale_default(size, nwidth, C.byref(b))
         assert [getattr(a, f[0]) for f in a._fields_] == [getattr(b, f[0]) for f in b._fields_]
+
+
+@pytest.mark.parametrize("inverted", [0, 1])
+def test_oracle_frame_to_rgb_vs_vectorised_formulation(orc, inverted):
+    """f3: the JNI shim's per-pixel branch chain (TSDRLibraryNDK.c:222-276; needs jni.h, cannot be built here)
+    restated in C by the oracle, cross-checked against a vectorised numpy formulation."""
+    rng = np.random.default_rng(8)
+    n = 20_000
+    fr = (rng.random(n) * 1.4 - 0.2).astype(np.float32)
+    fr[rng.integers(0, n, 50)] = 256.0
+    fr[rng.integers(0, n, 50)] = 512.0
+    fr[rng.integers(0, n, 50)] = 1024.0
+    fr[rng.integers(0, n, 50)] = 2048.0
+    fr[rng.integers(0, n, 20)] = np.float32(1.0)
+    fr[rng.integers(0, n, 20)] = np.float32(0.0)
+    fr[rng.integers(0, n, 20)] = np.float32(300.0)
+    prev = rng.integers(0, 1 << 24, n).astype(np.int32)
+    got = prev.copy()
+    orc.lib.orc_frame_to_rgb(fr, got, n, inverted)
+    g8 = (fr * np.float32(255.0)).astype(np.int32)  # C truncation for the values that take this branch
+    gray = np.where(inverted, 255 - g8, g8)
+    gray = gray | (gray << 8) | (gray << 16)
+    want = np.where((fr > 0) & (fr <= 1), gray,
+           np.where(fr <= 0, 0xFFFFFF if inverted else 0,
+           np.where(fr == 256.0, 255 << 16,
+           np.where(fr == 512.0, 255 << 8,
+           np.where(fr == 1024.0, 255,
+           np.where(fr == 2048.0, prev, 0 if inverted else 0xFFFFFF)))))).astype(np.int32)
+    assert np.array_equal(got, want)
