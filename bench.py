@@ -279,7 +279,7 @@ def main():
                 g.sync()  # the sums were accumulated on the side stream
             with torch.cuda.stream(ext):
                 # RCCL all-reduce over xGMI of the per-lag |R| sums of every rank's windows, in place
-                shard.allreduce_plots(red, nwin, dist, mean=False, total_windows=nwin * world)
+                shard.allreduce_plots(red, nwin, dist, mean=False, total_windows=nwin * world, force=args.force_dist)
             if args.overlap:
                 ext.synchronize()
             ac.finalize_sums(nwin * world)

@@ -34,15 +34,16 @@ def as_tensor(ptr, count, device):
     return torch.as_tensor(DeviceView(ptr, count), device=device)
 
 
-def allreduce_plots(sums, local_windows, dist=None, mean=True, total_windows=None):
+def allreduce_plots(sums, local_windows, dist=None, mean=True, total_windows=None, force=False):
     """sums: 1-D float64 torch tensor (device or CPU) or numpy array with this
     rank's per-lag sums of |R| (frame lags then line lags).  Returns (plots as
     the same type, total window count); plots are the global means, or the
     global sums when mean=False (the caller then divides on the device,
     tsdrgpu_autocorr_finalize_sums).  `dist` = torch.distributed or None for a
     single process.  total_windows: the global window count when the caller knows
-    it (skips the second all-reduce and its host synchronisation)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    it (skips the second all-reduce and its host synchronisation).  force: issue the
+    collective even in a one-rank group (exercises the RCCL launch path on one GPU)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         total = int(local_windows)
         return ((sums / max(total, 1)) if mean else sums), total
     import torch
