@@ -22,6 +22,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The context's two HIP streams (frame path / sync-detector chain + autocorrelation) only overlap when they sit on
+# different hardware queues.  ROCm hands out 4 per process by default and RCCL's own streams take part of them, so
+# with torch.distributed initialised both of ours landed on one queue (measured: chain no longer hidden, +0.1 ms
+# per step).  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: its HIP runtime is the one the process uses)
 
