@@ -216,6 +216,11 @@ int tsdrgpu_autocorr_device_plots(tsdrgpu_autocorr_t *ac, double **d_plots, int6
 int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t total_windows);
 /* argmax (lowest index wins ties, PlotVisualizer.java:233-236); syncs */
 int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, int32_t *line_idx);
+/* The same in two halves, so that the host does not have to wait for the device once per plot update:
+ * _async queues the argmax and the copy of its two indices, _result waits for that copy only (work queued
+ * after _async keeps the device busy meanwhile).  One outstanding request per object. */
+int tsdrgpu_autocorr_argmax_async(tsdrgpu_autocorr_t *ac);
+int tsdrgpu_autocorr_argmax_result(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, int32_t *line_idx);
 /* the raw correlation of the LAST window run (2*n floats), for stage tests */
 int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **d_corr, uint32_t *n);
 

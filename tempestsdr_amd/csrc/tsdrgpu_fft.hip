@@ -26,6 +26,8 @@ struct tsdrgpu_autocorr {
     float2 *d_expand;  // the same unpacked to n complex values, made on demand
     int *d_arg;
     int *h_arg;
+    hipEvent_t ev_arg;  // recorded behind the copy of d_arg to h_arg
+    int arg_pending;
     double *d_pval;  // argmax partials
     int *d_pidx;
     hipStream_t st;  // g->stream, or g->stream2 when set asynchronous
@@ -866,7 +868,8 @@ extern "C" int tsdrgpu_autocorr_create(tsdrgpu_t *g, tsdrgpu_autocorr_t **out, u
     if (hipMalloc(&ac->d_plots, sizeof(double) * L) != hipSuccess || hipMalloc(&ac->d_arg, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc(&ac->d_pval, 2 * ARGMAX_BLOCKS * sizeof(double)) != hipSuccess ||
         hipMalloc(&ac->d_pidx, 2 * ARGMAX_BLOCKS * sizeof(int)) != hipSuccess ||
-        hipHostMalloc(&ac->h_arg, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc(&ac->h_arg, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ac->ev_arg, hipEventDisableTiming) != hipSuccess) {
         free(ac);
         return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_create", "plots");
     }
@@ -888,6 +891,7 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
     (void)hipFree(ac->d_pval);
     (void)hipFree(ac->d_pidx);
     (void)hipHostFree(ac->h_arg);
+    (void)hipEventDestroy(ac->ev_arg);
     free(ac);
 }
 
@@ -1030,18 +1034,38 @@ extern "C" int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t t
     return TSDRGPU_OK;
 }
 
-extern "C" int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, int32_t *line_idx)
+// queue the two-stage argmax of the current plots and the copy of its result to pinned memory
+extern "C" int tsdrgpu_autocorr_argmax_async(tsdrgpu_autocorr_t *ac)
 {
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
+    if (ac->arg_pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_argmax_async", "the previous result was not collected");
     TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_partial, dim3(ARGMAX_BLOCKS, 2), 256, ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_pidx);
     TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_final, 2, 64, ac->d_pval, ac->d_pidx, ac->frame_len, ac->line_len, ac->d_arg);
     KERNEL_CHECK(g, "k_argmax");
     HIP_TRY(g, hipMemcpyAsync(ac->h_arg, ac->d_arg, 2 * sizeof(int), hipMemcpyDeviceToHost, ac->st));
-    HIP_TRY(g, hipStreamSynchronize(ac->st));
+    HIP_TRY(g, hipEventRecord(ac->ev_arg, ac->st));
+    ac->arg_pending = 1;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_argmax_result(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, int32_t *line_idx)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    if (!ac->arg_pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_argmax_result", "no argmax was queued");
+    HIP_TRY(g, hipEventSynchronize(ac->ev_arg));
+    ac->arg_pending = 0;
     if (frame_idx) *frame_idx = ac->h_arg[0];
     if (line_idx) *line_idx = ac->h_arg[1];
     return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, int32_t *line_idx)
+{
+    const int rc = tsdrgpu_autocorr_argmax_async(ac);
+    if (rc) return rc;
+    return tsdrgpu_autocorr_argmax_result(ac, frame_idx, line_idx);
 }
 
 extern "C" int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **d_corr, uint32_t *n)

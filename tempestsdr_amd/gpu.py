@@ -99,6 +99,8 @@ _SIGS = {
     "tsdrgpu_autocorr_plots": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
+    "tsdrgpu_autocorr_argmax_async": (C.c_int, [vp]),
+    "tsdrgpu_autocorr_argmax_result": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdrgpu_autocorr_argmax": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdrgpu_autocorr_last_corr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]),
     "tsdrgpu_superb_stitch": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp,
@@ -472,6 +474,14 @@ class Autocorr:
     def argmax(self):
         a, b = C.c_int32(), C.c_int32()
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_argmax(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def argmax_async(self):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_argmax_async(self.h))
+
+    def argmax_result(self):
+        a, b = C.c_int32(), C.c_int32()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_argmax_result(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def last_corr(self):

@@ -164,3 +164,22 @@ def test_superb_stitch_vs_oracle(orc):
     got = d_out.download()
     assert np.max(np.abs(got - want)) <= 1e-4 * np.max(np.abs(want))
     assert np.max(np.abs(got[:2048] - gold["superb_out_head"])) <= 1e-4 * np.max(np.abs(want))
+
+
+def test_argmax_async_result(orc):
+    """tsdrgpu_autocorr_argmax_async / _result == tsdrgpu_autocorr_argmax, with other work queued in between;
+    one outstanding request per object."""
+    g = ctx()
+    fs = 300_000
+    ac = gpu.Autocorr(g, fs)
+    x = (RNG.random(ac.capture) + (np.arange(ac.capture) % (fs // 61) < 400)).astype(np.float32)
+    d = g.to_device(x)
+    ac.run(d, False, ac.capture, 1)
+    want = ac.argmax()
+    ac.argmax_async()
+    with pytest.raises(gpu.TsdrGpuError):
+        ac.argmax_async()  # previous result not collected
+    g.am_demod(g.to_device(RNG.random(2048).astype(np.float32)), g.empty(1024), 1024)  # unrelated work behind it
+    assert ac.argmax_result() == want
+    with pytest.raises(gpu.TsdrGpuError):
+        ac.argmax_result()  # nothing queued
