@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the HIP path against the oracle (not part of the pytest suites: a soak).
+
+  resampler : random ratios (library-like r ~ 2, and arbitrary 0.05..7), random chunk sizes / counts, float and
+              IQ input, state carried over several calls                         -> bit-exact pixels + carried state
+  post-proc : random frame geometries 3x3 .. ~900x300, the 4 stage orders x autoshift x motion blur, random batch
+              splits, frames with sentinels / constant frames                    -> bit-exact frames, identical state
+  autocorr  : random sample rates                                                -> plots within 1e-4*max
+
+usage (on a GPU box):  python scripts/fuzz_parity.py [cases] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from oracle import oracle as orc  # noqa: E402
+from tempestsdr_amd import gpu  # noqa: E402
+import cases  # noqa: E402
+
+
+def fuzz_resampler(g, rng):
+    if rng.random() < 0.6:
+        x = rng.uniform(3.0, 4000.0)
+        up, down = float(int(2 * x)), x  # the library's r = floor(2x)/x
+    else:
+        up, down = float(rng.uniform(0.05, 7.0)), 1.0
+    iq = bool(rng.integers(0, 2))
+    rs_o, rs_g = orc.Resampler(), gpu.Resampler(g)
+    for _ in range(int(rng.integers(1, 4))):
+        chunk = int(rng.integers(1, 3000))
+        nch = int(rng.integers(1, 9))
+        n = chunk * nch
+        mag = rng.random(n).astype(np.float32) * np.float32(rng.choice([1.0, 50.0, 1e-3]))
+        if iq:
+            ph = rng.random(n) * 6.28
+            host = np.empty(2 * n, np.float32)
+            host[0::2] = (mag * np.cos(ph)).astype(np.float32)
+            host[1::2] = (mag * np.sin(ph)).astype(np.float32)
+            mag = orc.am_demod(host)
+        else:
+            host = mag
+        want = np.concatenate([rs_o.process(mag[c * chunk:(c + 1) * chunk], up, down) for c in range(nch)])
+        cap = rs_g.count(chunk, nch, up, down)
+        d_out = g.empty(cap + 8)
+        npix = rs_g.process(g.to_device(host), iq, chunk, nch, up, down, 0, d_out)
+        got = d_out.download()[:npix]
+        if npix != want.size or not np.array_equal(got, want, equal_nan=True):
+            return f"resampler up={up} down={down} iq={iq} chunk={chunk} nch={nch}"
+        con, off = rs_g.state()
+        if (con, off) != (rs_o.st.contrib, rs_o.st.offset):
+            return f"resampler state up={up} down={down} chunk={chunk}"
+    return None
+
+
+def fuzz_postproc(g, rng):
+    h = int(rng.integers(3, 300))
+    fs = int(rng.integers(20_000, 3_000_000))
+    geo = orc.geometry(fs, h, 60.0)
+    w = geo.width
+    if w < 3 or w > 1200 or w * h > 300_000:
+        return None
+    cfg = (int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), 0,
+           float(rng.choice([0.0, 0.0, 0.25, 0.5, 0.9375])))
+    lbs, aap, ash, pll, mb = cfg
+    F = int(rng.integers(1, 9))
+    frames = [cases.frame_pattern(w, h, int(rng.integers(0, 50)), rng) for _ in range(F)]
+    for fr in frames:
+        r = rng.random()
+        if r < 0.15:
+            fr[rng.integers(0, w * h, 5)] = np.float32(rng.choice([256.0, 512.0, 1024.0, 2048.0, -300.0]))
+        elif r < 0.2:
+            fr[:] = np.float32(rng.random())
+    opp = orc.PostProcess(geo)
+    want, states = [], []
+    for fr in frames:
+        want.append(opp.run(fr.copy(), mb, 0.1, lbs, aap, ash, pll, 0))
+        states.append(opp.state())
+    pp = gpu.PostProcess(g)
+    d_in = g.to_device(np.concatenate(frames))
+    d_out = g.empty(F * w * h)
+    infos, s = [], 0
+    while s < F:
+        k = int(rng.integers(1, F - s + 1))
+        mode = int(rng.integers(0, 2))
+        if mode == 0:
+            infos += pp.run(d_in, k, w, h, d_out, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * w * h, out_offset=s * w * h)
+        else:
+            pp.begin(d_in, k, w, h, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * w * h)
+            infos += pp.finish(d_out, out_offset=s * w * h)
+        s += k
+    got = d_out.download().reshape(F, -1)
+    for k in range(F):
+        si, sd = states[k]
+        i = infos[k]
+        if (i.dx, i.vx, i.stripx, i.dy, i.vy, i.stripy, i.locked) != tuple(si[:7]):
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"fuzz_pp_{fs}_{h}.npz"), frames=np.stack(frames), fs=fs, h=h,
+                                cfg=np.array(cfg), frame=k)
+            return (f"postproc state fs={fs} h={h} w={w} cfg={cfg} F={F} frame={k} gpu="
+                    f"{(i.dx, i.vx, i.stripx, i.dy, i.vy, i.stripy, i.locked)} oracle={tuple(int(v) for v in si[:7])}")
+        if not np.array_equal(got[k], want[k], equal_nan=True):
+            return f"postproc frame fs={fs} h={h} w={w} cfg={cfg} F={F} frame={k} maxdiff={np.nanmax(np.abs(got[k] - want[k]))}"
+    return None
+
+
+def fuzz_autocorr(g, rng):
+    fs = int(rng.integers(100_000, 1_200_000))
+    ac_o, ac = orc.Autocorr(fs), gpu.Autocorr(g, fs)
+    period = fs // int(rng.integers(56, 86))
+    x = (rng.random(ac.capture) * 0.5 + (np.arange(ac.capture) % period < period // 10)).astype(np.float32)
+    ac_o.run(x)
+    ac.run(g.to_device(x), False, ac.capture, 1)
+    f, l, _ = ac.plots()
+    if np.max(np.abs(f - ac_o.frame)) > 1e-4 * np.max(ac_o.frame) or np.max(np.abs(l - ac_o.line)) > 1e-4 * np.max(ac_o.line):
+        return f"autocorr fs={fs}"
+    return None
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    g = gpu.TsdrGpu(0)
+    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0}
+    for c in range(ncases):
+        kind = ("resampler", "postproc", "postproc", "resampler", "autocorr")[c % 5]
+        fn = {"resampler": fuzz_resampler, "postproc": fuzz_postproc, "autocorr": fuzz_autocorr}[kind]
+        try:
+            r = fn(g, rng)
+        except Exception as e:  # noqa: BLE001
+            r = f"{kind} raised {e!r}"
+        ran[kind] += 1
+        if r:
+            fails.append((c, r))
+            print("MISMATCH", c, r, flush=True)
+    print(f"fuzz: {ncases} cases {ran}, {len(fails)} mismatches, seed {seed}")
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

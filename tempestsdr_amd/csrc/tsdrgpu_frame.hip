@@ -360,7 +360,8 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
                                                            const double *__restrict__ strip_y,
                                                            const ChainOut *__restrict__ chain, StripScratch sc,
                                                            int strips_normalised, float t0, float t1, float t2, float t3,
-                                                           float t4)
+                                                           float t4, const float *__restrict__ fmin_,
+                                                           const float *__restrict__ fmax_)
 {
     __shared__ float data[STRIP_MAX];
     __shared__ float blur[STRIP_MAX];
@@ -371,14 +372,31 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
     const double *sp = (axis == 0 ? strip_x : strip_y) + (long long)f * 3 * n;
     const double cnt_all = (double)(axis == 0 ? H : W);
     const float lastmin = chain[f].lastmin, span = chain[f].span;
-    for (int i = tid; i < n; i += CHAIN_T) {
-        const double ns = sp[i], s = sp[n + i], c = sp[2 * n + i];
-        double v;
-        if (strips_normalised)  // strip of the autogained frame, from the raw frame's sums
-            v = (ns - (cnt_all - c) * (double)lastmin) / (double)span + s;
-        else
-            v = ns + s;
-        data[i] = (float)v;
+    // A frame whose pixels all hold ONE value (a blanked screen) is the degenerate case of the sync
+    // detector: every window fits equally well, and which strip size wins is decided by the last bit of
+    // the strip entries (through the float cast of their total, syncdetector.c:84).  There the strip must
+    // be the reference's own number: dsp_average_v_h (dsp.c:96-110) adds the pixels in f32 in raster
+    // order, i.e. each entry is the sequential f32 sum of `count` copies of the (autogained) value.
+    int any_sent = 0;
+    for (int i = tid; i < n; i += CHAIN_T) any_sent |= (sp[2 * n + i] != 0.0) ? 1 : 0;
+    any_sent = __syncthreads_or(any_sent);
+    const float fmn = fmin_[f], fmx = fmax_[f];
+    if (!any_sent && fmn == fmx) {
+        const float val = strips_normalised ? (fmn - lastmin) / span : fmn;
+        const int count = axis == 0 ? H : W;
+        float acc = 0.f;
+        for (int k = 0; k < count; k++) acc += val;
+        for (int i = tid; i < n; i += CHAIN_T) data[i] = acc;
+    } else {
+        for (int i = tid; i < n; i += CHAIN_T) {
+            const double ns = sp[i], s = sp[n + i], c = sp[2 * n + i];
+            double v;
+            if (strips_normalised)  // strip of the autogained frame, from the raw frame's sums
+                v = (ns - (cnt_all - c) * (double)lastmin) / (double)span + s;
+            else
+                v = ns + s;
+            data[i] = (float)v;
+        }
     }
     __syncthreads();
     // gaussianblur: out[(i+2)%n] = sum_k taps[k]*in[(i+k)%n], left to right in f32
@@ -1093,7 +1111,8 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
         TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
                                                                strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2],
-                                                               pp->taps[3], pp->taps[4]);
+                                                               pp->taps[3], pp->taps[4], pp->ext_fmin ? pp->ext_fmin : pp->d_fmin,
+                                                               pp->ext_fmax ? pp->ext_fmax : pp->d_fmax);
         KERNEL_CHECK(g, "k_strip_prepare");
         SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
         TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, pp->d_state, spec);
@@ -1344,7 +1363,10 @@ extern "C" int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float
     // ... the latency-bound sync detector (+ the painted lines) on the side stream
     HIP_TRY(g, hipStreamWaitEvent(g->stream2, pp->ev_stats, 0));
     pp->chain_st = g->stream2;
+    pp->ext_fmin = d_fmin;
+    pp->ext_fmax = d_fmax;
     rc = launch_chain(pp, d_frames, Ps, F, W, H, 0, 1, 1, prm);
+    pp->ext_fmin = pp->ext_fmax = nullptr;
     pp->chain_st = nullptr;
     if (rc) return rc;
     if (lines) {

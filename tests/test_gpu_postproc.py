@@ -311,3 +311,27 @@ def test_post_process_config2_and_config5_sizes(orc, fs, h, cfg, nfr):
         assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) == tuple(si[:7])
         assert (np.float32(info.lastmin), np.float32(info.lastmax)) == (np.float32(sd[0]), np.float32(sd[1]))
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("cfg", [(0, 0, 0, 0, 0.0), (0, 0, 1, 0, 0.5), (0, 1, 0, 0, 0.25), (1, 0, 1, 0, 0.0), (1, 1, 0, 0, 0.5)])
+@pytest.mark.parametrize("fs,h", [(2_062_155, 62), (1_823_633, 153), (400_000, 61)])
+def test_uniform_frames_keep_the_sync_state_identical(orc, cfg, fs, h):
+    """Frames whose pixels all hold one value (a blanked screen) are the sync detector's degenerate case: every
+    window fits equally well and the winning strip size is decided by the last bit of the collapsed strips.
+    The device then forms the strips as dsp_average_v_h does (sequential f32 sums), so dx / strip sizes — and
+    with them the rolled frames that follow — stay identical to the reference's.  (Found by scripts/fuzz_parity.py.)"""
+    g = ctx()
+    geo = orc.geometry(fs, h, 60.0)
+    w = geo.width
+    rng = np.random.default_rng(fs % 1000 + h)
+    frames = []
+    for k in range(14):
+        if k in (1, 4, 5, 9, 12):
+            frames.append(np.full(w * h, np.float32(rng.random()), np.float32))
+        else:
+            frames.append(cases.frame_pattern(w, h, int(rng.integers(0, 40)), rng))
+    want, states, _ = run_orc(orc, frames, fs, h, 60.0, cfg)
+    got, infos, _ = run_gpu(g, frames, w, h, cfg, 5)
+    for k, (info, (si, sd)) in enumerate(zip(infos, states)):
+        assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) == tuple(si[:7]), f"frame {k}"
+    assert np.array_equal(got, want, equal_nan=True)
