@@ -6,6 +6,7 @@
   post-proc : random frame geometries 3x3 .. ~900x300, the 4 stage orders x autoshift x motion blur, random batch
               splits, frames with sentinels / constant frames                    -> bit-exact frames, identical state
   autocorr  : random sample rates                                                -> plots within 1e-4*max
+  fft       : random power-of-two sizes 2 .. 2^17, both directions                -> 2e-6*max|X|
 
 usage (on a GPU box):  python scripts/fuzz_parity.py [cases] [seed]
 """
@@ -57,11 +58,15 @@ def fuzz_resampler(g, rng):
 
 
 def fuzz_postproc(g, rng):
-    h = int(rng.integers(3, 300))
-    fs = int(rng.integers(20_000, 3_000_000))
+    if rng.random() < 0.15:  # tiny geometries
+        h = int(rng.integers(2, 12))
+        fs = int(rng.integers(2, 40)) * 30 * h
+    else:
+        h = int(rng.integers(3, 300))
+        fs = int(rng.integers(20_000, 3_000_000))
     geo = orc.geometry(fs, h, 60.0)
     w = geo.width
-    if w < 3 or w > 1200 or w * h > 300_000:
+    if w < 2 or w > 3200 or w * h > 400_000:
         return None
     cfg = (int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), 0,
            float(rng.choice([0.0, 0.0, 0.25, 0.5, 0.9375])))
@@ -73,7 +78,13 @@ def fuzz_postproc(g, rng):
         if r < 0.15:
             fr[rng.integers(0, w * h, 5)] = np.float32(rng.choice([256.0, 512.0, 1024.0, 2048.0, -300.0]))
         elif r < 0.2:
-            fr[:] = np.float32(rng.random())
+            fr[:] = np.float32(rng.random())                      # uniform frame
+        elif r < 0.25:
+            fr[:] = np.where(fr > np.median(fr), np.float32(0.75), np.float32(0.125))  # two-valued
+        elif r < 0.3:
+            fr *= np.float32(rng.choice([200.0, 1e-4, -1.0]))     # large / tiny / negative ranges
+        elif r < 0.33:
+            fr[rng.integers(0, w * h, max(1, w * h // 3))] = np.float32(1024.0)  # a third of the frame sentinel
     opp = orc.PostProcess(geo)
     want, states = [], []
     for fr in frames:
@@ -85,11 +96,18 @@ def fuzz_postproc(g, rng):
     infos, s = [], 0
     while s < F:
         k = int(rng.integers(1, F - s + 1))
-        mode = int(rng.integers(0, 2))
+        mode = int(rng.integers(0, 3))
         if mode == 0:
             infos += pp.run(d_in, k, w, h, d_out, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * w * h, out_offset=s * w * h)
-        else:
+        elif mode == 1:
             pp.begin(d_in, k, w, h, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * w * h)
+            infos += pp.finish(d_out, out_offset=s * w * h)
+        else:  # fused run with the per-frame min/max supplied
+            mn = np.array([fr[np.abs(fr) <= 250].min() if np.any(np.abs(fr) <= 250) else np.inf for fr in frames[s:s + k]], np.float32)
+            mx = np.array([fr[np.abs(fr) <= 250].max() if np.any(np.abs(fr) <= 250) else -np.inf for fr in frames[s:s + k]], np.float32)
+            d_mn, d_mx = g.to_device(mn), g.to_device(mx)
+            pp.begin_minmax(d_in, k, w, h, d_mn.ptr, d_mx.ptr, d_out, mb, 0.1, lbs, aap, ash, pll, 0,
+                            frames_offset=s * w * h, out_offset=s * w * h)
             infos += pp.finish(d_out, out_offset=s * w * h)
         s += k
     got = d_out.download().reshape(F, -1)
@@ -120,15 +138,28 @@ def fuzz_autocorr(g, rng):
     return None
 
 
+def fuzz_fft(g, rng):
+    n = 1 << int(rng.integers(1, 18))
+    inverse = bool(rng.integers(0, 2))
+    z = (rng.standard_normal(2 * n) * rng.choice([1.0, 1e3, 1e-3])).astype(np.float32)
+    want = orc.fft_perform(z, inverse)
+    d = g.to_device(z)
+    g._ck(g.lib.tsdrgpu_fft(g.h, d.ptr, n, int(inverse)))
+    got = d.download()
+    if np.max(np.abs(got - want)) > 2e-6 * max(np.max(np.abs(want)), 1e-30) * max(1.0, np.log2(n) / 4):
+        return f"fft n={n} inverse={inverse} err={np.max(np.abs(got - want)) / np.max(np.abs(want))}"
+    return None
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     g = gpu.TsdrGpu(0)
-    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0}
+    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0}
     for c in range(ncases):
-        kind = ("resampler", "postproc", "postproc", "resampler", "autocorr")[c % 5]
-        fn = {"resampler": fuzz_resampler, "postproc": fuzz_postproc, "autocorr": fuzz_autocorr}[kind]
+        kind = ("resampler", "postproc", "postproc", "resampler", "autocorr", "fft")[c % 6]
+        fn = {"resampler": fuzz_resampler, "postproc": fuzz_postproc, "autocorr": fuzz_autocorr, "fft": fuzz_fft}[kind]
         try:
             r = fn(g, rng)
         except Exception as e:  # noqa: BLE001
