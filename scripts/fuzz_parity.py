@@ -7,6 +7,8 @@
               splits, frames with sentinels / constant frames                    -> bit-exact frames, identical state
   autocorr  : random sample rates                                                -> plots within 1e-4*max
   fft       : random power-of-two sizes 2 .. 2^17, both directions                -> 2e-6*max|X|
+  plot      : random plot sizes, widget widths, zoom / offset states              -> identical columns, lowest/highest, argmax
+  tracking  : random frame sizes / phases, several calls                          -> exact per-frame min/max
 
 usage (on a GPU box):  python scripts/fuzz_parity.py [cases] [seed]
 """
@@ -151,15 +153,80 @@ def fuzz_fft(g, rng):
     return None
 
 
+def fuzz_plot(g, rng):
+    size = int(rng.integers(1, 60_000))
+    nwidth = int(rng.integers(1, 2500))
+    data = rng.random(size) * rng.choice([1.0, 1e6, 1e-9])
+    if rng.random() < 0.3:
+        data[rng.integers(0, size, 4)] = data.max() * 2  # ties for the argmax
+    if rng.random() < 0.2:
+        data[:] = data[0]
+    so, sg = orc.PlotScale(), gpu.PlotScale()
+    zoom = float(rng.choice([1.0, 1.0, rng.uniform(0.001, 1.0)]))
+    offpx = int(rng.choice([0, 0, rng.integers(-200, 5000)]))
+    for sc in (so, sg):
+        span = float(size) * zoom
+        sc.one_val_in_pixels = nwidth / span
+        sc.one_px_in_values = span / nwidth
+        sc.offset_px = offpx
+        sc.offset_val = offpx * sc.one_px_in_values
+        sc.min_value = 0.0
+    want = orc.plot_populate(data, nwidth, so)
+    d = g.empty(2 * size, np.float32)
+    g._ck(g.lib.tsdrgpu_upload(g.h, d.ptr, data.ctypes.data, data.nbytes))
+    g.sync()
+    got = g.plot_columns(d.ptr, size, nwidth, sg)
+    if not np.array_equal(got[0], want[0]) or got[1:] != want[1:]:
+        return f"plot size={size} nwidth={nwidth} zoom={zoom} offpx={offpx}"
+    return None
+
+
+def fuzz_tracking(g, rng):
+    P = int(rng.integers(4096, 60_000))
+    phase = int(rng.integers(0, P))
+    rs = gpu.Resampler(g)
+    rs.track_frames(P, phase)
+    x = rng.uniform(3.0, 4000.0)
+    up, down = float(int(2 * x)), x
+    stream, mns, mxs = [], [], []
+    for _ in range(int(rng.integers(1, 4))):
+        chunk, nch = int(rng.integers(50, 9000)), int(rng.integers(1, 12))
+        n = chunk * nch
+        v = (rng.random(n) * 3 - 1).astype(np.float32)
+        if rng.random() < 0.5:
+            v[rng.integers(0, n, 3)] = np.float32(rng.choice([900.0, -700.0]))
+        cap = rs.count(chunk, nch, up, down)
+        d_out = g.empty(cap + 8)
+        npix = rs.process(g.to_device(v), False, chunk, nch, up, down, 0, d_out)
+        stream.append(d_out.download()[:npix])
+        mn, mx = rs.frame_minmax()
+        mns += list(mn)
+        mxs += list(mx)
+    s = np.concatenate([np.full(phase, np.float32(1e9), np.float32)] + stream)
+    nfr = s.size // P
+    if len(mns) != nfr:
+        return f"tracking count P={P} phase={phase}"
+    for f in range(nfr):
+        fr = s[f * P:(f + 1) * P]
+        if f == 0:
+            fr = fr[phase:]
+        ok = fr[np.abs(fr) <= 250.0]
+        want = (ok.min(), ok.max()) if ok.size else (np.float32(np.inf), np.float32(-np.inf))
+        if (mns[f], mxs[f]) != want:
+            return f"tracking P={P} phase={phase} frame={f}"
+    return None
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     g = gpu.TsdrGpu(0)
-    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0}
+    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0, "plot": 0, "tracking": 0}
     for c in range(ncases):
-        kind = ("resampler", "postproc", "postproc", "resampler", "autocorr", "fft")[c % 6]
-        fn = {"resampler": fuzz_resampler, "postproc": fuzz_postproc, "autocorr": fuzz_autocorr, "fft": fuzz_fft}[kind]
+        kind = ("resampler", "postproc", "postproc", "resampler", "autocorr", "fft", "plot", "tracking")[c % 8]
+        fn = {"resampler": fuzz_resampler, "postproc": fuzz_postproc, "autocorr": fuzz_autocorr, "fft": fuzz_fft,
+              "plot": fuzz_plot, "tracking": fuzz_tracking}[kind]
         try:
             r = fn(g, rng)
         except Exception as e:  # noqa: BLE001
