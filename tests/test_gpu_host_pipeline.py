@@ -54,12 +54,12 @@ def match_in_order(got, want):
     return hits
 
 
-def run_session(plugin, params, setup=None, nframes=8, during=None, timeout=40):
+def run_session(plugin, params, setup=None, nframes=8, during=None, timeout=40, height=H, refresh=FV):
     s = hu.Session()
     assert s.lib.tsdr_loadplugin(s.h, plugin.encode(), params.encode()) == 0, s.err()
     assert s.lib.tsdr_setbasefreq(s.h, 400_000_000) == 0
     assert s.lib.tsdr_setgain(s.h, 0.5) == 0
-    assert s.lib.tsdr_setresolution(s.h, H, FV) == 0
+    assert s.lib.tsdr_setresolution(s.h, height, refresh) == 0
     if setup:
         setup(s)
     s.start()
@@ -305,4 +305,37 @@ def test_superresolution_frames_match_oracle(orc, tmp_path):
     assert m >= 4
     for k in range(m):
         assert np.max(np.abs(got[k] - want[k])) <= 2e-3, k
+    s.close()
+
+
+@pytest.mark.parametrize("fs,mode,h,fv,block,cfg", [
+    (2_000_000, (200, 131, 160, 120), 131, 60.0, 40_000, (0.0, 0, 0, 1, 0)),     # small frames, many per block
+    (12_600_000, "640x480", 525, 59.94, 300_002, (0.25, 0, 1, 0, 0)),            # block not a multiple of anything
+    (25_000_000, "1024x768", 806, 60.0, 1_048_576, (0.0, 1, 1, 1, 0)),           # BASELINE config 2, GUI stage order
+])
+def test_pipeline_other_geometries(orc, tmp_path, fs, mode, h, fv, block, cfg):
+    """The engine at other sample rates / geometries / plugin block sizes: every delivered frame is an oracle
+    frame, in order, starting with the first."""
+    mb, lbs, aap, ash, pll = cfg
+    geo = orc.geometry(fs, h, fv)
+    nsamp = int(10.5 * fs / fv)
+    iq = synth.synth_iq(fs, mode, fv, nsamp, seed=0x5EED0000 + h)
+    path = tmp_path / "iq.f32"
+    iq.tofile(path)
+    plugin = hu.build_test_plugin()
+
+    def setup(s):
+        s.lib.tsdr_motionblur(s.h, mb)
+        s.lib.tsdr_setparameter_int(s.h, 6, lbs)
+        s.lib.tsdr_setparameter_int(s.h, 7, aap)
+        s.lib.tsdr_setparameter_int(s.h, 0, ash)
+
+    want = oracle_frames(orc, iq, geo, cfg)
+    assert len(want) >= 8
+    s, ok, rc = run_session(plugin, f"{path} {fs} {block} 8000", setup, nframes=len(want) - 3, height=h, refresh=fv, timeout=20)
+    assert ok and rc == 0 and s.status == 0, s.err()
+    assert len(s.frames) >= len(want) - 4
+    assert all((w_, h_) == (geo.width, h) for (w_, h_, _) in s.frames)
+    hits = match_in_order(s.frames, want)
+    assert hits[0] == 0
     s.close()
