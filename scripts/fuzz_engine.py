@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end run of the tsdr_* drop-in (plugin -> libTSDRLibrary.so -> HIP) against the oracle's
+deterministic driver: random sample rate / lines / refresh / plugin block size / stage order / autoshift / motion blur.
+Every delivered frame must equal an oracle frame, in order, starting with the first.
+
+usage (on a GPU box):  python scripts/fuzz_engine.py [sessions] [seed]
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle as orc  # noqa: E402
+from tempestsdr_amd import synth  # noqa: E402
+import host_util as hu  # noqa: E402
+
+
+def oracle_frames(iq, geo, cfg):
+    pix, _ = orc.demod_resample_stream(iq, geo)
+    P = geo.width * geo.height
+    pp = orc.PostProcess(geo)
+    mb, lbs, aap, ash = cfg
+    return [pp.run(pix[k * P:(k + 1) * P].copy(), mb, 0.1, lbs, aap, ash, 0, 0) for k in range(pix.size // P)]
+
+
+def one(rng, plugin, tmp):
+    h = int(rng.integers(40, 700))
+    fv = float(rng.choice([50.0, 59.94, 60.0, 75.0]))
+    fs = int(rng.integers(300_000, 20_000_000))
+    geo = orc.geometry(fs, h, fv)
+    if geo.width < 8 or geo.width * h > 1_500_000:
+        return None
+    tw = max(8, int(round(fs / (fv * h))))
+    mode = (tw, h, (tw * 4) // 5, (h * 9) // 10)
+    nsamp = int(rng.uniform(6.5, 12.5) * fs / fv)
+    iq = synth.synth_iq(fs, mode, fv, nsamp, seed=int(rng.integers(1, 1 << 30)))
+    path = os.path.join(tmp, "iq.f32")
+    iq.tofile(path)
+    block = 2 * int(rng.integers(1_000, max(1_001, min(600_000, nsamp // 4))))  # the test plugin sends whole blocks only
+    cfg = (float(rng.choice([0.0, 0.0, 0.25, 0.9375])), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+    mb, lbs, aap, ash = cfg
+    want = oracle_frames(iq, geo, cfg)
+    if len(want) < 5:
+        return None
+    s = hu.Session()
+    desc = f"fs={fs} h={h} fv={fv} w={geo.width} block={block} cfg={cfg} frames={len(want)}"
+    try:
+        assert s.lib.tsdr_loadplugin(s.h, plugin.encode(), f"{path} {fs} {block} 3000".encode()) == 0, s.err()
+        s.lib.tsdr_setbasefreq(s.h, 400_000_000)
+        s.lib.tsdr_setgain(s.h, 0.5)
+        assert s.lib.tsdr_setresolution(s.h, h, fv) == 0
+        s.lib.tsdr_motionblur(s.h, mb)
+        s.lib.tsdr_setparameter_int(s.h, 6, lbs)
+        s.lib.tsdr_setparameter_int(s.h, 7, aap)
+        s.lib.tsdr_setparameter_int(s.h, 0, ash)
+        s.start()
+        ok = s.wait_frames(len(want) - 3, 20)
+        rc = s.stop()
+        if not ok or rc != 0 or s.status != 0:
+            return f"session failed ({ok}, {rc}, {s.status}, {s.err()}) {desc}"
+        k, first = 0, None
+        for (w_, h_, a) in s.frames:
+            if (w_, h_) != (geo.width, h):
+                return f"geometry {(w_, h_)} {desc}"
+            while k < len(want) and not np.array_equal(a, want[k], equal_nan=True):
+                k += 1
+            if k >= len(want):
+                return f"a delivered frame matches no oracle frame {desc}"
+            first = k if first is None else first
+            k += 1
+        if first != 0:
+            return f"first delivered frame is oracle frame {first} {desc}"
+        if len(s.frames) < len(want) - 4:
+            return f"only {len(s.frames)} of {len(want)} frames {desc}"
+    finally:
+        s.close()
+    return ""
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    plugin = hu.build_test_plugin()
+    ran = fails = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for c in range(n):
+            r = one(rng, plugin, tmp)
+            if r is None:
+                continue
+            ran += 1
+            if r:
+                fails += 1
+                print("MISMATCH", c, r, flush=True)
+    print(f"engine fuzz: {ran} sessions, {fails} failures, seed {seed}")
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
