@@ -32,6 +32,7 @@ def fuzz_resampler(g, rng):
     else:
         up, down = float(rng.uniform(0.05, 7.0)), 1.0
     iq = bool(rng.integers(0, 2))
+    nearest = bool(rng.random() < 0.2)  # PARAM_NEAREST_NEIGHBOUR_RESAMPLING, dsp.c:274-276
     rs_o, rs_g = orc.Resampler(), gpu.Resampler(g)
     for _ in range(int(rng.integers(1, 4))):
         chunk = int(rng.integers(1, 3000))
@@ -46,13 +47,13 @@ def fuzz_resampler(g, rng):
             mag = orc.am_demod(host)
         else:
             host = mag
-        want = np.concatenate([rs_o.process(mag[c * chunk:(c + 1) * chunk], up, down) for c in range(nch)])
+        want = np.concatenate([rs_o.process(mag[c * chunk:(c + 1) * chunk], up, down, nearest) for c in range(nch)])
         cap = rs_g.count(chunk, nch, up, down)
         d_out = g.empty(cap + 8)
-        npix = rs_g.process(g.to_device(host), iq, chunk, nch, up, down, 0, d_out)
+        npix = rs_g.process(g.to_device(host), iq, chunk, nch, up, down, int(nearest), d_out)
         got = d_out.download()[:npix]
         if npix != want.size or not np.array_equal(got, want, equal_nan=True):
-            return f"resampler up={up} down={down} iq={iq} chunk={chunk} nch={nch}"
+            return f"resampler up={up} down={down} iq={iq} nearest={nearest} chunk={chunk} nch={nch}"
         con, off = rs_g.state()
         if (con, off) != (rs_o.st.contrib, rs_o.st.offset):
             return f"resampler state up={up} down={down} chunk={chunk}"
