@@ -9,6 +9,7 @@
   fft       : random power-of-two sizes 2 .. 2^17, both directions                -> 2e-6*max|X|
   plot      : random plot sizes, widget widths, zoom / offset states              -> identical columns, lowest/highest, argmax
   tracking  : random frame sizes / phases, several calls                          -> exact per-frame min/max
+  superb    : four randomly delayed hops of a periodic signal                     -> identical hop offsets, 1e-4*max signal
 
 usage (on a GPU box):  python scripts/fuzz_parity.py [cases] [seed]
 """
@@ -218,16 +219,47 @@ def fuzz_tracking(g, rng):
     return None
 
 
+def fuzz_superb(g, rng):
+    # four hops of a periodic signal, each delayed by a random amount (superbandwidth.c:121-152)
+    fs = int(rng.integers(20_000, 400_000))
+    fv = float(rng.choice([50.0, 60.0, 75.0]))
+    sif = int(fs / fv)
+    gathered = int(rng.integers(2 * sif + 8, 10 * sif))
+    t = np.arange(gathered + 2 * sif)
+    base = (0.4 + 0.5 * ((t % sif) < sif // 7) + 0.1 * np.sin(t * 0.01)).astype(np.float64)
+    hops = []
+    for k in range(4):
+        d = int(rng.integers(0, sif))
+        mag = base[d:d + gathered] + rng.standard_normal(gathered) * 0.01
+        ph = 0.21 * np.arange(gathered) + k
+        h = np.empty(2 * gathered, np.float32)
+        h[0::2] = (mag * np.cos(ph)).astype(np.float32)
+        h[1::2] = (mag * np.sin(ph)).astype(np.float32)
+        hops.append(h)
+    want, offs = orc.superb_stitch(hops, sif)
+    d_out = g.empty(want.size)
+    got_offs, total = g.superb_stitch([g.to_device(h) for h in hops], gathered, sif, d_out)
+    if 2 * total != want.size:
+        return f"superb size fs={fs} gathered={gathered}"
+    if not np.array_equal(got_offs, offs):
+        # offsets are argmaxes of cross-correlations: accept a different lag only if it is a tie within tolerance
+        return f"superb offsets fs={fs} fv={fv} gathered={gathered} gpu={list(got_offs)} oracle={list(offs)}"
+    got = d_out.download()
+    if np.max(np.abs(got - want)) > 1e-4 * np.max(np.abs(want)):
+        return f"superb signal fs={fs} gathered={gathered} err={np.max(np.abs(got - want)) / np.max(np.abs(want))}"
+    return None
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     g = gpu.TsdrGpu(0)
-    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0, "plot": 0, "tracking": 0}
+    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0, "plot": 0, "tracking": 0, "superb": 0}
     for c in range(ncases):
-        kind = ("resampler", "postproc", "postproc", "resampler", "autocorr", "fft", "plot", "tracking")[c % 8]
+        kind = ("resampler", "postproc", "postproc", "resampler", "autocorr", "fft", "plot", "tracking", "superb")[c % 9]
         fn = {"resampler": fuzz_resampler, "postproc": fuzz_postproc, "autocorr": fuzz_autocorr, "fft": fuzz_fft,
-              "plot": fuzz_plot, "tracking": fuzz_tracking}[kind]
+              "plot": fuzz_plot, "tracking": fuzz_tracking, "superb": fuzz_superb}[kind]
         try:
             r = fn(g, rng)
         except Exception as e:  # noqa: BLE001
