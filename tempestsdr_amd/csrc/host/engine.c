@@ -412,23 +412,27 @@ static void run_frames(struct engine *e)
 static void run_resampler(struct engine *e)
 {
     tsdr_lib_t *t = e->t;
-    pthread_mutex_lock(&t->lock);
-    const int W = t->width, H = t->height;
-    const double refresh = t->refreshrate;
-    const uint32_t fs = t->samplerate;
-    pthread_mutex_unlock(&t->lock);
-    if (W <= 0 || H <= 0 || !(refresh > 0)) return;
-    const int chunk = (int)(FRAMES_TO_POLL * fs / refresh); /* TSDRLibrary.c:335 */
-    if (chunk <= 0) return;
     const size_t per = e->iq_is_mag ? 1 : 2;
-    const double up = W * H * refresh, down = fs; /* TSDRLibrary.c:340 */
-    const int totalpixels = W * H;
     for (;;) {
+        /* the decimating thread re-reads the geometry for every chunk (TSDRLibrary.c:335-340): the frame-rate
+         * PLL and tsdr_setresolution change it while the stream runs */
+        pthread_mutex_lock(&t->lock);
+        const int W = t->width, H = t->height;
+        const double refresh = t->refreshrate;
+        const uint32_t fs = t->samplerate;
+        pthread_mutex_unlock(&t->lock);
+        if (W <= 0 || H <= 0 || !(refresh > 0)) return;
+        const int chunk = (int)(FRAMES_TO_POLL * fs / refresh); /* TSDRLibrary.c:335 */
+        if (chunk <= 0) return;
+        const double up = W * H * refresh, down = fs; /* TSDRLibrary.c:340 */
+        const int totalpixels = W * H;
         const size_t have = (e->iq.wr - e->iq.rd) / per;
         int nchunks = (int)(have / (size_t)chunk);
         if (nchunks <= 0) break;
-        /* while pixels are being skipped or a manual shift is pending go chunk by chunk like the reference */
-        if (e->pix_difference != 0 || t->syncoffset != 0) nchunks = 1;
+        /* while pixels are being skipped or a manual shift is pending go chunk by chunk like the reference;
+         * with the PLL on as well, because a frame completed by this chunk may nudge the refresh rate, which
+         * the next chunk's ratio must already see */
+        if (e->pix_difference != 0 || t->syncoffset != 0 || t->params_int[PARAM_INT_FRAMERATE_PLL]) nchunks = 1;
         else if (nchunks > 40) nchunks = 40;
         const int64_t count = tsdrgpu_resample_count(e->rs, (uint32_t)chunk, nchunks, up, down);
         if (count < 0 || !ensure_dev(e, &e->d_rs, &e->rs_cap, (size_t)count + 16)) return;

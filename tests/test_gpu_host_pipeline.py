@@ -339,3 +339,60 @@ def test_pipeline_other_geometries(orc, tmp_path, fs, mode, h, fv, block, cfg):
     hits = match_in_order(s.frames, want)
     assert hits[0] == 0
     s.close()
+
+
+def oracle_pll_stream(orc, iq, fs, h, fv, mb=0.0):
+    """The oracle's deterministic driver with the frame-rate PLL on, in the order the engine documents: a chunk is
+    resampled with the geometry of that moment (TSDRLibrary.c:335-340), every frame it completes is post-processed,
+    and a PLL nudge (syncdetector.c:141-151: refreshrate, then width / pixel rate through set_internal_samplerate)
+    is in force from the next chunk / frame cut on."""
+    geo = orc.geometry(fs, h, fv)
+    pp, rs = orc.PostProcess(geo), orc.Resampler()
+    mag = orc.am_demod(iq)
+    pos, buf, frames, rates = 0, np.zeros(0, np.float32), [], []
+    while True:
+        chunk = int(0.1 * fs / geo.refreshrate)
+        if pos + chunk > mag.size:
+            break
+        up, down = geo.width * geo.height * geo.refreshrate, float(fs)
+        buf = np.concatenate([buf, rs.process(mag[pos:pos + chunk], up, down)])
+        pos += chunk
+        while buf.size >= geo.width * geo.height:
+            P, w = geo.width * geo.height, geo.width
+            frames.append((w, pp.run(buf[:P].copy(), mb, 0.1, 0, 0, 0, 1, 0)))
+            buf = buf[P:]
+            rates.append(geo.refreshrate)
+    return frames, rates
+
+
+@pytest.mark.parametrize("fv_true", [60.02, 60.3])
+def test_pipeline_with_pll_matches_oracle(orc, tmp_path, fv_true):
+    """PARAM_INT_FRAMERATE_PLL through the whole library: the raster runs slightly faster than the configured
+    60 Hz, the PLL nudges the refresh rate frame by frame (at 60.3 Hz the derived width changes mid-stream), and
+    every delivered frame — size and content — is the oracle driver's, in order."""
+    fs, h, fv = 2_000_000, 131, 60.0
+    iq = synth.synth_iq(fs, (200, 131, 160, 120), fv_true, int(40 * fs / 60), seed=3)
+    want, rates = oracle_pll_stream(orc, iq, fs, h, fv)
+    assert len(want) >= 30 and len(set(rates)) > 5  # the PLL did fire
+    path = tmp_path / "pll.f32"
+    iq.tofile(path)
+    plugin = hu.build_test_plugin()
+
+    def setup(s):
+        s.lib.tsdr_setparameter_int(s.h, 1, 1)  # PARAM_INT_FRAMERATE_PLL
+
+    s, ok, rc = run_session(plugin, f"{path} {fs} 65536 4000", setup, nframes=len(want) - 3, height=h, refresh=fv, timeout=20)
+    assert ok and rc == 0 and s.status == 0, s.err()
+    k, first = 0, None
+    for (w_, h_, a) in s.frames:
+        while k < len(want) and not (want[k][0] == w_ and np.array_equal(a, want[k][1])):
+            k += 1
+        assert k < len(want), f"a delivered {w_}x{h_} frame matches no oracle frame after {first}"
+        first = k if first is None else first
+        k += 1
+    assert first == 0
+    if fv_true == 60.3:
+        assert len({w_ for (w_, _, _) in s.frames}) == 2  # the width change was delivered
+    pll_values = [v for v in s.values if v[0] == 0]  # VALUE_ID_PLL_FRAMERATE
+    assert pll_values
+    s.close()
