@@ -58,13 +58,38 @@ def one(rng, plugin, tmp):
     cfg = (float(rng.choice([0.0, 0.0, 0.25, 0.9375])), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)),
            int(rng.integers(0, 2)))
     mb, lbs, aap, ash, pll = cfg
-    want = oracle_frames(iq, fs, h, fv, cfg)
+    params = f"{path} {fs} {block} 3000"
+    stream = iq
+    per = block // 2
+    if pll == 0 and rng.random() < 0.4 and nsamp // per >= 6:  # (with the PLL the skip unit moves with the geometry)
+        # the plugin loses drop_n samples after block drop_at and reports them with the next block; the library
+        # then skips whole multiples of one frame's samples (dsp.c:313-368) — same bookkeeping on the oracle side
+        drop_at = int(rng.integers(1, nsamp // per - 3))
+        drop_n = int(rng.integers(1, max(2, min(nsamp // 6, 4 * per))))
+        params += f" {drop_at} {drop_n}"
+        unit = int(round(((geo.width * geo.height) << 1) * geo.pixeltimeoversampletime))
+        diff, pos, fwd = 0, 0, []
+        for b in range((nsamp - drop_n) // per):
+            dropped = drop_n if b == drop_at + 1 else 0
+            seg = iq[2 * pos:2 * (pos + per)]
+            pos += per
+            if b == drop_at:
+                pos += drop_n
+            diff = orc.lib.orc_dropped_shift_with(diff, unit, dropped)
+            if per <= diff:
+                diff -= per
+            else:
+                fwd.append(seg[2 * diff:])
+                diff = 0
+        stream = np.concatenate(fwd)
+    want = oracle_frames(stream, fs, h, fv, cfg)
     if len(want) < 5:
         return None
     s = hu.Session()
-    desc = f"fs={fs} h={h} fv={fv} fv_true={fv_true:.4f} w={geo.width} block={block} cfg={cfg} frames={len(want)}"
+    tail = params.split(" ", 1)[1]
+    desc = f"fs={fs} h={h} fv={fv} fv_true={fv_true:.4f} w={geo.width} block={block} cfg={cfg} params={tail} frames={len(want)}"
     try:
-        assert s.lib.tsdr_loadplugin(s.h, plugin.encode(), f"{path} {fs} {block} 3000".encode()) == 0, s.err()
+        assert s.lib.tsdr_loadplugin(s.h, plugin.encode(), params.encode()) == 0, s.err()
         s.lib.tsdr_setbasefreq(s.h, 400_000_000)
         s.lib.tsdr_setgain(s.h, 0.5)
         assert s.lib.tsdr_setresolution(s.h, h, fv) == 0
