@@ -61,6 +61,10 @@ struct tsdrgpu_postproc {
     double *d_strip_x, *d_strip_y;  // [F][3][n]: non-sentinel sum, sentinel sum, sentinel count
     size_t cap_fmin, cap_fmax, cap_sx, cap_sy;
     float *d_work;  // chain scratch: blurred strips + prefix sums
+    int *d_sflag;   // [F][2]: the strip of (frame, axis) holds equal entries -> take the reference-order sums
+    size_t cap_sflag;
+    float *d_exact; // [F][2][nmax] strips summed in the reference's order (filled for flagged frames only)
+    size_t cap_exact;
     size_t cap_work;
     ChainOut *d_chain;
     ChainOut *h_chain;  // pinned mirror
@@ -356,12 +360,91 @@ struct StripScratch {
     int nmax;
 };
 
+// ---------------------------------------------------------------------------
+// Exact ties.  The strips above come from exact f64 sums, the reference's from f32 additions in
+// raster order (dsp.c:96-110); they agree to ~1e-6 — except that where several window positions fit
+// EXACTLY equally (plateaus, periodic test patterns, blank frames) the reference's winner is decided
+// by its own rounding.  Equal window sums need equal strip entries, and exact f64 sums of noisy data
+// (almost) never collide, so: k_strip_flag sorts a strip's entries and flags (frame, axis) if many are equal
+// (or sentinels are present); for flagged frames k_exact_strips redoes the collapse literally — one
+// thread per column / per row adding the (autogained) pixels in f32 in the reference's order — and
+// k_strip_prepare takes those.  Unflagged frames (every measured frame) pay one early-exit each.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const double *__restrict__ strip_x,
+                                                        const double *__restrict__ strip_y, int *__restrict__ sflag)
+{
+    __shared__ unsigned long long keys[STRIP_MAX];
+    const int axis = blockIdx.x, f = blockIdx.y;
+    const int n = axis == 0 ? W : H;
+    const double *sp = (axis == 0 ? strip_x : strip_y) + (long long)f * 3 * n;
+    int m = 1;
+    while (m < n) m <<= 1;
+    int sent = 0;
+    for (int i = threadIdx.x; i < m; i += CHAIN_T) {
+        if (i < n) {
+            keys[i] = (unsigned long long)__double_as_longlong(sp[i]);
+            sent |= (sp[2 * n + i] != 0.0) ? 1 : 0;
+        } else {
+            keys[i] = 0xFFFFFFFFFFFFFFFFull - (unsigned)i;  // distinct padding, above every real sum
+        }
+    }
+    sent = __syncthreads_or(sent);
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < m; i += CHAIN_T) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long a = keys[i], b = keys[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // The sums are exact only down to the f32 tile partials of k_frame_stats, so a noisy frame shows a
+    // few accidental collisions (measured: 0-3 per 2962-entry strip); structure (plateaus, periodic
+    // patterns, blank frames) shows them by the hundred.  Flag from n/32 equal pairs on.
+    __shared__ int ndup;
+    if (threadIdx.x == 0) ndup = 0;
+    __syncthreads();
+    int dup = 0;
+    for (int i = threadIdx.x; i + 1 < n; i += CHAIN_T) dup += (keys[i] == keys[i + 1]) ? 1 : 0;
+    if (dup) atomicAdd(&ndup, dup);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int limit = n / 32 > 8 ? n / 32 : 8;
+        sflag[f * 2 + axis] = (ndup >= limit || sent) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ frames, long long fstride, int W, int H,
+                                                      const ChainOut *__restrict__ chain, int strips_normalised,
+                                                      const int *__restrict__ sflag, float *__restrict__ exact, int nmax)
+{
+    const int axis = blockIdx.y, f = blockIdx.z;
+    if (!sflag[f * 2 + axis]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = axis == 0 ? W : H;
+    if (i >= n) return;
+    const float *src = frames + (long long)f * fstride;
+    const float lastmin = chain[f].lastmin, span = chain[f].span;
+    const int count = axis == 0 ? H : W;
+    const long long step = axis == 0 ? W : 1, first = axis == 0 ? i : (long long)i * W;
+    float acc = 0.f;
+    for (int k = 0; k < count; k++) {
+        float v = src[first + k * step];
+        if (strips_normalised) v = (v > 250.0f || v < -250.0f) ? v : ((v - lastmin) / span);  // dsp.c:80-86
+        acc += v;
+    }
+    exact[((long long)f * 2 + axis) * nmax + i] = acc;
+}
+
 __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const double *__restrict__ strip_x,
                                                            const double *__restrict__ strip_y,
                                                            const ChainOut *__restrict__ chain, StripScratch sc,
                                                            int strips_normalised, float t0, float t1, float t2, float t3,
-                                                           float t4, const float *__restrict__ fmin_,
-                                                           const float *__restrict__ fmax_)
+                                                           float t4, const int *__restrict__ sflag,
+                                                           const float *__restrict__ exact)
 {
     __shared__ float data[STRIP_MAX];
     __shared__ float blur[STRIP_MAX];
@@ -372,21 +455,9 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
     const double *sp = (axis == 0 ? strip_x : strip_y) + (long long)f * 3 * n;
     const double cnt_all = (double)(axis == 0 ? H : W);
     const float lastmin = chain[f].lastmin, span = chain[f].span;
-    // A frame whose pixels all hold ONE value (a blanked screen) is the degenerate case of the sync
-    // detector: every window fits equally well, and which strip size wins is decided by the last bit of
-    // the strip entries (through the float cast of their total, syncdetector.c:84).  There the strip must
-    // be the reference's own number: dsp_average_v_h (dsp.c:96-110) adds the pixels in f32 in raster
-    // order, i.e. each entry is the sequential f32 sum of `count` copies of the (autogained) value.
-    int any_sent = 0;
-    for (int i = tid; i < n; i += CHAIN_T) any_sent |= (sp[2 * n + i] != 0.0) ? 1 : 0;
-    any_sent = __syncthreads_or(any_sent);
-    const float fmn = fmin_[f], fmx = fmax_[f];
-    if (!any_sent && fmn == fmx) {
-        const float val = strips_normalised ? (fmn - lastmin) / span : fmn;
-        const int count = axis == 0 ? H : W;
-        float acc = 0.f;
-        for (int k = 0; k < count; k++) acc += val;
-        for (int i = tid; i < n; i += CHAIN_T) data[i] = acc;
+    if (sflag[f * 2 + axis]) {  // reference-order sums, see k_strip_flag
+        const float *ex = exact + ((long long)f * 2 + axis) * sc.nmax;
+        for (int i = tid; i < n; i += CHAIN_T) data[i] = ex[i];
     } else {
         for (int i = tid; i < n; i += CHAIN_T) {
             const double ns = sp[i], s = sp[n + i], c = sp[2 * n + i];
@@ -1035,7 +1106,7 @@ extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
     (void)hipEventDestroy(pp->ev_stats);
     (void)hipEventDestroy(pp->ev_chain);
     void *bufs[] = {pp->d_state, pp->d_screen, pp->d_screen2, pp->d_dump, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
-                    pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain};
+                    pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain, pp->d_sflag, pp->d_exact};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (pp->h_chain) (void)hipHostFree(pp->h_chain);
@@ -1109,10 +1180,13 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         sc.blur = pp->d_work;
         sc.prefix = (double *)(pp->d_work + (((size_t)F * 2 * nmax + 1) & ~(size_t)1));
         sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
+        TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_sflag);
+        TSDR_LAUNCH(g, PROF_CHAIN, st, k_exact_strips, dim3((nmax + 255) / 256, 2, F), 256, frames, fstride, W, H, pp->d_chain, strips_normalised,
+                    pp->d_sflag, pp->d_exact, nmax);
+        KERNEL_CHECK(g, "k_exact_strips");
         TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
                                                                strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2],
-                                                               pp->taps[3], pp->taps[4], pp->ext_fmin ? pp->ext_fmin : pp->d_fmin,
-                                                               pp->ext_fmax ? pp->ext_fmax : pp->d_fmax);
+                                                               pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact);
         KERNEL_CHECK(g, "k_strip_prepare");
         SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
         TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, pp->d_state, spec);
@@ -1183,6 +1257,8 @@ static int pp_prepare(tsdrgpu_postproc_t *pp, int F, int W, int H, const tsdrgpu
         const size_t floats = (((size_t)F * 2 * nmax + 1) & ~(size_t)1) + 2 * ((size_t)F * 2 * (nmax + 1) + (size_t)F * 2) +
                               (size_t)F * 2 * (sizeof(SpecEntry) / sizeof(float)) + 16;
         if ((rc = ensure(g, &pp->d_work, &pp->cap_work, floats))) return rc;
+        if ((rc = ensure(g, &pp->d_sflag, &pp->cap_sflag, (size_t)F * 2))) return rc;
+        if ((rc = ensure(g, &pp->d_exact, &pp->cap_exact, (size_t)F * 2 * nmax))) return rc;
     }
     if (W > STRIP_MAX || H > STRIP_MAX) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "width/height above 16384");
     pp->chain_has_autogain = 0;
