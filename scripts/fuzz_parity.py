@@ -89,6 +89,11 @@ def fuzz_postproc(g, rng):
             fr *= np.float32(rng.choice([200.0, 1e-4, -1.0]))     # large / tiny / negative ranges
         elif r < 0.33:
             fr[rng.integers(0, w * h, max(1, w * h // 3))] = np.float32(1024.0)  # a third of the frame sentinel
+        elif r < 0.40:  # periodic structure: checkerboard / stripes with random pitch
+            yy, xx = np.mgrid[0:h, 0:w]
+            px, py = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+            pat = ((xx // px + (yy // py) * int(rng.integers(0, 2))) % 2) * np.float32(0.55) + np.float32(0.2)
+            fr[:] = pat.astype(np.float32).reshape(-1)
     opp = orc.PostProcess(geo)
     want, states = [], []
     for fr in frames:

@@ -403,7 +403,8 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const doub
         }
     // The sums are exact only down to the f32 tile partials of k_frame_stats, so a noisy frame shows a
     // few accidental collisions (measured: 0-3 per 2962-entry strip); structure (plateaus, periodic
-    // patterns, blank frames) shows them by the hundred.  Flag from n/32 equal pairs on.
+    // patterns, blank frames) shows them by the hundred.  Flag from n/32 equal pairs on (from one on for
+    // strips too short for accidents).
     __shared__ int ndup;
     if (threadIdx.x == 0) ndup = 0;
     __syncthreads();
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const doub
     if (dup) atomicAdd(&ndup, dup);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int limit = n / 32 > 8 ? n / 32 : 8;
+        const int limit = n < 256 ? 1 : (n / 32 > 8 ? n / 32 : 8);  // short strips: any collision is structure
         sflag[f * 2 + axis] = (ndup >= limit || sent) ? 1 : 0;
     }
 }

@@ -335,3 +335,34 @@ def test_uniform_frames_keep_the_sync_state_identical(orc, cfg, fs, h):
     for k, (info, (si, sd)) in enumerate(zip(infos, states)):
         assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) == tuple(si[:7]), f"frame {k}"
     assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("cfg", [(0, 0, 0, 0, 0.0), (1, 0, 0, 0, 0.0), (0, 1, 1, 0, 0.25), (1, 1, 0, 0, 0.5)])
+def test_structured_frames_keep_the_sync_state_identical(orc, cfg):
+    """Two-valued, checkerboard and striped frames: many window positions of the sync detector fit EXACTLY equally,
+    so the reference's winner hangs on the rounding of its f32 raster-order strip sums.  k_strip_flag notices the
+    equal strip entries and k_exact_strips re-collapses those frames in the reference's order: identical state."""
+    g = ctx()
+    fs, h = 849_898, 90
+    geo = orc.geometry(fs, h, 60.0)
+    w = geo.width
+    rng = np.random.default_rng(51)
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames = []
+    for k in range(12):
+        base = cases.frame_pattern(w, h, int(rng.integers(0, 40)), rng)
+        kind = k % 4
+        if kind == 0:
+            fr = np.where(base > np.median(base), np.float32(0.75), np.float32(0.125))
+        elif kind == 1:
+            fr = (((xx // 7 + yy // 5 + k) % 2) * np.float32(0.6) + np.float32(0.2)).astype(np.float32).reshape(-1)
+        elif kind == 2:
+            fr = (((xx + k) % 16 < 5) * np.float32(0.5) + np.float32(0.25)).astype(np.float32).reshape(-1)
+        else:
+            fr = base
+        frames.append(np.ascontiguousarray(fr, np.float32).reshape(-1))
+    want, states, _ = run_orc(orc, frames, fs, h, 60.0, cfg)
+    got, infos, _ = run_gpu(g, frames, w, h, cfg, 4)
+    for k, (info, (si, sd)) in enumerate(zip(infos, states)):
+        assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) == tuple(si[:7]), f"frame {k}"
+    assert np.array_equal(got, want, equal_nan=True)
