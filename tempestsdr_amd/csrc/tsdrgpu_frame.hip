@@ -371,24 +371,49 @@ struct StripScratch {
 // k_strip_prepare takes those.  Unflagged frames (every measured frame) pay one early-exit each.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const double *__restrict__ strip_x,
-                                                        const double *__restrict__ strip_y, int *__restrict__ sflag)
+                                                        const double *__restrict__ strip_y, const ChainOut *__restrict__ chain,
+                                                        int strips_normalised, int *__restrict__ sflag)
 {
     __shared__ unsigned long long keys[STRIP_MAX];
+    __shared__ double rlo[CHAIN_T / 64], rhi[CHAIN_T / 64];
     const int axis = blockIdx.x, f = blockIdx.y;
     const int n = axis == 0 ? W : H;
     const double *sp = (axis == 0 ? strip_x : strip_y) + (long long)f * 3 * n;
+    const double cnt_all = (double)(axis == 0 ? H : W);
+    const double lastmin = chain[f].lastmin, span = chain[f].span;
     int m = 1;
     while (m < n) m <<= 1;
     int sent = 0;
+    double lo = INFINITY, hi = -INFINITY;
     for (int i = threadIdx.x; i < m; i += CHAIN_T) {
         if (i < n) {
             keys[i] = (unsigned long long)__double_as_longlong(sp[i]);
             sent |= (sp[2 * n + i] != 0.0) ? 1 : 0;
+            const double v = strips_normalised ? (sp[i] - cnt_all * lastmin) / span : sp[i];  // the strip entry (no sentinels)
+            lo = fmin(lo, v);
+            hi = fmax(hi, v);
         } else {
             keys[i] = 0xFFFFFFFFFFFFFFFFull - (unsigned)i;  // distinct padding, above every real sum
         }
     }
+    // Low contrast is the other way to a coin toss: when the strip varies by less than ~1 % of its level
+    // (a frame that is nearly blank after the autogain), window fits differ by less than the rounding
+    // of the reference's own f32 sums, so the literal collapse is taken as well.
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, o, 64));
+        hi = fmax(hi, __shfl_down(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { rlo[threadIdx.x >> 6] = lo; rhi[threadIdx.x >> 6] = hi; }
     sent = __syncthreads_or(sent);
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < CHAIN_T / 64; w++) { lo = fmin(lo, rlo[w]); hi = fmax(hi, rhi[w]); }
+        const double level = fmax(fabs(lo), fabs(hi));
+        if (!(hi - lo > 1e-2 * level)) sent = 1;  // also true for NaN / empty
+        rlo[0] = (double)sent;
+    }
+    __syncthreads();
+    sent = rlo[0] != 0.0;
     for (int k = 2; k <= m; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < m; i += CHAIN_T) {
@@ -1181,7 +1206,8 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         sc.blur = pp->d_work;
         sc.prefix = (double *)(pp->d_work + (((size_t)F * 2 * nmax + 1) & ~(size_t)1));
         sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
-        TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_sflag);
+        TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, strips_normalised,
+                    pp->d_sflag);
         TSDR_LAUNCH(g, PROF_CHAIN, st, k_exact_strips, dim3((nmax + 255) / 256, 2, F), 256, frames, fstride, W, H, pp->d_chain, strips_normalised,
                     pp->d_sflag, pp->d_exact, nmax);
         KERNEL_CHECK(g, "k_exact_strips");
