@@ -134,6 +134,75 @@ def fuzz_postproc(g, rng):
     return None
 
 
+def fuzz_postproc_pll(g, rng):
+    """PLL on: one frame per call, the caller applies the nudge (rate and state must track the oracle's)."""
+    h = int(rng.integers(20, 200))
+    fs = int(rng.integers(100_000, 2_500_000))
+    geo = orc.geometry(fs, h, 60.0)
+    w = geo.width
+    if w < 8 or w * h > 250_000:
+        return None
+    cfg = (int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), 1, float(rng.choice([0.0, 0.5, 0.9375])))
+    lbs, aap, ash, pll, mb = cfg
+    drift = int(rng.integers(0, 6))
+    pp_o, pp_g = orc.PostProcess(geo), gpu.PostProcess(g)
+    d_in, d_out = g.empty(w * h), g.empty(w * h)
+    rate = 60.0
+    for k in range(int(rng.integers(3, 14))):
+        if geo.width != w:
+            break
+        fr = cases.frame_pattern(w, h, k * drift, rng)
+        want = pp_o.run(fr.copy(), mb, 0.1, lbs, aap, ash, 1, 0)
+        d_in.upload(fr)
+        info = pp_g.run(d_in, 1, w, h, d_out, mb, 0.1, lbs, aap, ash, 1, 0)[0]
+        rate -= info.frameratediff
+        si, sd = pp_o.state()
+        if rate != geo.refreshrate or info.pll_fired != si[7]:
+            return f"pll rate fs={fs} h={h} cfg={cfg} frame={k} gpu={rate} oracle={geo.refreshrate}"
+        if (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) != tuple(si[:7]):
+            return f"pll state fs={fs} h={h} cfg={cfg} frame={k}"
+        if not np.array_equal(d_out.download(), want, equal_nan=True):
+            return f"pll frame fs={fs} h={h} cfg={cfg} frame={k}"
+    return None
+
+
+def fuzz_autocorr_multi(g, rng):
+    """several windows, IQ or magnitude input, running mean over two calls, argmax rule"""
+    fs = int(rng.integers(100_000, 900_000))
+    ac_o, ac = orc.Autocorr(fs), gpu.Autocorr(g, fs)
+    nwin = int(rng.integers(2, 6))
+    from_iq = bool(rng.integers(0, 2))
+    period = fs // int(rng.integers(56, 86))
+    n = ac.capture * nwin
+    t = np.arange(n)
+    mag = (rng.random(n) * 0.4 + (t % period < period // 9) + 0.3 * ((t % max(period // int(rng.integers(100, 400)), 2)) == 0)).astype(np.float32)
+    if from_iq:
+        ph = 0.37 * t
+        host = np.empty(2 * n, np.float32)
+        host[0::2] = (mag * np.cos(ph)).astype(np.float32)
+        host[1::2] = (mag * np.sin(ph)).astype(np.float32)
+        mag = orc.am_demod(host)
+    else:
+        host = mag
+    for k in range(nwin):
+        ac_o.run(mag[k * ac.capture:(k + 1) * ac.capture])
+    d = g.to_device(host)
+    first = int(rng.integers(1, nwin))
+    ac.run(d, from_iq, ac.capture, first)
+    ac.run(d, from_iq, ac.capture, nwin - first, in_offset=first * ac.capture * (2 if from_iq else 1))
+    f, l, calls = ac.plots()
+    if calls != nwin:
+        return f"autocorr calls fs={fs}"
+    if np.max(np.abs(f - ac_o.frame)) > 1e-4 * np.max(ac_o.frame) or np.max(np.abs(l - ac_o.line)) > 1e-4 * np.max(ac_o.line):
+        return f"autocorr multi fs={fs} nwin={nwin} iq={from_iq}"
+    fi, li = ac.argmax()
+    if (fi, li) != (int(np.argmax(f)), int(np.argmax(l))):
+        return f"autocorr argmax rule fs={fs}"
+    if ac_o.frame[fi] < np.max(ac_o.frame) * (1 - 2e-4) or ac_o.line[li] < np.max(ac_o.line) * (1 - 2e-4):
+        return f"autocorr argmax fs={fs} nwin={nwin}"
+    return None
+
+
 def fuzz_autocorr(g, rng):
     fs = int(rng.integers(100_000, 1_200_000))
     ac_o, ac = orc.Autocorr(fs), gpu.Autocorr(g, fs)
@@ -260,11 +329,13 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     g = gpu.TsdrGpu(0)
-    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0, "plot": 0, "tracking": 0, "superb": 0}
+    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0, "plot": 0, "tracking": 0, "superb": 0, "pll": 0, "acmulti": 0}
     for c in range(ncases):
-        kind = ("resampler", "postproc", "postproc", "resampler", "autocorr", "fft", "plot", "tracking", "superb")[c % 9]
+        kind = ("resampler", "postproc", "postproc", "resampler", "autocorr", "fft", "plot", "tracking", "superb", "pll",
+                "acmulti")[c % 11]
         fn = {"resampler": fuzz_resampler, "postproc": fuzz_postproc, "autocorr": fuzz_autocorr, "fft": fuzz_fft,
-              "plot": fuzz_plot, "tracking": fuzz_tracking, "superb": fuzz_superb}[kind]
+              "plot": fuzz_plot, "tracking": fuzz_tracking, "superb": fuzz_superb, "pll": fuzz_postproc_pll,
+              "acmulti": fuzz_autocorr_multi}[kind]
         try:
             r = fn(g, rng)
         except Exception as e:  # noqa: BLE001
