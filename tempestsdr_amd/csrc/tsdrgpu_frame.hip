@@ -457,10 +457,22 @@ __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ 
     const int count = axis == 0 ? H : W;
     const long long step = axis == 0 ? W : 1, first = axis == 0 ? i : (long long)i * W;
     float acc = 0.f;
-    for (int k = 0; k < count; k++) {
-        float v = src[first + k * step];
-        if (strips_normalised) v = (v > 250.0f || v < -250.0f) ? v : ((v - lastmin) / span);  // dsp.c:80-86
-        acc += v;
+    int k = 0;
+    for (; k + 8 <= count; k += 8) {  // eight loads in flight, then the eight additions in the reference's order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[first + (k + u) * step];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            float t = v[u];
+            if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);  // dsp.c:80-86
+            acc += t;
+        }
+    }
+    for (; k < count; k++) {
+        float t = src[first + k * step];
+        if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);
+        acc += t;
     }
     exact[((long long)f * 2 + axis) * nmax + i] = acc;
 }
