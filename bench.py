@@ -402,6 +402,17 @@ def main():
         stage_ms = {k: round(v[0] / max(1, prof_steps), 4) for k, v in prof.items()}
 
         flag, llag = ac.flo + fi, ac.llo + li
+        md = gpu.ModeDetect()
+        accepted_after = None
+        for upd in range(1, 9):  # every step's plot update yields the same argmax pair on this stationary stream
+            det = md.feed(ac.flo, fi, ac.llo, li, fs)
+            if det.accepted and accepted_after is None:
+                accepted_after = upd
+        sweep = {"windows_per_s_autocorr_kernels": round(nwin * max(1, prof_steps) / (ac_ms * 1e-3), 1) if prof else None,
+                 "windows_per_s_whole_step": round(nwin * world / (ms_step * 1e-3), 1),
+                 "plot_updates_to_acceptance": accepted_after,
+                 "time_to_detection_ms": round(accepted_after * ms_step, 3) if accepted_after else None,
+                 "mode": det.mode_name.decode(errors="replace") if det.mode_id >= 0 else None}
         res = {
             "metric": ("IQ Msamples/s (+ reconstructed frames/s), 1080p60 target: demod+resample+frame post-processing+full "
                        "autocorrelation") if args.config == 2 else
@@ -433,6 +444,10 @@ def main():
             "stage_ms_per_step": stage_ms,
             "detected": {"frame_lag": int(flag), "line_lag": int(llag), "framerate": round(fs / flag, 4),
                          "height": int(round(flag / llag)), "linerate": round(fs / llag, 2)},
+            # the sweep of config 4 (same stream, mode unknown): windows correlated per second of wall clock by the
+            # autocorrelation kernels alone, and the GUI's acceptance rule (same fps/height seen 3 times before,
+            # Main.java:1233-1277) applied to one plot update per step
+            "sweep": sweep,
             "device": g.device_name(),
         }
         if world == 1 and not args.no_cpu_baseline and not args.force_dist:
