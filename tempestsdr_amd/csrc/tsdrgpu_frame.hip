@@ -365,37 +365,44 @@ struct StripScratch {
 // raster order (dsp.c:96-110); they agree to ~1e-6 — except that where several window positions fit
 // EXACTLY equally (plateaus, periodic test patterns, blank frames) the reference's winner is decided
 // by its own rounding.  Equal window sums need equal strip entries, and exact f64 sums of noisy data
-// (almost) never collide, so: k_strip_flag sorts a strip's entries and flags (frame, axis) if many are equal
-// (or sentinels are present); for flagged frames k_exact_strips redoes the collapse literally — one
+// (almost) never collide, so: k_strip_flag counts equal entries (hashed presence map in LDS) and flags
+// (frame, axis) if there are many (or sentinels are present, or the strip is nearly flat); for flagged frames k_exact_strips redoes the collapse literally — one
 // thread per column / per row adding the (autogained) pixels in f32 in the reference's order — and
 // k_strip_prepare takes those.  Unflagged frames (every measured frame) pay one early-exit each.
 // ---------------------------------------------------------------------------
+#define FLAG_BITS 20  // 2^20-bit presence map (128 KiB of LDS): equal sums always collide, unequal ones ~n^2/2^21 times
 __global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const double *__restrict__ strip_x,
                                                         const double *__restrict__ strip_y, const ChainOut *__restrict__ chain,
                                                         int strips_normalised, int *__restrict__ sflag)
 {
-    __shared__ unsigned long long keys[STRIP_MAX];
+    __shared__ unsigned bitmap[1u << (FLAG_BITS - 5)];
     __shared__ double rlo[CHAIN_T / 64], rhi[CHAIN_T / 64];
+    __shared__ int ndup, flagged;
     const int axis = blockIdx.x, f = blockIdx.y;
     const int n = axis == 0 ? W : H;
     const double *sp = (axis == 0 ? strip_x : strip_y) + (long long)f * 3 * n;
     const double cnt_all = (double)(axis == 0 ? H : W);
     const double lastmin = chain[f].lastmin, span = chain[f].span;
-    int m = 1;
-    while (m < n) m <<= 1;
-    int sent = 0;
+    for (unsigned i = threadIdx.x; i < (1u << (FLAG_BITS - 5)); i += CHAIN_T) bitmap[i] = 0u;
+    if (threadIdx.x == 0) { ndup = 0; flagged = 0; }
+    __syncthreads();
+    int sent = 0, dup = 0;
     double lo = INFINITY, hi = -INFINITY;
-    for (int i = threadIdx.x; i < m; i += CHAIN_T) {
-        if (i < n) {
-            keys[i] = (unsigned long long)__double_as_longlong(sp[i]);
-            sent |= (sp[2 * n + i] != 0.0) ? 1 : 0;
-            const double v = strips_normalised ? (sp[i] - cnt_all * lastmin) / span : sp[i];  // the strip entry (no sentinels)
-            lo = fmin(lo, v);
-            hi = fmax(hi, v);
-        } else {
-            keys[i] = 0xFFFFFFFFFFFFFFFFull - (unsigned)i;  // distinct padding, above every real sum
-        }
+    for (int i = threadIdx.x; i < n; i += CHAIN_T) {
+        const double ns = sp[i];
+        sent |= (sp[2 * n + i] != 0.0) ? 1 : 0;
+        const double v = strips_normalised ? (ns - cnt_all * lastmin) / span : ns;  // the strip entry (no sentinels)
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+        unsigned long long z = (unsigned long long)__double_as_longlong(ns);  // splitmix64 finaliser
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const unsigned bit = (unsigned)z & ((1u << FLAG_BITS) - 1u);
+        const unsigned old = atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+        dup += (old >> (bit & 31)) & 1u;
     }
+    if (dup) atomicAdd(&ndup, dup);
     // Low contrast is the other way to a coin toss: when the strip varies by less than ~1 % of its level
     // (a frame that is nearly blank after the autogain), window fits differ by less than the rounding
     // of the reference's own f32 sums, so the literal collapse is taken as well.
@@ -405,41 +412,17 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const doub
         hi = fmax(hi, __shfl_down(hi, o, 64));
     }
     if ((threadIdx.x & 63) == 0) { rlo[threadIdx.x >> 6] = lo; rhi[threadIdx.x >> 6] = hi; }
-    sent = __syncthreads_or(sent);
+    sent = __syncthreads_or(sent);  // also: ndup, rlo, rhi complete
     if (threadIdx.x == 0) {
         for (int w = 1; w < CHAIN_T / 64; w++) { lo = fmin(lo, rlo[w]); hi = fmax(hi, rhi[w]); }
         const double level = fmax(fabs(lo), fabs(hi));
-        if (!(hi - lo > 1e-2 * level)) sent = 1;  // also true for NaN / empty
-        rlo[0] = (double)sent;
-    }
-    __syncthreads();
-    sent = rlo[0] != 0.0;
-    for (int k = 2; k <= m; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < m; i += CHAIN_T) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const unsigned long long a = keys[i], b = keys[p];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    // The sums are exact only down to the f32 tile partials of k_frame_stats, so a noisy frame shows a
-    // few accidental collisions (measured: 0-3 per 2962-entry strip); structure (plateaus, periodic
-    // patterns, blank frames) shows them by the hundred.  Flag from n/32 equal pairs on (from one on for
-    // strips too short for accidents).
-    __shared__ int ndup;
-    if (threadIdx.x == 0) ndup = 0;
-    __syncthreads();
-    int dup = 0;
-    for (int i = threadIdx.x; i + 1 < n; i += CHAIN_T) dup += (keys[i] == keys[i + 1]) ? 1 : 0;
-    if (dup) atomicAdd(&ndup, dup);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int limit = n < 256 ? 1 : (n / 32 > 8 ? n / 32 : 8);  // short strips: any collision is structure
-        sflag[f * 2 + axis] = (ndup >= limit || sent) ? 1 : 0;
+        const bool flat = !(hi - lo > 1e-2 * level);  // also true for NaN / empty
+        // The sums are exact only down to the f32 tile partials of k_frame_stats, so a noisy frame shows a
+        // few accidental collisions (0-3 equal pairs per 2962-entry strip, plus ~4 of the map itself);
+        // structure (plateaus, periodic patterns, blank frames) shows them by the hundred.  Flag from n/32
+        // on (from one on for strips too short for accidents).
+        const int limit = n < 256 ? 1 : (n / 32 > 16 ? n / 32 : 16);
+        sflag[f * 2 + axis] = (ndup >= limit || sent || flat) ? 1 : 0;
     }
 }
 
