@@ -209,6 +209,13 @@ int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq
  * overlaps the frame path; each run still waits for everything queued on the
  * main stream before it.  tsdrgpu_sync() waits for both streams. */
 int tsdrgpu_autocorr_set_async(tsdrgpu_autocorr_t *ac, int on);
+/* Exact mode.  The default autocorrelation is a different FFT algorithm than the reference's and agrees with it
+ * to ~1e-6 of the plot maximum; where a plot holds exact mathematical ties (R[j] == R[N-j] inside the 8 MS/s
+ * frame-lag window) the reference's argmax is its own rounding noise.  With `on` the transforms are done in the
+ * reference's arithmetic (fft.c:96-176: radix-2 DIT, f64 butterflies on f32 storage, the sequential twiddle
+ * recurrence) and plots, argmax and tsdrgpu_autocorr_last_corr are BIT-IDENTICAL to the reference's.  About 7x
+ * slower (0.24 ms per 2^22-sample window); builds a table of N-1 f64 twiddle pairs (64 MB at 100 MS/s) on first use. */
+int tsdrgpu_autocorr_set_exact(tsdrgpu_autocorr_t *ac, int on);
 int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line,
                            uint64_t *h_calls); /* syncs */
 /* device plots: frame_len + line_len doubles, contiguous (frame first) */

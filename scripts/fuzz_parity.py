@@ -187,6 +187,15 @@ def fuzz_autocorr_multi(g, rng):
     for k in range(nwin):
         ac_o.run(mag[k * ac.capture:(k + 1) * ac.capture])
     d = g.to_device(host)
+    if rng.random() < 0.5:  # exact mode: bit-identical plots and argmax
+        ac.set_exact(True)
+        ac.run(d, from_iq, ac.capture, nwin)
+        f, l, _ = ac.plots()
+        if not (np.array_equal(f, ac_o.frame) and np.array_equal(l, ac_o.line)):
+            return f"autocorr exact fs={fs} nwin={nwin} iq={from_iq}"
+        if ac.argmax() != (int(np.argmax(ac_o.frame)), int(np.argmax(ac_o.line))):
+            return f"autocorr exact argmax fs={fs}"
+        return None
     first = int(rng.integers(1, nwin))
     ac.run(d, from_iq, ac.capture, first)
     ac.run(d, from_iq, ac.capture, nwin - first, in_offset=first * ac.capture * (2 if from_iq else 1))

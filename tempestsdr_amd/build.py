@@ -22,7 +22,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 # bit-exact stages: no FMA contraction (the reference is built without it)
 STRICT = ["-ffp-contract=off"]
 
-HIP_SOURCES = [("tsdrgpu_core.hip", STRICT), ("tsdrgpu_frame.hip", STRICT), ("tsdrgpu_fft.hip", []),
+HIP_SOURCES = [("tsdrgpu_core.hip", STRICT), ("tsdrgpu_frame.hip", STRICT), ("tsdrgpu_fft.hip", []), ("tsdrgpu_fftx.hip", STRICT),
                ("tsdrgpu_extras.hip", STRICT)]
 LIB = os.path.join(HERE, "libtsdrgpu.so")
 

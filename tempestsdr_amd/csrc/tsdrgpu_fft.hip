@@ -31,7 +31,13 @@ struct tsdrgpu_autocorr {
     double *d_pval;  // argmax partials
     int *d_pidx;
     hipStream_t st;  // g->stream, or g->stream2 when set asynchronous
+    // exact mode (tsdrgpu_autocorr_set_exact, tsdrgpu_fftx.hip)
+    int exact;
+    double2 *d_tw;   // the reference's twiddle recurrence values, n-1 entries
+    float2 *d_xz;    // AC_XBATCH windows of n complex points
+    float *d_xmag;   // and of n magnitudes
 };
+#define AC_XBATCH 4
 
 // ---------------------------------------------------------------------------
 // small DFTs in registers (forward, e^{-2 pi i/R})
@@ -892,6 +898,9 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
     (void)hipFree(ac->d_pidx);
     (void)hipHostFree(ac->h_arg);
     (void)hipEventDestroy(ac->ev_arg);
+    (void)hipFree(ac->d_tw);
+    (void)hipFree(ac->d_xz);
+    (void)hipFree(ac->d_xmag);
     free(ac);
 }
 
@@ -942,6 +951,18 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
         // side stream: everything already queued on the main stream (e.g. the producer of d_in) comes first
         HIP_TRY(g, hipEventRecord(g->fork, g->stream));
         HIP_TRY(g, hipStreamWaitEvent(ac->st, g->fork, 0));
+    }
+    if (ac->exact) {
+        for (int w0 = 0; w0 < nwindows; w0 += AC_XBATCH) {
+            const int cnt = nwindows - w0 < AC_XBATCH ? nwindows - w0 : AC_XBATCH;
+            const float *src = d_in + (size_t)w0 * (size_t)stride * (in_is_iq ? 2 : 1);
+            const int rc = fftx_autocorr(g, ac->st, src, in_is_iq, stride, cnt, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag, ac->frame_lo, ac->frame_len,
+                                         ac->line_lo, ac->line_len, ac->d_plots, (unsigned long long)(ac->calls + w0), mode);
+            if (rc) return rc;
+            ac->d_last = ac->d_xz + (size_t)(cnt - 1) * ac->n;  // the whole complex correlation of the last window
+        }
+        ac->calls += (uint64_t)nwindows;
+        return TSDRGPU_OK;
     }
     const uint32_t nh = ac->n / 2;
     const int L = ac->frame_len + ac->line_len;
@@ -1072,6 +1093,12 @@ extern "C" int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **
 {
     if (!ac || !ac->d_last) return TSDRGPU_ESTATE;
     tsdrgpu_t *g = ac->g;
+    if (ac->exact) {  // already n complex values
+        HIP_TRY(g, hipStreamSynchronize(ac->st));
+        if (d_corr) *d_corr = (const float *)ac->d_last;
+        if (n) *n = ac->n;
+        return TSDRGPU_OK;
+    }
     if (!ac->d_expand && hipMalloc(&ac->d_expand, sizeof(float2) * (size_t)ac->n) != hipSuccess)
         return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_last_corr", "buffer");
     const uint32_t nh = ac->n / 2;
@@ -1080,6 +1107,26 @@ extern "C" int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **
     HIP_TRY(g, hipStreamSynchronize(ac->st));
     if (d_corr) *d_corr = (const float *)ac->d_expand;
     if (n) *n = ac->n;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_set_exact(tsdrgpu_autocorr_t *ac, int on)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    HIP_TRY(g, hipStreamSynchronize(ac->st));
+    if (on && !ac->d_tw) {
+        int rc = fftx_build_table(g, ac->n, &ac->d_tw);
+        if (rc) return rc;
+        if (hipMalloc(&ac->d_xz, sizeof(float2) * (size_t)ac->n * AC_XBATCH) != hipSuccess ||
+            hipMalloc(&ac->d_xmag, sizeof(float) * (size_t)ac->n * AC_XBATCH) != hipSuccess) {
+            (void)hipFree(ac->d_xz);
+            ac->d_xz = nullptr;
+            return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_set_exact", "work buffers");
+        }
+    }
+    ac->exact = on ? 1 : 0;
+    ac->d_last = nullptr;  // the last correlation is kept in the mode's own layout
     return TSDRGPU_OK;
 }
 

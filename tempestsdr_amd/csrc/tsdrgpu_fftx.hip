@@ -1,0 +1,251 @@
+// tsdrgpu_fftx.hip — the reference's FFT, bit for bit (fft_perform, TempestSDR/src/fft.c:96-176), and the
+// autocorrelation built on it (fft.c:49-64, frameratedetector.c:34-62) as an optional EXACT mode of
+// tsdrgpu_autocorr_* (tsdrgpu_autocorr_set_exact).
+//
+// The default path (tsdrgpu_fft.hip) is a different algorithm — Stockham radix-128 passes on the real
+// window packed as N/2 complex points — and agrees with the reference to ~1e-6 of the plot maximum.
+// Where a plot holds exact mathematical ties (a circular autocorrelation is symmetric, R[j] == R[N-j],
+// and the 8 MS/s frame-lag window holds both) the reference's winner is its own rounding noise, so only
+// the same arithmetic can give the same answer.  That arithmetic is:
+//   * in-place radix-2 decimation in time on N complex points (the real window with zero imaginary
+//     parts), bit-reversal first;
+//   * per stage s the twiddle of butterfly q is NOT exp(-2 pi i q / 2^(s+1)) but the q-fold f64 product
+//     u <- u * w_s started from 1, and w_s itself comes from w_0 = -1 by the half-angle formulas with
+//     sqrt — reproduced here on the host, once per transform size, into a table of N-1 doubles pairs;
+//   * butterflies in f64 on f32 data, every stage's results rounded to f32 (fft.c stores floats);
+//   * forward transform divided by (float)N in f32; magnitude sqrtf(re*re + im*im) in f32; inverse
+//     transform with the conjugate twiddles (exactly the negated imaginary parts), unscaled;
+//   * running mean of sqrt(re^2 + im^2) in f64 over the lag windows.
+// Compiled with -ffp-contract=off; f32 division and sqrt correctly rounded.  Three trips over memory per
+// transform (7 + 7 + 8 stages at N = 2^22) through 4096-point LDS tiles whose values are kept as f32
+// between stages, which is precisely the reference's storage rounding.  About 7x the default path's time.
+#include "tsdrgpu_internal.h"
+#include <math.h>
+#include <stdlib.h>
+
+struct FftxTrip {
+    int s0;  // first stage of the trip
+    int L;   // stages in the trip: tile rows = 2^L elements 2^s0 apart
+};
+
+__device__ __forceinline__ unsigned fftx_rev(unsigned v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
+
+// One trip: stages s0 .. s0+L-1 on tiles of R = 2^L rows x C columns (R*C <= 4096).
+//  s0 == 0: the rows of column r are the 2^L elements of bit-reversed block B = rev(r), i.e. the source
+//           elements rev_L(t)*S + r, S = n >> L (coalesced in r); results go to z[B*R + t].
+//  s0 >  0: in place on z, element (row, c) of tile (group, c0) is z[group*2^(s0+L) + row*2^s0 + c0 + c].
+// src_mode (s0 == 0 only): 0 real floats, 1 interleaved IQ demodulated on the fly (TSDRLibrary.c:244-262).
+// epilogue (last trip of the forward transform): divide by nf, magnitude -> mag[] (real), fft.c:167-175,34-45.
+__global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src, int src_mode, long long src_stride,
+                                                   float2 *__restrict__ z, float *__restrict__ mag, unsigned n, int m, int s0, int L,
+                                                   int C, const double2 *__restrict__ tw, int inverse, int epilogue, float nf)
+{
+    __shared__ float2 t[4096 + 256];  // rows padded by one element: the block-wise write-back walks down a column
+    const unsigned R = 1u << L;
+    const unsigned Cp = (unsigned)C + 1u;
+    const unsigned tid = threadIdx.x;
+    const unsigned tile = blockIdx.x;
+    float2 *zb = z + (long long)blockIdx.y * n;
+    const unsigned total = R * (unsigned)C;  // elements of the tile
+    unsigned colbase = 0;                    // global column of tile column 0, for the twiddle index
+    unsigned S = 0, r0 = 0, group = 0;
+    if (s0 == 0) {
+        S = n >> L;
+        r0 = tile * (unsigned)C;
+        const float *sb = src + (long long)blockIdx.y * src_stride * (src_mode == 1 ? 2 : 1);
+        for (unsigned e = tid; e < total; e += 256) {
+            const unsigned row = e / (unsigned)C, c = e % (unsigned)C;
+            const unsigned long long at = (unsigned long long)fftx_rev(row, L) * S + r0 + c;
+            float v;
+            if (src_mode == 1) {
+                const float2 iq = ((const float2 *)sb)[at];
+                v = sqrtf(iq.x * iq.x + iq.y * iq.y);
+            } else {
+                v = sb[at];
+            }
+            t[row * Cp + c] = make_float2(v, 0.f);  // real_to_complex, fft.c:14-22
+        }
+    } else {
+        const unsigned per_group = (1u << s0) / (unsigned)C;
+        group = tile / per_group;
+        colbase = (tile % per_group) * (unsigned)C;
+        const unsigned long long gbase = (unsigned long long)group << (s0 + L);
+        for (unsigned e = tid; e < total; e += 256) {
+            const unsigned row = e / (unsigned)C, c = e % (unsigned)C;
+            t[row * Cp + c] = zb[gbase + ((unsigned long long)row << s0) + colbase + c];
+        }
+    }
+    __syncthreads();
+    const unsigned nbf = total >> 1;  // butterflies per stage in the tile
+    for (int ls = 0; ls < L; ls++) {
+        const int s = s0 + ls;
+        const unsigned halfrows = 1u << ls;
+        const double2 *ts = tw + ((1ull << s) - 1ull);  // this stage's u[q], q < 2^s
+        for (unsigned b = tid; b < nbf; b += 256) {
+            const unsigned br = b / (unsigned)C, c = b % (unsigned)C;
+            const unsigned ra = ((br >> ls) << (ls + 1)) | (br & (halfrows - 1u));
+            const unsigned rb = ra + halfrows;
+            const unsigned long long q = ((unsigned long long)(ra & (halfrows - 1u)) << s0) + (s0 ? colbase + c : 0u);
+            double2 u = ts[q];
+            if (inverse) u.y = -u.y;  // the inverse recurrence yields exactly the conjugates
+            const float2 za = t[ra * Cp + c], zq = t[rb * Cp + c];
+            const double tr = u.x * (double)zq.x - u.y * (double)zq.y;  // fft.c:153-154
+            const double ti = u.x * (double)zq.y + u.y * (double)zq.x;
+            t[rb * Cp + c] = make_float2((float)((double)za.x - tr), (float)((double)za.y - ti));
+            t[ra * Cp + c] = make_float2((float)((double)za.x + tr), (float)((double)za.y + ti));
+        }
+        __syncthreads();
+    }
+    if (s0 == 0) {
+        // column c is block B = rev_{m-L}(r0 + c): contiguous R results per block
+        for (unsigned e = tid; e < total; e += 256) {
+            const unsigned c = e / R, row = e % R;
+            const unsigned long long B = fftx_rev(r0 + c, m - L);
+            float2 v = t[row * Cp + c];
+            const unsigned long long at = B * R + row;
+            if (epilogue) {
+                v.x = v.x / nf;
+                v.y = v.y / nf;
+                mag[(long long)blockIdx.y * n + at] = sqrtf(v.x * v.x + v.y * v.y);
+            } else {
+                zb[at] = v;
+            }
+        }
+    } else {
+        const unsigned long long gbase = (unsigned long long)group << (s0 + L);
+        for (unsigned e = tid; e < total; e += 256) {
+            const unsigned row = e / (unsigned)C, c = e % (unsigned)C;
+            float2 v = t[row * Cp + c];
+            const unsigned long long at = gbase + ((unsigned long long)row << s0) + colbase + c;
+            if (epilogue) {
+                v.x = v.x / nf;
+                v.y = v.y / nf;
+                mag[(long long)blockIdx.y * n + at] = sqrtf(v.x * v.x + v.y * v.y);
+            } else {
+                zb[at] = v;
+            }
+        }
+    }
+}
+
+// accummulate (frameratedetector.c:34-62) on the complex correlation, in window order
+__global__ __launch_bounds__(256) void k_fftx_accumulate(const float2 *__restrict__ corr, unsigned n, int nwindows, int frame_lo,
+                                                         int frame_len, int line_lo, int line_len, double *__restrict__ plots,
+                                                         unsigned long long calls_before, int mode)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame_len + line_len) return;
+    const int lag = (i < frame_len) ? (frame_lo + i) : (line_lo + (i - frame_len));
+    double acc = plots[i];
+    for (int w = 0; w < nwindows; w++) {
+        const float2 v = corr[(long long)w * n + lag];
+        const double re = v.x, im = v.y;
+        const double now = sqrt(re * re + im * im);
+        if (mode == 0) {
+            const unsigned long long calls = calls_before + w + 1;
+            acc = (acc * (double)(calls - 1) + now) / (double)calls;  // calls == 1: (0*0 + now)/1 == now
+        } else {
+            acc += now;
+        }
+    }
+    plots[i] = acc;
+}
+
+// u[q] of every stage, exactly as fft.c:132-165 computes them while it runs
+int fftx_build_table(tsdrgpu_t *g, uint32_t n, double2 **d_tw)
+{
+    int m = 0;
+    while ((1u << m) < n) m++;
+    const size_t count = n > 1 ? (size_t)n - 1 : 1;
+    double2 *h = (double2 *)malloc(sizeof(double2) * count);
+    if (!h) return tsdr_fail(g, TSDRGPU_ENOMEM, "exact FFT", "twiddle table (host)");
+    double wr = -1.0, wi = 0.0;
+    size_t at = 0;
+    for (int s = 0; s < m; s++) {
+        const size_t half = (size_t)1 << s;
+        double ur = 1.0, ui = 0.0;
+        for (size_t q = 0; q < half; q++) {
+            h[at + q].x = ur;
+            h[at + q].y = ui;
+            const double nr = ur * wr - ui * wi;
+            ui = ur * wi + ui * wr;
+            ur = nr;
+        }
+        at += half;
+        wi = -sqrt((1.0 - wr) / 2.0);  // the forward direction; the inverse one is the exact negation
+        wr = sqrt((1.0 + wr) / 2.0);
+    }
+    if (m == 0) { h[0].x = 1.0; h[0].y = 0.0; }
+    int rc = TSDRGPU_OK;
+    if (hipMalloc((void **)d_tw, sizeof(double2) * count) != hipSuccess) {
+        rc = tsdr_fail(g, TSDRGPU_ENOMEM, "exact FFT", "twiddle table (device)");
+    } else if (hipMemcpy(*d_tw, h, sizeof(double2) * count, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(*d_tw);
+        *d_tw = nullptr;
+        rc = tsdr_fail(g, TSDRGPU_EHIP, "exact FFT", "twiddle table upload");
+    }
+    free(h);
+    return rc;
+}
+
+static int fftx_plan(int m, FftxTrip *trips)
+{
+    int count = 0;
+    if (m == 0) return 0;
+    const int first = m < 7 ? m : 7;
+    trips[count].s0 = 0;
+    trips[count].L = first;
+    count++;
+    int rest = m - first, s = first;
+    if (rest > 0) {
+        const int parts = (rest + 7) / 8;
+        for (int p = 0; p < parts; p++) {
+            const int L = rest / parts + (p < rest % parts ? 1 : 0);
+            trips[count].s0 = s;
+            trips[count].L = L;
+            count++;
+            s += L;
+        }
+    }
+    return count;
+}
+
+// One transform (forward: from `src`; inverse: from the real array `mag`) of `batch` windows into z.
+static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int src_mode, long long src_stride, float2 *z, float *mag,
+                          uint32_t n, int m, int batch, const double2 *d_tw, int inverse, int to_mag)
+{
+    FftxTrip trips[8];
+    const int nt = fftx_plan(m, trips);
+    for (int k = 0; k < nt; k++) {
+        const int s0 = trips[k].s0, L = trips[k].L;
+        const unsigned R = 1u << L;
+        unsigned C = 4096u / R;
+        const unsigned width = s0 == 0 ? (n >> L) : (1u << s0);  // columns available to a tile
+        if (C > width) C = width;
+        const unsigned tiles = n / (R * C);
+        const int epi = (to_mag && k == nt - 1) ? 1 : 0;
+        TSDR_LAUNCH(g, PROF_FFT_PASS, st, k_fftx_trip, dim3(tiles, batch), 256, src, src_mode, src_stride, z, mag, n, m, s0, L, (int)C, d_tw,
+                    inverse, epi, (float)n);
+    }
+    if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "exact FFT", "launch");
+    return TSDRGPU_OK;
+}
+
+// fft_autocorrelation + accummulate for `cnt` windows, exactly.  z: cnt*n complex, mag: cnt*n floats.
+int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
+                  const double2 *d_tw, float2 *z, float *mag, int frame_lo, int frame_len, int line_lo, int line_len, double *d_plots,
+                  unsigned long long calls_before, int mode)
+{
+    int m = 0;
+    while ((1u << m) < n) m++;
+    int rc;
+    if (m == 0) return tsdr_fail(g, TSDRGPU_EINVAL, "exact FFT", "transform too short");
+    // answer = IFFT( | FFT(x) / N | ), fft.c:49-64
+    if ((rc = fftx_transform(g, st, d_in, in_is_iq ? 1 : 0, stride, z, mag, n, m, cnt, d_tw, 0, 1))) return rc;
+    if ((rc = fftx_transform(g, st, mag, 0, (long long)n, z, mag, n, m, cnt, d_tw, 1, 0))) return rc;
+    const int L = frame_len + line_len;
+    TSDR_LAUNCH(g, PROF_ACCUMULATE, st, k_fftx_accumulate, (L + 255) / 256, 256, z, n, cnt, frame_lo, frame_len, line_lo, line_len, d_plots,
+                calls_before, mode);
+    if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "exact FFT", "accumulate");
+    return TSDRGPU_OK;
+}

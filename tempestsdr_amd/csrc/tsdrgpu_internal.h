@@ -106,3 +106,9 @@ int staging_release(tsdrgpu_t *g, StagingRing *r, int slot);            // recor
 
 // FFT engine (tsdrgpu_fft.hip), used by autocorrelation and super-bandwidth
 struct FftPlan;
+
+// Exact replica of the reference's FFT arithmetic (tsdrgpu_fftx.hip), the optional exact mode of the autocorrelation
+int fftx_build_table(tsdrgpu_t *g, uint32_t n, double2 **d_tw);
+int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
+                  const double2 *d_tw, float2 *z, float *mag, int frame_lo, int frame_len, int line_lo, int line_len, double *d_plots,
+                  unsigned long long calls_before, int mode);

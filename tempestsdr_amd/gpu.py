@@ -99,6 +99,7 @@ _SIGS = {
     "tsdrgpu_autocorr_plots": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
+    "tsdrgpu_autocorr_set_exact": (C.c_int, [vp, C.c_int]),
     "tsdrgpu_autocorr_argmax_async": (C.c_int, [vp]),
     "tsdrgpu_autocorr_argmax_result": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdrgpu_autocorr_argmax": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -475,6 +476,10 @@ class Autocorr:
         a, b = C.c_int32(), C.c_int32()
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_argmax(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_exact(self, on=True):
+        """The reference's own FFT arithmetic: plots / argmax / last_corr bit-identical (slower)."""
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_set_exact(self.h, int(on)))
 
     def argmax_async(self):
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_argmax_async(self.h))

@@ -183,3 +183,66 @@ def test_argmax_async_result(orc):
     assert ac.argmax_result() == want
     with pytest.raises(gpu.TsdrGpuError):
         ac.argmax_result()  # nothing queued
+
+
+@pytest.mark.parametrize("fs,nwin", [(300_000, 3), (2_000_000, 2), (8_000_000, 5), (777_777, 6)])
+@pytest.mark.parametrize("from_iq", [0, 1])
+def test_autocorr_exact_mode_is_bit_identical(orc, fs, nwin, from_iq):
+    """tsdrgpu_autocorr_set_exact: the reference's own FFT arithmetic (radix-2 DIT, f64 butterflies on f32
+    storage, sequential twiddle recurrence, fft.c:96-176).  Plots, their argmax — also on noise-like windows
+    and across the R[j] == R[N-j] tie of the 8 MS/s frame-lag window — and the last correlation are
+    BIT-IDENTICAL to the oracle's (which is pinned bit-exact against the compiled reference)."""
+    g = ctx()
+    ac_o = orc.Autocorr(fs)
+    ac = gpu.Autocorr(g, fs)
+    ac.set_exact(True)
+    period = fs // 61
+    xs = _periodic_windows(fs, nwin, ac.capture, period)
+    if from_iq:
+        iq = np.zeros((nwin, 2 * ac.capture), np.float32)
+        for k, x in enumerate(xs):
+            ph = 0.37 * np.arange(ac.capture)
+            iq[k, 0::2] = x * np.cos(ph)
+            iq[k, 1::2] = x * np.sin(ph)
+        xs = [orc.am_demod(iq[k]) for k in range(nwin)]
+        d_in = g.to_device(iq.reshape(-1))
+    else:
+        d_in = g.to_device(np.concatenate(xs))
+    for x in xs:
+        corr = ac_o.run(x)
+    ac.run(d_in, from_iq, ac.capture, 1)  # two calls: the running mean continues
+    ac.run(d_in, from_iq, ac.capture, nwin - 1, in_offset=ac.capture * (2 if from_iq else 1))
+    f, l, calls = ac.plots()
+    assert calls == nwin
+    assert np.array_equal(f, ac_o.frame)
+    assert np.array_equal(l, ac_o.line)
+    assert ac.argmax() == (int(np.argmax(ac_o.frame)), int(np.argmax(ac_o.line)))
+    last = ac.last_corr()
+    assert np.array_equal(last, corr[:last.size])
+    # and back to the default algorithm: within the tolerance of the exact one
+    ac.set_exact(False)
+    ac.reset()
+    ac.run(d_in, from_iq, ac.capture, nwin)
+    f2, l2, _ = ac.plots()
+    assert np.max(np.abs(f2 - f)) <= 1e-4 * np.max(f) and np.max(np.abs(l2 - l)) <= 1e-4 * np.max(l)
+
+
+@pytest.mark.parametrize("fs", [100_000_000, 200_000_000])
+def test_autocorr_exact_mode_full_size(orc, fs):
+    """BASELINE config 3/4 and 5 window sizes (N = 2^22 and 2^23): one raster window, exact mode, every lag of both
+    plots and the whole correlation bit-identical to the oracle (seconds of CPU)."""
+    g = ctx()
+    ac_o = orc.Autocorr(fs)
+    ac = gpu.Autocorr(g, fs)
+    ac.set_exact(True)
+    t = np.arange(ac.capture)
+    period = fs // 60
+    x = (0.05 + 0.5 * ((t % period) < period * 3 // 4) * (0.6 + 0.4 * ((t % (period // 1125)) < period // 1500))
+         + 0.02 * RNG.random(ac.capture)).astype(np.float32)
+    corr = ac_o.run(x)
+    ac.run(g.to_device(x), False, ac.capture, 1)
+    f, l, _ = ac.plots()
+    assert np.array_equal(f, ac_o.frame) and np.array_equal(l, ac_o.line)
+    assert ac.argmax() == (int(np.argmax(ac_o.frame)), int(np.argmax(ac_o.line)))
+    last = ac.last_corr()
+    assert np.array_equal(last, corr[:last.size])
