@@ -187,6 +187,9 @@ int tsdrgpu_postproc_strips(tsdrgpu_postproc_t *pp, float *h_colsum, float *h_ro
 /* fft_perform, fft.c:96-176: in-place complex FFT of n = 2^m points on
  * interleaved float32 (forward scaled by 1/n, inverse unscaled).  Asynchronous like the rest. */
 int tsdrgpu_fft(tsdrgpu_t *g, float *d_iq, uint32_t n, int inverse);
+/* The same transform in the reference's own arithmetic (see tsdrgpu_autocorr_set_exact): results bit-identical
+ * to fft_perform.  Keeps one twiddle table per context (rebuilt on the host when n changes). */
+int tsdrgpu_fft_exact(tsdrgpu_t *g, float *d_iq, uint32_t n, int inverse);
 
 /* frameratedetector_runontodata numerics (frameratedetector.c:87-126):
  * fft_autocorrelation (fft.c:49-64) of each capture window, then accummulate

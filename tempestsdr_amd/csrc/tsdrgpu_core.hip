@@ -43,6 +43,7 @@ extern "C" void tsdrgpu_destroy(tsdrgpu_t *g)
     }
     free(g->spans);
     if (g->fft_ws) hipFree(g->fft_ws);
+    if (g->fftx_tw) hipFree(g->fftx_tw);
     hipEventDestroy(g->t0);
     hipEventDestroy(g->t1);
     hipStreamDestroy(g->stream);

@@ -480,6 +480,36 @@ extern "C" int tsdrgpu_fft(tsdrgpu_t *g, float *d_iq, uint32_t n, int inverse)
     return TSDRGPU_OK;
 }
 
+// fft_perform in the reference's own arithmetic (tsdrgpu_fftx.hip): bit-identical, slower
+extern "C" int tsdrgpu_fft_exact(tsdrgpu_t *g, float *d_iq, uint32_t n, int inverse)
+{
+    if (!g || !d_iq || n == 0 || (n & (n - 1))) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_fft_exact", "n must be a power of two") : TSDRGPU_EINVAL;
+    if (n == 1) return TSDRGPU_OK;
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (g->fftx_n != n) {
+        if (g->fftx_tw) (void)hipFree(g->fftx_tw);
+        g->fftx_tw = nullptr;
+        g->fftx_n = 0;
+        double2 *tw = nullptr;
+        const int rc = fftx_build_table(g, n, &tw);
+        if (rc) return rc;
+        g->fftx_tw = tw;
+        g->fftx_n = n;
+    }
+    const size_t need = sizeof(float2) * (size_t)n;
+    if (g->fft_ws_bytes < need) {
+        if (g->fft_ws) (void)hipFree(g->fft_ws);
+        g->fft_ws = nullptr;
+        g->fft_ws_bytes = 0;
+        if (hipMalloc(&g->fft_ws, need) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_fft_exact", "work buffer");
+        g->fft_ws_bytes = need;
+    }
+    const int rc = fftx_perform(g, g->stream, (const float2 *)d_iq, (float2 *)g->fft_ws, n, (const double2 *)g->fftx_tw, inverse);
+    if (rc) return rc;
+    HIP_TRY(g, hipMemcpyAsync(d_iq, g->fft_ws, need, hipMemcpyDeviceToDevice, g->stream));
+    return TSDRGPU_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Real-input trick for the autocorrelation.  The capture window is real, so it is
 // transformed as nh = n/2 complex points z[m] = x[2m] + i x[2m+1]; with

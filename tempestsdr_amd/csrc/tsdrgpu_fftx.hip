@@ -34,8 +34,10 @@ __device__ __forceinline__ unsigned fftx_rev(unsigned v, int bits) { return bits
 //  s0 == 0: the rows of column r are the 2^L elements of bit-reversed block B = rev(r), i.e. the source
 //           elements rev_L(t)*S + r, S = n >> L (coalesced in r); results go to z[B*R + t].
 //  s0 >  0: in place on z, element (row, c) of tile (group, c0) is z[group*2^(s0+L) + row*2^s0 + c0 + c].
-// src_mode (s0 == 0 only): 0 real floats, 1 interleaved IQ demodulated on the fly (TSDRLibrary.c:244-262).
-// epilogue (last trip of the forward transform): divide by nf, magnitude -> mag[] (real), fft.c:167-175,34-45.
+// src_mode (s0 == 0 only): 0 real floats, 1 interleaved IQ demodulated on the fly (TSDRLibrary.c:244-262),
+//           2 complex.
+// epilogue (last trip of a forward transform): 1 = divide by nf, magnitude -> mag[] (real), fft.c:167-175,34-45;
+//           2 = divide by nf only.
 __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src, int src_mode, long long src_stride,
                                                    float2 *__restrict__ z, float *__restrict__ mag, unsigned n, int m, int s0, int L,
                                                    int C, const double2 *__restrict__ tw, int inverse, int epilogue, float nf)
@@ -52,10 +54,14 @@ __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src
     if (s0 == 0) {
         S = n >> L;
         r0 = tile * (unsigned)C;
-        const float *sb = src + (long long)blockIdx.y * src_stride * (src_mode == 1 ? 2 : 1);
+        const float *sb = src + (long long)blockIdx.y * src_stride * (src_mode == 0 ? 1 : 2);
         for (unsigned e = tid; e < total; e += 256) {
             const unsigned row = e / (unsigned)C, c = e % (unsigned)C;
             const unsigned long long at = (unsigned long long)fftx_rev(row, L) * S + r0 + c;
+            if (src_mode == 2) {  // complex input (fft_perform on a caller's buffer)
+                t[row * Cp + c] = ((const float2 *)sb)[at];
+                continue;
+            }
             float v;
             if (src_mode == 1) {
                 const float2 iq = ((const float2 *)sb)[at];
@@ -106,10 +112,9 @@ __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src
             if (epilogue) {
                 v.x = v.x / nf;
                 v.y = v.y / nf;
-                mag[(long long)blockIdx.y * n + at] = sqrtf(v.x * v.x + v.y * v.y);
-            } else {
-                zb[at] = v;
             }
+            if (epilogue == 1) mag[(long long)blockIdx.y * n + at] = sqrtf(v.x * v.x + v.y * v.y);
+            else zb[at] = v;
         }
     } else {
         const unsigned long long gbase = (unsigned long long)group << (s0 + L);
@@ -120,10 +125,9 @@ __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src
             if (epilogue) {
                 v.x = v.x / nf;
                 v.y = v.y / nf;
-                mag[(long long)blockIdx.y * n + at] = sqrtf(v.x * v.x + v.y * v.y);
-            } else {
-                zb[at] = v;
             }
+            if (epilogue == 1) mag[(long long)blockIdx.y * n + at] = sqrtf(v.x * v.x + v.y * v.y);
+            else zb[at] = v;
         }
     }
 }
@@ -212,7 +216,7 @@ static int fftx_plan(int m, FftxTrip *trips)
 
 // One transform (forward: from `src`; inverse: from the real array `mag`) of `batch` windows into z.
 static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int src_mode, long long src_stride, float2 *z, float *mag,
-                          uint32_t n, int m, int batch, const double2 *d_tw, int inverse, int to_mag)
+                          uint32_t n, int m, int batch, const double2 *d_tw, int inverse, int epilogue)
 {
     FftxTrip trips[8];
     const int nt = fftx_plan(m, trips);
@@ -223,7 +227,7 @@ static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int sr
         const unsigned width = s0 == 0 ? (n >> L) : (1u << s0);  // columns available to a tile
         if (C > width) C = width;
         const unsigned tiles = n / (R * C);
-        const int epi = (to_mag && k == nt - 1) ? 1 : 0;
+        const int epi = (k == nt - 1) ? epilogue : 0;
         TSDR_LAUNCH(g, PROF_FFT_PASS, st, k_fftx_trip, dim3(tiles, batch), 256, src, src_mode, src_stride, z, mag, n, m, s0, L, (int)C, d_tw,
                     inverse, epi, (float)n);
     }
@@ -248,4 +252,13 @@ int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq,
                 calls_before, mode);
     if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "exact FFT", "accumulate");
     return TSDRGPU_OK;
+}
+
+// fft_perform (fft.c:96-176) on n complex points: d_z -> d_work (n complex), exactly
+int fftx_perform(tsdrgpu_t *g, hipStream_t st, const float2 *d_z, float2 *d_work, uint32_t n, const double2 *d_tw, int inverse)
+{
+    int m = 0;
+    while ((1u << m) < n) m++;
+    if (m == 0) return TSDRGPU_OK;
+    return fftx_transform(g, st, (const float *)d_z, 2, (long long)n, d_work, nullptr, n, m, 1, d_tw, inverse, inverse ? 0 : 2);
 }

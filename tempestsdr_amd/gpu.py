@@ -90,6 +90,7 @@ _SIGS = {
     "tsdrgpu_postproc_finish": (C.c_int, [vp, vp, C.POINTER(PPFrameInfo)]),
     "tsdrgpu_postproc_strips": (C.c_int, [vp, vp, vp]),
     "tsdrgpu_fft": (C.c_int, [vp, vp, C.c_uint32, C.c_int]),
+    "tsdrgpu_fft_exact": (C.c_int, [vp, vp, C.c_uint32, C.c_int]),
     "tsdrgpu_autocorr_create": (C.c_int, [vp, C.POINTER(vp), C.c_uint32]),
     "tsdrgpu_autocorr_destroy": (None, [vp]),
     "tsdrgpu_autocorr_reset": (C.c_int, [vp]),
@@ -285,8 +286,9 @@ class TsdrGpu:
         self._ck(self.lib.tsdrgpu_frame_to_rgb(self.h, d_frame.at(frame_offset), d_rgb.ptr, npixels, int(inverted)))
 
     # ---- a13/a14 -------------------------------------------------------------
-    def fft_perform(self, d_iq, n, inverse, offset=0):
-        self._ck(self.lib.tsdrgpu_fft(self.h, d_iq.at(offset), n, int(inverse)))
+    def fft_perform(self, d_iq, n, inverse, offset=0, exact=False):
+        fn = self.lib.tsdrgpu_fft_exact if exact else self.lib.tsdrgpu_fft
+        self._ck(fn(self.h, d_iq.at(offset), n, int(inverse)))
 
     def superb_stitch(self, d_hops, gathered, samples_in_frame, d_out):
         ptrs = (vp * len(d_hops))(*[h.ptr for h in d_hops])

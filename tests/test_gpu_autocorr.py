@@ -246,3 +246,15 @@ def test_autocorr_exact_mode_full_size(orc, fs):
     assert ac.argmax() == (int(np.argmax(ac_o.frame)), int(np.argmax(ac_o.line)))
     last = ac.last_corr()
     assert np.array_equal(last, corr[:last.size])
+
+
+@pytest.mark.parametrize("n", [2, 4, 64, 128, 256, 4096, 1 << 15, 1 << 18])
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_fft_exact_is_bit_identical(orc, n, inverse):
+    """tsdrgpu_fft_exact == fft_perform (fft.c:96-176) bit for bit, both directions, sizes across the trip plans."""
+    g = ctx()
+    z = (np.random.default_rng(n + inverse).standard_normal(2 * n) * 3.0).astype(np.float32)
+    want = orc.fft_perform(z, inverse)
+    d = g.to_device(z)
+    g.fft_perform(d, n, inverse, exact=True)
+    assert np.array_equal(d.download(), want)
