@@ -284,6 +284,11 @@ static void run_detector(struct engine *e, uint32_t fs)
         e->ac = NULL;
         if (tsdrgpu_autocorr_create(e->g, &e->ac, fs)) return; /* rate too low for the lag windows */
         e->ac_rate = fs;
+        {   /* TSDR_GPU_EXACT_AUTOCORR=1: the frame-rate detector in the reference's own FFT arithmetic (plots and
+             * detected mode bit-identical to the CPU library; ~7x the transform time, still far above real time) */
+            const char *ex = getenv("TSDR_GPU_EXACT_AUTOCORR");
+            if (ex && ex[0] == '1') (void)tsdrgpu_autocorr_set_exact(e->ac, 1);
+        }
         uint32_t cap, n;
         tsdrgpu_autocorr_geometry(e->ac, &e->flo, &e->flen, &e->llo, &e->llen, &cap, &n);
         pthread_mutex_lock(&e->pm);

@@ -396,3 +396,22 @@ def test_pipeline_with_pll_matches_oracle(orc, tmp_path, fv_true):
     pll_values = [v for v in s.values if v[0] == 0]  # VALUE_ID_PLL_FRAMERATE
     assert pll_values
     s.close()
+
+
+def test_pipeline_exact_autocorr_plots_are_bit_identical(orc, iq_file, monkeypatch):
+    """TSDR_GPU_EXACT_AUTOCORR=1: the plots the library delivers equal the oracle's (= the reference's) exactly,
+    including the argmax across the R[j] == R[N-j] tie of this rate's frame-lag window."""
+    monkeypatch.setenv("TSDR_GPU_EXACT_AUTOCORR", "1")
+    path, iq = iq_file
+    plugin = hu.build_test_plugin()
+    s, ok, rc = run_session(plugin, f"{path} {FS} {BLOCK} 8000", nframes=8)
+    assert rc == 0 and s.status == 0, s.err()
+    frame_plots = [p for p in s.plots if p[0] == 0]
+    line_plots = [p for p in s.plots if p[0] == 1]
+    assert frame_plots and line_plots
+    ac = orc.Autocorr(FS)
+    ac.run(orc.am_demod(iq)[:orc.capture_size(FS)])
+    assert np.array_equal(frame_plots[0][2], ac.frame)
+    assert np.array_equal(line_plots[0][2], ac.line)
+    assert int(np.argmax(frame_plots[0][2])) == int(np.argmax(ac.frame))
+    s.close()
