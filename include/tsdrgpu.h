@@ -243,6 +243,10 @@ int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **d_corr, uin
 int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered,
                           int samples_in_frame, float *d_out, int32_t *h_offsets,
                           uint32_t *h_total);
+/* The same stitch with every transform in the reference's own arithmetic (see tsdrgpu_autocorr_set_exact): hop
+ * offsets and the stitched signal bit-identical to superb_ondataready. */
+int tsdrgpu_superb_stitch_exact(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered, int samples_in_frame,
+                                float *d_out, int32_t *h_offsets, uint32_t *h_total);
 
 /* ---- the components next to the hot path ------------------------- */
 /* f1: the RawFile plugin's sample formats decoded on the device

@@ -321,6 +321,12 @@ def fuzz_superb(g, rng):
         hops.append(h)
     want, offs = orc.superb_stitch(hops, sif)
     d_out = g.empty(want.size)
+    if rng.random() < 0.5:  # exact form: everything bit-identical
+        got_offs, total = g.superb_stitch([g.to_device(h) for h in hops], gathered, sif, d_out, exact=True)
+        nfft = 1 << int(np.floor(np.log2(max(total, 1))))
+        if 2 * total != want.size or not np.array_equal(got_offs, offs) or not np.array_equal(d_out.download()[:2 * nfft], want[:2 * nfft]):
+            return f"superb exact fs={fs} fv={fv} gathered={gathered}"
+        return None
     got_offs, total = g.superb_stitch([g.to_device(h) for h in hops], gathered, sif, d_out)
     if 2 * total != want.size:
         return f"superb size fs={fs} gathered={gathered}"

@@ -518,7 +518,11 @@ static int super_feed(struct engine *e, const float *d_blk, size_t nfloats, int6
                 int32_t offs[SUPER_HOPS];
                 uint32_t total = 0;
                 e->super_state = SUPER_STARTING;
-                if (tsdrgpu_superb_stitch(e->g, e->d_hops, SUPER_HOPS, gathered, e->super_frame, e->d_super_out, offs, &total)) return 0;
+                const char *ex = getenv("TSDR_GPU_EXACT_AUTOCORR"); /* the exact-FFT switch covers the stitch as well */
+                if ((ex && ex[0] == '1')
+                        ? tsdrgpu_superb_stitch_exact(e->g, e->d_hops, SUPER_HOPS, gathered, e->super_frame, e->d_super_out, offs, &total)
+                        : tsdrgpu_superb_stitch(e->g, e->d_hops, SUPER_HOPS, gathered, e->super_frame, e->d_super_out, offs, &total))
+                    return 0;
                 pthread_mutex_lock(&t->lock);
                 tsdr_geometry_update(t, SUPER_HOPS * e->super_rate); /* superbandwidth.c:151 */
                 pthread_mutex_unlock(&t->lock);

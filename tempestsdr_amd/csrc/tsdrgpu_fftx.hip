@@ -262,3 +262,136 @@ int fftx_perform(tsdrgpu_t *g, hipStream_t st, const float2 *d_z, float2 *d_work
     if (m == 0) return TSDRGPU_OK;
     return fftx_transform(g, st, (const float *)d_z, 2, (long long)n, d_work, nullptr, n, m, 1, d_tw, inverse, inverse ? 0 : 2);
 }
+
+// ---------------------------------------------------------------------------
+// Super-bandwidth stitch (superbandwidth.c:67-152, fft.c:69-93) with the exact FFT: the same sequence as
+// tsdrgpu_superb_stitch, every float operation in the reference's order (this file is -ffp-contract=off),
+// so hop offsets AND the stitched signal are bit-identical.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_x_abs_diff(const float2 *__restrict__ z, float2 *__restrict__ out, unsigned n)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 c = z[i];
+    const float cur = sqrtf(c.x * c.x + c.y * c.y);
+    float prev;
+    if (i == 0) prev = c.x * c.x + c.y * c.y;  // |z0|^2, superbandwidth.c:70
+    else {
+        const float2 p = z[i - 1];
+        prev = sqrtf(p.x * p.x + p.y * p.y);
+    }
+    out[i] = make_float2(cur - prev, 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_x_mul_conj(float2 *__restrict__ a, const float2 *__restrict__ b, unsigned n)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 x = a[i], y = b[i];
+    a[i] = make_float2(x.x * y.x + x.y * y.y, x.x * y.y - x.y * y.x);  // fft.c:80-89
+}
+
+__global__ __launch_bounds__(1024) void k_x_argmax_abs(const float2 *__restrict__ z, unsigned n, int *__restrict__ out_floats)
+{
+    float best = -1.f;
+    int at = 0x7fffffff;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+        const float2 c = z[i];
+        const float v = sqrtf(c.x * c.x + c.y * c.y);
+        if (v > best) { best = v; at = (int)i; }
+    }
+    __shared__ float sb[16];
+    __shared__ int si[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(at, o, 64);
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = at; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++)
+            if (sb[w] > best || (sb[w] == best && si[w] < at)) { best = sb[w]; at = si[w]; }
+        *out_floats = 2 * at;  // first maximum, offset in floats (superbandwidth.c:100-116)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_x_rotate(const float *__restrict__ in, float *__restrict__ out, unsigned nfloats,
+                                                  const int *__restrict__ off)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nfloats) return;
+    unsigned s = i + (unsigned)*off;
+    if (s >= nfloats) s -= nfloats;
+    out[i] = in[s];
+}
+
+static uint32_t x_pow2_floor(uint32_t v)
+{
+    uint32_t m = 0;
+    while ((v /= 2) != 0) m++;
+    return 1u << m;
+}
+
+extern "C" int tsdrgpu_superb_stitch_exact(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered, int samples_in_frame,
+                                           float *d_out, int32_t *h_offsets, uint32_t *h_total)
+{
+    if (!g || !d_hops || nhops < 1 || nhops > 64 || gathered < 2 || samples_in_frame < 1 || !d_out)
+        return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_superb_stitch_exact", "bad argument") : TSDRGPU_EINVAL;
+    const uint32_t per = x_pow2_floor((uint32_t)gathered);
+    const uint32_t total = (uint32_t)nhops * per;
+    const uint32_t nfl = per * 2;
+    const int bsize = ((int)nfl / samples_in_frame) * samples_in_frame;
+    if (bsize < 2) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_superb_stitch_exact", "hop shorter than one frame");
+    const uint32_t bn = x_pow2_floor((uint32_t)bsize) / 2;
+    const uint32_t nfft = x_pow2_floor(total);
+    hipStream_t st = g->stream;
+    HIP_TRY(g, hipStreamSynchronize(st));
+    double2 *tw_b = nullptr, *tw_p = nullptr, *tw_t = nullptr;
+    float2 *w = nullptr;
+    int *d_off = nullptr;
+    int rc = TSDRGPU_OK;
+    const size_t big = nfft > per ? nfft : per;
+    do {
+        if ((rc = fftx_build_table(g, bn, &tw_b)) || (rc = fftx_build_table(g, per, &tw_p)) || (rc = fftx_build_table(g, nfft, &tw_t))) break;
+        if (hipMalloc(&w, sizeof(float2) * (4 * (size_t)bn + 2 * big)) != hipSuccess || hipMalloc(&d_off, sizeof(int) * nhops) != hipSuccess) {
+            rc = tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_superb_stitch_exact", "work buffers");
+            break;
+        }
+        float2 *A = w, *B = w + bn, *FA = w + 2 * (size_t)bn, *FB = w + 3 * (size_t)bn, *T1 = w + 4 * (size_t)bn, *T2 = T1 + big;
+        (void)hipMemsetAsync(d_off, 0, sizeof(int) * nhops, st);
+        for (int i = 1; i < nhops && !rc; i++) {
+            TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_x_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_hops[0], A, bn);
+            TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_x_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_hops[i], B, bn);
+            if ((rc = fftx_perform(g, st, A, FA, bn, tw_b, 0)) || (rc = fftx_perform(g, st, B, FB, bn, tw_b, 0))) break;
+            TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_x_mul_conj, (bn + 255) / 256, 256, FA, FB, bn);
+            if ((rc = fftx_perform(g, st, FA, A, bn, tw_b, 1))) break;
+            TSDR_LAUNCH(g, PROF_ARGMAX, st, k_x_argmax_abs, 1, 1024, A, bn, d_off + i);
+            TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_x_rotate, (nfl + 255) / 256, 256, d_hops[i], (float *)T1, nfl, d_off + i);
+            if ((rc = fftx_perform(g, st, T1, T2, per, tw_p, 0))) break;
+            (void)hipMemcpyAsync(d_hops[i], T2, sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
+        }
+        if (rc) break;
+        if ((rc = fftx_perform(g, st, (const float2 *)d_hops[0], T2, per, tw_p, 0))) break;
+        (void)hipMemcpyAsync(d_hops[0], T2, sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
+        for (int i = 0; i < nhops; i++)
+            (void)hipMemcpyAsync(d_out + (size_t)i * per * 2, d_hops[i], sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
+        // inverse FFT over the largest power of two <= total (fft_perform truncates, fft.c:101-105)
+        (void)hipMemcpyAsync(T1, d_out, sizeof(float2) * nfft, hipMemcpyDeviceToDevice, st);
+        if ((rc = fftx_perform(g, st, T1, T2, nfft, tw_t, 1))) break;
+        (void)hipMemcpyAsync(d_out, T2, sizeof(float2) * nfft, hipMemcpyDeviceToDevice, st);
+        if (h_offsets && hipMemcpyAsync(h_offsets, d_off, sizeof(int) * nhops, hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_superb_stitch_exact", "copy back");
+    } while (0);
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_superb_stitch_exact", "stream");
+    if (hipGetLastError() != hipSuccess && !rc) rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_superb_stitch_exact", "kernel");
+    (void)hipFree(tw_b);
+    (void)hipFree(tw_p);
+    (void)hipFree(tw_t);
+    (void)hipFree(w);
+    (void)hipFree(d_off);
+    if (rc) return rc;
+    if (h_total) *h_total = total;
+    return TSDRGPU_OK;
+}

@@ -107,6 +107,8 @@ _SIGS = {
     "tsdrgpu_autocorr_last_corr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]),
     "tsdrgpu_superb_stitch": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
+    "tsdrgpu_superb_stitch_exact": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp,
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     "tsdrgpu_decode_samples": (C.c_int, [vp, vp, C.c_int, vp, C.c_int64]),
     "tsdrgpu_frame_to_rgb": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int]),
     "tsdrgpu_modedetect_create": (C.c_int, [C.POINTER(vp)]),
@@ -290,11 +292,12 @@ class TsdrGpu:
         fn = self.lib.tsdrgpu_fft_exact if exact else self.lib.tsdrgpu_fft
         self._ck(fn(self.h, d_iq.at(offset), n, int(inverse)))
 
-    def superb_stitch(self, d_hops, gathered, samples_in_frame, d_out):
+    def superb_stitch(self, d_hops, gathered, samples_in_frame, d_out, exact=False):
         ptrs = (vp * len(d_hops))(*[h.ptr for h in d_hops])
         offs = (C.c_int32 * len(d_hops))()
         total = C.c_uint32()
-        self._ck(self.lib.tsdrgpu_superb_stitch(self.h, ptrs, len(d_hops), gathered, samples_in_frame,
+        fn = self.lib.tsdrgpu_superb_stitch_exact if exact else self.lib.tsdrgpu_superb_stitch
+        self._ck(fn(self.h, ptrs, len(d_hops), gathered, samples_in_frame,
                                                 d_out.ptr, offs, C.byref(total)))
         return np.array(list(offs), np.int32), total.value
 

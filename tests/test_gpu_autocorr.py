@@ -258,3 +258,31 @@ def test_fft_exact_is_bit_identical(orc, n, inverse):
     d = g.to_device(z)
     g.fft_perform(d, n, inverse, exact=True)
     assert np.array_equal(d.download(), want)
+
+
+@pytest.mark.parametrize("fs,fv,mult", [(120_000, 60.0, 10.0), (333_000, 50.0, 4.3), (40_000, 75.0, 7.0)])
+def test_superb_stitch_exact_is_bit_identical(orc, fs, fv, mult):
+    """tsdrgpu_superb_stitch_exact: hop offsets and the stitched signal equal the oracle's bit for bit."""
+    g = ctx()
+    rng = np.random.default_rng(int(fs))
+    sif = int(fs / fv)
+    gathered = int(mult * sif)
+    t = np.arange(gathered + 2 * sif)
+    base = 0.4 + 0.5 * ((t % sif) < sif // 7) + 0.1 * np.sin(t * 0.01)
+    hops = []
+    for k in range(4):
+        d = int(rng.integers(0, sif))
+        mag = base[d:d + gathered] + rng.standard_normal(gathered) * 0.01
+        ph = 0.21 * np.arange(gathered) + k
+        h = np.empty(2 * gathered, np.float32)
+        h[0::2] = (mag * np.cos(ph)).astype(np.float32)
+        h[1::2] = (mag * np.sin(ph)).astype(np.float32)
+        hops.append(h)
+    want, offs = orc.superb_stitch(hops, sif)
+    d_out = g.empty(want.size)
+    got_offs, total = g.superb_stitch([g.to_device(h) for h in hops], gathered, sif, d_out, exact=True)
+    assert 2 * total == want.size
+    assert np.array_equal(got_offs, offs)
+    nfft = 1 << int(np.floor(np.log2(total)))
+    got = d_out.download()
+    assert np.array_equal(got[:2 * nfft], want[:2 * nfft])
