@@ -231,6 +231,9 @@ def fuzz_fft(g, rng):
     z = (rng.standard_normal(2 * n) * rng.choice([1.0, 1e3, 1e-3])).astype(np.float32)
     want = orc.fft_perform(z, inverse)
     d = g.to_device(z)
+    if rng.random() < 0.5:  # exact form
+        g.fft_perform(d, n, inverse, exact=True)
+        return None if np.array_equal(d.download(), want) else f"fft exact n={n} inverse={inverse}"
     g._ck(g.lib.tsdrgpu_fft(g.h, d.ptr, n, int(inverse)))
     got = d.download()
     if np.max(np.abs(got - want)) > 2e-6 * max(np.max(np.abs(want)), 1e-30) * max(1.0, np.log2(n) / 4):
