@@ -396,8 +396,8 @@ def main():
         chain_hidden = args.frames_per_launch <= 0 and not args.no_split
         fused = chain_hidden and args.fuse
         frame_kernels_ms = sum(prof.get(k, (0, 0))[0] for k in
-                               ("k_rs_tail+k_rs_chain", "k_rs_area", "k_frame_stats", "k_frame_reduce", "k_frame_pass") +
-                               (() if chain_hidden else ("k_chain",)))
+                               ("k_rs_tail+k_rs_chain", "k_rs_area", "k_frame_stats", "k_frame_pass") +
+                               (() if chain_hidden else ("k_frame_reduce", "k_chain")))  # the split run folds and chains aside
         frame_path_bytes = (8.0 * S + 16.0 * P) * (frames_total / world / args.steps) * max(1, prof_steps)
         stage_ms = {k: round(v[0] / max(1, prof_steps), 4) for k, v in prof.items()}
 

@@ -1164,20 +1164,33 @@ static int ensure(tsdrgpu_t *g, T **buf, size_t *cap, size_t need, bool zero = f
     return TSDRGPU_OK;
 }
 
-static int launch_stats(tsdrgpu_postproc_t *pp, const float *frames, long long fstride, int F, int W, int H, int want_strips)
+// the big pass over the frames (per-tile partials) ...
+static int launch_stats_tiles(tsdrgpu_postproc_t *pp, const float *frames, long long fstride, int F, int W, int H, int want_strips)
 {
     tsdrgpu_t *g = pp->g;
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
     const unsigned grid = (unsigned)tiles_x * tiles_y * F;
-    {
-        TSDR_LAUNCH(g, PROF_FRAME_STATS, g->stream, k_frame_stats, grid, 256, frames, fstride, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp,
-                                               pp->d_rowp, pp->d_tflag, want_strips);
-    }
+    TSDR_LAUNCH(g, PROF_FRAME_STATS, g->stream, k_frame_stats, grid, 256, frames, fstride, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp,
+                pp->d_rowp, pp->d_tflag, want_strips);
     KERNEL_CHECK(g, "k_frame_stats");
-    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, g->stream, k_frame_reduce, dim3(((W > H ? W : H) + 255) / 256, 3, F), 256, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp,
-                                                      pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_tflag, want_strips, 1, TILE_H);
+    return TSDRGPU_OK;
+}
+
+// ... and the small fold of the partials (on `st`: the split run puts it on the side stream with the chain)
+static int launch_stats_reduce(tsdrgpu_postproc_t *pp, hipStream_t st, int F, int W, int H, int want_strips)
+{
+    tsdrgpu_t *g = pp->g;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_frame_reduce, dim3(((W > H ? W : H) + 255) / 256, 3, F), 256, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax,
+                pp->d_colp, pp->d_rowp, pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_tflag, want_strips, 1, TILE_H);
     KERNEL_CHECK(g, "k_frame_reduce");
     return TSDRGPU_OK;
+}
+
+static int launch_stats(tsdrgpu_postproc_t *pp, const float *frames, long long fstride, int F, int W, int H, int want_strips)
+{
+    const int rc = launch_stats_tiles(pp, frames, fstride, F, W, H, want_strips);
+    return rc ? rc : launch_stats_reduce(pp, pp->g->stream, F, W, H, want_strips);
 }
 
 static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long fstride, int F, int W, int H, int do_autogain,
@@ -1393,9 +1406,10 @@ extern "C" int tsdrgpu_postproc_begin(tsdrgpu_postproc_t *pp, const float *d_fra
     int rc;
     if ((rc = pp_prepare(pp, F, W, H, prm))) return rc;
     const long long Ps = (long long)W * H;
-    if ((rc = launch_stats(pp, d_frames, Ps, F, W, H, 1))) return rc;
+    if ((rc = launch_stats_tiles(pp, d_frames, Ps, F, W, H, 1))) return rc;
     HIP_TRY(g, hipEventRecord(pp->ev_stats, g->stream));
     HIP_TRY(g, hipStreamWaitEvent(g->stream2, pp->ev_stats, 0));
+    if ((rc = launch_stats_reduce(pp, g->stream2, F, W, H, 1))) return rc;
     pp->chain_st = g->stream2;
     rc = launch_chain(pp, d_frames, Ps, F, W, H, 1, 1, 1, prm);
     pp->chain_st = nullptr;
