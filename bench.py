@@ -156,8 +156,8 @@ def cpu_baseline(iq_host, fs, h, fv, nframes, nwindows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--seconds", type=float, default=1.0, help="signal seconds per batch")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
                     help="BASELINE.json configs index (0-based): 2 = 100 MS/s 1080p60 (the headline metric, default), "
