@@ -145,6 +145,15 @@ typedef struct tsdrgpu_pp_frameinfo {
 int tsdrgpu_postproc_create(tsdrgpu_t *g, tsdrgpu_postproc_t **out);
 void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp);
 int tsdrgpu_postproc_reset(tsdrgpu_postproc_t *pp); /* dsp_post_process_init, dsp.c:112-132 */
+/* Exact ties.  The sync detector's strips (column / row sums) are formed from f64 tile sums here and by f32 additions in
+ * raster order in the reference (dsp.c:96-110); they agree to ~1e-6.  Frames whose strips hold exact ties (blank,
+ * plateaus, periodic patterns, nearly flat) are always re-collapsed in the reference's order, so those decisions are
+ * identical.  What remains is the rare decision whose margin over the runner-up is smaller than the reference's own
+ * rounding (measured: ~3e-5 of the decisions on smooth repeated frames): with `on`, such toss-ups are detected (margin
+ * test against the rounding of the reference's sums), the frames concerned get exact strips and the chain of the batch
+ * is run again — the sync state is then identical there too.  Costs ~0.1 ms per batch plus ~0.3 ms for each batch that
+ * holds a toss-up (about every batch on noisy rasters), on the chain's stream. */
+int tsdrgpu_postproc_set_exact_ties(tsdrgpu_postproc_t *pp, int on);
 /* Runs `nframes` consecutive frames (d_frames: nframes*width*height floats,
  * raster order) through dsp_post_process in order, as one batch of launches.
  * d_out receives every frame's result (what the reference hands to the video

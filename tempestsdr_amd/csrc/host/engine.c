@@ -629,6 +629,11 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
         free(e);
         return tsdr_set_error(t, TSDR_CANNOT_OPEN_DEVICE, "No usable MI355X/HIP device: this library has no CPU path.");
     }
+    {   /* TSDR_GPU_EXACT_SYNC=1: sync-detector decisions that are toss-ups at the precision of the collapsed strips are
+         * detected and redone with the reference's own strip arithmetic (tsdrgpu_postproc_set_exact_ties) */
+        const char *ex = getenv("TSDR_GPU_EXACT_SYNC");
+        if (ex && ex[0] == '1') (void)tsdrgpu_postproc_set_exact_ties(e->pp, 1);
+    }
     pthread_mutex_init(&e->qm, NULL); pthread_cond_init(&e->q_nonempty, NULL);
     pthread_mutex_init(&e->fm, NULL); pthread_cond_init(&e->f_nonempty, NULL);
     pthread_mutex_init(&e->pm, NULL); pthread_cond_init(&e->p_nonempty, NULL);

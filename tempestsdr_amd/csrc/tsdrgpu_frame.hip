@@ -61,6 +61,7 @@ struct tsdrgpu_postproc {
     double *d_strip_x, *d_strip_y;  // [F][3][n]: non-sentinel sum, sentinel sum, sentinel count
     size_t cap_fmin, cap_fmax, cap_sx, cap_sy;
     float *d_work;  // chain scratch: blurred strips + prefix sums
+    int exact_ties; // tsdrgpu_postproc_set_exact_ties: second chain run for toss-up decisions
     int *d_sflag;   // [F][2]: the strip of (frame, axis) holds equal entries -> take the reference-order sums
     size_t cap_sflag;
     float *d_exact; // [F][2][nmax] strips summed in the reference's order (filled for flagged frames only)
@@ -304,12 +305,23 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane)
 struct FitBest {
     double fit;
     int q;
+    int q2;         // where that runner-up starts
+    double second;  // the largest fit among the OTHER windows of this size (-1: none seen)
 };
 __device__ __forceinline__ FitBest better(FitBest a, FitBest b)
 {
-    // larger fit wins; on equal fits the earlier position (syncdetector.c:53 uses `>`)
-    if (b.fit > a.fit || (b.fit == a.fit && b.q < a.q)) return b;
-    return a;
+    // larger fit wins; on equal fits the earlier position (syncdetector.c:53 uses `>`); the loser and both
+    // runner-ups compete for `second`
+    const bool bwins = b.fit > a.fit || (b.fit == a.fit && b.q < a.q);
+    FitBest w = bwins ? b : a;
+    const FitBest l = bwins ? a : b;
+    double s2 = w.second;
+    int p2 = w.q2;
+    if (l.second > s2) { s2 = l.second; p2 = l.q2; }
+    if (l.q != 0x7fffffff && l.fit > s2) { s2 = l.fit; p2 = l.q; }
+    w.second = s2;
+    w.q2 = p2;
+    return w;
 }
 
 __global__ __launch_bounds__(64) void k_autogain_chain(int F, const float *__restrict__ frames, long long fstride,
@@ -426,38 +438,68 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const doub
     }
 }
 
+// grid (ceil(max(W, ceil(H/64)*256) / 256), 2, F).  axis 0: one thread per column walks down the rows (coalesced
+// across the columns, 16 loads in flight).  axis 1: a workgroup takes 64 rows and walks along them in 64-column
+// tiles staged through LDS (coalesced loads), one thread per row adding its 64 values in order.
 __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ frames, long long fstride, int W, int H,
                                                       const ChainOut *__restrict__ chain, int strips_normalised,
-                                                      const int *__restrict__ sflag, float *__restrict__ exact, int nmax)
+                                                      const int *__restrict__ sflag, float *__restrict__ exact, int nmax,
+                                                      const int *__restrict__ redo)
 {
     const int axis = blockIdx.y, f = blockIdx.z;
+    if (redo && !*redo) return;
     if (!sflag[f * 2 + axis]) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = axis == 0 ? W : H;
-    if (i >= n) return;
     const float *src = frames + (long long)f * fstride;
     const float lastmin = chain[f].lastmin, span = chain[f].span;
-    const int count = axis == 0 ? H : W;
-    const long long step = axis == 0 ? W : 1, first = axis == 0 ? i : (long long)i * W;
-    float acc = 0.f;
-    int k = 0;
-    for (; k + 8 <= count; k += 8) {  // eight loads in flight, then the eight additions in the reference's order
-        float v[8];
+    float *out = exact + ((long long)f * 2 + axis) * nmax;
+    if (axis == 0) {
+        const int x = blockIdx.x * blockDim.x + threadIdx.x;
+        if (x >= W) return;
+        float acc = 0.f;
+        int y = 0;
+        for (; y + 16 <= H; y += 16) {
+            float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = src[first + (k + u) * step];
+            for (int u = 0; u < 16; u++) v[u] = src[(long long)(y + u) * W + x];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            float t = v[u];
-            if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);  // dsp.c:80-86
+            for (int u = 0; u < 16; u++) {
+                float t = v[u];
+                if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);  // dsp.c:80-86
+                acc += t;
+            }
+        }
+        for (; y < H; y++) {
+            float t = src[(long long)y * W + x];
+            if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);
             acc += t;
         }
+        out[x] = acc;
+        return;
     }
-    for (; k < count; k++) {
-        float t = src[first + k * step];
-        if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);
-        acc += t;
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64;
+    if (r0 >= H) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int r = wave * 16 + i, y = r0 + r, x = c0 + lane;
+            float t = 0.f;
+            if (y < H && x < W) {
+                t = src[(long long)y * W + x];
+                if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);
+            }
+            tile[r][lane] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int cols = W - c0 < 64 ? W - c0 : 64;
+            for (int c = 0; c < cols; c++) acc += tile[threadIdx.x][c];
+        }
+        __syncthreads();
     }
-    exact[((long long)f * 2 + axis) * nmax + i] = acc;
+    if (threadIdx.x < 64 && r0 + (int)threadIdx.x < H) out[r0 + threadIdx.x] = acc;
 }
 
 __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const double *__restrict__ strip_x,
@@ -465,8 +507,9 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
                                                            const ChainOut *__restrict__ chain, StripScratch sc,
                                                            int strips_normalised, float t0, float t1, float t2, float t3,
                                                            float t4, const int *__restrict__ sflag,
-                                                           const float *__restrict__ exact)
+                                                           const float *__restrict__ exact, const int *__restrict__ redo)
 {
+    if (redo && !*redo) return;
     __shared__ float data[STRIP_MAX];
     __shared__ float blur[STRIP_MAX];
     __shared__ double wsum[16];
@@ -604,11 +647,16 @@ __device__ void strip_search(SearchShared &S, const double *__restrict__ P, int 
             l = (S.wlo[k][w] < l) ? S.wlo[k][w] : l;
             h = (S.whi[k][w] > h) ? S.whi[k][w] : h;
         }
-        const double band = 1e-9 * (fabs(l) + fabs(h)) + 1e-300;
+        // windows within 4e-6 of an extreme sum are evaluated: the winner is among those within 1e-9, the rest
+        // supply the runner-up for the toss-up test of k_sync_chain (whose tolerance, expressed in window sums,
+        // is ~4*sqrt(2/strip)*7e-7 of the sum: below 1e-6 for every strip size)
+        const double band = 4e-6 * (fabs(l) + fabs(h)) + 1e-300;
         lo_b[k] = l + band;
         hi_b[k] = h - band;
         mine[k].fit = -1.0;
         mine[k].q = 0x7fffffff;
+        mine[k].q2 = 0;
+        mine[k].second = -1.0;
     }
 #pragma unroll 4
     for (int q = tid; q < n; q += SYNC_T) {
@@ -621,7 +669,14 @@ __device__ void strip_search(SearchShared &S, const double *__restrict__ P, int 
             if (sum <= lo_b[k] || sum >= hi_b[k]) {
                 const double d = ((double)totalf - sum) / c1[k] - sum / c2[k];
                 const double fit = d * d;
-                if (fit > mine[k].fit) { mine[k].fit = fit; mine[k].q = q; }  // q ascending per thread
+                if (fit > mine[k].fit) {  // q ascending per thread
+                    if (mine[k].q != 0x7fffffff) { mine[k].second = mine[k].fit; mine[k].q2 = mine[k].q; }
+                    mine[k].fit = fit;
+                    mine[k].q = q;
+                } else if (fit > mine[k].second) {
+                    mine[k].second = fit;
+                    mine[k].q2 = q;
+                }
             }
         }
     }
@@ -633,6 +688,8 @@ __device__ void strip_search(SearchShared &S, const double *__restrict__ P, int 
             FitBest other;
             other.fit = __shfl_down(b.fit, o, 64);
             other.q = __shfl_down(b.q, o, 64);
+            other.q2 = __shfl_down(b.q2, o, 64);
+            other.second = __shfl_down(b.second, o, 64);
             b = better(b, other);
         }
         if (lane == 0) S.wbest[k][wave] = b;
@@ -657,9 +714,10 @@ struct SpecEntry {
 // k_sync_chain consumes these results while the prediction holds and searches on its own
 // where it does not.
 __global__ __launch_bounds__(SYNC_T) void k_sync_search(int W, int H, StripScratch sc, const PpState *__restrict__ state,
-                                                        SpecEntry *__restrict__ spec)
+                                                        SpecEntry *__restrict__ spec, const int *__restrict__ redo)
 {
     __shared__ SearchShared S;
+    if (redo && !*redo) return;
     const int axis = blockIdx.x, f = blockIdx.y;
     const int n = axis == 0 ? W : H;
     int minsize = axis == 0 ? (int)(W * 0.05f) : (int)(H * 0.01f);  // syncdetector.c:178-179
@@ -678,12 +736,19 @@ struct ChainShared {
     int f, cur, dx, vx;
 };
 
+// First run of a batch (redo == nullptr): starts from `state`, leaves a copy of that starting state in `saved`
+// and marks in amb[f*2+axis] every decision whose margin over the runner-up (another window position of the
+// chosen size, or another size) is inside the rounding of the reference's own f32 strip sums — those could
+// fall the other way there.  Second run (redo != nullptr, after k_redo_prepare made the marked frames' strips
+// exact): does nothing unless *redo, else starts again from `saved`.
 __global__ __launch_bounds__(SYNC_T) void k_sync_chain(int F, int W, int H, StripScratch sc, PpState *__restrict__ state,
                                                        ChainOut *__restrict__ out, const SpecEntry *__restrict__ spec,
-                                                       int pll_enabled)
+                                                       int pll_enabled, PpState *__restrict__ saved, int *__restrict__ amb,
+                                                       const int *__restrict__ redo)
 {
     __shared__ SearchShared S;
     __shared__ ChainShared C;
+    if (redo && !*redo) return;
     const bool xblock = blockIdx.x == 0;
     const int axis = blockIdx.x;
     const int n = xblock ? W : H;
@@ -693,11 +758,20 @@ __global__ __launch_bounds__(SYNC_T) void k_sync_chain(int F, int W, int H, Stri
     const double lowpass = xblock ? 0.9 : 0.1;
     const int half = n >> 1;
 
-    int dx = xblock ? state->dx_x : state->dx_y;
-    int vx = xblock ? state->vx_x : state->vx_y;
-    int cur = xblock ? state->strip_x : state->strip_y;
-    double avg_speed = state->avg_speed;
-    int locked = state->locked;
+    const PpState *from = redo ? saved : state;
+    int dx = xblock ? from->dx_x : from->dx_y;
+    int vx = xblock ? from->vx_x : from->vx_y;
+    int cur = xblock ? from->strip_x : from->strip_y;
+    double avg_speed = from->avg_speed;
+    int locked = from->locked;
+    if (!redo && tid == 0) {  // each block saves the fields it owns
+        if (xblock) {
+            saved->dx_x = dx; saved->vx_x = vx; saved->strip_x = cur;
+            saved->locked = locked; saved->avg_speed = avg_speed;
+        } else {
+            saved->dx_y = dx; saved->vx_y = vx; saved->strip_y = cur;
+        }
+    }
     int pred[5];
     const int cur0 = sync_sizes(cur, minsize, half, pred);  // what k_sync_search assumed
 
@@ -712,12 +786,37 @@ __global__ __launch_bounds__(SYNC_T) void k_sync_chain(int F, int W, int H, Stri
                 const FitBest *res = have_search ? S.best : spec[f * 2 + axis].best;
                 have_search = false;
                 double bestfit = -1.0;
-                int bestq = 0, bestsize = cc;
+                int bestq = 0, bestsize = cc, bestk = 0;
 #pragma unroll
                 for (int k = 0; k < 5; k++) {
                     if (sizes[k] <= 0) continue;
                     // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
-                    if (k == 0 || res[k].fit > bestfit) { bestfit = res[k].fit; bestq = res[k].q; bestsize = sizes[k]; }
+                    if (k == 0 || res[k].fit > bestfit) { bestfit = res[k].fit; bestq = res[k].q; bestsize = sizes[k]; bestk = k; }
+                }
+                if (!redo && amb) {
+                    // Would the reference's rounding have chosen otherwise?  Its strip entries (sequential f32 sums of
+                    // ~10^3 pixels) carry ~7e-7 of relative error each, independently; two windows differ in m
+                    // entries, so their sums move against each other by ~sqrt(m)*7e-7*entry, the mean difference d
+                    // by that times (1/rest + 1/strip), and fit = d*d by 2|d| times that.  Four sigmas.
+                    const double entry = fabs(sc.total[f * 2 + axis]) / (double)n;
+                    const double sd = sqrt(bestfit > 0.0 ? bestfit : 0.0);
+                    const double per = 1.0 / (double)(n - bestsize) + 1.0 / (double)bestsize;
+                    int toss = 0;
+                    if (res[bestk].second >= 0.0) {
+                        int shift = res[bestk].q2 - bestq;
+                        if (shift < 0) shift = -shift;
+                        if (shift > n - shift) shift = n - shift;
+                        const int m = 2 * (shift < bestsize ? shift : bestsize);
+                        const double tol = 8.0 * sd * sqrt((double)m) * 7e-7 * entry * per;
+                        toss |= !(bestfit - res[bestk].second > tol);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 5; k++)
+                        if (k != bestk && sizes[k] > 0) {
+                            const double tol = 8.0 * sd * sqrt((double)(bestsize + sizes[k])) * 7e-7 * entry * per;
+                            toss |= !(fabs(bestfit - res[k].fit) > tol);
+                        }
+                    amb[f * 2 + axis] = toss;
                 }
                 // window start q carries the label of the index just removed (q-1); start 0 is labelled 0
                 const int beststart = bestq > 0 ? bestq - 1 : 0;
@@ -1108,7 +1207,7 @@ extern "C" int tsdrgpu_postproc_create(tsdrgpu_t *g, tsdrgpu_postproc_t **out)
     if (!pp) return TSDRGPU_ENOMEM;
     pp->g = g;
     gaussian_taps(pp->taps);
-    if (hipMalloc(&pp->d_state, sizeof(PpState)) != hipSuccess) { free(pp); return TSDRGPU_ENOMEM; }
+    if (hipMalloc(&pp->d_state, 2 * sizeof(PpState)) != hipSuccess) { free(pp); return TSDRGPU_ENOMEM; }  // [1]: the sync chain's batch-start copy
     if (hipEventCreateWithFlags(&pp->ev_stats, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&pp->ev_chain, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(pp->d_state);
@@ -1164,6 +1263,20 @@ static int ensure(tsdrgpu_t *g, T **buf, size_t *cap, size_t need, bool zero = f
     return TSDRGPU_OK;
 }
 
+// Between the two runs of the sync chain: frames with a toss-up decision whose strips are not yet the
+// reference's own get them (sflag), and *redo tells the second run whether there is anything to do.
+__global__ __launch_bounds__(256) void k_redo_prepare(int count, const int *__restrict__ amb, int *__restrict__ sflag, int *__restrict__ redo)
+{
+    int any = 0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x)
+        if (amb[i] && !sflag[i]) {
+            sflag[i] = 1;
+            any = 1;
+        }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) *redo = any;
+}
+
 // the big pass over the frames (per-tile partials) ...
 static int launch_stats_tiles(tsdrgpu_postproc_t *pp, const float *frames, long long fstride, int F, int W, int H, int want_strips)
 {
@@ -1216,17 +1329,26 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
         TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, strips_normalised,
                     pp->d_sflag);
-        TSDR_LAUNCH(g, PROF_CHAIN, st, k_exact_strips, dim3((nmax + 255) / 256, 2, F), 256, frames, fstride, W, H, pp->d_chain, strips_normalised,
-                    pp->d_sflag, pp->d_exact, nmax);
-        KERNEL_CHECK(g, "k_exact_strips");
-        TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
-                                                               strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2],
-                                                               pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact);
-        KERNEL_CHECK(g, "k_strip_prepare");
         SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
-        TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, pp->d_state, spec);
-        KERNEL_CHECK(g, "k_sync_search");
-        TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll);
+        int *d_amb = pp->d_sflag + (size_t)F * 2, *d_redo = d_amb + (size_t)F * 2;
+        const int *const no_gate = nullptr;
+        const unsigned exact_blocks = (unsigned)(((W + 255) / 256) > ((H + 63) / 64) ? ((W + 255) / 256) : ((H + 63) / 64));
+        // run 1 as speculated; with exact ties on, run 2 (five empty launches unless needed) repeats the chain for a
+        // batch in which some decision was a toss-up at the precision of the strips, those frames' strips made exact
+        const int runs = pp->exact_ties ? 2 : 1;
+        for (int run = 0; run < runs; run++) {
+            const int *gate = run ? d_redo : no_gate;
+            if (run) TSDR_LAUNCH(g, PROF_CHAIN, st, k_redo_prepare, 1, 256, 2 * F, d_amb, pp->d_sflag, d_redo);
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_exact_strips, dim3(exact_blocks, 2, F), 256, frames, fstride, W, H, pp->d_chain, strips_normalised,
+                        pp->d_sflag, pp->d_exact, nmax, gate);
+            KERNEL_CHECK(g, "k_exact_strips");
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
+                        strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, gate);
+            KERNEL_CHECK(g, "k_strip_prepare");
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, run ? pp->d_state + 1 : pp->d_state, spec, gate);
+            KERNEL_CHECK(g, "k_sync_search");
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1, pp->exact_ties ? d_amb : (int *)nullptr, gate);
+        }
         KERNEL_CHECK(g, "k_sync_chain");
     }
     return TSDRGPU_OK;
@@ -1292,7 +1414,7 @@ static int pp_prepare(tsdrgpu_postproc_t *pp, int F, int W, int H, const tsdrgpu
         const size_t floats = (((size_t)F * 2 * nmax + 1) & ~(size_t)1) + 2 * ((size_t)F * 2 * (nmax + 1) + (size_t)F * 2) +
                               (size_t)F * 2 * (sizeof(SpecEntry) / sizeof(float)) + 16;
         if ((rc = ensure(g, &pp->d_work, &pp->cap_work, floats))) return rc;
-        if ((rc = ensure(g, &pp->d_sflag, &pp->cap_sflag, (size_t)F * 2))) return rc;
+        if ((rc = ensure(g, &pp->d_sflag, &pp->cap_sflag, (size_t)F * 4 + 4))) return rc;  // flags, toss-up marks, redo
         if ((rc = ensure(g, &pp->d_exact, &pp->cap_exact, (size_t)F * 2 * nmax))) return rc;
     }
     if (W > STRIP_MAX || H > STRIP_MAX) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "width/height above 16384");
@@ -1514,6 +1636,13 @@ extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsd
     int rc;
     if ((rc = launch_pass(pp, PASS_NORMALISE | map | lines | PASS_IIR, pp->p_frames, Ps, d_out, Ps, F, W, H, a))) return rc;
     if (h_info) return pp_copy_info(pp, F, h_info);
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_set_exact_ties(tsdrgpu_postproc_t *pp, int on)
+{
+    if (!pp) return TSDRGPU_EINVAL;
+    pp->exact_ties = on ? 1 : 0;
     return TSDRGPU_OK;
 }
 

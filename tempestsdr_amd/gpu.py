@@ -83,6 +83,7 @@ _SIGS = {
     "tsdrgpu_postproc_create": (C.c_int, [vp, C.POINTER(vp)]),
     "tsdrgpu_postproc_destroy": (None, [vp]),
     "tsdrgpu_postproc_reset": (C.c_int, [vp]),
+    "tsdrgpu_postproc_set_exact_ties": (C.c_int, [vp, C.c_int]),
     "tsdrgpu_postproc_run": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams), vp,
                                        C.POINTER(PPFrameInfo)]),
     "tsdrgpu_postproc_begin": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams)]),
@@ -386,6 +387,10 @@ class PostProcess:
 
     def reset(self):
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_reset(self.h))
+
+    def set_exact_ties(self, on=True):
+        """Detect sync-detector decisions that are toss-ups at the precision of the strips and redo them exactly."""
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_set_exact_ties(self.h, int(on)))
 
     def run(self, d_frames, nframes, width, height, d_out, motionblur=0.0, lowpasscoeff=0.1,
             lowpass_before_sync=0, autogain_after_proc=0, autoshift=0, pll=0, superres=0,
