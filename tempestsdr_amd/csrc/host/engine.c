@@ -286,8 +286,8 @@ static void run_detector(struct engine *e, uint32_t fs)
         e->ac_rate = fs;
         {   /* TSDR_GPU_EXACT_AUTOCORR=1: the frame-rate detector in the reference's own FFT arithmetic (plots and
              * detected mode bit-identical to the CPU library; ~7x the transform time, still far above real time) */
-            const char *ex = getenv("TSDR_GPU_EXACT_AUTOCORR");
-            if (ex && ex[0] == '1') (void)tsdrgpu_autocorr_set_exact(e->ac, 1);
+            const char *ex = getenv("TSDR_GPU_EXACT_AUTOCORR"), *all = getenv("TSDR_GPU_EXACT");
+            if ((ex && ex[0] == '1') || (all && all[0] == '1')) (void)tsdrgpu_autocorr_set_exact(e->ac, 1);
         }
         uint32_t cap, n;
         tsdrgpu_autocorr_geometry(e->ac, &e->flo, &e->flen, &e->llo, &e->llen, &cap, &n);
@@ -518,8 +518,8 @@ static int super_feed(struct engine *e, const float *d_blk, size_t nfloats, int6
                 int32_t offs[SUPER_HOPS];
                 uint32_t total = 0;
                 e->super_state = SUPER_STARTING;
-                const char *ex = getenv("TSDR_GPU_EXACT_AUTOCORR"); /* the exact-FFT switch covers the stitch as well */
-                if ((ex && ex[0] == '1')
+                const char *ex = getenv("TSDR_GPU_EXACT_AUTOCORR"), *all = getenv("TSDR_GPU_EXACT"); /* covers the stitch too */
+                if (((ex && ex[0] == '1') || (all && all[0] == '1'))
                         ? tsdrgpu_superb_stitch_exact(e->g, e->d_hops, SUPER_HOPS, gathered, e->super_frame, e->d_super_out, offs, &total)
                         : tsdrgpu_superb_stitch(e->g, e->d_hops, SUPER_HOPS, gathered, e->super_frame, e->d_super_out, offs, &total))
                     return 0;
@@ -631,8 +631,8 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     }
     {   /* TSDR_GPU_EXACT_SYNC=1: sync-detector decisions that are toss-ups at the precision of the collapsed strips are
          * detected and redone with the reference's own strip arithmetic (tsdrgpu_postproc_set_exact_ties) */
-        const char *ex = getenv("TSDR_GPU_EXACT_SYNC");
-        if (ex && ex[0] == '1') (void)tsdrgpu_postproc_set_exact_ties(e->pp, 1);
+        const char *ex = getenv("TSDR_GPU_EXACT_SYNC"), *all = getenv("TSDR_GPU_EXACT");
+        if ((ex && ex[0] == '1') || (all && all[0] == '1')) (void)tsdrgpu_postproc_set_exact_ties(e->pp, 1);
     }
     pthread_mutex_init(&e->qm, NULL); pthread_cond_init(&e->q_nonempty, NULL);
     pthread_mutex_init(&e->fm, NULL); pthread_cond_init(&e->f_nonempty, NULL);
