@@ -415,3 +415,22 @@ def test_pipeline_exact_autocorr_plots_are_bit_identical(orc, iq_file, monkeypat
     assert np.array_equal(line_plots[0][2], ac.line)
     assert int(np.argmax(frame_plots[0][2])) == int(np.argmax(ac.frame))
     s.close()
+
+
+def test_pipeline_all_exact_modes(orc, iq_file, monkeypatch):
+    """TSDR_GPU_EXACT=1 (exact autocorrelation + exact sync ties) leaves the delivered frames what they were — the
+    oracle's — and makes the plots bit-identical."""
+    monkeypatch.setenv("TSDR_GPU_EXACT", "1")
+    path, iq = iq_file
+    plugin = hu.build_test_plugin()
+    geo = orc.geometry(FS, H, FV)
+    want = oracle_frames(orc, iq, geo)
+    s, ok, rc = run_session(plugin, f"{path} {FS} {BLOCK} 8000", nframes=len(want) - 3, timeout=20)
+    assert ok and rc == 0 and s.status == 0, s.err()
+    hits = match_in_order(s.frames, want)
+    assert hits[0] == 0 and len(hits) >= len(want) - 4
+    ac = orc.Autocorr(FS)
+    ac.run(orc.am_demod(iq)[:orc.capture_size(FS)])
+    frame_plots = [p for p in s.plots if p[0] == 0]
+    assert frame_plots and np.array_equal(frame_plots[0][2], ac.frame)
+    s.close()
