@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — TempestSDR hot path on MI355X: IQ Msamples/s (+ frames/s).
 
-One "step" = one pass of the whole hot path over one HBM-resident batch of
-synthetic IQ (BASELINE.json configs[2]: 100 MS/s, 1920x1080@60 raster, i.e.
-h=1125 total lines -> 2962x1125 frames):
+One "pass" = the whole hot path over one HBM-resident batch of synthetic IQ
+(BASELINE.json configs[2]: 100 MS/s, 1920x1080@60 raster, i.e. h=1125 total
+lines -> 2962x1125 frames; 1 s of signal); one "step" = --passes (40) such
+passes back to back, so that 20 steps time more than a second of GPU work.
+A pass is:
 
     a1+a2  fused AM demod + area resample      IQ -> pixel stream   (600 chunks)
     a3..a8 dsp_post_process, library-default stage order, every frame delivered
@@ -162,6 +164,13 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
                     help="BASELINE.json configs index (0-based): 2 = 100 MS/s 1080p60 (the headline metric, default), "
                          "1 = 25 MS/s 1024x768, 4 = 200 MS/s 2160p with 15/16 motion blur (use --seconds 0.5)")
+    ap.add_argument("--passes", type=int, default=40,
+                    help="passes over the HBM-resident batch per step (a step = passes x seconds of signal), so that "
+                         "the default 20-30 steps give a timed region of more than a second")
+    ap.add_argument("--fast-sync", action="store_true",
+                    help="opt out of the contract-exact sync detector (tsdrgpu_postproc_set_exact_ties(0)); the default "
+                         "— and what the library ships — redoes toss-up decisions with the reference's own strip sums")
+    ap.add_argument("--plan", type=int, default=3, choices=[3, 5], help="autocorrelation transform plan (trips over HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="split the frame path of a step into sub-batches of about this many frames (0 = one batch)")
@@ -222,7 +231,9 @@ def main():
 
     rs = gpu.Resampler(g)
     pp = gpu.PostProcess(g)
+    pp.set_exact_ties(not args.fast_sync)
     ac = gpu.Autocorr(g, fs)
+    ac.set_plan(args.plan)
     nwin = nsamples // ac.capture
     max_pix = int(nsamples * (up / down)) + 64 + P  # + a carried partial frame
     pix = torch.empty(max_pix, dtype=torch.float32, device=dev)
@@ -251,7 +262,14 @@ def main():
             ac.reset()
             ac.run(d_iq, 1, ac.capture, nwin, mode=1)
 
+    arg_pending = [False]
+
     def step():
+        for _ in range(args.passes - 1):
+            one_pass(False)
+        return one_pass(True)
+
+    def one_pass(last):
         nonlocal carry, frames_done
         split = args.frames_per_launch <= 0 and not args.no_split
         fuse = split and args.fuse
@@ -298,6 +316,15 @@ def main():
             if args.overlap:
                 ext.synchronize()
             ac.finalize_sums(nwin * world)
+        # every pass ends with a plot update: the argmax is queued behind the pass and collected one pass later,
+        # so the host keeps queueing while the device works (one device sync per STEP)
+        if arg_pending[0]:
+            ac.argmax_result()
+            arg_pending[0] = False
+        if not last:
+            ac.argmax_async()
+            arg_pending[0] = True
+            return None
         fi_li = ac.argmax()  # waits for the side stream
         g.sync()             # and the frames of this step
         return fi_li
@@ -319,8 +346,11 @@ def main():
     barrier()
     frames_done = 0
     t0 = time.perf_counter()
+    step_s = []
     for _ in range(args.steps):
-        fi, li = step()
+        ts = time.perf_counter()
+        fi, li = step()  # ends with a device sync
+        step_s.append(time.perf_counter() - ts)
     barrier()
     dt = time.perf_counter() - t0
     frames_timed = frames_done
@@ -330,15 +360,33 @@ def main():
     # right here with the events on, live in this process, for the roofline object.
     prof, prof_steps, dt_prof = {}, 0, 0.0
     if not args.no_profile:
-        prof_steps = max(1, min(args.steps, 5))
+        prof_steps = 5  # passes
         g.profile_begin()
         tp = time.perf_counter()
         for _ in range(prof_steps):
-            step()
+            one_pass(True)
         barrier()
         dt_prof = time.perf_counter() - tp
         prof = g.profile_end()
     frames_done = frames_timed
+
+    # side metric: the detector in the reference's own FFT arithmetic (what tsdr_readasync uses by default)
+    exact_ac = None
+    if rank == 0 and not args.no_profile and not sharded:
+        acx = gpu.Autocorr(g, fs)
+        acx.set_exact(True)
+        acx.run(d_iq, 1, acx.capture, min(nwin, 4), mode=0)  # builds the twiddle table, warms up
+        g.sync()
+        tx = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            acx.run(d_iq, 1, acx.capture, nwin, mode=0)
+        g.sync()
+        tx = time.perf_counter() - tx
+        exact_ac = {"windows_per_s": round(reps * nwin / tx, 1), "ms_per_window": round(tx / (reps * nwin) * 1e3, 4),
+                    "realtime_factor": round(reps * nwin * acx.capture / tx / fs, 1),
+                    "note": "tsdrgpu_autocorr_set_exact: plots bit-identical to fft.c; the engine's default detector"}
+        acx.destroy()
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -351,68 +399,100 @@ def main():
         frames_total = float(frames_done)
 
     if rank == 0:
-        total_samples = float(nsamples) * args.steps * world
+        passes_timed = args.steps * args.passes
+        total_samples = float(nsamples) * passes_timed * world
         ms_step = dt / args.steps * 1e3
-        # ---- roofline of the dominant kernel (live HIP-event timings of the timed region)
+        ms_pass = ms_step / args.passes
+        frames_pass = frames_total / world / passes_timed  # frames one rank completes per pass
         N, L = ac.n, ac.flen + ac.llen
         S = fs / fv
-        # The autocorrelation of one window is carried by three kernels (FFT passes, the fused middle pass,
-        # the lag accumulation); SURVEY 8(d)'s 28N+16L bytes per window is the figure for all of them together,
-        # so each kernel is credited with the share of those bytes equal to its share of the group's time:
-        # achieved(k_fft_lds) == (28N+16L)*windows / (t_fft + t_mid + t_acc), i.e. never more than the
-        # whole autocorrelation achieves.
-        ac_group = ("k_fft_lds", "k_ac_mid", "k_accumulate")
-        ac_ms = sum(prof.get(k, (0.0, 0))[0] for k in ac_group) or 1.0
-        ac_bytes_step = (28.0 * N + 16.0 * L) * nwin * max(1, prof_steps)
+        np_ = max(1, prof_steps)  # instrumented passes
 
-        def ac_share(k):
-            t, n = prof.get(k, (0.0, 1))
-            return ac_bytes_step * (t / ac_ms) / max(1, n)
+        def per_pass(k):  # (ms per pass, launches per pass) of one profiler stage
+            t, n = prof.get(k, (0.0, 0))
+            return t / np_, n / np_
 
-        alg_bytes = {
-            "k_fft_lds": ac_share("k_fft_lds"),
-            "k_ac_mid": ac_share("k_ac_mid"),
-            # frame path 8S+16P per frame = resample (8S+4P) + stats (4P) + normalise/IIR pass (8P)
-            "k_rs_area": (8.0 * S + 4.0 * P) * (nsamples / S),
-            "k_frame_stats": 4.0 * P * (frames_total / world / args.steps),
-            "k_frame_pass": 8.0 * P * (frames_total / world / args.steps),
-        }
-        dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
-        roofline = None
-        if dom in alg_bytes:
-            avg_ms = prof[dom][0] / prof[dom][1]
-            ach = alg_bytes[dom] / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom)
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes[dom]),
-                        "measured_over": f"{prof_steps} steps repeated with per-dispatch HIP events right after the timed "
-                                         f"region ({dt_prof / prof_steps * 1e3:.3f} ms/step instrumented)"}
-        # with the split run the chain kernels execute on the side stream behind the FFT passes: their
-        # (contended) durations are listed in stage_ms_per_step but are not on the critical path
+        # ---- rooflines, every figure recomputable from the numbers printed here.
+        # Kernels whose algorithmic bytes SURVEY 8(d) states separately get their own entry:
+        #   frame path 8S+16P per frame = resampler (8S+4P) + statistics (4P) + normalise/IIR pass (8P)
+        # The autocorrelation has ONE figure, 28N+16L per window, for all of its kernels together, so it gets one
+        # group entry: bytes per window x windows / (sum of its kernels' durations).
+        own = {"k_rs_area": (8.0 * S + 4.0 * P) * (nsamples / S),
+               "k_frame_stats": 4.0 * P * frames_pass,
+               "k_frame_pass": 8.0 * P * frames_pass}
+        kernels = {}
+        for k, bytes_pass in own.items():
+            ms, n = per_pass(k)
+            if n:
+                kernels[k] = {"launches_per_pass": round(n, 2), "avg_launch_ms": round(ms / n, 4),
+                              "alg_bytes_per_launch": int(bytes_pass / n),
+                              "achieved_GBs": round(bytes_pass / (ms * 1e-3) / 1e9, 1),
+                              "frac": round(bytes_pass / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        ac_group = [k for k in ("k_ac_cols", "k_ac_rows", "k_fft_lds", "k_ac_mid", "k_accumulate") if k in prof]
+        ac_ms = sum(per_pass(k)[0] for k in ac_group)
+        ac_launches = sum(per_pass(k)[1] for k in ac_group)
+        ac_bytes_pass = (28.0 * N + 16.0 * L) * nwin
+        trips = "3 (columns, row pairs with the fused split, columns)" if "k_ac_cols" in prof else "5 (three radix-128 passes each way, the middle two fused)"
+        autocorr = None
+        if ac_ms:
+            autocorr = {"kernels": ac_group, "launches_per_pass": round(ac_launches, 2), "group_ms_per_pass": round(ac_ms, 4),
+                        "alg_bytes_per_window": int(28 * N + 16 * L), "windows_per_pass": nwin,
+                        "achieved_GBs": round(ac_bytes_pass / (ac_ms * 1e-3) / 1e9, 1),
+                        "frac": round(ac_bytes_pass / (ac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "trips_over_hbm_per_window": trips,
+                        "note": "28N+16L is SURVEY 8(d)'s one-pass-per-transform figure for the whole group; the packed-real "
+                                "three-trip plan moves less than that (DESIGN.md section 4), so frac is bytes-credited, not bytes-moved"}
+        # with the split run the chain kernels execute on the side stream behind the autocorrelation: their
+        # (contended) durations are listed in stage_ms_per_pass but are not on the critical path
         chain_hidden = args.frames_per_launch <= 0 and not args.no_split
         fused = chain_hidden and args.fuse
-        frame_kernels_ms = sum(prof.get(k, (0, 0))[0] for k in
-                               ("k_rs_tail+k_rs_chain", "k_rs_area", "k_frame_stats", "k_frame_pass") +
-                               (() if chain_hidden else ("k_frame_reduce", "k_chain")))  # the split run folds and chains aside
-        frame_path_bytes = (8.0 * S + 16.0 * P) * (frames_total / world / args.steps) * max(1, prof_steps)
-        stage_ms = {k: round(v[0] / max(1, prof_steps), 4) for k, v in prof.items()}
+        frame_group = ("k_rs_tail+k_rs_chain", "k_rs_area", "k_frame_stats", "k_frame_pass") + (() if chain_hidden else ("k_frame_reduce", "k_chain"))
+        frame_ms = sum(per_pass(k)[0] for k in frame_group)
+        frame_bytes_pass = (8.0 * S + 16.0 * P) * frames_pass
+        stage_ms = {k: round(v[0] / np_, 4) for k, v in prof.items()}
+
+        # the `roofline` object: the entry that takes the most time per pass (a kernel, or the autocorrelation group)
+        traffic_all, traffic_src = {}, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic_all = json.load(open(tpath))
+            traffic_src = "profiles/pmc_traffic.json: " + str(traffic_all.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                                               "of an earlier run of this command (not collected live)"))
+        cand = {k: per_pass(k)[0] for k in kernels}
+        if autocorr:
+            cand["autocorrelation"] = ac_ms
+        roofline = None
+        if cand:
+            dom = max(cand, key=cand.get)
+            if dom == "autocorrelation":
+                roofline = {"bound": "hbm", "kernel": "autocorrelation group: " + "+".join(ac_group),
+                            "achieved": autocorr["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": autocorr["frac"],
+                            "traffic": sum(traffic_all.get(k, 0) or 0 for k in ac_group) or None,
+                            "avg_launch_ms": round(ac_ms, 4), "alg_bytes_per_launch": int(ac_bytes_pass),
+                            "launch": f"one pass = {nwin} windows = {round(ac_launches)} launches of the group (SURVEY 8(d) gives "
+                                      "bytes per window for the group, not per kernel)"}
+            else:
+                e = kernels[dom]
+                roofline = {"bound": "hbm", "kernel": dom, "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": e["frac"], "traffic": traffic_all.get(dom), "avg_launch_ms": e["avg_launch_ms"],
+                            "alg_bytes_per_launch": e["alg_bytes_per_launch"]}
+            roofline["traffic_source"] = traffic_src
+            roofline["measured_over"] = (f"{np_} passes repeated with per-dispatch HIP events right after the timed region "
+                                         f"({dt_prof / np_ * 1e3:.3f} ms/pass instrumented vs {ms_pass:.3f} ms/pass timed)")
 
         flag, llag = ac.flo + fi, ac.llo + li
         md = gpu.ModeDetect()
         accepted_after = None
-        for upd in range(1, 9):  # every step's plot update yields the same argmax pair on this stationary stream
+        for upd in range(1, 9):  # every pass's plot update yields the same argmax pair on this stationary stream
             det = md.feed(ac.flo, fi, ac.llo, li, fs)
             if det.accepted and accepted_after is None:
                 accepted_after = upd
-        sweep = {"windows_per_s_autocorr_kernels": round(nwin * max(1, prof_steps) / (ac_ms * 1e-3), 1) if prof else None,
-                 "windows_per_s_whole_step": round(nwin * world / (ms_step * 1e-3), 1),
+        sweep = {"windows_per_s_autocorr_kernels": round(nwin / (ac_ms * 1e-3), 1) if ac_ms else None,
+                 "windows_per_s_whole_pass": round(nwin * world / (ms_pass * 1e-3), 1),
                  "plot_updates_to_acceptance": accepted_after,
-                 "time_to_detection_ms": round(accepted_after * ms_step, 3) if accepted_after else None,
+                 "time_to_detection_ms": round(accepted_after * ms_pass, 3) if accepted_after else None,
                  "mode": det.mode_name.decode(errors="replace") if det.mode_id >= 0 else None}
+        srt = sorted(step_s)
         res = {
             "metric": ("IQ Msamples/s (+ reconstructed frames/s), 1080p60 target: demod+resample+frame post-processing+full "
                        "autocorrelation") if args.config == 2 else
@@ -422,32 +502,40 @@ def main():
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl_name} (h={h} -> {W}x{h} frames), {args.seconds:g} s batch resident in HBM, "
-                                   f"{nchunks} resample chunks, {nwin} autocorrelation windows of N=2^{int(np.log2(N))} per step",
-                       "samples_per_step_per_gpu": nsamples, "stage_order": "library default (autogain, sync, IIR)"},
+                                   f"{nchunks} resample chunks, {nwin} autocorrelation windows of N=2^{int(np.log2(N))} per pass; "
+                                   f"a step = {args.passes} passes = {args.passes * args.seconds:g} s of signal",
+                       "samples_per_step_per_gpu": nsamples * args.passes, "passes_per_step": args.passes,
+                       "stage_order": "library default (autogain, sync, IIR)",
+                       "sync_detector": "fast (toss-ups not redone)" if args.fast_sync else
+                                        "contract-exact: toss-up decisions redone with the reference's own strip sums (library default)",
+                       "autocorrelation": f"float32 transform, {trips.split(' ')[0]}-trip plan (the engine's default detector "
+                                          "uses the bit-exact form, see exact_autocorr)"},
+            "ms_per_pass": round(ms_pass, 4),
+            "step_ms": {"min": round(srt[0] * 1e3, 3), "median": round(srt[len(srt) // 2] * 1e3, 3), "max": round(srt[-1] * 1e3, 3),
+                        "timed_region_s": round(dt, 3)},
             "frames_per_s": round(frames_total / dt, 1),
             "realtime_factor": round(total_samples / dt / fs / world, 2),
             "roofline": roofline,
-            "frame_path": {"kernels_ms_per_step": round(frame_kernels_ms / max(1, prof_steps), 3),
-                           "achieved_GBs": round(frame_path_bytes / (frame_kernels_ms * 1e-3) / 1e9, 1) if frame_kernels_ms else None,
-                           "frac": round(frame_path_bytes / (frame_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_kernels_ms else None,
-                           "alg_bytes_per_frame": int(8 * S + 16 * P),
+            "kernels": kernels,
+            "frame_path": {"kernels_ms_per_pass": round(frame_ms, 4),
+                           "achieved_GBs": round(frame_bytes_pass / (frame_ms * 1e-3) / 1e9, 1) if frame_ms else None,
+                           "frac": round(frame_bytes_pass / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_ms else None,
+                           "alg_bytes_per_frame": int(8 * S + 16 * P), "frames_per_pass": round(frames_pass, 3),
                            "chain": "on the side stream, overlapped with the autocorrelation" if chain_hidden else "in line",
                            "statistics": "min/max in k_rs_area, row/column sums in the normalise/IIR pass (12P bytes per frame "
                                          "instead of 16P)" if fused else "k_frame_stats"},
-            "autocorrelation": {"kernels_ms_per_step": round(ac_ms / max(1, prof_steps), 3),
-                                "achieved_GBs": round(ac_bytes_step / (ac_ms * 1e-3) / 1e9, 1),
-                                "frac": round(ac_bytes_step / (ac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "alg_bytes_per_window": int(28 * N + 16 * L),
-                                "fft_pass_launches_per_step": prof.get("k_fft_lds", (0, 0))[1] // max(1, prof_steps),
-                                "note": "28N+16L assumes one HBM pass per transform; N=2^22 needs 3 radix-128 passes each way "
-                                        "(the middle two fused into k_ac_mid), i.e. 5 passes over the packed spectrum"},
-            "stage_ms_per_step": stage_ms,
+            "autocorrelation": autocorr,
+            "whole_pass": {"alg_bytes": int(frame_bytes_pass + ac_bytes_pass),
+                           "achieved_GBs": round((frame_bytes_pass + ac_bytes_pass) / (ms_pass * 1e-3) / 1e9, 1),
+                           "frac": round((frame_bytes_pass + ac_bytes_pass) / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "stage_ms_per_pass": stage_ms,
             "detected": {"frame_lag": int(flag), "line_lag": int(llag), "framerate": round(fs / flag, 4),
                          "height": int(round(flag / llag)), "linerate": round(fs / llag, 2)},
             # the sweep of config 4 (same stream, mode unknown): windows correlated per second of wall clock by the
             # autocorrelation kernels alone, and the GUI's acceptance rule (same fps/height seen 3 times before,
-            # Main.java:1233-1277) applied to one plot update per step
+            # Main.java:1233-1277) applied to one plot update per pass
             "sweep": sweep,
+            "exact_autocorr": exact_ac,
             "device": g.device_name(),
         }
         if world == 1 and not args.no_cpu_baseline and not args.force_dist:

@@ -228,6 +228,13 @@ int tsdrgpu_autocorr_set_async(tsdrgpu_autocorr_t *ac, int on);
  * recurrence) and plots, argmax and tsdrgpu_autocorr_last_corr are BIT-IDENTICAL to the reference's.  About 7x
  * slower (0.24 ms per 2^22-sample window); builds a table of N-1 f64 twiddle pairs (64 MB at 100 MS/s) on first use. */
 int tsdrgpu_autocorr_set_exact(tsdrgpu_autocorr_t *ac, int on);
+/* Transform plan of the default (non-exact) form.  3 (default where it applies: capture windows of 2^17 ..
+ * 2^23 samples, i.e. 2.4 .. 297 MS/s): the packed window of nh = N/2 complex points is treated as an
+ * (nh/4096) x 4096 matrix — column DFTs, then the row pairs (k, nh-k) with the packed-real split, 1/N, the
+ * magnitude and the inverse row DFTs fused in LDS, then column DFTs storing only the two lag windows: three
+ * trips over HBM per window.  5: the Stockham radix-128 plan of round 1 (three passes each way, the middle two
+ * fused), also what other sizes fall back to.  Same tolerance either way. */
+int tsdrgpu_autocorr_set_plan(tsdrgpu_autocorr_t *ac, int trips);
 int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line,
                            uint64_t *h_calls); /* syncs */
 /* device plots: frame_len + line_len doubles, contiguous (frame first) */

@@ -1,0 +1,427 @@
+// fft4step.h — register DFTs, twiddle helpers and the THREE-TRIP ("four-step") plan of the
+// autocorrelation (fft_autocorrelation, TempestSDR/src/fft.c:49-64) for gfx950.
+//
+// The capture window (real, N samples) is transformed as nh = N/2 complex points
+// z[m] = x[2m] + i x[2m+1] (tsdrgpu_fft.hip explains the packed-real split).  With nh = N1 * N2,
+// N2 = 4096, input index n = N2*n1 + n2 and output index k = k1 + N1*k2:
+//
+//   Z[k1 + N1 k2] = sum_n2 w_N2^(n2 k2) [ w_nh^(n2 k1) sum_n1 z[N2 n1 + n2] w_N1^(n1 k1) ]
+//
+//   trip 1  k_ac_cols<.., false>   column DFTs of length N1 over n1 (rows N2 apart, tiles of C >= 16
+//                                  neighbouring columns = runs of >= 128 bytes), am_demod fused into the
+//                                  load; Y[k1][n2] stored at [k1*N2 + n2]
+//   trip 2  k_ac_rows              for the row pair (k1, N1-k1), 16 KiB contiguous each: twiddle
+//                                  w_nh^(n2 k1), DFT-4096 in LDS, the packed-real split / 1/N /
+//                                  magnitude / re-pack on the pairs Z[k] <-> Z[nh-k] (which live in
+//                                  exactly these two rows), the DFT-4096 of the inverse transform and
+//                                  its twiddle; stored in place
+//   trip 3  k_ac_cols<.., true>    column DFTs over k1; conjugate; only the two lag windows the
+//                                  detector reads (frameratedetector.c:115-118) are stored
+//
+// i.e. 8N + 4N | 4N + 4N | 4N + (lags) bytes per window with fused demodulation — below SURVEY 8(d)'s
+// one-pass-per-transform figure of 28N + 16L, where the previous plan (three radix-128 Stockham passes
+// each way, the middle two fused) made five trips.
+//
+// Everything here is plain C++ over float2 so that tests/emu can run the very same kernels on the CPU
+// (threads = pthreads, __shared__ = static, __syncthreads = barrier) against numpy before a GPU sees them.
+#pragma once
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+
+// ---------------------------------------------------------------------------
+// small DFTs in registers (forward, e^{-2 pi i/R}), outputs in natural order
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void dft2(float2 &a, float2 &b)
+{
+    const float2 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+
+__device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+{
+    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
+    const float2 s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+    a0 = cadd(s02, s13);
+    a1 = cadd(d02, d13);
+    a2 = csub(s02, s13);
+    a3 = csub(d02, d13);
+}
+
+template <int R>
+__device__ __forceinline__ void dft_reg(float2 (&v)[R]);
+
+template <>
+__device__ __forceinline__ void dft_reg<1>(float2 (&v)[1]) {}
+template <>
+__device__ __forceinline__ void dft_reg<2>(float2 (&v)[2]) { dft2(v[0], v[1]); }
+template <>
+__device__ __forceinline__ void dft_reg<4>(float2 (&v)[4]) { dft4(v[0], v[1], v[2], v[3]); }
+
+template <>
+__device__ __forceinline__ void dft_reg<8>(float2 (&v)[8])
+{
+    // 8 = 2 x 4: X[k1 + 2*k2] = sum_{n2<4} w8^{n2*k1} (sum_{n1<2} x[4*n1+n2] w2^{n1 k1}) w4^{n2 k2}
+    const float h = 0.70710678118654752440f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft2(v[n2], v[n2 + 4]);
+    v[5] = cmul(v[5], make_float2(h, -h));
+    v[6] = mul_mi(v[6]);
+    v[7] = cmul(v[7], make_float2(-h, -h));
+    dft4(v[0], v[1], v[2], v[3]);  // k1 = 0 -> X[0], X[2], X[4], X[6]
+    dft4(v[4], v[5], v[6], v[7]);  // k1 = 1 -> X[1], X[3], X[5], X[7]
+    const float2 x0 = v[0], x2 = v[1], x4 = v[2], x6 = v[3];
+    const float2 x1 = v[4], x3 = v[5], x5 = v[6], x7 = v[7];
+    v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6; v[7] = x7;
+}
+
+template <>
+__device__ __forceinline__ void dft_reg<16>(float2 (&v)[16])
+{
+    // 16 = 4 x 4: a[n2][k1] = DFT4 over n1 of x[4*n1+n2]; times w16^{n2*k1}; X[k1+4*k2] = DFT4 over n2
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft4(v[n2], v[n2 + 4], v[n2 + 8], v[n2 + 12]);
+    v[5] = cmul(v[5], make_float2(c1, -s1));     // n2=1,k1=1: w^1
+    v[6] = cmul(v[6], make_float2(h, -h));       // n2=2,k1=1: w^2
+    v[7] = cmul(v[7], make_float2(s1, -c1));     // n2=3,k1=1: w^3
+    v[9] = cmul(v[9], make_float2(h, -h));       // n2=1,k1=2: w^2
+    v[10] = mul_mi(v[10]);                       // n2=2,k1=2: w^4
+    v[11] = cmul(v[11], make_float2(-h, -h));    // n2=3,k1=2: w^6
+    v[13] = cmul(v[13], make_float2(s1, -c1));   // n2=1,k1=3: w^3
+    v[14] = cmul(v[14], make_float2(-h, -h));    // n2=2,k1=3: w^6
+    v[15] = cmul(v[15], make_float2(-c1, s1));   // n2=3,k1=3: w^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+    float2 t[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) t[k1 + 4 * k2] = v[4 * k1 + k2];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = t[i];
+}
+
+// ---------------------------------------------------------------------------
+// twiddles: exp(-2 pi i e / span) for a power-of-two span, from an exactly representable dyadic fraction
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float2 tw_exact(unsigned e, unsigned mask, float inv)
+{
+    float sn, cs;
+    sincospif((float)(e & mask) * inv, &sn, &cs);
+    return make_float2(cs, sn);
+}
+
+// pw[i] = w^(e1*i), i < M (a power of two): log2(M) accurate evaluations, the rest complex products of
+// depth <= log2(M)-1 (a few f32 ulps)
+template <int M>
+__device__ __forceinline__ void tw_powers(float2 (&pw)[M], unsigned e1, unsigned mask, float inv)
+{
+    pw[0] = make_float2(1.f, 0.f);
+#pragma unroll
+    for (int bit = 1; bit < M; bit <<= 1) {
+        pw[bit] = tw_exact(e1 * (unsigned)bit, mask, inv);
+#pragma unroll
+        for (int i = bit + 1; i < 2 * bit; i++) pw[i] = cmul(pw[bit], pw[i - bit]);
+    }
+}
+
+// Output filter of a transform's last pass: when `on`, only outputs whose index lies in one of two
+// ranges are stored (the autocorrelation reads nothing but its two lag windows, frameratedetector.c:
+// 115-118), except for transform `full_b` of the batch, which is stored whole.
+struct FftKeep {
+    int on;
+    int full_b;
+    unsigned lo0, hi0, lo1, hi1;
+};
+
+// Packed-real split of the autocorrelation (see tsdrgpu_fft.hip): A = Z[k], bm = Z[nh-k],
+// wk = exp(-i pi k/nh); returns Zin[k] (*zk) and Zin[nh-k] (*zkm) of the inverse transform's input.
+__device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, unsigned nh, float2 *zk, float2 *zkm)
+{
+    const float inv_n = 1.0f / (float)(2 * nh);
+    const float2 b = make_float2(bm.x, -bm.y);
+    const float cs = wk.x, sn = wk.y;
+    const float2 sum = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+    const float2 dif = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+    const float2 t = cmul(make_float2(cs, sn), dif);
+    const float2 xk = make_float2(sum.x + t.y, sum.y - t.x);
+    const float2 xm = make_float2(sum.x - t.y, -(sum.y + t.x));
+    const float mk = sqrtf(xk.x * xk.x + xk.y * xk.y) * inv_n;
+    const float mm = sqrtf(xm.x * xm.x + xm.y * xm.y) * inv_n;
+    const float s = mk + mm, d = mk - mm;
+    *zk = make_float2(s + sn * d, cs * d);
+    *zkm = make_float2(s - sn * d, cs * d);
+}
+
+// ---------------------------------------------------------------------------
+// trips 1 and 3: column DFTs of length N1 = 2^LOGN1 (16..1024), rows N2 = nh/N1 elements apart.
+// A workgroup owns C neighbouring columns (C = 16 for N1 >= 256, else 4096/N1: at least 4096 points);
+// every thread holds 16 points.  Stockham passes of radix {2,4,8 first if log2(N1) is no multiple of
+// 4, then 16 ...} with the tile exchanged through LDS as [point][column] between passes: the first pass
+// loads from global memory, the last one stores to it, so a 512-point column costs two LDS round trips.
+//   IN_MODE 0: complex input (trip 3)
+//   IN_MODE 3: real samples packed two per point; IN_MODE 4: the same, demodulated from interleaved IQ
+//              (am_demod, TSDRLibrary.c:244-262) — trip 1
+//   LAST: conjugate the result and store only what `keep` asks for (trip 3)
+// ---------------------------------------------------------------------------
+#define AC4_ROW 4096u  // N2: the row length of the plan
+
+template <int LOGN1>
+struct ColGeom {
+    static constexpr unsigned N1 = 1u << LOGN1;
+    static constexpr unsigned C = (N1 >= 256u) ? 16u : 4096u / N1;
+    static constexpr unsigned NT = N1 * C / 16u;  // threads per workgroup
+    static constexpr unsigned Q = N1 / 16u;
+    static constexpr int R0 = (LOGN1 % 4) ? (1 << (LOGN1 % 4)) : 16;  // radix of the first pass
+    static constexpr int NP = (LOGN1 + 3) / 4;                       // passes
+};
+
+template <int IN_MODE>
+__device__ __forceinline__ float2 ac4_load(const void *__restrict__ base, long long at, bool al16)
+{
+    if (IN_MODE == 0) return ((const float2 *)base)[at];
+    if (IN_MODE == 3) {
+        const float *x = (const float *)base;
+        return make_float2(x[2 * at], x[2 * at + 1]);
+    }
+    const float2 *x = (const float2 *)base;
+    float2 a, b;
+    if (al16) {
+        const float4 t = *reinterpret_cast<const float4 *>(x + 2 * at);
+        a = make_float2(t.x, t.y);
+        b = make_float2(t.z, t.w);
+    } else {
+        a = x[2 * at];
+        b = x[2 * at + 1];
+    }
+    return make_float2(sqrtf(a.x * a.x + a.y * a.y), sqrtf(b.x * b.x + b.y * b.y));
+}
+
+template <int LOGN1, int IN_MODE, bool LAST>
+__global__ __launch_bounds__(ColGeom<LOGN1>::NT) void k_ac_cols(const void *__restrict__ xin, long long in_stride,
+                                                                float2 *__restrict__ y, unsigned nh, FftKeep keep)
+{
+    typedef ColGeom<LOGN1> G;
+    constexpr unsigned N1 = G::N1, C = G::C, NT = G::NT, Q = G::Q;
+    constexpr int R0 = G::R0, NP = G::NP, G0 = 16 / R0;
+    __shared__ float2 L[N1 * C];
+    __shared__ float2 twN[N1];
+    const unsigned N2 = nh / N1;
+    const unsigned tid = threadIdx.x;
+    const unsigned c = tid % C, q = tid / C;
+    const unsigned b = blockIdx.y;
+    // consecutive tiles go to the same XCD (workgroups are dealt round-robin to the 8 XCDs): the IQ rows
+    // of a window start on 8-byte boundaries only, so neighbouring tiles share a cache line at each end
+    const unsigned gx = gridDim.x;
+    const unsigned tile = (gx % 8u == 0u) ? (blockIdx.x % 8u) * (gx / 8u) + blockIdx.x / 8u : blockIdx.x;
+    const unsigned col = tile * C + c;
+    for (unsigned e = tid; e < N1; e += NT) {
+        float sn, cs;
+        sincospif(-2.0f * (float)e / (float)N1, &sn, &cs);
+        twN[e] = make_float2(cs, sn);
+    }
+    const void *xb;
+    bool al16 = false;
+    if (IN_MODE == 0) xb = (const void *)((const float2 *)xin + (long long)b * in_stride);
+    else if (IN_MODE == 3) xb = (const void *)((const float *)xin + (long long)b * in_stride);
+    else {
+        xb = (const void *)((const float2 *)xin + (long long)b * in_stride);
+        al16 = (((unsigned long long)xb) & 15ull) == 0ull;
+    }
+    float2 *yb = y + (long long)b * nh;
+
+    float2 v[16];
+    // ---- pass 0 (Ns = 1, radix R0): butterfly a of this thread is column point jb = q + Q*a
+#pragma unroll
+    for (int a = 0; a < G0; a++)
+#pragma unroll
+        for (int t = 0; t < R0; t++) {
+            const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
+            v[a * R0 + t] = ac4_load<IN_MODE>(xb, (long long)row * N2 + col, al16);
+        }
+#pragma unroll
+    for (int a = 0; a < G0; a++) dft_reg<R0>(*reinterpret_cast<float2(*)[R0]>(&v[a * R0]));
+
+    if (NP > 1) {
+#pragma unroll
+        for (int a = 0; a < G0; a++)
+#pragma unroll
+            for (int u = 0; u < R0; u++) L[((q + Q * (unsigned)a) * (unsigned)R0 + (unsigned)u) * C + c] = v[a * R0 + u];
+        __syncthreads();  // tile and twN[] complete
+        unsigned Ns = (unsigned)R0;
+#pragma unroll
+        for (int pass = 1; pass < NP; pass++) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) v[t] = L[(q + (unsigned)t * Q) * C + c];
+            const unsigned k = q & (Ns - 1u);
+            const unsigned unit = N1 / (Ns * 16u);
+#pragma unroll
+            for (int t = 1; t < 16; t++) v[t] = cmul(v[t], twN[((unsigned)t * k * unit) & (N1 - 1u)]);
+            dft_reg<16>(v);
+            if (pass < NP - 1) {
+                __syncthreads();  // every read of this pass done before the tile is overwritten
+#pragma unroll
+                for (int u = 0; u < 16; u++) L[((q - k) * 16u + k + (unsigned)u * Ns) * C + c] = v[u];
+                __syncthreads();
+                Ns *= 16u;
+            }
+        }
+    }
+    // ---- store: the last pass has Ns*R = N1, so thread q holds rows q + u*(N1/16) (R0 outputs per
+    // butterfly when the only pass is pass 0)
+    constexpr int RL = (NP > 1) ? 16 : R0;  // radix of the last pass
+    constexpr int GL = 16 / RL;
+#pragma unroll
+    for (int a = 0; a < GL; a++)
+#pragma unroll
+        for (int u = 0; u < RL; u++) {
+            const unsigned row = q + Q * (unsigned)a + (unsigned)u * (N1 / (unsigned)RL);
+            const unsigned m = row * N2 + col;
+            float2 o = v[a * RL + u];
+            if (LAST) {
+                o.y = -o.y;
+                if (keep.on && (int)b != keep.full_b && !((m >= keep.lo0 && m < keep.hi0) || (m >= keep.lo1 && m < keep.hi1))) continue;
+            }
+            yb[m] = o;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// trip 2: one workgroup of 512 threads per row pair (k1, N1-k1); threads 0..255 own row k1, 256..511
+// its mirror.  Workgroup 0 takes the two rows that mirror onto themselves (k1 = 0 and k1 = N1/2).
+// DFT-4096 = three radix-16 Stockham passes; thread j holds points j + 256 t before and after.
+// The row buffers are padded by one element per 16 so that the stride-16 stores of the first pass
+// spread over the banks.
+// ---------------------------------------------------------------------------
+// Row buffers are padded by one element per 16 (index p lives at p + (p >> 4)), so that the stride-16
+// stores of the first pass spread over the banks.  The padded positions are written out as base + constant
+// (e.g. pad(j + 256 t) = j + (j >> 4) + 272 t) so that they become immediate offsets of the DS instructions.
+#define AC4_ROWBUF (4096 + 256 + 16)
+
+// keeps the compiler from carrying the first transform's address registers through to the second one
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AC4_LAUNDER(x) asm volatile("" : "+v"(x))
+#else
+#define AC4_LAUNDER(x) (void)(x)
+#endif
+
+// in: v[t] = x[j + 256 t]; out: v[u] = X[j + 256 u].  All threads of the workgroup must call it (barriers);
+// Lr is the caller's row buffer, which must not be in use on entry.  Twiddles come from two 256-entry
+// LDS tables, tw256[e] = w_256^e and tw4k[e] = w_4096^e (e < 256): no transcendental per point.
+__device__ __forceinline__ void ac4_fft4096(float2 (&v)[16], float2 *Lr, unsigned j, const float2 *tw256, const float2 *tw4k)
+{
+    const unsigned k = j & 15u, jh = j >> 4;
+    float2 *const Lj = Lr + (j + jh);  // pad(j + 256 t) = j + (j >> 4) + 272 t
+    dft_reg<16>(v);  // pass 0, Ns = 1: pad(16 j + u) = 17 j + u
+    {
+        float2 *const Lw = Lr + 17u * j;
+#pragma unroll
+        for (int u = 0; u < 16; u++) Lw[u] = v[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = Lj[272 * t];
+    // pass 1, Ns = 16: w_256^(t k)
+#pragma unroll
+    for (int t = 1; t < 16; t++) v[t] = cmul(v[t], tw256[(unsigned)t * k]);
+    dft_reg<16>(v);
+    __syncthreads();
+    {   // pad(256 jh + k + 16 u) = 272 jh + k + 17 u
+        float2 *const Lw = Lr + (272u * jh + k);
+#pragma unroll
+        for (int u = 0; u < 16; u++) Lw[17 * u] = v[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = Lj[272 * t];
+    // pass 2, Ns = 256: w_4096^(t j) = w_256^(t (j >> 4)) * w_4096^(t (j & 15))
+#pragma unroll
+    for (int t = 1; t < 16; t++) v[t] = cmul(v[t], cmul(tw256[((unsigned)t * jh) & 255u], tw4k[(unsigned)t * k]));
+    dft_reg<16>(v);
+}
+
+// v[t] *= w_nh^(k1 (j + 256 t)) = base * srow[t]: the twiddle between the column and the row transforms
+// (both directions); base = w_nh^(k1 j) is the thread's own, srow[t] = w_nh^(256 k1 t) the row's (LDS).
+__device__ __forceinline__ void ac4_row_twiddle(float2 (&v)[16], float2 base, const float2 *srow)
+{
+    v[0] = cmul(v[0], base);
+#pragma unroll
+    for (int t = 1; t < 16; t++) v[t] = cmul(v[t], cmul(base, srow[t]));
+}
+
+__global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsigned nh)
+{
+    __shared__ float2 buf[2][AC4_ROWBUF];
+    __shared__ float2 tw256[256], tw4k[256];
+    __shared__ float2 srow[2][16];
+    const unsigned N1 = nh / AC4_ROW;
+    const unsigned tid = threadIdx.x, half = tid >> 8, j = tid & 255u;
+    const unsigned wg = blockIdx.x;
+    const bool selfpair = wg == 0;
+    const unsigned k1 = selfpair ? (half ? N1 / 2u : 0u) : (half ? N1 - wg : wg);
+    float2 *zrow = z + (long long)blockIdx.y * nh + (long long)k1 * AC4_ROW;
+    float2 *Lr = buf[half];
+    float2 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = zrow[j + 256u * (unsigned)t];
+    {
+        float sn, cs;
+        if (half == 0u) {
+            sincospif(-(float)j * (1.0f / 128.0f), &sn, &cs);
+            tw256[j] = make_float2(cs, sn);
+        } else {
+            sincospif(-(float)j * (1.0f / 2048.0f), &sn, &cs);
+            tw4k[j] = make_float2(cs, sn);
+        }
+        if (j < 16u) srow[half][j] = tw_exact(256u * k1 * j, nh - 1u, -2.0f / (float)nh);
+    }
+    const float2 base = tw_exact(k1 * j, nh - 1u, -2.0f / (float)nh);
+    __syncthreads();  // tables ready
+    ac4_row_twiddle(v, base, srow[half]);
+    ac4_fft4096(v, Lr, j, tw256, tw4k);  // v[u] = Z[k1 + N1 (j + 256 u)]
+    __syncthreads();
+    {
+        float2 *const Lj = Lr + (j + (j >> 4));
+#pragma unroll
+        for (int u = 0; u < 16; u++) Lj[272 * u] = v[u];
+    }
+    __syncthreads();
+    // split: Z[k] pairs with Z[nh-k]: (k1, k2) <-> (N1-k1, N2-1-k2), for k1 = 0: (0, (N2-k2) mod N2)
+    {
+        const float2 *Lp = selfpair ? Lr : buf[1u - half];
+        float sn, cs;
+        sincospif(-(float)(k1 + N1 * j) * (1.0f / (float)nh), &sn, &cs);  // exp(-i pi k/nh), k = k1 + N1 (j + 256 u)
+        const float2 w0 = make_float2(cs, sn);
+        // partner of k2 = j + 256 u: pb - 256 u with pb = 4095 - j (row 0: 4096 - j; its k2 = 0 would wrap to 0,
+        // but that element takes the special formula below and ignores the partner), padded like everything else
+        const unsigned pb = ((selfpair && half == 0u) ? AC4_ROW : AC4_ROW - 1u) - j;
+        const float2 *const Lq = Lp + (pb + (pb >> 4)) - 272u * 15u;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const float2 bm = Lq[272 * (15 - u)];
+            const float2 wk = u ? cmul(w0, tw256[8u * (unsigned)u]) : w0;  // times exp(-i pi u/16)
+            float2 zk, zkm;
+            ac_split_pair(v[u], bm, wk, nh, &zk, &zkm);
+            if (u == 0 && k1 == 0u && j == 0u) {
+                const float inv_n = 1.0f / (float)(2u * nh);
+                const float m0 = fabsf(v[0].x + v[0].y) * inv_n;  // X[0]  = Re Z0 + Im Z0
+                const float mh = fabsf(v[0].x - v[0].y) * inv_n;  // X[nh] = Re Z0 - Im Z0
+                zk = make_float2(m0 + mh, m0 - mh);
+            }
+            v[u] = make_float2(zk.x, -zk.y);  // conjugated input: inverse = conj(FFT(conj(.)))
+        }
+    }
+    __syncthreads();  // partner reads done before the buffers are reused
+    unsigned j2 = j;
+    AC4_LAUNDER(j2);
+    ac4_fft4096(v, Lr, j2, tw256, tw4k);
+    // row k1 of the inverse's input side, output position n2 = j + 256 u, times w_nh^(n2 k1); the
+    // conjugation that completes the inverse is applied by trip 3 after ITS forward column transform
+    ac4_row_twiddle(v, base, srow[half]);
+#pragma unroll
+    for (int u = 0; u < 16; u++) zrow[j2 + 256u * (unsigned)u] = v[u];
+}

@@ -138,7 +138,7 @@ extern "C" int tsdrgpu_timer_stop_ms(tsdrgpu_t *g, float *ms)
 // ---------------------------------------------------------------------------
 static const char *const kStageNames[PROF_COUNT] = {"k_demod", "k_rs_tail+k_rs_chain", "k_rs_area", "k_rs_nearest",
                                                     "k_frame_stats", "k_frame_reduce", "k_chain", "k_frame_pass",
-                                                    "k_fft_lds", "k_ac_mid", "k_accumulate", "superb_misc", "k_argmax", "extras"};
+                                                    "k_fft_lds", "k_ac_mid", "k_ac_cols", "k_ac_rows", "k_accumulate", "superb_misc", "k_argmax", "extras"};
 
 void prof_pair(tsdrgpu_t *g, int stage, hipEvent_t *a, hipEvent_t *b)
 {

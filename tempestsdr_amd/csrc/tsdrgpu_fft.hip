@@ -10,6 +10,7 @@
 // radix-2 stage with f64 butterflies, so the two differ at the 1e-7 level of
 // the largest term (tolerance stated in tests/test_gpu_autocorr.py).
 #include "tsdrgpu_internal.h"
+#include "fft4step.h"
 
 #define AC_SUBBATCH 8
 
@@ -31,6 +32,7 @@ struct tsdrgpu_autocorr {
     double *d_pval;  // argmax partials
     int *d_pidx;
     hipStream_t st;  // g->stream, or g->stream2 when set asynchronous
+    int plan5;       // tsdrgpu_autocorr_set_plan: 1 = the five-trip Stockham plan even where the three-trip one applies
     // exact mode (tsdrgpu_autocorr_set_exact, tsdrgpu_fftx.hip)
     int exact;
     double2 *d_tw;   // the reference's twiddle recurrence values, n-1 entries
@@ -39,9 +41,7 @@ struct tsdrgpu_autocorr {
 };
 #define AC_XBATCH 4
 
-// ---------------------------------------------------------------------------
-// small DFTs in registers (forward, e^{-2 pi i/R})
-// ---------------------------------------------------------------------------
+// (register DFTs, twiddle helpers and the three-trip autocorrelation kernels: fft4step.h)
 template <int IN_MODE>
 __device__ __forceinline__ float2 fft_load(const void *__restrict__ xin, long long base, long long at)
 {
@@ -58,86 +58,6 @@ __device__ __forceinline__ float2 fft_load(const void *__restrict__ xin, long lo
     const float2 *x = (const float2 *)xin + base;
     const float2 a = x[2 * at], b = x[2 * at + 1];
     return make_float2(sqrtf(a.x * a.x + a.y * a.y), sqrtf(b.x * b.x + b.y * b.y));
-}
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-
-__device__ __forceinline__ void dft2(float2 &a, float2 &b)
-{
-    const float2 t = a;
-    a = cadd(t, b);
-    b = csub(t, b);
-}
-
-__device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
-{
-    // outputs in natural order
-    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
-    const float2 s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
-    a0 = cadd(s02, s13);
-    a1 = cadd(d02, d13);
-    a2 = csub(s02, s13);
-    a3 = csub(d02, d13);
-}
-
-template <int R>
-__device__ __forceinline__ void dft_reg(float2 (&v)[R]);
-
-template <>
-__device__ __forceinline__ void dft_reg<1>(float2 (&v)[1]) {}
-template <>
-__device__ __forceinline__ void dft_reg<2>(float2 (&v)[2]) { dft2(v[0], v[1]); }
-template <>
-__device__ __forceinline__ void dft_reg<4>(float2 (&v)[4]) { dft4(v[0], v[1], v[2], v[3]); }
-
-template <>
-__device__ __forceinline__ void dft_reg<8>(float2 (&v)[8])
-{
-    // 8 = 2 x 4: X[k1 + 2*k2] = sum_{n2<4} w8^{n2*k1} (sum_{n1<2} x[4*n1+n2] w2^{n1 k1}) w4^{n2 k2}
-    const float h = 0.70710678118654752440f;
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) dft2(v[n2], v[n2 + 4]);
-    // twiddles w8^{n2} on the k1 = 1 row (v[4..7])
-    v[5] = cmul(v[5], make_float2(h, -h));
-    v[6] = mul_mi(v[6]);
-    v[7] = cmul(v[7], make_float2(-h, -h));
-    dft4(v[0], v[1], v[2], v[3]);  // k1 = 0 -> X[0], X[2], X[4], X[6]
-    dft4(v[4], v[5], v[6], v[7]);  // k1 = 1 -> X[1], X[3], X[5], X[7]
-    const float2 x0 = v[0], x2 = v[1], x4 = v[2], x6 = v[3];
-    const float2 x1 = v[4], x3 = v[5], x5 = v[6], x7 = v[7];
-    v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6; v[7] = x7;
-}
-
-template <>
-__device__ __forceinline__ void dft_reg<16>(float2 (&v)[16])
-{
-    // 16 = 4 x 4: a[n2][k1] = DFT4 over n1 of x[4*n1+n2]; times w16^{n2*k1}; X[k1+4*k2] = DFT4 over n2
-    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) dft4(v[n2], v[n2 + 4], v[n2 + 8], v[n2 + 12]);
-    // now v[n2 + 4*k1] = a[n2][k1]; multiply by w16^{n2*k1}
-    v[5] = cmul(v[5], make_float2(c1, -s1));     // n2=1,k1=1: w^1
-    v[6] = cmul(v[6], make_float2(h, -h));       // n2=2,k1=1: w^2
-    v[7] = cmul(v[7], make_float2(s1, -c1));     // n2=3,k1=1: w^3
-    v[9] = cmul(v[9], make_float2(h, -h));       // n2=1,k1=2: w^2
-    v[10] = mul_mi(v[10]);                       // n2=2,k1=2: w^4
-    v[11] = cmul(v[11], make_float2(-h, -h));    // n2=3,k1=2: w^6
-    v[13] = cmul(v[13], make_float2(s1, -c1));   // n2=1,k1=3: w^3
-    v[14] = cmul(v[14], make_float2(-h, -h));    // n2=2,k1=3: w^6
-    v[15] = cmul(v[15], make_float2(-c1, s1));   // n2=3,k1=3: w^9
-#pragma unroll
-    for (int k1 = 0; k1 < 4; k1++) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
-    // v[4*k1 + k2] = X[k1 + 4*k2] -> transpose to natural order
-    float2 t[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 4; k1++)
-#pragma unroll
-        for (int k2 = 0; k2 < 4; k2++) t[k1 + 4 * k2] = v[4 * k1 + k2];
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = t[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -209,25 +129,6 @@ __global__ __launch_bounds__(256) void k_fft_pass(const void *__restrict__ xin, 
 // The exponent factors as (q*G)*k + a*k + (16*i)*k, so 1 + log2(G) + log2(R1) = 5 accurately evaluated
 // sincospif's (powers of two of each factor) and a few complex products replace 16 evaluations; a
 // product chain is at most 4 deep, i.e. a few f32 ulps.  (The passes were VALU-bound on sincospif.)
-__device__ __forceinline__ float2 tw_exact(unsigned e, unsigned mask, float inv)
-{
-    float sn, cs;
-    sincospif((float)(e & mask) * inv, &sn, &cs);
-    return make_float2(cs, sn);
-}
-
-template <int M>
-__device__ __forceinline__ void tw_powers(float2 (&pw)[M], unsigned e1, unsigned mask, float inv)
-{
-    pw[0] = make_float2(1.f, 0.f);
-#pragma unroll
-    for (int bit = 1; bit < M; bit <<= 1) {
-        pw[bit] = tw_exact(e1 * (unsigned)bit, mask, inv);
-#pragma unroll
-        for (int i = bit + 1; i < 2 * bit; i++) pw[i] = cmul(pw[bit], pw[i - bit]);
-    }
-}
-
 template <int R1>
 __device__ __forceinline__ void outer_twiddles(float2 (&v)[16], unsigned q, unsigned k, unsigned span)
 {
@@ -246,14 +147,6 @@ __device__ __forceinline__ void outer_twiddles(float2 (&v)[16], unsigned q, unsi
     }
 }
 
-// Output filter of a transform's last pass: when `on`, only outputs whose index lies in one of two
-// ranges are stored (the autocorrelation reads nothing but its two lag windows, frameratedetector.c:
-// 115-118), except for transform `full_b` of the batch, which is stored whole.
-struct FftKeep {
-    int on;
-    int full_b;
-    unsigned lo0, hi0, lo1, hi1;
-};
 static const FftKeep KEEP_ALL = {0, -1, 0u, 0u, 0u, 0u};
 
 template <int R1, int IN_MODE, bool OUT_MAG>
@@ -573,24 +466,6 @@ __global__ __launch_bounds__(256) void k_ac_split(float2 *__restrict__ z, unsign
 // Column 0 mirrors onto itself and is handled by workgroup 0 (ac_mid_col0).  Saves writing the spectrum,
 // the k_ac_split round trip and re-reading it: 64 of 224 MB per 2^22-sample window.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, unsigned nh, float2 *zk, float2 *zkm)
-{
-    // see k_ac_split: A = Z[k], B = conj(Z[nh-k]), wk = exp(-i pi k/nh); returns Zin[k], Zin[nh-k]
-    const float inv_n = 1.0f / (float)(2 * nh);
-    const float2 b = make_float2(bm.x, -bm.y);
-    const float cs = wk.x, sn = wk.y;
-    const float2 sum = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-    const float2 dif = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-    const float2 t = cmul(make_float2(cs, sn), dif);
-    const float2 xk = make_float2(sum.x + t.y, sum.y - t.x);
-    const float2 xm = make_float2(sum.x - t.y, -(sum.y + t.x));
-    const float mk = sqrtf(xk.x * xk.x + xk.y * xk.y) * inv_n;
-    const float mm = sqrtf(xm.x * xm.x + xm.y * xm.y) * inv_n;
-    const float s = mk + mm, d = mk - mm;
-    *zk = make_float2(s + sn * d, cs * d);
-    *zkm = make_float2(s - sn * d, cs * d);
-}
-
 template <int R>
 __device__ __forceinline__ void ac_mid_col0(const float2 *__restrict__ xb, float2 *__restrict__ yb, unsigned nh, float2 *col,
                                             float2 *tw)
@@ -876,6 +751,39 @@ __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ 
     if (threadIdx.x == 0) out[plot] = ((plot == 0 ? frame_len : line_len) > 0) ? at : -1;
 }
 
+// ---------------------------------------------------------------------------
+// three-trip plan (fft4step.h): nh = N1 * 4096 with N1 = 16 .. 1024
+// ---------------------------------------------------------------------------
+static bool ac4_supported(uint32_t nh) { return nh >= 4096u * 16u && nh <= 4096u * 1024u; }
+
+template <int LOGN1>
+static void launch_ac4_n1(tsdrgpu_t *g, hipStream_t st, const float *src, int in_is_iq, long long stride, int cnt, uint32_t nh, float2 *work,
+                          float2 *out, const FftKeep &keep)
+{
+    typedef ColGeom<LOGN1> G;
+    const dim3 cgrid(AC4_ROW / G::C, cnt);
+    if (in_is_iq) TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 4, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
+    else TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 3, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
+    TSDR_LAUNCH(g, PROF_AC_ROWS, st, k_ac_rows, dim3((1u << LOGN1) / 2u, cnt), 512, work, nh);
+    TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 0, true>), cgrid, G::NT, (const void *)work, (long long)nh, out, nh, keep);
+}
+
+static void launch_ac4(tsdrgpu_t *g, hipStream_t st, const float *src, int in_is_iq, long long stride, int cnt, uint32_t nh, float2 *work,
+                       float2 *out, const FftKeep &keep)
+{
+    int logn1 = 0;
+    while ((4096u << logn1) < nh) logn1++;
+    switch (logn1) {
+        case 4: launch_ac4_n1<4>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
+        case 5: launch_ac4_n1<5>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
+        case 6: launch_ac4_n1<6>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
+        case 7: launch_ac4_n1<7>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
+        case 8: launch_ac4_n1<8>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
+        case 9: launch_ac4_n1<9>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
+        default: launch_ac4_n1<10>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
+    }
+}
+
 extern "C" int tsdrgpu_autocorr_create(tsdrgpu_t *g, tsdrgpu_autocorr_t **out, uint32_t samplerate)
 {
     if (!g || !out || samplerate == 0) return TSDRGPU_EINVAL;
@@ -1009,7 +917,20 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
         const unsigned Ns_last = nh / R_last;
         const bool fused = nh >= 4096 && plan.count >= 2 && Ns_last >= 2u * (2048u / R_last);
         float2 *corr_;
-        if (fused) {
+        // lags stored by the last pass: complex point m holds lags 2m, 2m+1; the call's final window is stored
+        // whole for tsdrgpu_autocorr_last_corr
+        FftKeep keep;
+        keep.on = 1;
+        keep.full_b = (w0 + cnt == nwindows) ? cnt - 1 : -1;
+        keep.lo0 = (unsigned)ac->frame_lo / 2;
+        keep.hi0 = (unsigned)(ac->frame_lo + ac->frame_len + 1) / 2;
+        keep.lo1 = (unsigned)ac->line_lo / 2;
+        keep.hi1 = (unsigned)(ac->line_lo + ac->line_len + 1) / 2;
+        if (ac4_supported(nh) && !ac->plan5) {
+            // three trips (fft4step.h): columns -> row pairs (in place) -> columns
+            launch_ac4(g, ac->st, src, in_is_iq, stride, cnt, nh, ac->d_a, ac->d_b, keep);
+            corr_ = ac->d_b;
+        } else if (fused) {
             // forward passes but the last ...
             float2 *z = run_fft_range(g, src, in_is_iq ? 4 : 3, stride, ac->d_a, ac->d_b, nh, cnt, plan.radix, plan.count, 0,
                                       plan.count - 1, 1, 0, 0, false, 1.0f, ac->st);
@@ -1028,13 +949,7 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
             for (int i = 0; i < plan.count; i++) rev[i] = plan.radix[plan.count - 1 - i];
             // the last pass stores only the two lag windows (complex point m holds lags 2m, 2m+1), plus the
             // whole correlation of the call's final window for tsdrgpu_autocorr_last_corr
-            FftKeep keep;
             keep.on = plan.count >= 2 ? 1 : 0;  // with 2 passes the "last" one is pass 1 of rev[], still Ns > 1
-            keep.full_b = (w0 + cnt == nwindows) ? cnt - 1 : -1;
-            keep.lo0 = (unsigned)ac->frame_lo / 2;
-            keep.hi0 = (unsigned)(ac->frame_lo + ac->frame_len + 1) / 2;
-            keep.lo1 = (unsigned)ac->line_lo / 2;
-            keep.hi1 = (unsigned)(ac->line_lo + ac->line_len + 1) / 2;
             corr_ = run_fft_range(g, mid, 0, nh, ac->d_a, ac->d_b, nh, cnt, rev, plan.count, 1, plan.count, (unsigned)R_last, 1, 1,
                                   false, 1.0f, ac->st, keep);
         } else {
@@ -1166,6 +1081,13 @@ extern "C" int tsdrgpu_autocorr_set_async(tsdrgpu_autocorr_t *ac, int on)
     tsdrgpu_t *g = ac->g;
     HIP_TRY(g, hipStreamSynchronize(ac->st));
     ac->st = on ? g->stream2 : g->stream;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_set_plan(tsdrgpu_autocorr_t *ac, int trips)
+{
+    if (!ac || (trips != 3 && trips != 5)) return ac ? tsdr_fail(ac->g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_set_plan", "trips must be 3 or 5") : TSDRGPU_EINVAL;
+    ac->plan5 = trips == 5 ? 1 : 0;
     return TSDRGPU_OK;
 }
 

@@ -444,11 +444,12 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const doub
 __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ frames, long long fstride, int W, int H,
                                                       const ChainOut *__restrict__ chain, int strips_normalised,
                                                       const int *__restrict__ sflag, float *__restrict__ exact, int nmax,
-                                                      const int *__restrict__ redo)
+                                                      const int *__restrict__ redo, const int *__restrict__ only)
 {
     const int axis = blockIdx.y, f = blockIdx.z;
     if (redo && !*redo) return;
     if (!sflag[f * 2 + axis]) return;
+    if (only && !only[f * 2 + axis]) return;  // second run: the first one already made this strip exact
     const float *src = frames + (long long)f * fstride;
     const float lastmin = chain[f].lastmin, span = chain[f].span;
     float *out = exact + ((long long)f * 2 + axis) * nmax;
@@ -573,6 +574,7 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
 }
 
 #define SYNC_T 256
+#define CHAIN_STAGE 128  // frames whose search results k_sync_chain stages in LDS at a time
 
 struct SearchShared {
     FitBest wbest[5][SYNC_T / 64];
@@ -714,11 +716,15 @@ struct SpecEntry {
 // k_sync_chain consumes these results while the prediction holds and searches on its own
 // where it does not.
 __global__ __launch_bounds__(SYNC_T) void k_sync_search(int W, int H, StripScratch sc, const PpState *__restrict__ state,
-                                                        SpecEntry *__restrict__ spec, const int *__restrict__ redo)
+                                                        SpecEntry *__restrict__ spec, const int *__restrict__ redo,
+                                                        const int *__restrict__ only)
 {
     __shared__ SearchShared S;
     if (redo && !*redo) return;
     const int axis = blockIdx.x, f = blockIdx.y;
+    // second run: the batch starts from the same state, so the speculation of every frame whose strip did not
+    // change still stands
+    if (only && !only[f * 2 + axis]) return;
     const int n = axis == 0 ? W : H;
     int minsize = axis == 0 ? (int)(W * 0.05f) : (int)(H * 0.01f);  // syncdetector.c:178-179
     if (minsize < 1) minsize = 1;
@@ -775,97 +781,109 @@ __global__ __launch_bounds__(SYNC_T) void k_sync_chain(int F, int W, int H, Stri
     int pred[5];
     const int cur0 = sync_sizes(cur, minsize, half, pred);  // what k_sync_search assumed
 
+    // The walk is a scalar recurrence on lane 0; what it reads per frame (the speculative search results and
+    // the strip's total) is staged in LDS by the whole workgroup, CHAIN_STAGE frames at a time, so that the
+    // walk never waits for a global load (its stores are fire and forget).
+    __shared__ FitBest sspec[CHAIN_STAGE][5];
+    __shared__ double stotal[CHAIN_STAGE];
     int f = 0;
     bool have_search = false;  // S.best holds this frame's own search
-    while (f < F) {
-        if (tid == 0) {
-            for (; f < F; f++) {
-                int sizes[5];
-                const int cc = sync_sizes(cur, minsize, half, sizes);
-                if (!have_search && cc != cur0) break;  // misprediction: the workgroup searches frame f
-                const FitBest *res = have_search ? S.best : spec[f * 2 + axis].best;
-                have_search = false;
-                double bestfit = -1.0;
-                int bestq = 0, bestsize = cc, bestk = 0;
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    if (sizes[k] <= 0) continue;
-                    // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
-                    if (k == 0 || res[k].fit > bestfit) { bestfit = res[k].fit; bestq = res[k].q; bestsize = sizes[k]; bestk = k; }
-                }
-                if (!redo && amb) {
-                    // Would the reference's rounding have chosen otherwise?  Its strip entries (sequential f32 sums of
-                    // ~10^3 pixels) carry ~7e-7 of relative error each, independently; two windows differ in m
-                    // entries, so their sums move against each other by ~sqrt(m)*7e-7*entry, the mean difference d
-                    // by that times (1/rest + 1/strip), and fit = d*d by 2|d| times that.  Four sigmas.
-                    const double entry = fabs(sc.total[f * 2 + axis]) / (double)n;
-                    const double sd = sqrt(bestfit > 0.0 ? bestfit : 0.0);
-                    const double per = 1.0 / (double)(n - bestsize) + 1.0 / (double)bestsize;
-                    int toss = 0;
-                    if (res[bestk].second >= 0.0) {
-                        int shift = res[bestk].q2 - bestq;
-                        if (shift < 0) shift = -shift;
-                        if (shift > n - shift) shift = n - shift;
-                        const int m = 2 * (shift < bestsize ? shift : bestsize);
-                        const double tol = 8.0 * sd * sqrt((double)m) * 7e-7 * entry * per;
-                        toss |= !(bestfit - res[bestk].second > tol);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 5; k++)
-                        if (k != bestk && sizes[k] > 0) {
-                            const double tol = 8.0 * sd * sqrt((double)(bestsize + sizes[k])) * 7e-7 * entry * per;
-                            toss |= !(fabs(bestfit - res[k].fit) > tol);
-                        }
-                    amb[f * 2 + axis] = toss;
-                }
-                // window start q carries the label of the index just removed (q-1); start 0 is labelled 0
-                const int beststart = bestq > 0 ? bestq - 1 : 0;
-                float *gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
-                gblur[beststart] = PIX_B;  // syncdetector.c:98-99
-                gblur[(beststart + bestsize) % n] = PIX_B;
-
-                const int h2 = n / 2;
-                int centre = (beststart + bestsize / 2) % n;
-                int ndx = dx;
-                const int rawdiff = centre - ndx;
-                if (rawdiff > h2) ndx += n;
-                else if (rawdiff < -h2) centre += n;
-                const int last = ndx;
-                // operands are far below 2^31: the reference's int64 round-and-modulo in 32 bits
-                ndx = ((int)round(centre * lowpass + (1.0 - lowpass) * ndx)) % n;
-                const int rawvx = ndx - last;
-                vx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
-                dx = ndx;
-                cur = bestsize;
-                ChainOut *o = &out[f];
-                if (xblock) {
-                    // frameratepll, syncdetector.c:133-153
-                    avg_speed = avg_speed * 0.99 + 0.01 * vx;
-                    locked = (avg_speed < 0.5 && avg_speed > -0.5) ? 1 : 0;
-                    int fired = 0;
-                    double diff = 0.0;
-                    if (pll_enabled && vx != 0) {
-                        diff = locked ? (avg_speed * 0.000001) : (vx * 0.00001);
-                        fired = 1;
-                    }
-                    o->dx = dx; o->vx = vx; o->stripx = cur;
-                    o->locked = locked; o->pll_fired = fired;
-                    o->avg_speed = avg_speed; o->frameratediff = diff;
-                } else {
-                    o->dy = dx; o->vy = vx; o->stripy = cur;
-                }
-            }
-            C.f = f;
-            C.cur = cur;
-        }
+    for (int fbase = 0; fbase < F; fbase += CHAIN_STAGE) {
+        const int flimit = (F - fbase < CHAIN_STAGE) ? F : fbase + CHAIN_STAGE;
+        __syncthreads();  // the previous stage's entries are no longer read
+        for (int i = tid; i < (flimit - fbase) * 5; i += SYNC_T) sspec[i / 5][i % 5] = spec[(fbase + i / 5) * 2 + axis].best[i % 5];
+        for (int i = tid; i < flimit - fbase; i += SYNC_T) stotal[i] = sc.total[(fbase + i) * 2 + axis];
         __syncthreads();
-        f = C.f;
-        if (f >= F) break;
-        // frame f starts from a size the speculation did not cover
-        int sizes[5];
-        sync_sizes(C.cur, minsize, half, sizes);
-        strip_search(S, sc.prefix + ((long long)f * 2 + axis) * (sc.nmax + 1), n, sizes);
-        have_search = true;  // only lane 0's copy matters
+        while (f < flimit) {
+            if (tid == 0) {
+                for (; f < flimit; f++) {
+                    int sizes[5];
+                    const int cc = sync_sizes(cur, minsize, half, sizes);
+                    if (!have_search && cc != cur0) break;  // misprediction: the workgroup searches frame f
+                    const FitBest *res = have_search ? S.best : sspec[f - fbase];
+                    have_search = false;
+                    double bestfit = -1.0;
+                    int bestq = 0, bestsize = cc, bestk = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        if (sizes[k] <= 0) continue;
+                        // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
+                        if (k == 0 || res[k].fit > bestfit) { bestfit = res[k].fit; bestq = res[k].q; bestsize = sizes[k]; bestk = k; }
+                    }
+                    if (!redo && amb) {
+                        // Would the reference's rounding have chosen otherwise?  Its strip entries (sequential f32 sums of
+                        // ~10^3 pixels) carry ~7e-7 of relative error each, independently; two windows differ in m
+                        // entries, so their sums move against each other by ~sqrt(m)*7e-7*entry, the mean difference d
+                        // by that times (1/rest + 1/strip), and fit = d*d by 2|d| times that.  Four sigmas.
+                        const double entry = fabs(stotal[f - fbase]) / (double)n;
+                        const double sd = sqrt(bestfit > 0.0 ? bestfit : 0.0);
+                        const double per = 1.0 / (double)(n - bestsize) + 1.0 / (double)bestsize;
+                        int toss = 0;
+                        if (res[bestk].second >= 0.0) {
+                            int shift = res[bestk].q2 - bestq;
+                            if (shift < 0) shift = -shift;
+                            if (shift > n - shift) shift = n - shift;
+                            const int m = 2 * (shift < bestsize ? shift : bestsize);
+                            const double tol = 8.0 * sd * sqrt((double)m) * 7e-7 * entry * per;
+                            toss |= !(bestfit - res[bestk].second > tol);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 5; k++)
+                            if (k != bestk && sizes[k] > 0) {
+                                const double tol = 8.0 * sd * sqrt((double)(bestsize + sizes[k])) * 7e-7 * entry * per;
+                                toss |= !(fabs(bestfit - res[k].fit) > tol);
+                            }
+                        amb[f * 2 + axis] = toss;
+                    }
+                    // window start q carries the label of the index just removed (q-1); start 0 is labelled 0
+                    const int beststart = bestq > 0 ? bestq - 1 : 0;
+                    float *gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
+                    gblur[beststart] = PIX_B;  // syncdetector.c:98-99
+                    gblur[(beststart + bestsize) % n] = PIX_B;
+
+                    const int h2 = n / 2;
+                    int centre = (beststart + bestsize / 2) % n;
+                    int ndx = dx;
+                    const int rawdiff = centre - ndx;
+                    if (rawdiff > h2) ndx += n;
+                    else if (rawdiff < -h2) centre += n;
+                    const int last = ndx;
+                    // operands are far below 2^31: the reference's int64 round-and-modulo in 32 bits
+                    ndx = ((int)round(centre * lowpass + (1.0 - lowpass) * ndx)) % n;
+                    const int rawvx = ndx - last;
+                    vx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
+                    dx = ndx;
+                    cur = bestsize;
+                    ChainOut *o = &out[f];
+                    if (xblock) {
+                        // frameratepll, syncdetector.c:133-153
+                        avg_speed = avg_speed * 0.99 + 0.01 * vx;
+                        locked = (avg_speed < 0.5 && avg_speed > -0.5) ? 1 : 0;
+                        int fired = 0;
+                        double diff = 0.0;
+                        if (pll_enabled && vx != 0) {
+                            diff = locked ? (avg_speed * 0.000001) : (vx * 0.00001);
+                            fired = 1;
+                        }
+                        o->dx = dx; o->vx = vx; o->stripx = cur;
+                        o->locked = locked; o->pll_fired = fired;
+                        o->avg_speed = avg_speed; o->frameratediff = diff;
+                    } else {
+                        o->dy = dx; o->vy = vx; o->stripy = cur;
+                    }
+                }
+                C.f = f;
+                C.cur = cur;
+            }
+            __syncthreads();
+            f = C.f;
+            if (f >= flimit) break;
+            // frame f starts from a size the speculation did not cover
+            int sizes[5];
+            sync_sizes(C.cur, minsize, half, sizes);
+            strip_search(S, sc.prefix + ((long long)f * 2 + axis) * (sc.nmax + 1), n, sizes);
+            have_search = true;  // only lane 0's copy matters
+        }
     }
     if (tid == 0) {
         if (xblock) {
@@ -1214,6 +1232,7 @@ extern "C" int tsdrgpu_postproc_create(tsdrgpu_t *g, tsdrgpu_postproc_t **out)
         free(pp);
         return TSDRGPU_EHIP;
     }
+    pp->exact_ties = 1;  // contract-exact sync decisions by default (tsdrgpu_postproc_set_exact_ties(pp, 0) opts out)
     *out = pp;
     return tsdrgpu_postproc_reset(pp);
 }
@@ -1265,14 +1284,18 @@ static int ensure(tsdrgpu_t *g, T **buf, size_t *cap, size_t need, bool zero = f
 
 // Between the two runs of the sync chain: frames with a toss-up decision whose strips are not yet the
 // reference's own get them (sflag), and *redo tells the second run whether there is anything to do.
-__global__ __launch_bounds__(256) void k_redo_prepare(int count, const int *__restrict__ amb, int *__restrict__ sflag, int *__restrict__ redo)
+__global__ __launch_bounds__(256) void k_redo_prepare(int count, const int *__restrict__ amb, int *__restrict__ sflag, int *__restrict__ redo,
+                                                      int *__restrict__ fresh)
 {
     int any = 0;
-    for (int i = threadIdx.x; i < count; i += blockDim.x)
-        if (amb[i] && !sflag[i]) {
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const int now = (amb[i] && !sflag[i]) ? 1 : 0;
+        fresh[i] = now;  // strips that change between the two runs
+        if (now) {
             sflag[i] = 1;
             any = 1;
         }
+    }
     any = __syncthreads_or(any);
     if (threadIdx.x == 0) *redo = any;
 }
@@ -1330,7 +1353,7 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, strips_normalised,
                     pp->d_sflag);
         SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
-        int *d_amb = pp->d_sflag + (size_t)F * 2, *d_redo = d_amb + (size_t)F * 2;
+        int *d_amb = pp->d_sflag + (size_t)F * 2, *d_fresh = d_amb + (size_t)F * 2, *d_redo = d_fresh + (size_t)F * 2;
         const int *const no_gate = nullptr;
         const unsigned exact_blocks = (unsigned)(((W + 255) / 256) > ((H + 63) / 64) ? ((W + 255) / 256) : ((H + 63) / 64));
         // run 1 as speculated; with exact ties on, run 2 (five empty launches unless needed) repeats the chain for a
@@ -1338,14 +1361,15 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         const int runs = pp->exact_ties ? 2 : 1;
         for (int run = 0; run < runs; run++) {
             const int *gate = run ? d_redo : no_gate;
-            if (run) TSDR_LAUNCH(g, PROF_CHAIN, st, k_redo_prepare, 1, 256, 2 * F, d_amb, pp->d_sflag, d_redo);
+            const int *only = run ? d_fresh : no_gate;
+            if (run) TSDR_LAUNCH(g, PROF_CHAIN, st, k_redo_prepare, 1, 256, 2 * F, d_amb, pp->d_sflag, d_redo, d_fresh);
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_exact_strips, dim3(exact_blocks, 2, F), 256, frames, fstride, W, H, pp->d_chain, strips_normalised,
-                        pp->d_sflag, pp->d_exact, nmax, gate);
+                        pp->d_sflag, pp->d_exact, nmax, gate, only);
             KERNEL_CHECK(g, "k_exact_strips");
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
                         strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, gate);
             KERNEL_CHECK(g, "k_strip_prepare");
-            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, run ? pp->d_state + 1 : pp->d_state, spec, gate);
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, run ? pp->d_state + 1 : pp->d_state, spec, gate, only);
             KERNEL_CHECK(g, "k_sync_search");
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1, pp->exact_ties ? d_amb : (int *)nullptr, gate);
         }
@@ -1414,7 +1438,7 @@ static int pp_prepare(tsdrgpu_postproc_t *pp, int F, int W, int H, const tsdrgpu
         const size_t floats = (((size_t)F * 2 * nmax + 1) & ~(size_t)1) + 2 * ((size_t)F * 2 * (nmax + 1) + (size_t)F * 2) +
                               (size_t)F * 2 * (sizeof(SpecEntry) / sizeof(float)) + 16;
         if ((rc = ensure(g, &pp->d_work, &pp->cap_work, floats))) return rc;
-        if ((rc = ensure(g, &pp->d_sflag, &pp->cap_sflag, (size_t)F * 4 + 4))) return rc;  // flags, toss-up marks, redo
+        if ((rc = ensure(g, &pp->d_sflag, &pp->cap_sflag, (size_t)F * 6 + 4))) return rc;  // flags, toss-up marks, fresh marks, redo
         if ((rc = ensure(g, &pp->d_exact, &pp->cap_exact, (size_t)F * 2 * nmax))) return rc;
     }
     if (W > STRIP_MAX || H > STRIP_MAX) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "width/height above 16384");

@@ -22,6 +22,8 @@ enum ProfStage {
     PROF_FRAME_PASS,
     PROF_FFT_PASS,
     PROF_AC_SPLIT,
+    PROF_AC_COLS,
+    PROF_AC_ROWS,
     PROF_ACCUMULATE,
     PROF_SUPERB_MISC,
     PROF_ARGMAX,

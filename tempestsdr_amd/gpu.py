@@ -102,6 +102,7 @@ _SIGS = {
     "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
     "tsdrgpu_autocorr_set_exact": (C.c_int, [vp, C.c_int]),
+    "tsdrgpu_autocorr_set_plan": (C.c_int, [vp, C.c_int]),
     "tsdrgpu_autocorr_argmax_async": (C.c_int, [vp]),
     "tsdrgpu_autocorr_argmax_result": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdrgpu_autocorr_argmax": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -490,6 +491,10 @@ class Autocorr:
     def set_exact(self, on=True):
         """The reference's own FFT arithmetic: plots / argmax / last_corr bit-identical (slower)."""
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_set_exact(self.h, int(on)))
+
+    def set_plan(self, trips):
+        """3: three-trip (four-step) transform plan where it applies (default); 5: the round-1 Stockham plan."""
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_set_plan(self.h, int(trips)))
 
     def argmax_async(self):
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_argmax_async(self.h))

@@ -148,6 +148,60 @@ def test_autocorr_config3_window(orc):
     assert abs((ac.flo + fi) - period) <= 1  # detected frame lag = the true period
 
 
+@pytest.mark.parametrize("fs,nwin,from_iq", [(4_000_000, 3, 1), (8_000_000, 2, 0), (12_600_000, 2, 1), (25_000_000, 9, 1),
+                                             (50_000_000, 1, 0), (100_000_000, 2, 1), (200_000_000, 1, 1)])
+def test_autocorr_three_trip_plan(orc, fs, nwin, from_iq):
+    """The three-trip transform plan (fft4step.h: column DFTs of N1 = 16 .. 1024 points, 4096-point row pairs
+    with the fused split, column DFTs storing the lag windows) for every column length, against the oracle
+    (same bounds as the other plan: plots 1e-4 * max, last correlation 2e-6 * max) and against the five-trip
+    plan on the same input."""
+    g = ctx()
+    ac_o = orc.Autocorr(fs)
+    ac = gpu.Autocorr(g, fs)
+    assert 1 << 17 <= ac.n <= 1 << 23
+    period = int(fs / 60.0)
+    rng = np.random.default_rng(fs % 1000)
+    stride = ac.capture  # odd for most rates: every second IQ window starts on an 8-byte boundary only
+    tot = nwin * stride
+    x = rng.random(tot).astype(np.float32) * np.float32(0.3) + (np.arange(tot) % period < period // 10).astype(np.float32)
+    if from_iq:
+        ph = 0.37 * np.arange(tot)
+        iq = np.empty(2 * tot, np.float32)
+        iq[0::2] = x * np.cos(ph)
+        iq[1::2] = x * np.sin(ph)
+        mag = orc.am_demod(iq)
+        d_in = g.to_device(iq)
+    else:
+        mag = x
+        d_in = g.to_device(x)
+    for k in range(nwin):
+        corr = ac_o.run(mag[k * stride:(k + 1) * stride])
+    ac.run(d_in, from_iq, stride, nwin)
+    f, l, calls = ac.plots()
+    assert calls == nwin
+    assert np.max(np.abs(f - ac_o.frame)) <= 1e-4 * np.max(ac_o.frame)
+    assert np.max(np.abs(l - ac_o.line)) <= 1e-4 * np.max(ac_o.line)
+    fi, li = ac.argmax()
+    assert (fi, li) == (int(np.argmax(f)), int(np.argmax(l)))
+    # R[j] == R[N-j]: where the frame-lag window holds a peak and its mirror the winner is rounding noise
+    assert ac_o.frame[fi] >= np.max(ac_o.frame) * (1 - 2e-4) and ac_o.line[li] >= np.max(ac_o.line) * (1 - 2e-4)
+    last = ac.last_corr()
+    assert np.max(np.abs(last - corr[:last.size])) <= 2e-6 * np.max(np.abs(corr))
+    assert np.all(last[1::2] == 0.0)
+    ac5 = gpu.Autocorr(g, fs)
+    ac5.set_plan(5)
+    ac5.run(d_in, from_iq, stride, nwin)
+    f5, l5, _ = ac5.plots()
+    assert np.max(np.abs(f5 - f)) <= 2e-5 * np.max(f) and np.max(np.abs(l5 - l)) <= 2e-5 * np.max(l)
+    # split calls continue the running mean exactly like one call
+    if nwin > 1:
+        ac.reset()
+        ac.run(d_in, from_iq, stride, 1)
+        ac.run(d_in, from_iq, stride, nwin - 1, in_offset=stride * (2 if from_iq else 1))
+        f2, l2, _ = ac.plots()
+        assert np.array_equal(f2, f) and np.array_equal(l2, l)
+
+
 def test_superb_stitch_vs_oracle(orc):
     g = ctx()
     gold = golden()
