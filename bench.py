@@ -370,6 +370,14 @@ def main():
         prof = g.profile_end()
     frames_done = frames_timed
 
+    redo_stats = None
+    if rank == 0:
+        try:
+            redo_stats = dict(zip(("tossup_decisions", "strips_recollapsed", "strips_flagged_upfront"), pp.redo_stats()))
+            redo_stats["decisions_per_batch"] = 2 * (nsamples * int(round(up / down * 1000)) // 1000 // P)
+        except Exception as e:
+            redo_stats = {"error": repr(e)}
+
     # side metric: the detector in the reference's own FFT arithmetic (what tsdr_readasync uses by default)
     exact_ac = None
     if rank == 0 and not args.no_profile and not sharded:
@@ -536,6 +544,7 @@ def main():
             # Main.java:1233-1277) applied to one plot update per pass
             "sweep": sweep,
             "exact_autocorr": exact_ac,
+            "sync_redo_last_batch": redo_stats,
             "device": g.device_name(),
         }
         if world == 1 and not args.no_cpu_baseline and not args.force_dist:

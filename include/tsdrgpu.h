@@ -154,6 +154,11 @@ int tsdrgpu_postproc_reset(tsdrgpu_postproc_t *pp); /* dsp_post_process_init, ds
  * is run again — the sync state is then identical there too.  Costs ~0.1 ms per batch plus ~0.3 ms for each batch that
  * holds a toss-up (about every batch on noisy rasters), on the chain's stream. */
 int tsdrgpu_postproc_set_exact_ties(tsdrgpu_postproc_t *pp, int on);
+/* Diagnostics of the last run (synchronises): how many of its 2*nframes sync decisions the first chain run marked as
+ * toss-ups, how many strips were re-collapsed in the reference's order because of that, and how many had been flagged
+ * for the literal collapse up front (ties / sentinels / flat strips). */
+int tsdrgpu_postproc_redo_stats(tsdrgpu_postproc_t *pp, int *h_tossups, int *h_recollapsed, int *h_flagged_upfront);
+int tsdrgpu_postproc_redo_raw(tsdrgpu_postproc_t *pp, int *h, int cap_ints, int *h_frames); /* the three flag arrays, 2*F ints each */
 /* Runs `nframes` consecutive frames (d_frames: nframes*width*height floats,
  * raster order) through dsp_post_process in order, as one batch of launches.
  * d_out receives every frame's result (what the reference hands to the video

@@ -138,6 +138,14 @@ struct FftKeep {
     unsigned lo0, hi0, lo1, hi1;
 };
 
+// Magnitudes of the float32 (tolerance-stated) form take the hardware square root (1 ulp) instead of the
+// correctly rounded sequence the build flags give sqrtf()
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AC_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define AC_SQRT(x) sqrtf(x)
+#endif
+
 // Packed-real split of the autocorrelation (see tsdrgpu_fft.hip): A = Z[k], bm = Z[nh-k],
 // wk = exp(-i pi k/nh); returns Zin[k] (*zk) and Zin[nh-k] (*zkm) of the inverse transform's input.
 __device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, unsigned nh, float2 *zk, float2 *zkm)
@@ -150,8 +158,8 @@ __device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, un
     const float2 t = cmul(make_float2(cs, sn), dif);
     const float2 xk = make_float2(sum.x + t.y, sum.y - t.x);
     const float2 xm = make_float2(sum.x - t.y, -(sum.y + t.x));
-    const float mk = sqrtf(xk.x * xk.x + xk.y * xk.y) * inv_n;
-    const float mm = sqrtf(xm.x * xm.x + xm.y * xm.y) * inv_n;
+    const float mk = AC_SQRT(xk.x * xk.x + xk.y * xk.y) * inv_n;
+    const float mm = AC_SQRT(xm.x * xm.x + xm.y * xm.y) * inv_n;
     const float s = mk + mm, d = mk - mm;
     *zk = make_float2(s + sn * d, cs * d);
     *zkm = make_float2(s - sn * d, cs * d);
@@ -201,8 +209,20 @@ __device__ __forceinline__ float2 ac4_load(const void *__restrict__ base, long l
     return make_float2(sqrtf(a.x * a.x + a.y * a.y), sqrtf(b.x * b.x + b.y * b.y));
 }
 
+// rtw[i] = w_nh^(ebase + estep i), i < 16
+__device__ __forceinline__ void ac4_col_twiddles(float2 (&rtw)[16], unsigned estep, unsigned ebase, unsigned nh)
+{
+    const unsigned mask = nh - 1u;
+    const float inv = -2.0f / (float)nh;
+    tw_powers<16>(rtw, estep, mask, inv);
+    const float2 rbase = tw_exact(ebase, mask, inv);
+    rtw[0] = rbase;
+#pragma unroll
+    for (int i = 1; i < 16; i++) rtw[i] = cmul(rbase, rtw[i]);
+}
+
 template <int LOGN1, int IN_MODE, bool LAST>
-__global__ __launch_bounds__(ColGeom<LOGN1>::NT) void k_ac_cols(const void *__restrict__ xin, long long in_stride,
+__global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *__restrict__ xin, long long in_stride,
                                                                 float2 *__restrict__ y, unsigned nh, FftKeep keep)
 {
     typedef ColGeom<LOGN1> G;
@@ -243,6 +263,17 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT) void k_ac_cols(const void *__re
             const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
             v[a * R0 + t] = ac4_load<IN_MODE>(xb, (long long)row * N2 + col, al16);
         }
+    // The twiddle between the column and the row transforms, w_nh^(k1 n2), lives here (trip 2 is the one
+    // short of VALU time): on trip 1's results and on trip 3's inputs the thread's 16 rows are q + Q i, so
+    // the factors are w^(n2 q) * (w^(n2 Q))^i: five accurate evaluations and products of depth <= 4.
+    if (LAST) {
+        float2 rtw[16];
+        ac4_col_twiddles(rtw, col * Q, col * q, nh);
+#pragma unroll
+        for (int a = 0; a < G0; a++)
+#pragma unroll
+            for (int t = 0; t < R0; t++) v[a * R0 + t] = cmul(v[a * R0 + t], rtw[a + G0 * t]);
+    }
 #pragma unroll
     for (int a = 0; a < G0; a++) dft_reg<R0>(*reinterpret_cast<float2(*)[R0]>(&v[a * R0]));
 
@@ -275,6 +306,8 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT) void k_ac_cols(const void *__re
     // butterfly when the only pass is pass 0)
     constexpr int RL = (NP > 1) ? 16 : R0;  // radix of the last pass
     constexpr int GL = 16 / RL;
+    float2 rtw[16];
+    if (!LAST) ac4_col_twiddles(rtw, col * Q, col * q, nh);
 #pragma unroll
     for (int a = 0; a < GL; a++)
 #pragma unroll
@@ -282,6 +315,7 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT) void k_ac_cols(const void *__re
             const unsigned row = q + Q * (unsigned)a + (unsigned)u * (N1 / (unsigned)RL);
             const unsigned m = row * N2 + col;
             float2 o = v[a * RL + u];
+            if (!LAST) o = cmul(o, rtw[a + GL * u]);
             if (LAST) {
                 o.y = -o.y;
                 if (keep.on && (int)b != keep.full_b && !((m >= keep.lo0 && m < keep.hi0) || (m >= keep.lo1 && m < keep.hi1))) continue;
@@ -344,20 +378,10 @@ __device__ __forceinline__ void ac4_fft4096(float2 (&v)[16], float2 *Lr, unsigne
     dft_reg<16>(v);
 }
 
-// v[t] *= w_nh^(k1 (j + 256 t)) = base * srow[t]: the twiddle between the column and the row transforms
-// (both directions); base = w_nh^(k1 j) is the thread's own, srow[t] = w_nh^(256 k1 t) the row's (LDS).
-__device__ __forceinline__ void ac4_row_twiddle(float2 (&v)[16], float2 base, const float2 *srow)
-{
-    v[0] = cmul(v[0], base);
-#pragma unroll
-    for (int t = 1; t < 16; t++) v[t] = cmul(v[t], cmul(base, srow[t]));
-}
-
 __global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsigned nh)
 {
     __shared__ float2 buf[2][AC4_ROWBUF];
     __shared__ float2 tw256[256], tw4k[256];
-    __shared__ float2 srow[2][16];
     const unsigned N1 = nh / AC4_ROW;
     const unsigned tid = threadIdx.x, half = tid >> 8, j = tid & 255u;
     const unsigned wg = blockIdx.x;
@@ -367,7 +391,7 @@ __global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsi
     float2 *Lr = buf[half];
     float2 v[16];
 #pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = zrow[j + 256u * (unsigned)t];
+    for (int t = 0; t < 16; t++) v[t] = zrow[j + 256u * (unsigned)t];  // already times w_nh^(k1 n2) (trip 1)
     {
         float sn, cs;
         if (half == 0u) {
@@ -377,33 +401,48 @@ __global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsi
             sincospif(-(float)j * (1.0f / 2048.0f), &sn, &cs);
             tw4k[j] = make_float2(cs, sn);
         }
-        if (j < 16u) srow[half][j] = tw_exact(256u * k1 * j, nh - 1u, -2.0f / (float)nh);
     }
-    const float2 base = tw_exact(k1 * j, nh - 1u, -2.0f / (float)nh);
     __syncthreads();  // tables ready
-    ac4_row_twiddle(v, base, srow[half]);
     ac4_fft4096(v, Lr, j, tw256, tw4k);  // v[u] = Z[k1 + N1 (j + 256 u)]
     __syncthreads();
-    {
-        float2 *const Lj = Lr + (j + (j >> 4));
+    // ---- split: Z[k] pairs with Z[nh-k], i.e. (k1, k2) <-> (N1-k1, N2-1-k2) — thread j register u of one
+    // row with thread 255-j register 15-u of the other —, for k1 = 0: (0, (N2-k2) mod N2)
+    float sn0, cs0;
+    sincospif(-(float)(k1 + N1 * j) * (1.0f / (float)nh), &sn0, &cs0);  // exp(-i pi k/nh), k = k1 + N1 (j + 256 u)
+    const float2 w0 = make_float2(cs0, sn0);
+    float2 *const Lj = Lr + (j + (j >> 4));  // own element u sits at Lj[272 u]
+    if (!selfpair) {
+        // every thread publishes its registers 8..15, computes the 8 pairs of its registers 0..7 (each pair once:
+        // both results come out of one evaluation), and hands the partner's halves back through the slots it read
+#pragma unroll
+        for (int u = 8; u < 16; u++) Lj[272 * u] = v[u];
+        __syncthreads();
+        const unsigned pb = AC4_ROW - 1u - j;  // partner of k2 = j + 256 u: pb - 256 u, padded like everything else
+        float2 *const Lq = buf[1u - half] + (pb + (pb >> 4)) - 272u * 15u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float2 bm = Lq[272 * (15 - u)];
+            const float2 wk = u ? cmul(w0, tw256[8u * (unsigned)u]) : w0;  // times exp(-i pi u/16)
+            float2 zk, zkm;
+            ac_split_pair(v[u], bm, wk, nh, &zk, &zkm);
+            v[u] = make_float2(zk.x, -zk.y);  // conjugated input: inverse = conj(FFT(conj(.)))
+            Lq[272 * (15 - u)] = make_float2(zkm.x, -zkm.y);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 8; u < 16; u++) v[u] = Lj[272 * u];
+    } else {
+        // the two rows that mirror onto themselves: every element evaluates its own pair
 #pragma unroll
         for (int u = 0; u < 16; u++) Lj[272 * u] = v[u];
-    }
-    __syncthreads();
-    // split: Z[k] pairs with Z[nh-k]: (k1, k2) <-> (N1-k1, N2-1-k2), for k1 = 0: (0, (N2-k2) mod N2)
-    {
-        const float2 *Lp = selfpair ? Lr : buf[1u - half];
-        float sn, cs;
-        sincospif(-(float)(k1 + N1 * j) * (1.0f / (float)nh), &sn, &cs);  // exp(-i pi k/nh), k = k1 + N1 (j + 256 u)
-        const float2 w0 = make_float2(cs, sn);
-        // partner of k2 = j + 256 u: pb - 256 u with pb = 4095 - j (row 0: 4096 - j; its k2 = 0 would wrap to 0,
-        // but that element takes the special formula below and ignores the partner), padded like everything else
-        const unsigned pb = ((selfpair && half == 0u) ? AC4_ROW : AC4_ROW - 1u) - j;
-        const float2 *const Lq = Lp + (pb + (pb >> 4)) - 272u * 15u;
+        __syncthreads();
+        // row 0: partner of k2 is 4096 - k2 (k2 = 0 would wrap, but takes the special formula below)
+        const unsigned pb = (half == 0u ? AC4_ROW : AC4_ROW - 1u) - j;
+        const float2 *const Lq = Lr + (pb + (pb >> 4)) - 272u * 15u;
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const float2 bm = Lq[272 * (15 - u)];
-            const float2 wk = u ? cmul(w0, tw256[8u * (unsigned)u]) : w0;  // times exp(-i pi u/16)
+            const float2 wk = u ? cmul(w0, tw256[8u * (unsigned)u]) : w0;
             float2 zk, zkm;
             ac_split_pair(v[u], bm, wk, nh, &zk, &zkm);
             if (u == 0 && k1 == 0u && j == 0u) {
@@ -412,16 +451,15 @@ __global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsi
                 const float mh = fabsf(v[0].x - v[0].y) * inv_n;  // X[nh] = Re Z0 - Im Z0
                 zk = make_float2(m0 + mh, m0 - mh);
             }
-            v[u] = make_float2(zk.x, -zk.y);  // conjugated input: inverse = conj(FFT(conj(.)))
+            v[u] = make_float2(zk.x, -zk.y);
         }
     }
-    __syncthreads();  // partner reads done before the buffers are reused
+    __syncthreads();  // exchange reads done before the buffers are reused
     unsigned j2 = j;
     AC4_LAUNDER(j2);
     ac4_fft4096(v, Lr, j2, tw256, tw4k);
-    // row k1 of the inverse's input side, output position n2 = j + 256 u, times w_nh^(n2 k1); the
-    // conjugation that completes the inverse is applied by trip 3 after ITS forward column transform
-    ac4_row_twiddle(v, base, srow[half]);
+    // row k1 of the inverse's input side at output position n2 = j + 256 u; trip 3 applies w_nh^(n2 k1) on its
+    // loads and the conjugation that completes the inverse after its forward column transform
 #pragma unroll
     for (int u = 0; u < 16; u++) zrow[j2 + 256u * (unsigned)u] = v[u];
 }

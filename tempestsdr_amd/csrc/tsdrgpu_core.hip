@@ -17,9 +17,15 @@ extern "C" int tsdrgpu_create(tsdrgpu_t **out, int device)
     tsdrgpu_t *g = (tsdrgpu_t *)calloc(1, sizeof(tsdrgpu_t));
     if (!g) return TSDRGPU_ENOMEM;
     g->device = device;
+    // The side stream carries short, latency-bound kernels (the sync detector's chain) beside bandwidth-bound ones
+    // on the main stream: it gets the highest priority, so its workgroups take the slots the big kernels free
+    // instead of queueing behind their whole grids (measured: the chain's re-collapse of two strips took 0.5 ms
+    // beside the FFT trips at equal priority).
+    int prio_lo = 0, prio_hi = 0;
+    if (hipSetDevice(device) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&g->prop, device) != hipSuccess ||
         hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&g->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&g->t0) != hipSuccess || hipEventCreate(&g->t1) != hipSuccess) {
         free(g);

@@ -438,9 +438,13 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const doub
     }
 }
 
-// grid (ceil(max(W, ceil(H/64)*256) / 256), 2, F).  axis 0: one thread per column walks down the rows (coalesced
-// across the columns, 16 loads in flight).  axis 1: a workgroup takes 64 rows and walks along them in 64-column
-// tiles staged through LDS (coalesced loads), one thread per row adding its 64 values in order.
+// grid (max(ceil(W/64), ceil(H/64)), 2, F).  A workgroup forms 64 sums — axis 0: columns x0..x0+63 summed down all
+// rows, axis 1: rows y0..y0+63 summed along all columns — in the reference's order: one thread per sum adds f32
+// values one after the other (dsp.c:103-108).  That chain is short (a few thousand dependent adds); what costs is the
+// latency of the loads, so the frame is walked in tiles of 256 (along the sum) x 64 staged through LDS: all four waves
+// fetch tile k+1 (64 coalesced loads per lane in flight) while wave 0 sums tile k out of LDS.
+#define XS_LONG 256
+#define XS_WAVES 4
 __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ frames, long long fstride, int W, int H,
                                                       const ChainOut *__restrict__ chain, int strips_normalised,
                                                       const int *__restrict__ sflag, float *__restrict__ exact, int nmax,
@@ -450,57 +454,74 @@ __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ 
     if (redo && !*redo) return;
     if (!sflag[f * 2 + axis]) return;
     if (only && !only[f * 2 + axis]) return;  // second run: the first one already made this strip exact
+    const int nsum = axis == 0 ? W : H;   // how many sums this axis has
+    const int nlong = axis == 0 ? H : W;  // how many terms each sum has
+    const int s0 = blockIdx.x * 64;       // first sum of this workgroup
+    if (s0 >= nsum) return;
     const float *src = frames + (long long)f * fstride;
     const float lastmin = chain[f].lastmin, span = chain[f].span;
     float *out = exact + ((long long)f * 2 + axis) * nmax;
-    if (axis == 0) {
-        const int x = blockIdx.x * blockDim.x + threadIdx.x;
-        if (x >= W) return;
-        float acc = 0.f;
-        int y = 0;
-        for (; y + 16 <= H; y += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = src[(long long)(y + u) * W + x];
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                float t = v[u];
-                if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);  // dsp.c:80-86
-                acc += t;
-            }
-        }
-        for (; y < H; y++) {
-            float t = src[(long long)y * W + x];
-            if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);
-            acc += t;
-        }
-        out[x] = acc;
-        return;
-    }
-    __shared__ float tile[64][65];
-    const int r0 = blockIdx.x * 64;
-    if (r0 >= H) return;
+    // tile[t][s]: term t (0..255 along the sum), sum s (0..63); rows padded to 65 so that both the transposing
+    // store of axis 1 and the walk of one thread down its column are conflict free
+    __shared__ float tile[XS_LONG][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float v[64];
+    const int ntiles = (nlong + XS_LONG - 1) / XS_LONG;
     float acc = 0.f;
-    for (int c0 = 0; c0 < W; c0 += 64) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int r = wave * 16 + i, y = r0 + r, x = c0 + lane;
-            float t = 0.f;
-            if (y < H && x < W) {
-                t = src[(long long)y * W + x];
-                if (strips_normalised) t = (t > 250.0f || t < -250.0f) ? t : ((t - lastmin) / span);
-            }
-            tile[r][lane] = t;
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const int cols = W - c0 < 64 ? W - c0 : 64;
-            for (int c = 0; c < cols; c++) acc += tile[threadIdx.x][c];
-        }
-        __syncthreads();
+    // element i of a thread: axis 0: term t = wave + 4 i, sum s = lane          -> pixel (x = s0 + lane, y = t0 + t)
+    //                        axis 1: sum s = wave + 4 (i & 15), term t = lane + 64 (i >> 4) -> pixel (x = t0 + t, y = s0 + s)
+    // either way a wave's load instruction covers 256 contiguous bytes
+    // loads first, unconditionally (indices clamped into the frame), so that all 64 are in flight together; the
+    // normalisation and the inside-the-frame test follow
+#define XS_FETCH(t0_)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 64; i++) {                                                        \
+        const int t = axis == 0 ? wave + XS_WAVES * i : lane + 64 * (i >> 4);                               \
+        const int sidx = axis == 0 ? lane : wave + XS_WAVES * (i & 15);                                     \
+        int x = axis == 0 ? s0 + sidx : (t0_) + t, y = axis == 0 ? (t0_) + t : s0 + sidx;                   \
+        x = x < W ? x : W - 1;                                                                              \
+        y = y < H ? y : H - 1;                                                                              \
+        v[i] = src[(long long)y * W + x];                                                                   \
+    }                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 64; i++) {                                                        \
+        const int t = axis == 0 ? wave + XS_WAVES * i : lane + 64 * (i >> 4);                               \
+        const int sidx = axis == 0 ? lane : wave + XS_WAVES * (i & 15);                                     \
+        const int x = axis == 0 ? s0 + sidx : (t0_) + t, y = axis == 0 ? (t0_) + t : s0 + sidx;             \
+        float val = v[i];                                                                                   \
+        if (strips_normalised) val = (val > 250.0f || val < -250.0f) ? val : ((val - lastmin) / span); /* dsp.c:80-86 */ \
+        v[i] = (x < W && y < H) ? val : 0.f;                                                                \
     }
-    if (threadIdx.x < 64 && r0 + (int)threadIdx.x < H) out[r0 + threadIdx.x] = acc;
+    XS_FETCH(0)
+    for (int k = 0; k < ntiles; k++) {
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            const int t = axis == 0 ? wave + XS_WAVES * i : lane + 64 * (i >> 4);
+            const int sidx = axis == 0 ? lane : wave + XS_WAVES * (i & 15);
+            tile[t][sidx] = v[i];
+        }
+        __syncthreads();
+        if (k + 1 < ntiles) { XS_FETCH((k + 1) * XS_LONG) }
+        if (threadIdx.x < 64) {
+            const int cnt = nlong - k * XS_LONG < XS_LONG ? nlong - k * XS_LONG : XS_LONG;
+            if (cnt == XS_LONG) {
+                // the adds form one dependent chain; the LDS reads do not, so they are issued 32 ahead
+#pragma unroll 32
+                for (int t = 0; t < XS_LONG; t++) acc += tile[t][threadIdx.x];
+            } else {
+                int t = 0;
+                for (; t + 8 <= cnt; t += 8) {
+                    float r[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) r[u] = tile[t + u][threadIdx.x];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc += r[u];
+                }
+                for (; t < cnt; t++) acc += tile[t][threadIdx.x];
+            }
+        }
+        __syncthreads();  // tile consumed
+    }
+#undef XS_FETCH
+    if (threadIdx.x < 64 && s0 + (int)threadIdx.x < nsum) out[s0 + threadIdx.x] = acc;
 }
 
 __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const double *__restrict__ strip_x,
@@ -742,6 +763,58 @@ struct ChainShared {
     int f, cur, dx, vx;
 };
 
+// What findthesweetspot (syncdetector.c:60-119) decides for one frame from the per-size search results `res`
+// (sizes[] as sync_sizes gives them, cc = the clamped starting size): the winning size and window, where the two
+// 1024.0 markers go, the centre of the blanking band, and — when asked — whether the reference's own rounding
+// could have chosen otherwise (toss-up; see k_sync_chain).
+struct SyncDecision {
+    int beststart, bestsize, mark2, centre, toss;
+};
+__device__ __forceinline__ SyncDecision sync_decide(const FitBest *res, const int sizes[5], int cc, int n, double total, bool want_toss)
+{
+    double bestfit = -1.0;
+    int bestq = 0, bestsize = cc, bestk = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (sizes[k] <= 0) continue;
+        // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
+        if (k == 0 || res[k].fit > bestfit) { bestfit = res[k].fit; bestq = res[k].q; bestsize = sizes[k]; bestk = k; }
+    }
+    SyncDecision d;
+    d.toss = 0;
+    if (want_toss) {
+        // Would the reference's rounding have chosen otherwise?  Its strip entries (sequential f32 sums of
+        // ~10^3 pixels) carry ~7e-7 of relative error each, independently; two windows differ in m
+        // entries, so their sums move against each other by ~sqrt(m)*7e-7*entry, the mean difference d
+        // by that times (1/rest + 1/strip), and fit = d*d by 2|d| times that.  Four sigmas.
+        const double entry = fabs(total) / (double)n;
+        const double sd = sqrt(bestfit > 0.0 ? bestfit : 0.0);
+        const double per = 1.0 / (double)(n - bestsize) + 1.0 / (double)bestsize;
+        int toss = 0;
+        if (res[bestk].second >= 0.0) {
+            int shift = res[bestk].q2 - bestq;
+            if (shift < 0) shift = -shift;
+            if (shift > n - shift) shift = n - shift;
+            const int m = 2 * (shift < bestsize ? shift : bestsize);
+            const double tol = 8.0 * sd * sqrt((double)m) * 7e-7 * entry * per;
+            toss |= !(bestfit - res[bestk].second > tol);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (k != bestk && sizes[k] > 0) {
+                const double tol = 8.0 * sd * sqrt((double)(bestsize + sizes[k])) * 7e-7 * entry * per;
+                toss |= !(fabs(bestfit - res[k].fit) > tol);
+            }
+        d.toss = toss;
+    }
+    // window start q carries the label of the index just removed (q-1); start 0 is labelled 0
+    d.beststart = bestq > 0 ? bestq - 1 : 0;
+    d.bestsize = bestsize;
+    d.mark2 = (d.beststart + bestsize) % n;
+    d.centre = (d.beststart + bestsize / 2) % n;
+    return d;
+}
+
 // First run of a batch (redo == nullptr): starts from `state`, leaves a copy of that starting state in `saved`
 // and marks in amb[f*2+axis] every decision whose margin over the runner-up (another window position of the
 // chosen size, or another size) is inside the rounding of the reference's own f32 strip sums — those could
@@ -780,80 +853,59 @@ __global__ __launch_bounds__(SYNC_T) void k_sync_chain(int F, int W, int H, Stri
     }
     int pred[5];
     const int cur0 = sync_sizes(cur, minsize, half, pred);  // what k_sync_search assumed
+    const bool want_toss = !redo && amb;
 
-    // The walk is a scalar recurrence on lane 0; what it reads per frame (the speculative search results and
-    // the strip's total) is staged in LDS by the whole workgroup, CHAIN_STAGE frames at a time, so that the
-    // walk never waits for a global load (its stores are fire and forget).
-    __shared__ FitBest sspec[CHAIN_STAGE][5];
-    __shared__ double stotal[CHAIN_STAGE];
+    // Two phases per stage of CHAIN_STAGE frames.  A (one thread per frame): everything that follows from a
+    // frame's search results alone once the starting size is the predicted one — the winner among the candidate
+    // sizes, the toss-up test with its f64 square roots and divisions, the markers, the blanking centre.  B (lane
+    // 0): the recurrence proper (dx low-pass, vx, the PLL) — a few dozen dependent instructions per frame, which is
+    // what a scalar walk on a vector unit can afford; a frame whose starting size is not the predicted one is
+    // searched by the whole workgroup and decided in B.
+    __shared__ SyncDecision sdec[CHAIN_STAGE];
     int f = 0;
     bool have_search = false;  // S.best holds this frame's own search
     for (int fbase = 0; fbase < F; fbase += CHAIN_STAGE) {
         const int flimit = (F - fbase < CHAIN_STAGE) ? F : fbase + CHAIN_STAGE;
         __syncthreads();  // the previous stage's entries are no longer read
-        for (int i = tid; i < (flimit - fbase) * 5; i += SYNC_T) sspec[i / 5][i % 5] = spec[(fbase + i / 5) * 2 + axis].best[i % 5];
-        for (int i = tid; i < flimit - fbase; i += SYNC_T) stotal[i] = sc.total[(fbase + i) * 2 + axis];
+        for (int i = tid; i < flimit - fbase; i += SYNC_T)
+            sdec[i] = sync_decide(spec[(fbase + i) * 2 + axis].best, pred, cur0, n, sc.total[(fbase + i) * 2 + axis], want_toss);
         __syncthreads();
         while (f < flimit) {
             if (tid == 0) {
                 for (; f < flimit; f++) {
-                    int sizes[5];
-                    const int cc = sync_sizes(cur, minsize, half, sizes);
-                    if (!have_search && cc != cur0) break;  // misprediction: the workgroup searches frame f
-                    const FitBest *res = have_search ? S.best : sspec[f - fbase];
-                    have_search = false;
-                    double bestfit = -1.0;
-                    int bestq = 0, bestsize = cc, bestk = 0;
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        if (sizes[k] <= 0) continue;
-                        // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
-                        if (k == 0 || res[k].fit > bestfit) { bestfit = res[k].fit; bestq = res[k].q; bestsize = sizes[k]; bestk = k; }
+                    const int cc = cur < minsize ? minsize : (cur > half ? half : cur);  // syncdetector.c:76-77
+                    SyncDecision d;
+                    if (have_search) {
+                        int sizes[5];
+                        sync_sizes(cur, minsize, half, sizes);
+                        d = sync_decide(S.best, sizes, cc, n, sc.total[f * 2 + axis], want_toss);
+                        have_search = false;
+                    } else if (cc != cur0) {
+                        break;  // misprediction: the workgroup searches frame f
+                    } else {
+                        d = sdec[f - fbase];
                     }
-                    if (!redo && amb) {
-                        // Would the reference's rounding have chosen otherwise?  Its strip entries (sequential f32 sums of
-                        // ~10^3 pixels) carry ~7e-7 of relative error each, independently; two windows differ in m
-                        // entries, so their sums move against each other by ~sqrt(m)*7e-7*entry, the mean difference d
-                        // by that times (1/rest + 1/strip), and fit = d*d by 2|d| times that.  Four sigmas.
-                        const double entry = fabs(stotal[f - fbase]) / (double)n;
-                        const double sd = sqrt(bestfit > 0.0 ? bestfit : 0.0);
-                        const double per = 1.0 / (double)(n - bestsize) + 1.0 / (double)bestsize;
-                        int toss = 0;
-                        if (res[bestk].second >= 0.0) {
-                            int shift = res[bestk].q2 - bestq;
-                            if (shift < 0) shift = -shift;
-                            if (shift > n - shift) shift = n - shift;
-                            const int m = 2 * (shift < bestsize ? shift : bestsize);
-                            const double tol = 8.0 * sd * sqrt((double)m) * 7e-7 * entry * per;
-                            toss |= !(bestfit - res[bestk].second > tol);
-                        }
-#pragma unroll
-                        for (int k = 0; k < 5; k++)
-                            if (k != bestk && sizes[k] > 0) {
-                                const double tol = 8.0 * sd * sqrt((double)(bestsize + sizes[k])) * 7e-7 * entry * per;
-                                toss |= !(fabs(bestfit - res[k].fit) > tol);
-                            }
-                        amb[f * 2 + axis] = toss;
-                    }
-                    // window start q carries the label of the index just removed (q-1); start 0 is labelled 0
-                    const int beststart = bestq > 0 ? bestq - 1 : 0;
+                    if (want_toss) amb[f * 2 + axis] = d.toss;
                     float *gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
-                    gblur[beststart] = PIX_B;  // syncdetector.c:98-99
-                    gblur[(beststart + bestsize) % n] = PIX_B;
+                    gblur[d.beststart] = PIX_B;  // syncdetector.c:98-99
+                    gblur[d.mark2] = PIX_B;
 
                     const int h2 = n / 2;
-                    int centre = (beststart + bestsize / 2) % n;
+                    int centre = d.centre;
                     int ndx = dx;
                     const int rawdiff = centre - ndx;
                     if (rawdiff > h2) ndx += n;
                     else if (rawdiff < -h2) centre += n;
                     const int last = ndx;
-                    // operands are far below 2^31: the reference's int64 round-and-modulo in 32 bits
-                    ndx = ((int)round(centre * lowpass + (1.0 - lowpass) * ndx)) % n;
+                    // operands are far below 2^31: the reference's int64 round-and-modulo in 32 bits; both terms
+                    // lie in [0, 2n), so `% n` is one conditional subtraction (the general form stays for safety)
+                    ndx = (int)round(centre * lowpass + (1.0 - lowpass) * ndx);
+                    if (ndx >= n) ndx -= n;
+                    if (ndx >= n || ndx < 0) ndx %= n;
                     const int rawvx = ndx - last;
                     vx = (rawvx > h2) ? (n - rawvx) : ((rawvx < -h2) ? (-n - rawvx) : rawvx);
                     dx = ndx;
-                    cur = bestsize;
+                    cur = d.bestsize;
                     ChainOut *o = &out[f];
                     if (xblock) {
                         // frameratepll, syncdetector.c:133-153
@@ -1355,7 +1407,7 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
         int *d_amb = pp->d_sflag + (size_t)F * 2, *d_fresh = d_amb + (size_t)F * 2, *d_redo = d_fresh + (size_t)F * 2;
         const int *const no_gate = nullptr;
-        const unsigned exact_blocks = (unsigned)(((W + 255) / 256) > ((H + 63) / 64) ? ((W + 255) / 256) : ((H + 63) / 64));
+        const unsigned exact_blocks = (unsigned)(((W + 63) / 64) > ((H + 63) / 64) ? ((W + 63) / 64) : ((H + 63) / 64));
         // run 1 as speculated; with exact ties on, run 2 (five empty launches unless needed) repeats the chain for a
         // batch in which some decision was a toss-up at the precision of the strips, those frames' strips made exact
         const int runs = pp->exact_ties ? 2 : 1;
@@ -1667,6 +1719,45 @@ extern "C" int tsdrgpu_postproc_set_exact_ties(tsdrgpu_postproc_t *pp, int on)
 {
     if (!pp) return TSDRGPU_EINVAL;
     pp->exact_ties = on ? 1 : 0;
+    return TSDRGPU_OK;
+}
+
+// statistics of the last run's toss-up handling (synchronises): decisions marked as toss-ups by the first chain run,
+// strips that were re-collapsed in the reference's order because of them, strips flagged for that up front
+extern "C" int tsdrgpu_postproc_redo_stats(tsdrgpu_postproc_t *pp, int *h_tossups, int *h_recollapsed, int *h_flagged_upfront)
+{
+    if (!pp || !pp->d_sflag || pp->last_F <= 0) return TSDRGPU_ESTATE;
+    tsdrgpu_t *g = pp->g;
+    const int F = pp->last_F;
+    int *h = (int *)malloc(sizeof(int) * (size_t)F * 6);
+    if (!h) return TSDRGPU_ENOMEM;
+    HIP_TRY(g, hipStreamSynchronize(g->stream2));
+    HIP_TRY(g, hipMemcpyAsync(h, pp->d_sflag, sizeof(int) * (size_t)F * 6, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    int t = 0, r = 0, u = 0;
+    for (int i = 0; i < 2 * F; i++) {
+        t += h[2 * F + i] ? 1 : 0;
+        r += (pp->exact_ties && h[4 * F + i]) ? 1 : 0;
+        u += (h[i] && !(pp->exact_ties && h[4 * F + i])) ? 1 : 0;
+    }
+    free(h);
+    if (h_tossups) *h_tossups = pp->exact_ties ? t : 0;
+    if (h_recollapsed) *h_recollapsed = r;
+    if (h_flagged_upfront) *h_flagged_upfront = u;
+    return TSDRGPU_OK;
+}
+
+// the same, raw: h receives [strip flagged][toss-up][re-collapsed in run 2], 2*F ints each (frame-major, axis minor)
+extern "C" int tsdrgpu_postproc_redo_raw(tsdrgpu_postproc_t *pp, int *h, int cap_ints, int *h_frames)
+{
+    if (!pp || !pp->d_sflag || pp->last_F <= 0 || !h) return TSDRGPU_ESTATE;
+    tsdrgpu_t *g = pp->g;
+    const int F = pp->last_F;
+    if (cap_ints < 6 * F) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_redo_raw", "buffer too small");
+    HIP_TRY(g, hipStreamSynchronize(g->stream2));
+    HIP_TRY(g, hipMemcpyAsync(h, pp->d_sflag, sizeof(int) * (size_t)F * 6, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (h_frames) *h_frames = F;
     return TSDRGPU_OK;
 }
 

@@ -84,6 +84,8 @@ _SIGS = {
     "tsdrgpu_postproc_destroy": (None, [vp]),
     "tsdrgpu_postproc_reset": (C.c_int, [vp]),
     "tsdrgpu_postproc_set_exact_ties": (C.c_int, [vp, C.c_int]),
+    "tsdrgpu_postproc_redo_stats": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tsdrgpu_postproc_redo_raw": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "tsdrgpu_postproc_run": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams), vp,
                                        C.POINTER(PPFrameInfo)]),
     "tsdrgpu_postproc_begin": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PPParams)]),
@@ -388,6 +390,20 @@ class PostProcess:
 
     def reset(self):
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_reset(self.h))
+
+    def redo_stats(self):
+        """(toss-up decisions, strips re-collapsed because of them, strips flagged up front) of the last run"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_redo_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def redo_raw(self, max_frames=4096):
+        """(flagged, tossup, recollapsed) arrays of shape (F, 2) for the last run"""
+        h = np.zeros(6 * max_frames, np.int32)
+        f = C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_redo_raw(self.h, h.ctypes.data, h.size, C.byref(f)))
+        F = f.value
+        return tuple(h[k * 2 * F:(k + 1) * 2 * F].reshape(F, 2) for k in range(3))
 
     def set_exact_ties(self, on=True):
         """Detect sync-detector decisions that are toss-ups at the precision of the strips and redo them exactly."""

@@ -135,7 +135,8 @@ def test_autocorr_config3_window(orc):
     ac = gpu.Autocorr(g, fs)
     assert ac.n == 1 << 22 and ac.capture == 5_636_363
     period = fs // 60
-    x = RNG.random(ac.capture).astype(np.float32) * np.float32(0.3)
+    rng = np.random.default_rng(2203)  # its own stream: the result must not depend on which tests ran before
+    x = rng.random(ac.capture).astype(np.float32) * np.float32(0.3)
     x += (np.arange(ac.capture) % period < period // 10).astype(np.float32)
     ac_o = orc.Autocorr(fs)
     ac_o.run(x)
@@ -145,7 +146,9 @@ def test_autocorr_config3_window(orc):
     assert np.max(np.abs(l - ac_o.line)) <= 1e-4 * np.max(ac_o.line)
     fi, li = ac.argmax()
     assert fi == int(np.argmax(ac_o.frame)) and li == int(np.argmax(ac_o.line))
-    assert abs((ac.flo + fi) - period) <= 1  # detected frame lag = the true period
+    # the detected frame lag is the true period up to what the noise does to the triangular peak of a 2.5-period
+    # window (the oracle's own argmax, asserted identical above, moves by a few lags from seed to seed)
+    assert abs((ac.flo + fi) - period) <= 8
 
 
 @pytest.mark.parametrize("fs,nwin,from_iq", [(4_000_000, 3, 1), (8_000_000, 2, 0), (12_600_000, 2, 1), (25_000_000, 9, 1),
