@@ -57,7 +57,35 @@ int tsdrgpu_free_host(tsdrgpu_t *g, void *h_ptr);
 int tsdrgpu_upload(tsdrgpu_t *g, void *d_dst, const void *h_src, size_t bytes);
 int tsdrgpu_download(tsdrgpu_t *g, void *h_dst, const void *d_src, size_t bytes);
 int tsdrgpu_copy(tsdrgpu_t *g, void *d_dst, const void *d_src, size_t bytes);
+int tsdrgpu_copy2(tsdrgpu_t *g, void *d_dst1, void *d_dst2, const void *d_src, size_t bytes); /* one launch, two destinations */
 int tsdrgpu_zero(tsdrgpu_t *g, void *d_ptr, size_t bytes);
+
+/* ---- lanes and events: what a streaming host needs to overlap PCIe copies with compute ------------
+ * A context owns four in-order queues ("lanes"): COMPUTE (the stream every kernel entry point above and below
+ * uses), SIDE (the high-priority side stream: sync-detector chain, asynchronous autocorrelation), UPLOAD and
+ * DOWNLOAD (copy engines).  Nothing orders two lanes except events.  All of this is thread safe as long as each
+ * lane is fed by one thread at a time (the engine: the plugin's thread feeds UPLOAD, the device thread the rest). */
+#define TSDRGPU_LANE_COMPUTE 0
+#define TSDRGPU_LANE_SIDE 1
+#define TSDRGPU_LANE_UPLOAD 2
+#define TSDRGPU_LANE_DOWNLOAD 3
+typedef struct tsdrgpu_event tsdrgpu_event_t;
+int tsdrgpu_event_create(tsdrgpu_t *g, tsdrgpu_event_t **out);
+void tsdrgpu_event_destroy(tsdrgpu_t *g, tsdrgpu_event_t *ev);
+int tsdrgpu_event_record(tsdrgpu_t *g, tsdrgpu_event_t *ev, int lane); /* completes when everything queued on `lane` so far has */
+int tsdrgpu_lane_wait(tsdrgpu_t *g, int lane, tsdrgpu_event_t *ev);    /* work queued on `lane` from now on waits for ev */
+int tsdrgpu_event_sync(tsdrgpu_t *g, tsdrgpu_event_t *ev);            /* the calling host thread waits */
+int tsdrgpu_event_done(tsdrgpu_t *g, tsdrgpu_event_t *ev);            /* 1 done, 0 not yet, < 0 error */
+int tsdrgpu_lane_sync(tsdrgpu_t *g, int lane);                        /* the calling host thread waits for the lane */
+int tsdrgpu_upload_lane(tsdrgpu_t *g, void *d_dst, const void *h_src, size_t bytes);   /* asynchronous, UPLOAD lane */
+int tsdrgpu_download_lane(tsdrgpu_t *g, void *h_dst, const void *d_src, size_t bytes); /* asynchronous, DOWNLOAD lane */
+/* Page-locks memory the caller does not own the allocation of (e.g. a source plugin's sample buffer), so that
+ * tsdrgpu_upload_lane can DMA straight out of it instead of through a pinned bounce buffer. */
+int tsdrgpu_host_register(tsdrgpu_t *g, void *h_ptr, size_t bytes);
+int tsdrgpu_host_unregister(tsdrgpu_t *g, void *h_ptr);
+/* Makes the context's device the calling thread's current HIP device; call once from every thread that uses
+ * the context (allocation entry points do it themselves). */
+int tsdrgpu_bind_thread(tsdrgpu_t *g);
 
 /* event timing on the context's stream (used by bench.py for the roofline leg) */
 int tsdrgpu_timer_start(tsdrgpu_t *g);
@@ -194,6 +222,9 @@ int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsdrgpu_pp_fra
 int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width, int height,
                                   const tsdrgpu_pp_params_t *params, const float *d_fmin, const float *d_fmax,
                                   float *d_out);
+/* The per-frame record of the last run, without a host synchronisation: packs nframes tsdrgpu_pp_frameinfo_t
+ * into the caller's DEVICE buffer on the COMPUTE lane (download it on any lane behind an event). */
+int tsdrgpu_postproc_info_pack(tsdrgpu_postproc_t *pp, tsdrgpu_pp_frameinfo_t *d_info, int nframes);
 /* strips of the last frame run (after blur + markers), for stage-level tests */
 int tsdrgpu_postproc_strips(tsdrgpu_postproc_t *pp, float *h_colsum, float *h_rowsum); /* syncs */
 
@@ -242,6 +273,9 @@ int tsdrgpu_autocorr_set_exact(tsdrgpu_autocorr_t *ac, int on);
 int tsdrgpu_autocorr_set_plan(tsdrgpu_autocorr_t *ac, int trips);
 int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line,
                            uint64_t *h_calls); /* syncs */
+/* the same copies queued on the object's lane without waiting: h_* must be pinned and stay valid until an event
+ * recorded on that lane (COMPUTE, or SIDE after tsdrgpu_autocorr_set_async) behind this call has completed */
+int tsdrgpu_autocorr_plots_async(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line, uint64_t *h_calls);
 /* device plots: frame_len + line_len doubles, contiguous (frame first) */
 int tsdrgpu_autocorr_device_plots(tsdrgpu_autocorr_t *ac, double **d_plots, int64_t *count);
 int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t total_windows);

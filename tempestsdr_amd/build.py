@@ -3,6 +3,7 @@ the gpurun snapshot; a JIT cache would not):
 
   tempestsdr_amd/libtsdrgpu.so     HIP kernels + the tsdrgpu_* C ABI (include/tsdrgpu.h)
   tempestsdr_amd/libTSDRLibrary.so the drop-in tsdr_* host library (C) on top of it
+  tempestsdr_amd/libTSDRPlugin_Mem.so an in-memory replay source plugin (tsdrplugin_* ABI)
 
 hipcc cross-compiles for gfx950 without a GPU.
 """
@@ -64,6 +65,11 @@ def build(force=False, verbose=True):
     host = os.path.join(CSRC, "host")
     if os.path.isdir(host) and os.path.exists(os.path.join(host, "Makefile")):
         subprocess.run(["make", "-C", host, "-s"], check=True)
+    # source plugins shipped with the library (tsdrplugin_* ABI, include/TSDRPlugin.h)
+    mem_src = os.path.join(CSRC, "plugins", "TSDRPlugin_Mem.c")
+    mem_so = os.path.join(HERE, "libTSDRPlugin_Mem.so")
+    if force or _newer(mem_so, [mem_src] + _headers()):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", mem_so, mem_src], check=True)
     return LIB
 
 

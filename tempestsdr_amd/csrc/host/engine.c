@@ -4,17 +4,27 @@
  * postprocessingthread -> videodecodingthread through three float ring buffers,
  * with frameratedetector_thread and super_thread on the side
  * (TempestSDR/src/TSDRLibrary.c:264-418, frameratedetector.c:128-187,
- * superbandwidth.c:154-254).  Here:
+ * superbandwidth.c:154-254).  Here four host threads feed four device queues
+ * ("lanes", include/tsdrgpu.h) that only events order, so PCIe copies in both
+ * directions overlap the kernels:
  *
- *   plugin thread   on_block(): copy the IQ block into a pinned slot, return
- *   device thread   upload, then queue fused demod+resample, batched frame
- *                   post-processing and the autocorrelation on the GPU stream
- *   video thread    frame callback          (reference: videodecodingthread)
- *   plot thread     plot + value callbacks  (reference: frameratedetector_thread)
+ *   plugin thread   on_block(): DMA of the IQ block into a device slot on the UPLOAD
+ *                   lane — straight out of the plugin's own buffer when that can be
+ *                   page-locked, through a pinned bounce buffer otherwise —, then a
+ *                   descriptor into the input queue
+ *   device thread   queues, without ever waiting for the device in steady state:
+ *                   slot -> sample streams, fused demod+resample straight into the pixel
+ *                   stream, batched frame post-processing into a ring of output buffers
+ *                   (COMPUTE lane), the frame-rate detector (SIDE lane), the frames' and
+ *                   plots' way back to pinned memory (DOWNLOAD / SIDE lane)
+ *   video thread    waits for a frame's download event, then the frame callback
+ *                   (reference: videodecodingthread)
+ *   plot thread     waits for the plots' event, then plot + value callbacks
+ *                   (reference: frameratedetector_thread)
  *
  * Sample / pixel skipping after drops follows dsp_dropped_compensation_*
  * (dsp.c:313-368) so frames stay aligned, and back-pressure is lossy in whole
- * blocks like the reference's circular buffers.
+ * blocks / whole frames like the reference's circular buffers.
  */
 #include <math.h>
 #include <stdio.h>
@@ -24,9 +34,11 @@
 
 #include "tsdr_host.h"
 
-#define NSLOT 8          /* pinned input blocks in flight */
-#define NFRAMEQ 4        /* frames waiting for the video callback */
-#define MAX_FRAME_BATCH 8
+#define NSLOT 8            /* input blocks in flight */
+#define NFRAMEQ 8          /* frames on their way to / waiting for the video callback */
+#define NOUT 3             /* post-processed batches whose frames may still be downloading */
+#define MAX_FRAME_BATCH 16
+#define MAX_HOSTREG 512    /* page-locked ranges of plugin memory */
 #define NORMALISATION_LOWPASS_COEFF (0.1f) /* TSDRLibrary.c:37 */
 #define FRAMES_TO_POLL (0.1)               /* TSDRLibrary.c:41 */
 #define AUTOGAIN_REPORT_EVERY_FRAMES (5)   /* dsp.c:20 */
@@ -44,11 +56,37 @@ typedef struct {
 } devstream_t;
 
 typedef struct {
-    float *h; /* pinned */
+    float *h;     /* pinned frame */
     size_t cap;
     int width, height;
-    int ready;
+    tsdrgpu_pp_frameinfo_t *h_info; /* pinned; the frame's post-processing record */
+    int announce_autogain;
+    tsdrgpu_event_t *ready; /* recorded on the DOWNLOAD lane behind the frame's copies */
 } frame_slot_t;
+
+typedef struct {
+    float *d; size_t cap;              /* F frames */
+    tsdrgpu_pp_frameinfo_t *d_info;    /* F records */
+    int info_cap;
+    tsdrgpu_event_t *done, *last_dl;   /* batch computed (COMPUTE) / its last download queued (DOWNLOAD) */
+    int busy;
+} out_buf_t;
+
+typedef struct {
+    float *h; size_t hcap;   /* pinned bounce buffer (used when the plugin's memory cannot be page-locked) */
+    float *d; size_t dcap;   /* device copy of the block */
+    size_t nfloats;
+    int64_t dropped;
+    tsdrgpu_event_t *consumed; /* COMPUTE lane is done reading d */
+    int consumed_valid;
+} in_slot_t;
+
+typedef struct {
+    int32_t flo, flen, llo, llen;
+    uint32_t rate;
+    double *h_frame, *h_line; /* pinned */
+    uint64_t calls;
+} plot_msg_t;
 
 struct engine {
     tsdr_lib_t *t;
@@ -59,27 +97,33 @@ struct engine {
     tsdrgpu_resampler_t *rs;
     tsdrgpu_postproc_t *pp;
     tsdrgpu_autocorr_t *ac;
-    uint32_t ac_rate;
+    uint32_t ac_rate, ac_failed_rate;
+    uint32_t ac_capture;
+    tsdrgpu_event_t *det_read; /* SIDE lane is done reading the detector's sample stream */
+    int det_read_valid;
 
     /* input queue */
-    struct { float *h; size_t cap, nfloats; int64_t dropped; } slot[NSLOT];
+    in_slot_t slot[NSLOT];
     int q_head, q_count;
     int64_t pending_drop;
     pthread_mutex_t qm;
     pthread_cond_t q_nonempty;
+    int plugin_thread_bound;
+    int zero_copy;
+    struct { char *p; size_t n; } reg[MAX_HOSTREG];
+    int nreg;
 
-    float *d_block; size_t block_cap;
     devstream_t iq;   /* samples for the resampler (interleaved IQ; magnitude in super mode) */
     int iq_is_mag;
     devstream_t det;  /* samples for the frame-rate detector */
     devstream_t pix;  /* resampled pixel stream */
-    float *d_rs; size_t rs_cap;
-    float *d_out; size_t out_cap;
+    float *d_rs; size_t rs_cap; /* resampler scratch for the calls whose first pixels are skipped */
+    out_buf_t out[NOUT];
+    int out_next;
 
     int64_t dev_difference; /* samples still to skip (process(), TSDRLibrary.c:284-295) */
     int64_t pix_difference; /* pixels still to skip (decimatingthread, TSDRLibrary.c:342-346) */
     int pp_runs;
-    int last_w, last_h;
 
     /* video delivery */
     frame_slot_t fq[NFRAMEQ];
@@ -87,15 +131,21 @@ struct engine {
     pthread_mutex_t fm;
     pthread_cond_t f_nonempty;
 
-    /* plot delivery */
-    double *h_frameplot, *h_lineplot;
-    int32_t flo, flen, llo, llen;
-    uint64_t plot_calls;
+    /* plot delivery: one message in flight; its geometry travels with it (the detector may be rebuilt for a
+     * new sample rate while the host still looks at the previous plots) */
+    plot_msg_t plot;
+    tsdrgpu_event_t *plot_ready;
     int plot_pending, plot_reset_announce, plot_dumped_announce;
     pthread_mutex_t pm;
     pthread_cond_t p_nonempty;
 
     volatile int alive; /* delivery threads keep going */
+
+    /* TSDR_GPU_STATS=1: where the host threads spend their time (printed to stderr when the run ends) */
+    int stats;
+    double t_start;
+    double s_plugin_busy, s_plugin_dma, s_dev_busy, s_dev_wait_out, s_video_wait, s_video_cb;
+    long n_blocks, n_blocks_lost, n_frames_made, n_frames_lost, n_batches, n_resample_calls, n_windows;
 
     /* super-bandwidth */
     int super_state, super_hop, super_gathered, super_to_gather, super_frame, super_to_pause;
@@ -121,12 +171,26 @@ static int gpu_ok(struct engine *e, int rc, const char *what)
     return 0;
 }
 
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static void deadline_ms(struct timespec *ts, long ms)
+{
+    clock_gettime(CLOCK_REALTIME, ts);
+    ts->tv_nsec += ms * 1000000L;
+    if (ts->tv_nsec >= 1000000000L) { ts->tv_sec++; ts->tv_nsec -= 1000000000L; }
+}
+
 static int stream_reserve(struct engine *e, devstream_t *s, size_t extra)
 {
     if (s->wr + extra <= s->cap) return 1;
     const size_t live = s->wr - s->rd;
     size_t need = live + extra;
-    if (need <= s->cap && s->d_alt) { /* compact into the twin buffer */
+    if (need <= s->cap && s->d_alt) { /* compact into the twin buffer (COMPUTE lane: ordered behind every reader) */
         if (live && !gpu_ok(e, tsdrgpu_copy(e->g, s->d_alt, s->d + s->rd, live * sizeof(float)), "compact")) return 0;
         float *tmp = s->d; s->d = s->d_alt; s->d_alt = tmp;
         s->rd = 0; s->wr = live;
@@ -134,7 +198,10 @@ static int stream_reserve(struct engine *e, devstream_t *s, size_t extra)
     }
     size_t cap = need * 2 + 4096;
     float *n1 = NULL, *n2 = NULL;
-    if (tsdrgpu_alloc(e->g, (void **)&n1, cap * sizeof(float)) || tsdrgpu_alloc(e->g, (void **)&n2, cap * sizeof(float))) return 0;
+    if (tsdrgpu_alloc(e->g, (void **)&n1, cap * sizeof(float)) || tsdrgpu_alloc(e->g, (void **)&n2, cap * sizeof(float))) {
+        tsdrgpu_free(e->g, n1);
+        return 0;
+    }
     if (live && !gpu_ok(e, tsdrgpu_copy(e->g, n1, s->d + s->rd, live * sizeof(float)), "grow")) return 0;
     tsdrgpu_sync(e->g);
     tsdrgpu_free(e->g, s->d);
@@ -171,52 +238,107 @@ static int ensure_dev(struct engine *e, float **buf, size_t *cap, size_t need)
 }
 
 /* ---- plugin thread -------------------------------------------------------------- */
+/* Is [p, p+n) page-locked for DMA?  Plugins hand over the same buffer (RawFile, UHD) or blocks of one region
+ * (file replays) again and again, so ranges are registered on first sight and remembered; anything that cannot
+ * be registered (or overlaps a registered range only partly) goes through the slot's pinned bounce buffer. */
+static int plugin_memory_pinned(struct engine *e, void *p, size_t n)
+{
+    if (!e->zero_copy) return 0;
+    char *c = (char *)p;
+    for (int i = 0; i < e->nreg; i++) {
+        if (c >= e->reg[i].p && c + n <= e->reg[i].p + e->reg[i].n) return 1;
+        if (c < e->reg[i].p + e->reg[i].n && e->reg[i].p < c + n) return 0; /* partial overlap */
+    }
+    if (e->nreg == MAX_HOSTREG) return 0;
+    if (tsdrgpu_host_register(e->g, p, n)) {
+        if (e->nreg == 0) e->zero_copy = 0; /* the very first attempt failed: this memory cannot be page-locked */
+        return 0;
+    }
+    e->reg[e->nreg].p = c;
+    e->reg[e->nreg].n = n;
+    e->nreg++;
+    return 1;
+}
+
 static void on_block(float *buf, uint64_t items, void *ctx, int64_t dropped)
 {
     struct engine *e = (struct engine *)ctx;
     if (!e->t->running || (items & 1)) return;
+    if (!e->plugin_thread_bound) { tsdrgpu_bind_thread(e->g); e->plugin_thread_bound = 1; }
+    const double t0 = e->stats ? now_s() : 0.0;
     pthread_mutex_lock(&e->qm);
     if (e->q_count == NSLOT) { /* device thread is behind: lose the whole block */
+        e->pending_drop += (int64_t)(items / 2) + dropped;
+        e->n_blocks_lost++;
+        pthread_mutex_unlock(&e->qm);
+        return;
+    }
+    in_slot_t *s = &e->slot[(e->q_head + e->q_count) % NSLOT]; /* only this thread produces: the slot stays ours */
+    pthread_mutex_unlock(&e->qm);
+    int ok = 1;
+    if (items) {
+        const size_t bytes = (size_t)items * sizeof(float);
+        if (s->consumed_valid) { tsdrgpu_event_sync(e->g, s->consumed); s->consumed_valid = 0; } /* long done in practice */
+        if (s->dcap < items) {
+            tsdrgpu_free(e->g, s->d);
+            s->d = NULL; s->dcap = 0;
+            if (tsdrgpu_alloc(e->g, (void **)&s->d, bytes) == 0) s->dcap = items; else ok = 0;
+        }
+        const void *src = buf;
+        if (ok && !plugin_memory_pinned(e, buf, bytes)) {
+            if (s->hcap < items) {
+                tsdrgpu_free_host(e->g, s->h);
+                s->h = NULL; s->hcap = 0;
+                if (tsdrgpu_alloc_host(e->g, (void **)&s->h, bytes) == 0) s->hcap = items; else ok = 0;
+            }
+            if (ok) { memcpy(s->h, buf, bytes); src = s->h; }
+        }
+        /* the plugin's buffer is ours only until we return: wait for the DMA (about 40 us for RawFile's 2 MB) */
+        const double t1 = e->stats ? now_s() : 0.0;
+        if (ok) ok = tsdrgpu_upload_lane(e->g, s->d, src, bytes) == 0 && tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD) == 0;
+        if (e->stats) e->s_plugin_dma += now_s() - t1;
+    }
+    pthread_mutex_lock(&e->qm);
+    if (!ok) { /* could not stage the block: count it as lost, like a full queue */
         e->pending_drop += (int64_t)(items / 2) + dropped;
         pthread_mutex_unlock(&e->qm);
         return;
     }
-    const int s = (e->q_head + e->q_count) % NSLOT;
-    if (e->slot[s].cap < items) {
-        pthread_mutex_unlock(&e->qm); /* allocation outside the lock; only this thread produces */
-        float *h = NULL;
-        if (tsdrgpu_alloc_host(e->g, (void **)&h, (size_t)items * sizeof(float))) return;
-        pthread_mutex_lock(&e->qm);
-        tsdrgpu_free_host(e->g, e->slot[s].h);
-        e->slot[s].h = h;
-        e->slot[s].cap = items;
-    }
-    if (items) memcpy(e->slot[s].h, buf, (size_t)items * sizeof(float));
-    e->slot[s].nfloats = items;
-    e->slot[s].dropped = dropped + e->pending_drop;
+    s->nfloats = items;
+    s->dropped = dropped + e->pending_drop;
     e->pending_drop = 0;
     e->q_count++;
+    e->n_blocks++;
     pthread_cond_signal(&e->q_nonempty);
     pthread_mutex_unlock(&e->qm);
+    if (e->stats) e->s_plugin_busy += now_s() - t0;
 }
 
 /* ---- video thread ---------------------------------------------------------------- */
 static void *video_thread(void *arg)
 {
     struct engine *e = (struct engine *)arg;
+    tsdr_lib_t *t = e->t;
+    tsdrgpu_bind_thread(e->g);
     pthread_mutex_lock(&e->fm);
     while (e->alive || e->fq_count) {
         if (!e->fq_count) {
             struct timespec ts;
-            clock_gettime(CLOCK_REALTIME, &ts);
-            ts.tv_nsec += 30 * 1000000L;
-            if (ts.tv_nsec >= 1000000000L) { ts.tv_sec++; ts.tv_nsec -= 1000000000L; }
+            deadline_ms(&ts, 30);
             pthread_cond_timedwait(&e->f_nonempty, &e->fm, &ts);
             continue;
         }
         frame_slot_t *f = &e->fq[e->fq_head];
         pthread_mutex_unlock(&e->fm);
-        if (e->t->running) e->cb(f->h, f->width, f->height, e->cbctx);
+        const double t0 = e->stats ? now_s() : 0.0;
+        const int arrived = tsdrgpu_event_sync(e->g, f->ready) == 0;
+        const double t1 = e->stats ? now_s() : 0.0;
+        if (arrived && t->running) {
+            /* dsp.c:231-235: autogain values every 7th frame */
+            if (f->announce_autogain) tsdr_announce_value(t, VALUE_ID_AUTOGAIN_VALUES, f->h_info->lastmin, f->h_info->lastmax);
+            e->cb(f->h, f->width, f->height, e->cbctx);
+        }
+        if (e->stats) { e->s_video_wait += t1 - t0; e->s_video_cb += now_s() - t1; }
         pthread_mutex_lock(&e->fm);
         e->fq_head = (e->fq_head + 1) % NFRAMEQ;
         e->fq_count--;
@@ -230,29 +352,29 @@ static void *plot_thread(void *arg)
 {
     struct engine *e = (struct engine *)arg;
     tsdr_lib_t *t = e->t;
+    tsdrgpu_bind_thread(e->g);
     pthread_mutex_lock(&e->pm);
     while (e->alive) {
         if (!e->plot_pending && !e->plot_reset_announce && !e->plot_dumped_announce) {
             struct timespec ts;
-            clock_gettime(CLOCK_REALTIME, &ts);
-            ts.tv_nsec += 30 * 1000000L;
-            if (ts.tv_nsec >= 1000000000L) { ts.tv_sec++; ts.tv_nsec -= 1000000000L; }
+            deadline_ms(&ts, 30);
             pthread_cond_timedwait(&e->p_nonempty, &e->pm, &ts);
             continue;
         }
         const int reset = e->plot_reset_announce, dumped = e->plot_dumped_announce, plots = e->plot_pending;
         e->plot_reset_announce = e->plot_dumped_announce = 0;
-        /* the arrays stay untouched by the device thread while plot_pending is set */
+        /* the message (arrays and geometry) stays untouched by the device thread while plot_pending is set */
         pthread_mutex_unlock(&e->pm);
         if (reset) tsdr_announce_value(t, VALUE_ID_AUTOCORRECT_RESET, 0, 0);
         if (dumped) tsdr_announce_value(t, VALUE_ID_AUTOCORRECT_DUMPED, 0, 0);
-        if (plots) {
+        if (plots && tsdrgpu_event_sync(e->g, e->plot_ready) == 0) {
+            const plot_msg_t *m = &e->plot;
             tsdr_on_plot_ready_callback pcb = t->plotready_callback;
             if (pcb) { /* frameratedetector.c:121-124 */
-                pcb(PLOT_ID_FRAME, e->flo, e->h_frameplot, e->flen, e->ac_rate, t->callbackctx);
-                pcb(PLOT_ID_LINE, e->llo, e->h_lineplot, e->llen, e->ac_rate, t->callbackctx);
+                pcb(PLOT_ID_FRAME, m->flo, m->h_frame, m->flen, m->rate, t->callbackctx);
+                pcb(PLOT_ID_LINE, m->llo, m->h_line, m->llen, m->rate, t->callbackctx);
             }
-            tsdr_announce_value(t, VALUE_ID_AUTOCORRECT_FRAMES_COUNT, 0, (double)e->plot_calls);
+            tsdr_announce_value(t, VALUE_ID_AUTOCORRECT_FRAMES_COUNT, 0, (double)m->calls);
         }
         pthread_mutex_lock(&e->pm);
         if (plots) e->plot_pending = 0;
@@ -267,14 +389,15 @@ static void dump_autocorr(struct engine *e) /* dump_autocorrect, frameratedetect
     const float *d_corr = NULL;
     uint32_t n = 0;
     if (tsdrgpu_autocorr_last_corr(e->ac, &d_corr, &n)) return;
-    const uint32_t maxels = n / 2; /* fft_getrealsize(size)/2 floats */
-    float *h = (float *)malloc(sizeof(float) * (maxels + 2));
+    /* the reference walks the first fft_getrealsize(2*capture)/2 = n floats of the correlation, i.e. n/2 rows */
+    const uint32_t maxels = n;
+    float *h = (float *)malloc(sizeof(float) * ((size_t)maxels + 2));
     if (!h) return;
-    if (tsdrgpu_download(e->g, h, d_corr, sizeof(float) * (maxels + 2)) == 0 && tsdrgpu_sync(e->g) == 0) {
+    if (tsdrgpu_download(e->g, h, d_corr, sizeof(float) * maxels) == 0 && tsdrgpu_sync(e->g) == 0) {
         FILE *f = fopen("autocorr.csv", "w");
         if (f) {
             fprintf(f, "%s, %s\n", "ms", "dB");
-            for (uint32_t i = 0; i < maxels; i += 2) {
+            for (uint32_t i = 0; i + 1 < maxels; i += 2) {
                 const double re = h[i], im = h[i + 1];
                 fprintf(f, "%f, %f\n", 1000.0 * (i / 2) / (double)e->ac_rate, 10.0 * log10(sqrt(re * re + im * im)));
             }
@@ -284,34 +407,62 @@ static void dump_autocorr(struct engine *e) /* dump_autocorrect, frameratedetect
     free(h);
 }
 
+static void detector_rebuild(struct engine *e, uint32_t fs)
+{
+    if (e->ac) tsdrgpu_autocorr_destroy(e->ac);
+    e->ac = NULL;
+    e->ac_rate = 0;
+    if (tsdrgpu_autocorr_create(e->g, &e->ac, fs)) { /* rate too low for the lag windows, or no memory */
+        e->ac = NULL;
+        e->ac_failed_rate = fs;
+        return;
+    }
+    /* The frame-rate detector runs in the reference's own FFT arithmetic by default: plots, their argmax and so
+     * the detected mode are bit-identical to the CPU library's (0.25 ms per 100 MS/s window against 56 ms of
+     * signal).  TSDR_GPU_EXACT_AUTOCORR=0 / TSDR_GPU_EXACT=0 select the fast transform (plots within 1e-4*max). */
+    if (exact_wanted("TSDR_GPU_EXACT_AUTOCORR")) (void)tsdrgpu_autocorr_set_exact(e->ac, 1);
+    (void)tsdrgpu_autocorr_set_async(e->ac, 1); /* SIDE lane: beside the frame path */
+    plot_msg_t nm;
+    memset(&nm, 0, sizeof(nm));
+    uint32_t n = 0;
+    tsdrgpu_autocorr_geometry(e->ac, &nm.flo, &nm.flen, &nm.llo, &nm.llen, &e->ac_capture, &n);
+    nm.rate = fs;
+    if (tsdrgpu_alloc_host(e->g, (void **)&nm.h_frame, sizeof(double) * (size_t)nm.flen) ||
+        tsdrgpu_alloc_host(e->g, (void **)&nm.h_line, sizeof(double) * (size_t)nm.llen)) {
+        tsdrgpu_free_host(e->g, nm.h_frame);
+        tsdrgpu_autocorr_destroy(e->ac);
+        e->ac = NULL;
+        e->ac_failed_rate = fs;
+        return;
+    }
+    /* swap the message inside the critical section, once the host is done with the previous plots */
+    pthread_mutex_lock(&e->pm);
+    while (e->plot_pending && e->alive) {
+        pthread_mutex_unlock(&e->pm);
+        struct timespec ts = {0, 1000000};
+        nanosleep(&ts, NULL);
+        pthread_mutex_lock(&e->pm);
+    }
+    plot_msg_t old = e->plot;
+    e->plot = nm;
+    pthread_mutex_unlock(&e->pm);
+    tsdrgpu_free_host(e->g, old.h_frame);
+    tsdrgpu_free_host(e->g, old.h_line);
+    e->ac_rate = fs;
+    e->ac_failed_rate = 0;
+}
+
 static void run_detector(struct engine *e, uint32_t fs)
 {
     tsdr_lib_t *t = e->t;
-    if (t->params_int[PARAM_AUTOCORR_PLOTS_OFF]) { e->det.rd = e->det.wr = 0; return; }
+    if (t->params_int[PARAM_AUTOCORR_PLOTS_OFF] || e->iq_is_mag) { e->det.rd = e->det.wr = 0; return; } /* nothing is fed in super mode */
+    if (fs == e->ac_failed_rate) { e->det.rd = e->det.wr = 0; return; } /* no detector exists for this rate */
     if (!e->ac || e->ac_rate != fs) {
-        if (e->ac) tsdrgpu_autocorr_destroy(e->ac);
-        e->ac = NULL;
-        if (tsdrgpu_autocorr_create(e->g, &e->ac, fs)) return; /* rate too low for the lag windows */
-        e->ac_rate = fs;
-        /* The frame-rate detector runs in the reference's own FFT arithmetic by default: plots, their argmax and so
-         * the detected mode are bit-identical to the CPU library's (0.24 ms per 100 MS/s window against 56 ms of
-         * signal).  TSDR_GPU_EXACT_AUTOCORR=0 / TSDR_GPU_EXACT=0 select the fast transform (plots within 1e-4*max). */
-        if (exact_wanted("TSDR_GPU_EXACT_AUTOCORR")) (void)tsdrgpu_autocorr_set_exact(e->ac, 1);
-        uint32_t cap, n;
-        tsdrgpu_autocorr_geometry(e->ac, &e->flo, &e->flen, &e->llo, &e->llen, &cap, &n);
-        pthread_mutex_lock(&e->pm);
-        while (e->plot_pending && e->alive) { pthread_mutex_unlock(&e->pm); struct timespec ts = {0, 1000000}; nanosleep(&ts, NULL); pthread_mutex_lock(&e->pm); }
-        tsdrgpu_free_host(e->g, e->h_frameplot);
-        tsdrgpu_free_host(e->g, e->h_lineplot);
-        e->h_frameplot = e->h_lineplot = NULL;
-        tsdrgpu_alloc_host(e->g, (void **)&e->h_frameplot, sizeof(double) * e->flen);
-        tsdrgpu_alloc_host(e->g, (void **)&e->h_lineplot, sizeof(double) * e->llen);
-        pthread_mutex_unlock(&e->pm);
+        detector_rebuild(e, fs);
+        if (!e->ac) { e->det.rd = e->det.wr = 0; return; }
     }
-    uint32_t capture = 0;
-    tsdrgpu_autocorr_geometry(e->ac, NULL, NULL, NULL, NULL, &capture, NULL);
-    const size_t per = e->iq_is_mag ? 1 : 2;
-    while ((e->det.wr - e->det.rd) / per >= capture && t->running) {
+    const uint32_t capture = e->ac_capture;
+    while ((e->det.wr - e->det.rd) / 2 >= capture && t->running) {
         if (t->detector_purge) { /* frameratedetector.c:171-176 */
             t->detector_purge = 0;
             tsdrgpu_autocorr_reset(e->ac);
@@ -327,23 +478,29 @@ static void run_detector(struct engine *e, uint32_t fs)
                 pthread_mutex_unlock(&e->pm);
             }
         }
-        if (!gpu_ok(e, tsdrgpu_autocorr_run(e->ac, e->det.d + e->det.rd, !e->iq_is_mag, capture, 1, 0), "autocorr")) return;
-        e->det.rd += (size_t)capture * per;
+        if (!gpu_ok(e, tsdrgpu_autocorr_run(e->ac, e->det.d + e->det.rd, 1, capture, 1, 0), "autocorr")) return;
+        e->det.rd += (size_t)capture * 2;
+        e->n_windows++;
+        /* the window is read on the SIDE lane; the COMPUTE lane must not recycle that memory before (process_block) */
+        if (tsdrgpu_event_record(e->g, e->det_read, TSDRGPU_LANE_SIDE) == 0) e->det_read_valid = 1;
+        else tsdrgpu_sync(e->g);
         if (t->params_int[PARAM_AUTOCORR_DUMP]) {
             t->params_int[PARAM_AUTOCORR_DUMP] = 0;
             dump_autocorr(e);
             pthread_mutex_lock(&e->pm);
             e->plot_dumped_announce = 1;
+            pthread_cond_signal(&e->p_nonempty);
             pthread_mutex_unlock(&e->pm);
         }
         pthread_mutex_lock(&e->pm);
         const int busy = e->plot_pending; /* host still showing the previous plot: skip this update */
         pthread_mutex_unlock(&e->pm);
-        if (!busy && e->h_frameplot && e->h_lineplot) {
+        if (!busy) {
             uint64_t calls = 0;
-            if (tsdrgpu_autocorr_plots(e->ac, e->h_frameplot, e->h_lineplot, &calls) == 0) {
+            if (tsdrgpu_autocorr_plots_async(e->ac, e->plot.h_frame, e->plot.h_line, &calls) == 0 &&
+                tsdrgpu_event_record(e->g, e->plot_ready, TSDRGPU_LANE_SIDE) == 0) {
                 pthread_mutex_lock(&e->pm);
-                e->plot_calls = calls;
+                e->plot.calls = calls;
                 e->plot_pending = 1;
                 pthread_cond_signal(&e->p_nonempty);
                 pthread_mutex_unlock(&e->pm);
@@ -352,30 +509,24 @@ static void run_detector(struct engine *e, uint32_t fs)
     }
 }
 
-static void deliver_frames(struct engine *e, int F, int W, int H, const tsdrgpu_pp_frameinfo_t *info)
+/* Queues the way back of a batch's frames: DOWNLOAD lane behind the batch's COMPUTE event, one pinned slot and one
+ * event per frame; the video thread picks a frame up when its event has fired.  A full queue drops the frame (the
+ * viewer is slower than the stream), like the reference's lossy video ring. */
+static void deliver_frames(struct engine *e, out_buf_t *ob, int F, int W, int H)
 {
-    tsdr_lib_t *t = e->t;
     const size_t P = (size_t)W * H;
+    int queued = 0;
     for (int f = 0; f < F; f++) {
-        /* dsp.c:231-235: autogain values every 7th frame */
-        if (e->pp_runs++ > AUTOGAIN_REPORT_EVERY_FRAMES) {
-            e->pp_runs = 0;
-            tsdr_announce_value(t, VALUE_ID_AUTOGAIN_VALUES, info[f].lastmin, info[f].lastmax);
-        }
-        if (info[f].pll_fired) { /* syncdetector.c:149-151 */
-            pthread_mutex_lock(&t->lock);
-            t->refreshrate -= info[f].frameratediff;
-            tsdr_geometry_update(t, t->samplerate);
-            const double rate = t->refreshrate;
-            pthread_mutex_unlock(&t->lock);
-            tsdr_announce_value(t, VALUE_ID_PLL_FRAMERATE, rate, 0);
-        }
+        const int announce = e->pp_runs++ > AUTOGAIN_REPORT_EVERY_FRAMES;
+        if (announce) e->pp_runs = 0;
+        e->n_frames_made++;
         pthread_mutex_lock(&e->fm);
-        if (e->fq_count == NFRAMEQ) { /* viewer is slower than the stream: drop the frame */
+        if (e->fq_count == NFRAMEQ) {
             pthread_mutex_unlock(&e->fm);
+            e->n_frames_lost++;
             continue;
         }
-        frame_slot_t *s = &e->fq[(e->fq_head + e->fq_count) % NFRAMEQ];
+        frame_slot_t *s = &e->fq[(e->fq_head + e->fq_count) % NFRAMEQ]; /* free: only this thread produces */
         pthread_mutex_unlock(&e->fm);
         if (s->cap < P) {
             tsdrgpu_free_host(e->g, s->h);
@@ -383,13 +534,20 @@ static void deliver_frames(struct engine *e, int F, int W, int H, const tsdrgpu_
             if (tsdrgpu_alloc_host(e->g, (void **)&s->h, P * sizeof(float))) continue;
             s->cap = P;
         }
-        if (tsdrgpu_download(e->g, s->h, e->d_out + (size_t)f * P, P * sizeof(float)) || tsdrgpu_sync(e->g)) continue;
+        if (!queued && tsdrgpu_lane_wait(e->g, TSDRGPU_LANE_DOWNLOAD, ob->done)) return;
+        if (tsdrgpu_download_lane(e->g, s->h, ob->d + (size_t)f * P, P * sizeof(float)) ||
+            tsdrgpu_download_lane(e->g, s->h_info, ob->d_info + f, sizeof(tsdrgpu_pp_frameinfo_t)) ||
+            tsdrgpu_event_record(e->g, s->ready, TSDRGPU_LANE_DOWNLOAD))
+            continue;
+        queued++;
         s->width = W; s->height = H;
+        s->announce_autogain = announce;
         pthread_mutex_lock(&e->fm);
         e->fq_count++;
         pthread_cond_signal(&e->f_nonempty);
         pthread_mutex_unlock(&e->fm);
     }
+    if (queued && tsdrgpu_event_record(e->g, ob->last_dl, TSDRGPU_LANE_DOWNLOAD) == 0) ob->busy = 1;
 }
 
 static void run_frames(struct engine *e)
@@ -414,11 +572,38 @@ static void run_frames(struct engine *e)
         prm.motionblur = t->motionblur;
         prm.lowpasscoeff = NORMALISATION_LOWPASS_COEFF;
         if (prm.pll) F = 1; /* the PLL's nudge feeds back into the geometry between frames */
-        if (!ensure_dev(e, &e->d_out, &e->out_cap, P * (size_t)F)) return;
-        tsdrgpu_pp_frameinfo_t info[MAX_FRAME_BATCH];
-        if (!gpu_ok(e, tsdrgpu_postproc_run(e->pp, e->pix.d + e->pix.rd, F, W, H, &prm, e->d_out, info), "postproc")) return;
+        out_buf_t *ob = &e->out[e->out_next];
+        e->out_next = (e->out_next + 1) % NOUT;
+        if (ob->busy) { /* its frames have left the device? */
+            const double t0 = e->stats ? now_s() : 0.0;
+            tsdrgpu_event_sync(e->g, ob->last_dl);
+            ob->busy = 0;
+            if (e->stats) e->s_dev_wait_out += now_s() - t0;
+        }
+        e->n_batches++;
+        if (!ensure_dev(e, &ob->d, &ob->cap, P * (size_t)F)) return;
+        if (ob->info_cap < F) {
+            tsdrgpu_sync(e->g);
+            tsdrgpu_free(e->g, ob->d_info);
+            ob->d_info = NULL; ob->info_cap = 0;
+            if (tsdrgpu_alloc(e->g, (void **)&ob->d_info, sizeof(tsdrgpu_pp_frameinfo_t) * MAX_FRAME_BATCH)) return;
+            ob->info_cap = MAX_FRAME_BATCH;
+        }
+        tsdrgpu_pp_frameinfo_t info;
+        if (!gpu_ok(e, tsdrgpu_postproc_run(e->pp, e->pix.d + e->pix.rd, F, W, H, &prm, ob->d, prm.pll ? &info : NULL), "postproc")) return;
+        if (!gpu_ok(e, tsdrgpu_postproc_info_pack(e->pp, ob->d_info, F), "info") ||
+            !gpu_ok(e, tsdrgpu_event_record(e->g, ob->done, TSDRGPU_LANE_COMPUTE), "event"))
+            return;
         e->pix.rd += P * (size_t)F;
-        deliver_frames(e, F, W, H, info);
+        if (prm.pll && info.pll_fired) { /* syncdetector.c:149-151: the one place the host has to see a result at once */
+            pthread_mutex_lock(&t->lock);
+            t->refreshrate -= info.frameratediff;
+            tsdr_geometry_update(t, t->samplerate);
+            const double rate = t->refreshrate;
+            pthread_mutex_unlock(&t->lock);
+            tsdr_announce_value(t, VALUE_ID_PLL_FRAMERATE, rate, 0);
+        }
+        deliver_frames(e, ob, F, W, H);
     }
 }
 
@@ -448,19 +633,32 @@ static void run_resampler(struct engine *e)
         if (e->pix_difference != 0 || t->syncoffset != 0 || t->params_int[PARAM_INT_FRAMERATE_PLL]) nchunks = 1;
         else if (nchunks > 40) nchunks = 40;
         const int64_t count = tsdrgpu_resample_count(e->rs, (uint32_t)chunk, nchunks, up, down);
-        if (count < 0 || !ensure_dev(e, &e->d_rs, &e->rs_cap, (size_t)count + 16)) return;
+        if (count < 0) return;
+        e->n_resample_calls++;
+        const int nearest = (int)t->params_int[PARAM_NEAREST_NEIGHBOUR_RESAMPLING];
         int64_t n = 0;
-        if (!gpu_ok(e, tsdrgpu_resample(e->rs, e->iq.d + e->iq.rd, !e->iq_is_mag, (uint32_t)chunk, nchunks, up, down,
-                                        (int)t->params_int[PARAM_NEAREST_NEIGHBOUR_RESAMPLING], e->d_rs, (int64_t)e->rs_cap, &n),
-                    "resample"))
-            return;
-        e->iq.rd += (size_t)nchunks * chunk * per;
-        /* dsp_dropped_compensation_add with a ring that always accepts (dsp.c:326-346) */
-        if ((int64_t)n <= e->pix_difference) e->pix_difference -= n;
-        else {
-            if (!stream_append(e, &e->pix, e->d_rs + e->pix_difference, (size_t)(n - e->pix_difference))) return;
-            e->pix_difference = 0;
+        if (e->pix_difference == 0) {
+            /* the usual case: straight into the pixel stream */
+            if (!stream_reserve(e, &e->pix, (size_t)count)) return;
+            if (!gpu_ok(e, tsdrgpu_resample(e->rs, e->iq.d + e->iq.rd, !e->iq_is_mag, (uint32_t)chunk, nchunks, up, down, nearest,
+                                            e->pix.d + e->pix.wr, (int64_t)(e->pix.cap - e->pix.wr), &n),
+                        "resample"))
+                return;
+            e->pix.wr += (size_t)n;
+        } else {
+            /* dsp_dropped_compensation_add with a ring that always accepts (dsp.c:326-346) */
+            if (!ensure_dev(e, &e->d_rs, &e->rs_cap, (size_t)count + 16)) return;
+            if (!gpu_ok(e, tsdrgpu_resample(e->rs, e->iq.d + e->iq.rd, !e->iq_is_mag, (uint32_t)chunk, nchunks, up, down, nearest,
+                                            e->d_rs, (int64_t)e->rs_cap, &n),
+                        "resample"))
+                return;
+            if ((int64_t)n <= e->pix_difference) e->pix_difference -= n;
+            else {
+                if (!stream_append(e, &e->pix, e->d_rs + e->pix_difference, (size_t)(n - e->pix_difference))) return;
+                e->pix_difference = 0;
+            }
         }
+        e->iq.rd += (size_t)nchunks * chunk * per;
         /* manual sync, TSDRLibrary.c:345-346 */
         const int so = t->syncoffset;
         t->syncoffset = 0;
@@ -508,11 +706,11 @@ static int super_feed(struct engine *e, const float *d_blk, size_t nfloats, int6
         if (dropped) { e->super_gathered = 0; return 0; }
         const int now = (int)(nfloats / 2);
         if (e->super_gathered + now < e->super_to_gather) {
-            tsdrgpu_copy(e->g, e->d_hops[e->super_hop] + 2 * (size_t)e->super_gathered, d_blk, nfloats * sizeof(float));
+            if (!gpu_ok(e, tsdrgpu_copy(e->g, e->d_hops[e->super_hop] + 2 * (size_t)e->super_gathered, d_blk, nfloats * sizeof(float)), "hop copy")) return 0;
             e->super_gathered += now;
         } else {
             const int remain = e->super_to_gather - e->super_gathered;
-            tsdrgpu_copy(e->g, e->d_hops[e->super_hop] + 2 * (size_t)e->super_gathered, d_blk, (size_t)remain * 2 * sizeof(float));
+            if (!gpu_ok(e, tsdrgpu_copy(e->g, e->d_hops[e->super_hop] + 2 * (size_t)e->super_gathered, d_blk, (size_t)remain * 2 * sizeof(float)), "hop copy")) return 0;
             e->super_gathered += remain;
             e->super_hop++;
             const int gathered = e->super_gathered;
@@ -544,23 +742,22 @@ static int super_feed(struct engine *e, const float *d_blk, size_t nfloats, int6
     return 0;
 }
 
-static void process_block(struct engine *e, const float *h, size_t nfloats, int64_t dropped)
+/* One plugin block, already on the device (slot->d): everything below only queues work. */
+static void process_block(struct engine *e, in_slot_t *slot)
 {
     tsdr_lib_t *t = e->t;
-    if (nfloats) {
-        if (!ensure_dev(e, &e->d_block, &e->block_cap, nfloats)) return;
-        if (!gpu_ok(e, tsdrgpu_upload(e->g, e->d_block, h, nfloats * sizeof(float)), "upload")) return;
-    }
+    const float *d_blk = slot->d;
+    const size_t nfloats = slot->nfloats;
+    const int64_t dropped = slot->dropped;
     const size_t size2 = nfloats / 2;
 
     if (t->params_int[PARAM_AUTOCORR_SUPERRESOLUTION]) { /* TSDRLibrary.c:271-279 */
         if (!e->iq_is_mag) { e->iq.rd = e->iq.wr = 0; e->det.rd = e->det.wr = 0; e->iq_is_mag = 1; }
         uint32_t total = 0;
-        if (nfloats && super_feed(e, e->d_block, nfloats, dropped, &total)) {
+        if (nfloats && super_feed(e, d_blk, nfloats, dropped, &total)) {
             /* am_demod of the stitched buffer, then on to the resampler at 4x the rate */
-            if (!stream_reserve(e, &e->iq, total)) return;
-            if (!gpu_ok(e, tsdrgpu_am_demod(e->g, e->d_super_out, e->iq.d + e->iq.wr, total), "am_demod")) return;
-            e->iq.wr += total;
+            if (stream_reserve(e, &e->iq, total) && gpu_ok(e, tsdrgpu_am_demod(e->g, e->d_super_out, e->iq.d + e->iq.wr, total), "am_demod"))
+                e->iq.wr += total;
         }
     } else {
         if (e->iq_is_mag || e->super_state != SUPER_STOPPED) { /* superb_stop, superbandwidth.c:256-264 */
@@ -578,44 +775,57 @@ static void process_block(struct engine *e, const float *h, size_t nfloats, int6
         const int drop_all = (int64_t)size2 <= e->dev_difference;
         const int plots_on = !t->params_int[PARAM_AUTOCORR_PLOTS_OFF];
         /* frameratedetector_run, frameratedetector.c:215-230 */
-        if (plots_on) {
-            if (dropped != 0) e->det.rd = e->det.wr = 0;
-            else if (!drop_all && nfloats) stream_append(e, &e->det, e->d_block, nfloats);
+        if (plots_on && e->det_read_valid) { /* appends may compact the stream into memory an earlier window still occupies */
+            tsdrgpu_lane_wait(e->g, TSDRGPU_LANE_COMPUTE, e->det_read);
+            e->det_read_valid = 0;
         }
-        /* dsp_dropped_compensation_add, dsp.c:326-346 */
-        if (drop_all) e->dev_difference -= (int64_t)size2;
-        else {
-            stream_append(e, &e->iq, e->d_block + 2 * e->dev_difference, nfloats - 2 * (size_t)e->dev_difference);
-            e->dev_difference = 0;
+        if (plots_on && dropped != 0) e->det.rd = e->det.wr = 0;
+        if (plots_on && dropped == 0 && !drop_all && nfloats && e->dev_difference == 0 && stream_reserve(e, &e->det, nfloats) &&
+            stream_reserve(e, &e->iq, nfloats)) {
+            /* the usual block — nothing lost, nothing to skip — goes to both streams in one launch */
+            if (gpu_ok(e, tsdrgpu_copy2(e->g, e->det.d + e->det.wr, e->iq.d + e->iq.wr, d_blk, nfloats * sizeof(float)), "append")) {
+                e->det.wr += nfloats;
+                e->iq.wr += nfloats;
+            }
+        } else {
+            if (plots_on && dropped == 0 && !drop_all && nfloats && !stream_append(e, &e->det, d_blk, nfloats)) e->det.rd = e->det.wr = 0;
+            /* dsp_dropped_compensation_add, dsp.c:326-346 */
+            if (drop_all) e->dev_difference -= (int64_t)size2;
+            else if (stream_append(e, &e->iq, d_blk + 2 * e->dev_difference, nfloats - 2 * (size_t)e->dev_difference)) e->dev_difference = 0;
         }
     }
-    if (nfloats) tsdrgpu_sync(e->g); /* the pinned slot is recycled as soon as we return */
-    run_resampler(e);
-    run_detector(e, t->samplerate);
+    /* the plugin thread may refill this slot once the COMPUTE lane has read it */
+    if (nfloats && tsdrgpu_event_record(e->g, slot->consumed, TSDRGPU_LANE_COMPUTE) == 0) slot->consumed_valid = 1;
+    else if (nfloats) tsdrgpu_sync(e->g);
 }
 
 static void *device_thread(void *arg)
 {
     struct engine *e = (struct engine *)arg;
     tsdr_lib_t *t = e->t;
+    tsdrgpu_bind_thread(e->g);
     while (t->running) {
         pthread_mutex_lock(&e->qm);
         if (!e->q_count) {
             struct timespec ts;
-            clock_gettime(CLOCK_REALTIME, &ts);
-            ts.tv_nsec += 30 * 1000000L;
-            if (ts.tv_nsec >= 1000000000L) { ts.tv_sec++; ts.tv_nsec -= 1000000000L; }
+            deadline_ms(&ts, 30);
             pthread_cond_timedwait(&e->q_nonempty, &e->qm, &ts);
             pthread_mutex_unlock(&e->qm);
             continue;
         }
-        const int s = e->q_head;
+        /* everything that is queued goes into the sample streams first: when the source runs ahead, the resampler and
+         * the frame path below then work on several blocks per launch instead of one */
+        const int head = e->q_head, n = e->q_count;
         pthread_mutex_unlock(&e->qm);
-        process_block(e, e->slot[s].h, e->slot[s].nfloats, e->slot[s].dropped);
+        const double t0 = e->stats ? now_s() : 0.0;
+        for (int i = 0; i < n; i++) process_block(e, &e->slot[(head + i) % NSLOT]);
         pthread_mutex_lock(&e->qm);
-        e->q_head = (e->q_head + 1) % NSLOT;
-        e->q_count--;
+        e->q_head = (e->q_head + n) % NSLOT;
+        e->q_count -= n;
         pthread_mutex_unlock(&e->qm);
+        run_resampler(e);
+        run_detector(e, t->samplerate);
+        if (e->stats) e->s_dev_busy += now_s() - t0;
     }
     return NULL;
 }
@@ -631,8 +841,23 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     int dev = 0;
     const char *env = getenv("TSDR_GPU_DEVICE");
     if (env) dev = atoi(env);
-    if (tsdrgpu_create(&e->g, dev) || tsdrgpu_resampler_create(e->g, &e->rs) || tsdrgpu_postproc_create(e->g, &e->pp)) {
-        if (e->g) tsdrgpu_destroy(e->g);
+    int ok = tsdrgpu_create(&e->g, dev) == 0 && tsdrgpu_resampler_create(e->g, &e->rs) == 0 && tsdrgpu_postproc_create(e->g, &e->pp) == 0 &&
+             tsdrgpu_event_create(e->g, &e->plot_ready) == 0 && tsdrgpu_event_create(e->g, &e->det_read) == 0;
+    for (int i = 0; ok && i < NSLOT; i++) ok = tsdrgpu_event_create(e->g, &e->slot[i].consumed) == 0;
+    for (int i = 0; ok && i < NFRAMEQ; i++)
+        ok = tsdrgpu_event_create(e->g, &e->fq[i].ready) == 0 && tsdrgpu_alloc_host(e->g, (void **)&e->fq[i].h_info, sizeof(tsdrgpu_pp_frameinfo_t)) == 0;
+    for (int i = 0; ok && i < NOUT; i++) ok = tsdrgpu_event_create(e->g, &e->out[i].done) == 0 && tsdrgpu_event_create(e->g, &e->out[i].last_dl) == 0;
+    if (!ok) {
+        if (e->g) {
+            for (int i = 0; i < NSLOT; i++) tsdrgpu_event_destroy(e->g, e->slot[i].consumed);
+            for (int i = 0; i < NFRAMEQ; i++) { tsdrgpu_event_destroy(e->g, e->fq[i].ready); tsdrgpu_free_host(e->g, e->fq[i].h_info); }
+            for (int i = 0; i < NOUT; i++) { tsdrgpu_event_destroy(e->g, e->out[i].done); tsdrgpu_event_destroy(e->g, e->out[i].last_dl); }
+            tsdrgpu_event_destroy(e->g, e->plot_ready);
+            tsdrgpu_event_destroy(e->g, e->det_read);
+            if (e->pp) tsdrgpu_postproc_destroy(e->pp);
+            if (e->rs) tsdrgpu_resampler_destroy(e->rs);
+            tsdrgpu_destroy(e->g);
+        }
         free(e);
         return tsdr_set_error(t, TSDR_CANNOT_OPEN_DEVICE, "No usable MI355X/HIP device: this library has no CPU path.");
     }
@@ -640,6 +865,15 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
      * with the reference's own strip arithmetic (tsdrgpu_postproc_set_exact_ties; on by default in the library as
      * well).  TSDR_GPU_EXACT_SYNC=0 / TSDR_GPU_EXACT=0 opt out. */
     (void)tsdrgpu_postproc_set_exact_ties(e->pp, exact_wanted("TSDR_GPU_EXACT_SYNC"));
+    {
+        const char *st = getenv("TSDR_GPU_STATS");
+        e->stats = st && st[0] == '1';
+        e->t_start = now_s();
+    }
+    {   /* TSDR_GPU_ZEROCOPY=0: always go through the pinned bounce buffers */
+        const char *z = getenv("TSDR_GPU_ZEROCOPY");
+        e->zero_copy = !(z && z[0] == '0');
+    }
     pthread_mutex_init(&e->qm, NULL); pthread_cond_init(&e->q_nonempty, NULL);
     pthread_mutex_init(&e->fm, NULL); pthread_cond_init(&e->f_nonempty, NULL);
     pthread_mutex_init(&e->pm, NULL); pthread_cond_init(&e->p_nonempty, NULL);
@@ -664,16 +898,45 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     pthread_join(th_video, NULL);
     pthread_join(th_plot, NULL);
 
+    if (e->stats) {
+        const double T = now_s() - e->t_start;
+        fprintf(stderr,
+                "tsdr stats: %.2f s | blocks in %ld lost %ld | frames made %ld lost-to-viewer %ld in %ld batches | resample calls %ld | windows %ld | "
+                "page-locked ranges %d\n"
+                "tsdr stats: plugin thread busy %.0f%% (DMA wait %.0f%%) | device thread busy %.0f%% (waiting for output buffers %.0f%%) | "
+                "video thread: waiting for frames %.0f%%, in the callback %.0f%%\n",
+                T, e->n_blocks, e->n_blocks_lost, e->n_frames_made, e->n_frames_lost, e->n_batches, e->n_resample_calls, e->n_windows, e->nreg,
+                100 * e->s_plugin_busy / T, 100 * e->s_plugin_dma / T, 100 * e->s_dev_busy / T, 100 * e->s_dev_wait_out / T,
+                100 * e->s_video_wait / T, 100 * e->s_video_cb / T);
+    }
+    tsdrgpu_bind_thread(e->g);
     tsdrgpu_sync(e->g);
+    tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD);
+    tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_DOWNLOAD);
     if (e->super_state != SUPER_STOPPED && t->plugin.loaded) t->plugin.setbasefreq(t->centfreq);
-    for (int i = 0; i < NSLOT; i++) tsdrgpu_free_host(e->g, e->slot[i].h);
-    for (int i = 0; i < NFRAMEQ; i++) tsdrgpu_free_host(e->g, e->fq[i].h);
+    for (int i = 0; i < e->nreg; i++) tsdrgpu_host_unregister(e->g, e->reg[i].p); /* before the plugin frees its memory */
+    for (int i = 0; i < NSLOT; i++) {
+        tsdrgpu_free_host(e->g, e->slot[i].h);
+        tsdrgpu_free(e->g, e->slot[i].d);
+        tsdrgpu_event_destroy(e->g, e->slot[i].consumed);
+    }
+    for (int i = 0; i < NFRAMEQ; i++) {
+        tsdrgpu_free_host(e->g, e->fq[i].h);
+        tsdrgpu_free_host(e->g, e->fq[i].h_info);
+        tsdrgpu_event_destroy(e->g, e->fq[i].ready);
+    }
+    for (int i = 0; i < NOUT; i++) {
+        tsdrgpu_free(e->g, e->out[i].d);
+        tsdrgpu_free(e->g, e->out[i].d_info);
+        tsdrgpu_event_destroy(e->g, e->out[i].done);
+        tsdrgpu_event_destroy(e->g, e->out[i].last_dl);
+    }
     for (int i = 0; i < SUPER_HOPS; i++) tsdrgpu_free(e->g, e->d_hops[i]);
-    tsdrgpu_free_host(e->g, e->h_frameplot);
-    tsdrgpu_free_host(e->g, e->h_lineplot);
-    tsdrgpu_free(e->g, e->d_block);
+    tsdrgpu_free_host(e->g, e->plot.h_frame);
+    tsdrgpu_free_host(e->g, e->plot.h_line);
+    tsdrgpu_event_destroy(e->g, e->plot_ready);
+    tsdrgpu_event_destroy(e->g, e->det_read);
     tsdrgpu_free(e->g, e->d_rs);
-    tsdrgpu_free(e->g, e->d_out);
     tsdrgpu_free(e->g, e->d_super_out);
     stream_free(e, &e->iq); stream_free(e, &e->det); stream_free(e, &e->pix);
     if (e->ac) tsdrgpu_autocorr_destroy(e->ac);

@@ -80,7 +80,7 @@ void tsdr_free(tsdr_lib_t **pt)
     tsdr_lib_t *t = *pt;
     t->callback = NULL;
     t->plotready_callback = NULL;
-    if (t->nativerunning) tsdr_stop(t);
+    tsdr_stop(t); /* also waits while tsdr_readasync is still tearing the pipeline down on its own */
     plugin_host_close(&t->plugin);
     free(t->errormsg);
     pthread_cond_destroy(&t->stopped);
@@ -231,13 +231,18 @@ int tsdr_setparameter_double(tsdr_lib_t *t, int parameter, double value) /* TSDR
 
 int tsdr_stop(tsdr_lib_t *t) /* TSDRLibrary.c:213-224 */
 {
-    if (!t->running) return ok(t);
-    const int status = t->plugin.stop();
-    /* wait until tsdr_readasync has torn the pipeline down */
+    pthread_mutex_lock(&t->lock);
+    const int was_running = t->running;
+    pthread_mutex_unlock(&t->lock);
+    const int status = (was_running && t->plugin.loaded) ? t->plugin.stop() : TSDR_OK;
+    /* Wait until tsdr_readasync has torn the pipeline down — also when the plugin's readasync returned on its
+     * own and the teardown is merely still in progress (running already 0, nativerunning still 1): nobody may
+     * unload the plugin or free the library under it. */
     pthread_mutex_lock(&t->lock);
     t->running = 0;
     while (t->nativerunning) pthread_cond_wait(&t->stopped, &t->lock);
     pthread_mutex_unlock(&t->lock);
+    if (!was_running) return ok(t);
     return plugin_result(t, status);
 }
 

@@ -26,6 +26,8 @@ extern "C" int tsdrgpu_create(tsdrgpu_t **out, int device)
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&g->prop, device) != hipSuccess ||
         hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->up, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->down, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&g->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&g->t0) != hipSuccess || hipEventCreate(&g->t1) != hipSuccess) {
         free(g);
@@ -41,6 +43,10 @@ extern "C" void tsdrgpu_destroy(tsdrgpu_t *g)
     hipSetDevice(g->device);
     hipStreamSynchronize(g->stream);
     hipStreamSynchronize(g->stream2);
+    hipStreamSynchronize(g->up);
+    hipStreamSynchronize(g->down);
+    hipStreamDestroy(g->up);
+    hipStreamDestroy(g->down);
     hipStreamDestroy(g->stream2);
     hipEventDestroy(g->fork);
     for (int i = 0; i < g->cap_spans; i++) {
@@ -90,7 +96,8 @@ extern "C" int tsdrgpu_free(tsdrgpu_t *g, void *d_ptr)
 extern "C" int tsdrgpu_alloc_host(tsdrgpu_t *g, void **h_ptr, size_t bytes)
 {
     if (!g || !h_ptr) return TSDRGPU_EINVAL;
-    if (hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+    HIP_TRY(g, hipSetDevice(g->device));
+    if (hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess)
         return tsdr_fail(g, TSDRGPU_ENOMEM, "hipHostMalloc", "out of pinned memory");
     return TSDRGPU_OK;
 }
@@ -118,12 +125,139 @@ extern "C" int tsdrgpu_copy(tsdrgpu_t *g, void *d_dst, const void *d_src, size_t
     if (bytes) HIP_TRY(g, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g->stream));
     return TSDRGPU_OK;
 }
+// one launch that copies a block to two destinations (the engine appends every plugin block to the resampler's and to
+// the detector's sample stream): dwordx4 when all three pointers allow, dwords otherwise
+__global__ __launch_bounds__(256) void k_copy2(const float *__restrict__ src, float *__restrict__ d1, float *__restrict__ d2, long long n, int vec)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if (vec) {
+        const long long nq = n / 4;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
+            const float4 v = reinterpret_cast<const float4 *>(src)[i];
+            reinterpret_cast<float4 *>(d1)[i] = v;
+            reinterpret_cast<float4 *>(d2)[i] = v;
+        }
+        for (long long i = nq * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { d1[i] = src[i]; d2[i] = src[i]; }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const float v = src[i]; d1[i] = v; d2[i] = v; }
+    }
+}
+extern "C" int tsdrgpu_copy2(tsdrgpu_t *g, void *d_dst1, void *d_dst2, const void *d_src, size_t bytes)
+{
+    if (!g || (bytes & 3)) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_copy2", "size must be a multiple of 4") : TSDRGPU_EINVAL;
+    if (!bytes) return TSDRGPU_OK;
+    const long long n = (long long)(bytes / 4);
+    const int vec = ((((uintptr_t)d_dst1) | ((uintptr_t)d_dst2) | ((uintptr_t)d_src)) & 15) == 0;
+    long long blocks = (n / (vec ? 4 : 1) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_copy2, (unsigned)blocks, 256, (const float *)d_src, (float *)d_dst1, (float *)d_dst2, n, vec);
+    KERNEL_CHECK(g, "k_copy2");
+    return TSDRGPU_OK;
+}
 extern "C" int tsdrgpu_zero(tsdrgpu_t *g, void *d_ptr, size_t bytes)
 {
     if (!g) return TSDRGPU_EINVAL;
     if (bytes) HIP_TRY(g, hipMemsetAsync(d_ptr, 0, bytes, g->stream));
     return TSDRGPU_OK;
 }
+// ---- lanes and events -------------------------------------------------------------------------------
+static hipStream_t lane_stream(tsdrgpu_t *g, int lane)
+{
+    switch (lane) {
+        case TSDRGPU_LANE_COMPUTE: return g->stream;
+        case TSDRGPU_LANE_SIDE: return g->stream2;
+        case TSDRGPU_LANE_UPLOAD: return g->up;
+        case TSDRGPU_LANE_DOWNLOAD: return g->down;
+    }
+    return nullptr;
+}
+extern "C" int tsdrgpu_bind_thread(tsdrgpu_t *g)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    HIP_TRY(g, hipSetDevice(g->device));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_event_create(tsdrgpu_t *g, tsdrgpu_event_t **out)
+{
+    if (!g || !out) return TSDRGPU_EINVAL;
+    hipEvent_t ev = nullptr;
+    HIP_TRY(g, hipSetDevice(g->device));
+    HIP_TRY(g, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *out = (tsdrgpu_event_t *)ev;
+    return TSDRGPU_OK;
+}
+extern "C" void tsdrgpu_event_destroy(tsdrgpu_t *g, tsdrgpu_event_t *ev)
+{
+    (void)g;
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+extern "C" int tsdrgpu_event_record(tsdrgpu_t *g, tsdrgpu_event_t *ev, int lane)
+{
+    if (!g || !ev || !lane_stream(g, lane)) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_event_record", "bad lane") : TSDRGPU_EINVAL;
+    HIP_TRY(g, hipEventRecord((hipEvent_t)ev, lane_stream(g, lane)));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_lane_wait(tsdrgpu_t *g, int lane, tsdrgpu_event_t *ev)
+{
+    if (!g || !ev || !lane_stream(g, lane)) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_lane_wait", "bad lane") : TSDRGPU_EINVAL;
+    HIP_TRY(g, hipStreamWaitEvent(lane_stream(g, lane), (hipEvent_t)ev, 0));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_event_sync(tsdrgpu_t *g, tsdrgpu_event_t *ev)
+{
+    if (!g || !ev) return TSDRGPU_EINVAL;
+    HIP_TRY(g, hipEventSynchronize((hipEvent_t)ev));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_event_done(tsdrgpu_t *g, tsdrgpu_event_t *ev)
+{
+    if (!g || !ev) return TSDRGPU_EINVAL;
+    const hipError_t e = hipEventQuery((hipEvent_t)ev);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return tsdr_fail(g, TSDRGPU_EHIP, "hipEventQuery", hipGetErrorString(e));
+}
+extern "C" int tsdrgpu_lane_sync(tsdrgpu_t *g, int lane)
+{
+    if (!g || !lane_stream(g, lane)) return TSDRGPU_EINVAL;
+    HIP_TRY(g, hipStreamSynchronize(lane_stream(g, lane)));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_upload_lane(tsdrgpu_t *g, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    if (bytes) HIP_TRY(g, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g->up));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_download_lane(tsdrgpu_t *g, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (!g) return TSDRGPU_EINVAL;
+    if (bytes) HIP_TRY(g, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g->down));
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_host_register(tsdrgpu_t *g, void *h_ptr, size_t bytes)
+{
+    if (!g || !h_ptr || !bytes) return TSDRGPU_EINVAL;
+    HIP_TRY(g, hipSetDevice(g->device));
+    const hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // not sticky: the caller falls back to a bounce buffer
+        return tsdr_fail(g, TSDRGPU_EHIP, "hipHostRegister", hipGetErrorString(e));
+    }
+    return TSDRGPU_OK;
+}
+extern "C" int tsdrgpu_host_unregister(tsdrgpu_t *g, void *h_ptr)
+{
+    if (!g || !h_ptr) return TSDRGPU_EINVAL;
+    const hipError_t e = hipHostUnregister(h_ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return tsdr_fail(g, TSDRGPU_EHIP, "hipHostUnregister", hipGetErrorString(e));
+    }
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_timer_start(tsdrgpu_t *g)
 {
     if (!g) return TSDRGPU_EINVAL;
@@ -765,7 +899,8 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
     const int slot = staging_acquire(g, &rs->ring, bytes);
     if (slot < 0) return slot;
     RsChunk *tab = (RsChunk *)rs->ring.h[slot];
-    build_chunks(&rs->offset, chunk, nchunks, up, down, tab);
+    double new_offset = rs->offset;  // committed only once nothing below can fail any more
+    build_chunks(&new_offset, chunk, nchunks, up, down, tab);
     unsigned max_out = 0;
     for (int c = 0; c < nchunks; c++) max_out = tab[c].n_out > max_out ? tab[c].n_out : max_out;
     if (track) {
@@ -868,6 +1003,7 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
     }
     rc = staging_release(g, &rs->ring, slot);
     if (rc) return rc;
+    rs->offset = new_offset;
     if (h_n_out) *h_n_out = total;
     return TSDRGPU_OK;
 }

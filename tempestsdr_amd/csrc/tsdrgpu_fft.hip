@@ -981,6 +981,16 @@ extern "C" int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, d
     return TSDRGPU_OK;
 }
 
+extern "C" int tsdrgpu_autocorr_plots_async(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line, uint64_t *h_calls)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    if (h_frame) HIP_TRY(g, hipMemcpyAsync(h_frame, ac->d_plots, sizeof(double) * ac->frame_len, hipMemcpyDeviceToHost, ac->st));
+    if (h_line) HIP_TRY(g, hipMemcpyAsync(h_line, ac->d_plots + ac->frame_len, sizeof(double) * ac->line_len, hipMemcpyDeviceToHost, ac->st));
+    if (h_calls) *h_calls = ac->calls;  // host-side count: known without the device
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_autocorr_device_plots(tsdrgpu_autocorr_t *ac, double **d_plots, int64_t *count)
 {
     if (!ac) return TSDRGPU_EINVAL;

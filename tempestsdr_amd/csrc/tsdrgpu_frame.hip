@@ -1715,6 +1715,32 @@ extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsd
     return TSDRGPU_OK;
 }
 
+__global__ void k_info_pack(const ChainOut *__restrict__ chain, tsdrgpu_pp_frameinfo_t *__restrict__ out, int F)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const ChainOut c = chain[f];
+    tsdrgpu_pp_frameinfo_t o;
+    o.lastmin = c.lastmin; o.lastmax = c.lastmax;
+    o.dx = c.dx; o.vx = c.vx; o.stripx = c.stripx;
+    o.dy = c.dy; o.vy = c.vy; o.stripy = c.stripy;
+    o.locked = c.locked; o.pll_fired = c.pll_fired;
+    o.avg_speed = c.avg_speed; o.frameratediff = c.frameratediff;
+    out[f] = o;
+}
+
+extern "C" int tsdrgpu_postproc_info_pack(tsdrgpu_postproc_t *pp, tsdrgpu_pp_frameinfo_t *d_info, int nframes)
+{
+    if (!pp || !d_info || nframes < 0) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    if (nframes > pp->last_F || !pp->d_chain) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_info_pack", "no run of that many frames");
+    if (pp->pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_info_pack", "a split run is open");
+    if (nframes == 0) return TSDRGPU_OK;
+    TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_info_pack, (nframes + 63) / 64, 64, pp->d_chain, d_info, nframes);
+    KERNEL_CHECK(g, "k_info_pack");
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_postproc_set_exact_ties(tsdrgpu_postproc_t *pp, int on)
 {
     if (!pp) return TSDRGPU_EINVAL;

@@ -40,6 +40,7 @@ struct tsdrgpu {
     int device;
     hipStream_t stream;
     hipStream_t stream2;  // side stream: the autocorrelation can run beside the frame path
+    hipStream_t up, down; // copy lanes (tsdrgpu_upload_lane / tsdrgpu_download_lane)
     hipEvent_t fork;      // orders stream2 behind what is already queued on `stream`
     hipEvent_t t0, t1;
     char err[512];

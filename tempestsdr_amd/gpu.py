@@ -64,6 +64,21 @@ _SIGS = {
     "tsdrgpu_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "tsdrgpu_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "tsdrgpu_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tsdrgpu_copy2": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+    "tsdrgpu_event_create": (C.c_int, [vp, C.POINTER(vp)]),
+    "tsdrgpu_event_destroy": (None, [vp, vp]),
+    "tsdrgpu_event_record": (C.c_int, [vp, vp, C.c_int]),
+    "tsdrgpu_lane_wait": (C.c_int, [vp, C.c_int, vp]),
+    "tsdrgpu_event_sync": (C.c_int, [vp, vp]),
+    "tsdrgpu_event_done": (C.c_int, [vp, vp]),
+    "tsdrgpu_lane_sync": (C.c_int, [vp, C.c_int]),
+    "tsdrgpu_upload_lane": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tsdrgpu_download_lane": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tsdrgpu_host_register": (C.c_int, [vp, vp, C.c_size_t]),
+    "tsdrgpu_host_unregister": (C.c_int, [vp, vp]),
+    "tsdrgpu_bind_thread": (C.c_int, [vp]),
+    "tsdrgpu_postproc_info_pack": (C.c_int, [vp, vp, C.c_int]),
+    "tsdrgpu_autocorr_plots_async": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_zero": (C.c_int, [vp, vp, C.c_size_t]),
     "tsdrgpu_timer_start": (C.c_int, [vp]),
     "tsdrgpu_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),

@@ -1,0 +1,92 @@
+"""ctypes view of the tsdr_* host API (include/TSDRLibrary.h) as libTSDRLibrary.so exports it — the calls the
+Java GUI issues through its JNI shim — plus a whole-library throughput run used by bench.py
+and scripts/e2e_bench.py.  Host-side plumbing only: every sample goes through the C library."""
+import ctypes as C
+import os
+import threading
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libTSDRLibrary.so")
+MEM_PLUGIN = os.path.join(HERE, "libTSDRPlugin_Mem.so")
+
+FRAME_CB = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p)
+VALUE_CB = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_double, C.c_void_p)
+PLOT_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_uint32, C.c_void_p)
+
+TSDR_SYMBOLS = ["tsdr_free", "tsdr_getctx", "tsdr_getlasterrortext", "tsdr_getsamplerate", "tsdr_init",
+                "tsdr_isrunning", "tsdr_loadplugin", "tsdr_motionblur", "tsdr_readasync", "tsdr_reset",
+                "tsdr_setbasefreq", "tsdr_setgain", "tsdr_setparameter_double", "tsdr_setparameter_int",
+                "tsdr_setresolution", "tsdr_stop", "tsdr_sync", "tsdr_unloadplugin"]
+
+
+def load(path=LIB):
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.tsdr_init.argtypes = [C.POINTER(vp), VALUE_CB, PLOT_CB, vp]
+    lib.tsdr_init.restype = None
+    lib.tsdr_free.argtypes = [C.POINTER(vp)]
+    lib.tsdr_free.restype = None
+    lib.tsdr_getctx.argtypes = [vp]
+    lib.tsdr_getctx.restype = vp
+    lib.tsdr_getlasterrortext.argtypes = [vp]
+    lib.tsdr_getlasterrortext.restype = C.c_char_p
+    lib.tsdr_loadplugin.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.tsdr_unloadplugin.argtypes = [vp]
+    lib.tsdr_setresolution.argtypes = [vp, C.c_int, C.c_double]
+    lib.tsdr_setbasefreq.argtypes = [vp, C.c_uint32]
+    lib.tsdr_setgain.argtypes = [vp, C.c_float]
+    lib.tsdr_motionblur.argtypes = [vp, C.c_float]
+    lib.tsdr_sync.argtypes = [vp, C.c_int, C.c_int]
+    lib.tsdr_setparameter_int.argtypes = [vp, C.c_int, C.c_uint32]
+    lib.tsdr_setparameter_double.argtypes = [vp, C.c_int, C.c_double]
+    lib.tsdr_readasync.argtypes = [vp, FRAME_CB, vp]
+    lib.tsdr_stop.argtypes = [vp]
+    lib.tsdr_isrunning.argtypes = [vp]
+    lib.tsdr_getsamplerate.argtypes = [vp]
+    lib.tsdr_reset.argtypes = [vp]
+    lib.tsdr_reset.restype = None
+    return lib
+
+
+def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, setup=None, free=True):
+    """Loads `plugin` into the library at `libpath`, lets it stream for `seconds` and counts what reaches the
+    callbacks.  Both the reference's pipeline and ours are lossy by design (whole blocks / frames are dropped when a
+    stage cannot keep up), so frames delivered per wall second x samples per frame is the effective rate."""
+    lib = load(libpath)
+    vp = C.c_void_p
+    cnt = {"frames": 0, "plots": 0, "w": 0, "h": 0}
+
+    def on_frame(buf, w, h, ctx):
+        cnt["frames"] += 1
+        cnt["w"], cnt["h"] = w, h
+
+    def on_plot(pid, off, vals, size, rate, ctx):
+        cnt["plots"] += 1
+
+    cbs = (FRAME_CB(on_frame), VALUE_CB(lambda *a: None), PLOT_CB(on_plot))
+    h = vp()
+    lib.tsdr_init(C.byref(h), cbs[1], cbs[2], None)
+    pbuf = C.create_string_buffer(params.encode())
+    rc = lib.tsdr_loadplugin(h, plugin.encode(), pbuf)
+    if rc != 0:
+        raise RuntimeError(f"tsdr_loadplugin: {rc} {lib.tsdr_getlasterrortext(h)}")
+    lib.tsdr_setgain(h, 0.5)
+    lib.tsdr_motionblur(h, 0.0)
+    if lib.tsdr_setresolution(h, height, fv) != 0:
+        raise RuntimeError("tsdr_setresolution")
+    if setup:
+        setup(lib, h)
+    status = {}
+    th = threading.Thread(target=lambda: status.setdefault("rc", lib.tsdr_readasync(h, cbs[0], None)))
+    th.start()
+    time.sleep(warmup)  # device context, buffers, page-locking of the source's memory
+    f0, p0, t0 = cnt["frames"], cnt["plots"], time.time()
+    time.sleep(seconds)
+    f1, p1, t1 = cnt["frames"], cnt["plots"], time.time()
+    lib.tsdr_stop(h)
+    th.join(30)
+    if free:  # the reference's own tsdr_free() frees an uninitialised pointer: callers skip it there
+        lib.tsdr_free(C.byref(h))
+    return {"frames_per_s": (f1 - f0) / (t1 - t0), "plots_per_s": (p1 - p0) / (t1 - t0), "width": cnt["w"], "height": cnt["h"],
+            "status": status.get("rc")}

@@ -7,21 +7,19 @@ import subprocess
 import threading
 import time
 
+import sys
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tempestsdr_amd", "libTSDRLibrary.so")
 PLUGIN_SRC = os.path.join(ROOT, "tests", "plugins", "tsdr_test_plugin.c")
 PLUGIN = os.path.join(ROOT, "tests", "plugins", "libtsdr_test_plugin.so")
+MEM_PLUGIN = os.path.join(ROOT, "tempestsdr_amd", "libTSDRPlugin_Mem.so")
 
-FRAME_CB = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p)
-VALUE_CB = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_double, C.c_void_p)
-PLOT_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_uint32, C.c_void_p)
-
-TSDR_SYMBOLS = ["tsdr_free", "tsdr_getctx", "tsdr_getlasterrortext", "tsdr_getsamplerate", "tsdr_init",
-                "tsdr_isrunning", "tsdr_loadplugin", "tsdr_motionblur", "tsdr_readasync", "tsdr_reset",
-                "tsdr_setbasefreq", "tsdr_setgain", "tsdr_setparameter_double", "tsdr_setparameter_int",
-                "tsdr_setresolution", "tsdr_stop", "tsdr_sync", "tsdr_unloadplugin"]
+from tempestsdr_amd.tsdrlib import FRAME_CB, VALUE_CB, PLOT_CB, TSDR_SYMBOLS, load as _load  # noqa: E402,F401
 
 
 def build_test_plugin():
@@ -32,32 +30,7 @@ def build_test_plugin():
 
 
 def load():
-    lib = C.CDLL(LIB)
-    vp = C.c_void_p
-    lib.tsdr_init.argtypes = [C.POINTER(vp), VALUE_CB, PLOT_CB, vp]
-    lib.tsdr_init.restype = None
-    lib.tsdr_free.argtypes = [C.POINTER(vp)]
-    lib.tsdr_free.restype = None
-    lib.tsdr_getctx.argtypes = [vp]
-    lib.tsdr_getctx.restype = vp
-    lib.tsdr_getlasterrortext.argtypes = [vp]
-    lib.tsdr_getlasterrortext.restype = C.c_char_p
-    lib.tsdr_loadplugin.argtypes = [vp, C.c_char_p, C.c_char_p]
-    lib.tsdr_unloadplugin.argtypes = [vp]
-    lib.tsdr_setresolution.argtypes = [vp, C.c_int, C.c_double]
-    lib.tsdr_setbasefreq.argtypes = [vp, C.c_uint32]
-    lib.tsdr_setgain.argtypes = [vp, C.c_float]
-    lib.tsdr_motionblur.argtypes = [vp, C.c_float]
-    lib.tsdr_sync.argtypes = [vp, C.c_int, C.c_int]
-    lib.tsdr_setparameter_int.argtypes = [vp, C.c_int, C.c_uint32]
-    lib.tsdr_setparameter_double.argtypes = [vp, C.c_int, C.c_double]
-    lib.tsdr_readasync.argtypes = [vp, FRAME_CB, vp]
-    lib.tsdr_stop.argtypes = [vp]
-    lib.tsdr_isrunning.argtypes = [vp]
-    lib.tsdr_getsamplerate.argtypes = [vp]
-    lib.tsdr_reset.argtypes = [vp]
-    lib.tsdr_reset.restype = None
-    return lib
+    return _load(LIB)
 
 
 class Session:

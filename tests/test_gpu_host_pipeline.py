@@ -398,6 +398,40 @@ def test_pipeline_with_pll_matches_oracle(orc, tmp_path, fv_true):
     s.close()
 
 
+@pytest.mark.parametrize("zerocopy", ["1", "0"])
+def test_pipeline_mem_plugin_matches_oracle(orc, iq_file, monkeypatch, zerocopy):
+    """The in-memory replay source shipped with the library (libTSDRPlugin_Mem.so): blocks are DMA'd straight out of
+    the plugin's page-locked pages (TSDR_GPU_ZEROCOPY=1, default) or through the pinned bounce buffers (=0); either
+    way every delivered frame is the oracle's, in order from the first, and the first plot is the oracle's exactly."""
+    monkeypatch.setenv("TSDR_GPU_ZEROCOPY", zerocopy)
+    path, iq = iq_file
+    geo = orc.geometry(FS, H, FV)
+    want = oracle_frames(orc, iq, geo)
+    s, ok, rc = run_session(hu.MEM_PLUGIN, f"{path} {FS} {BLOCK} 1 6000", nframes=len(want) - 3, timeout=20)
+    assert ok and rc == 0 and s.status == 0, s.err()
+    hits = match_in_order(s.frames, want)
+    assert hits[0] == 0 and len(hits) >= len(want) - 4
+    ac = orc.Autocorr(FS)
+    ac.run(orc.am_demod(iq)[:orc.capture_size(FS)])
+    frame_plots = [p for p in s.plots if p[0] == 0]
+    assert frame_plots and np.array_equal(frame_plots[0][2], ac.frame)
+    s.close()
+
+
+def test_pipeline_free_running_source(orc, iq_file):
+    """The same source free-running (no pacing, looping over the recording): the library may lose whole blocks when
+    its input queue is full and whole frames when the viewer is slow (both lossy by design, like the reference's
+    rings), but it keeps delivering frames of the right geometry and the session stops cleanly."""
+    path, iq = iq_file
+    s, ok, rc = run_session(hu.MEM_PLUGIN, f"{path} {FS} {BLOCK} 0 0", nframes=100, timeout=30)
+    assert rc == 0 and s.status == 0, s.err()
+    geo = orc.geometry(FS, H, FV)
+    assert len(s.frames) >= 50 and all((w, h) == (geo.width, H) for (w, h, _) in s.frames)
+    assert all(np.isfinite(a).all() for (_, _, a) in s.frames[:20])
+    assert [p for p in s.plots if p[0] == 0]
+    s.close()
+
+
 def test_pipeline_fast_modes_opt_out(orc, iq_file, monkeypatch):
     """TSDR_GPU_EXACT=0 selects the fast forms (three-trip float32 transform, no toss-up redo): frames still the
     oracle's on this input, plots within the stated float tolerance (1e-4 * max) with a peak that is a peak of
