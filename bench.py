@@ -33,7 +33,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: its HIP runtime is the one the process uses)
 
-from tempestsdr_amd import gpu, shard, synth  # noqa: E402
+from tempestsdr_amd import gpu, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -181,6 +181,11 @@ def main():
                     help="also launch k_demod_vec4 over the batch (known 8 B read + 4 B written per sample) so that "
                          "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE readings can be calibrated (scripts/pmc_summarize.py)")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel events in the timed region (no roofline object)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak (default) = every rank runs the whole path on its own 1 s slice of the stream and owns "
+                         "that slice's capture windows; strong = ONE stream: every rank holds the same batch, the frame path "
+                         "is replicated (its recurrences do not shard in time) and capture window k is transformed by rank "
+                         "k mod N only.  Either way the per-lag sums meet in one RCCL all-reduce per pass")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (sums + all-reduce + finalize) even with one rank; used to "
                          "exercise the RCCL path on a 1-GPU box")
@@ -227,8 +232,9 @@ def main():
     up, down = W * h * fv, float(fs)
 
     g = gpu.TsdrGpu(local)
-    # each rank owns a different slice of the stream (weak scaling: fixed work per GPU)
-    iq = synth_iq_torch(fs, mode, fv, nsamples, rank * nsamples, 0x5EED0003, dev)
+    # weak scaling: each rank owns a different slice of the stream (fixed work per GPU); strong: the same batch everywhere
+    strong = sharded and args.scaling == "strong"
+    iq = synth_iq_torch(fs, mode, fv, nsamples, 0 if strong else rank * nsamples, 0x5EED0003, dev)
     torch.cuda.synchronize()
     d_iq = DevPtr(iq)
 
@@ -244,12 +250,17 @@ def main():
     out = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
     d_pix, d_out = DevPtr(pix), DevPtr(out)
     plots_ptr, plots_n = ac.device_plots()
-    red = ext = None
+    comm = None
     if sharded:
-        # the library's plot buffer seen as a torch tensor (zero copy) and its stream as a torch stream, so
-        # the RCCL all-reduce is ordered on the same stream as the kernels: no host synchronisation
-        red = shard.as_tensor(plots_ptr, plots_n, dev)
-        ext = torch.cuda.ExternalStream(g.stream(), device=dev)
+        # RCCL from C (tsdrgpu_rccl.hip): the all-reduce is queued by the library on the autocorrelation's own lane,
+        # ordered with its kernels, no host synchronisation.  torch.distributed only ships the 128-byte id (and
+        # provides the barrier / max-over-ranks of the timing contract).
+        ident = [gpu.Comm.unique_id(g) if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        comm = gpu.Comm(g, world, rank, ident[0])
+    my_windows = len(range(rank, nwin, world)) if strong else nwin
+    total_windows = nwin if strong else nwin * world
 
     carry = 0  # pixels left over from the previous step (a frame straddling two batches)
     frames_done = 0
@@ -261,6 +272,9 @@ def main():
     def run_autocorr():
         if not sharded:
             ac.run(d_iq, 1, ac.capture, nwin, mode=0)
+        elif strong:  # windows rank, rank + world, ... of the one stream
+            ac.reset()
+            ac.run(d_iq, 1, ac.capture * world, my_windows, mode=1, in_offset=2 * rank * ac.capture)
         else:
             ac.reset()
             ac.run(d_iq, 1, ac.capture, nwin, mode=1)
@@ -311,14 +325,9 @@ def main():
             carry = rem
             frames_done += F
         if sharded:
-            if args.overlap:
-                g.sync()  # the sums were accumulated on the side stream
-            with torch.cuda.stream(ext):
-                # RCCL all-reduce over xGMI of the per-lag |R| sums of every rank's windows, in place
-                shard.allreduce_plots(red, nwin, dist, mean=False, total_windows=nwin * world, force=args.force_dist)
-            if args.overlap:
-                ext.synchronize()
-            ac.finalize_sums(nwin * world)
+            # ncclAllReduce(ncclDouble, ncclSum) over xGMI of the per-lag |R| sums of every rank's windows, in place in the
+            # library's plot buffer, then the division by the global window count
+            ac.allreduce(comm, total_windows)
         # every pass ends with a plot update: the argmax is queued behind the pass and collected one pass later,
         # so the host keeps queueing while the device works (one device sync per STEP)
         if arg_pending[0]:
@@ -432,7 +441,7 @@ def main():
 
     if rank == 0:
         passes_timed = args.steps * args.passes
-        total_samples = float(nsamples) * passes_timed * world
+        total_samples = float(nsamples) * passes_timed * (1 if strong else world)
         ms_step = dt / args.steps * 1e3
         ms_pass = ms_step / args.passes
         frames_pass = frames_total / world / passes_timed  # frames one rank completes per pass
@@ -463,12 +472,12 @@ def main():
         ac_group = [k for k in ("k_ac_cols", "k_ac_rows", "k_fft_lds", "k_ac_mid", "k_accumulate") if k in prof]
         ac_ms = sum(per_pass(k)[0] for k in ac_group)
         ac_launches = sum(per_pass(k)[1] for k in ac_group)
-        ac_bytes_pass = (28.0 * N + 16.0 * L) * nwin
+        ac_bytes_pass = (28.0 * N + 16.0 * L) * my_windows
         trips = "3 (columns, row pairs with the fused split, columns)" if "k_ac_cols" in prof else "5 (three radix-128 passes each way, the middle two fused)"
         autocorr = None
         if ac_ms:
             autocorr = {"kernels": ac_group, "launches_per_pass": round(ac_launches, 2), "group_ms_per_pass": round(ac_ms, 4),
-                        "alg_bytes_per_window": int(28 * N + 16 * L), "windows_per_pass": nwin,
+                        "alg_bytes_per_window": int(28 * N + 16 * L), "windows_per_pass": my_windows,
                         "achieved_GBs": round(ac_bytes_pass / (ac_ms * 1e-3) / 1e9, 1),
                         "frac": round(ac_bytes_pass / (ac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "trips_over_hbm_per_window": trips,
@@ -531,7 +540,7 @@ def main():
                       f"IQ Msamples/s (+ reconstructed frames/s), {mode}@60 (configs[{args.config}], not the headline config)",
             "value": round(total_samples / dt / 1e6, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl_name} (h={h} -> {W}x{h} frames), {args.seconds:g} s batch resident in HBM, "
                                    f"{nchunks} resample chunks, {nwin} autocorrelation windows of N=2^{int(np.log2(N))} per pass; "
@@ -545,8 +554,8 @@ def main():
             "ms_per_pass": round(ms_pass, 4),
             "step_ms": {"min": round(srt[0] * 1e3, 3), "median": round(srt[len(srt) // 2] * 1e3, 3), "max": round(srt[-1] * 1e3, 3),
                         "timed_region_s": round(dt, 3)},
-            "frames_per_s": round(frames_total / dt, 1),
-            "realtime_factor": round(total_samples / dt / fs / world, 2),
+            "frames_per_s": round(frames_total / (world if strong else 1) / dt, 1),
+            "realtime_factor": round(total_samples / dt / fs / (1 if strong else world), 2),
             "roofline": roofline,
             "kernels": kernels,
             "frame_path": {"kernels_ms_per_pass": round(frame_ms, 4),
@@ -581,6 +590,8 @@ def main():
             except Exception as e:  # the baseline is a reported number, never the product path
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
+    if comm is not None:
+        comm.destroy()
     g.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -289,6 +289,26 @@ int tsdrgpu_autocorr_argmax_result(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, i
 /* the raw correlation of the LAST window run (2*n floats), for stage tests */
 int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **d_corr, uint32_t *n);
 
+int tsdrgpu_autocorr_lane(tsdrgpu_autocorr_t *ac); /* TSDRGPU_LANE_COMPUTE, or _SIDE after tsdrgpu_autocorr_set_async */
+
+/* ---- the sweep across GPUs — one process per GPU, one exchange over RCCL / xGMI ------------------
+ * Capture windows are independent; the reference only forms their running mean (accummulate,
+ * frameratedetector.c:51-60).  Rank r of `world` takes windows r, r+world, ... with tsdrgpu_autocorr_run(mode 1)
+ * (plain per-lag sums) and tsdrgpu_autocorr_allreduce then leaves the global plots — sum over all ranks / total
+ * window count — on every rank: ncclAllReduce(ncclDouble, ncclSum) of frame_len + line_len values queued on the
+ * autocorrelation's own lane (no host synchronisation), then tsdrgpu_autocorr_finalize_sums.  Equal to the
+ * single-rank running mean up to f64 rounding (1e-15 relative).
+ * Bootstrap like any NCCL program: rank 0 calls tsdrgpu_rccl_unique_id and ships the 128 bytes to the other
+ * ranks by whatever means the host has (MPI, a TCP store, torch.distributed's broadcast); every rank then calls
+ * tsdrgpu_comm_create.  RCCL is dlopen'ed at first use: no link-time dependency, never loaded on one GPU. */
+#define TSDRGPU_RCCL_ID_BYTES 128
+typedef struct tsdrgpu_comm tsdrgpu_comm_t;
+int tsdrgpu_rccl_unique_id(void *id128);
+int tsdrgpu_comm_create(tsdrgpu_t *g, tsdrgpu_comm_t **out, int world, int rank, const void *id128);
+void tsdrgpu_comm_destroy(tsdrgpu_comm_t *c);
+int tsdrgpu_comm_allreduce_f64(tsdrgpu_comm_t *c, double *d_buf, int64_t count, int lane); /* in place, ncclSum */
+int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t *c, uint64_t total_windows);
+
 /* ---- a13/a14: super-bandwidth stitch --------------------------------------------- */
 /* superb_ondataready, superbandwidth.c:121-152 (complex_to_abs_diff :67-81,
  * superb_bestfit :83-119, fft_crosscorrelation fft.c:69-93).  d_hops: nhops

@@ -24,7 +24,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 STRICT = ["-ffp-contract=off"]
 
 HIP_SOURCES = [("tsdrgpu_core.hip", STRICT), ("tsdrgpu_frame.hip", STRICT), ("tsdrgpu_fft.hip", []), ("tsdrgpu_fftx.hip", STRICT),
-               ("tsdrgpu_extras.hip", STRICT)]
+               ("tsdrgpu_extras.hip", STRICT), ("tsdrgpu_rccl.hip", [])]
 LIB = os.path.join(HERE, "libtsdrgpu.so")
 
 
@@ -58,7 +58,7 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError("compile failed: " + " ".join(cmd))
     if force or _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -1094,6 +1094,8 @@ extern "C" int tsdrgpu_autocorr_set_async(tsdrgpu_autocorr_t *ac, int on)
     return TSDRGPU_OK;
 }
 
+extern "C" int tsdrgpu_autocorr_lane(tsdrgpu_autocorr_t *ac) { return (ac && ac->st == ac->g->stream2) ? TSDRGPU_LANE_SIDE : TSDRGPU_LANE_COMPUTE; }
+
 extern "C" int tsdrgpu_autocorr_set_plan(tsdrgpu_autocorr_t *ac, int trips)
 {
     if (!ac || (trips != 3 && trips != 5)) return ac ? tsdr_fail(ac->g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_set_plan", "trips must be 3 or 5") : TSDRGPU_EINVAL;

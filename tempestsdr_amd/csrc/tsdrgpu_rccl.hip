@@ -1,0 +1,125 @@
+// tsdrgpu_rccl.hip — the one exchange step of the multi-GPU autocorrelation sweep: every rank (one
+// process per GPU) keeps per-lag SUMS of |R| over the capture windows it owns (tsdrgpu_autocorr_run mode 1); one
+// ncclAllReduce(ncclDouble, ncclSum) of frame_len + line_len doubles (5.4 MB at 100 MS/s) over xGMI, queued on the
+// autocorrelation's own lane, then the division by the global window count, give every rank the plots the reference
+// forms as a running mean (accummulate, frameratedetector.c:51-60).
+//
+// RCCL is resolved with dlopen at first use (librccl.so.1 of the ROCm install), so the library itself has no link-time
+// dependency on it and single-GPU hosts never load it.
+#include <dlfcn.h>
+
+#include "tsdrgpu_internal.h"
+
+// the slice of rccl.h this file needs (ABI of RCCL 2.x as shipped with ROCm 6/7)
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { ncclSuccess_ = 0 };
+enum { ncclFloat64_ = 8 };  // ncclDataType_t: ncclDouble
+enum { ncclSum_ = 0 };      // ncclRedOp_t
+
+struct RcclApi {
+    void *dl;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+};
+static RcclApi g_rccl;
+
+static const RcclApi *rccl()
+{
+    if (g_rccl.dl) return &g_rccl;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *dl = nullptr;
+    for (const char *n : names)
+        if ((dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!dl) return nullptr;
+    RcclApi a;
+    a.dl = dl;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(dl, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(dl, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(dl, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(dl, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(dl, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
+        dlclose(dl);
+        return nullptr;
+    }
+    g_rccl = a;
+    return &g_rccl;
+}
+
+struct tsdrgpu_comm {
+    tsdrgpu_t *g;
+    ncclComm_t comm;
+    int world, rank;
+};
+
+extern "C" int tsdrgpu_rccl_unique_id(void *id128)
+{
+    if (!id128) return TSDRGPU_EINVAL;
+    const RcclApi *r = rccl();
+    if (!r) return TSDRGPU_ESTATE;
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccess_) return TSDRGPU_EHIP;
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_comm_create(tsdrgpu_t *g, tsdrgpu_comm_t **out, int world, int rank, const void *id128)
+{
+    if (!g || !out || !id128 || world < 1 || rank < 0 || rank >= world) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_comm_create", "bad argument") : TSDRGPU_EINVAL;
+    const RcclApi *r = rccl();
+    if (!r) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_comm_create", "librccl.so.1 not found");
+    HIP_TRY(g, hipSetDevice(g->device));
+    tsdrgpu_comm_t *c = (tsdrgpu_comm_t *)calloc(1, sizeof(*c));
+    if (!c) return TSDRGPU_ENOMEM;
+    ncclUniqueId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    const ncclResult_t rc = r->CommInitRank(&c->comm, world, id, rank);
+    if (rc != ncclSuccess_) {
+        free(c);
+        return tsdr_fail(g, TSDRGPU_EHIP, "ncclCommInitRank", r->GetErrorString(rc));
+    }
+    c->g = g;
+    c->world = world;
+    c->rank = rank;
+    *out = c;
+    return TSDRGPU_OK;
+}
+
+extern "C" void tsdrgpu_comm_destroy(tsdrgpu_comm_t *c)
+{
+    if (!c) return;
+    const RcclApi *r = rccl();
+    if (r && c->comm) (void)r->CommDestroy(c->comm);
+    free(c);
+}
+
+// all-reduce of a caller buffer of doubles on a lane of the context (building block; also what the frame path's
+// row-band exchange uses)
+extern "C" int tsdrgpu_comm_allreduce_f64(tsdrgpu_comm_t *c, double *d_buf, int64_t count, int lane)
+{
+    if (!c || !d_buf || count < 0) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = c->g;
+    const RcclApi *r = rccl();
+    if (!r) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_comm_allreduce_f64", "librccl.so.1 not found");
+    hipStream_t st = lane == TSDRGPU_LANE_SIDE ? g->stream2 : g->stream;
+    const ncclResult_t rc = r->AllReduce(d_buf, d_buf, (size_t)count, ncclFloat64_, ncclSum_, c->comm, st);
+    if (rc != ncclSuccess_) return tsdr_fail(g, TSDRGPU_EHIP, "ncclAllReduce", r->GetErrorString(rc));
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t *c, uint64_t total_windows)
+{
+    if (!ac || !c || total_windows == 0) return TSDRGPU_EINVAL;
+    double *d_plots = nullptr;
+    int64_t count = 0;
+    int rc = tsdrgpu_autocorr_device_plots(ac, &d_plots, &count);
+    if (rc) return rc;
+    rc = tsdrgpu_comm_allreduce_f64(c, d_plots, count, tsdrgpu_autocorr_lane(ac));
+    if (rc) return rc;
+    return tsdrgpu_autocorr_finalize_sums(ac, total_windows);
+}

@@ -79,6 +79,12 @@ _SIGS = {
     "tsdrgpu_bind_thread": (C.c_int, [vp]),
     "tsdrgpu_postproc_info_pack": (C.c_int, [vp, vp, C.c_int]),
     "tsdrgpu_autocorr_plots_async": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
+    "tsdrgpu_autocorr_lane": (C.c_int, [vp]),
+    "tsdrgpu_rccl_unique_id": (C.c_int, [vp]),
+    "tsdrgpu_comm_create": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, vp]),
+    "tsdrgpu_comm_destroy": (None, [vp]),
+    "tsdrgpu_comm_allreduce_f64": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
+    "tsdrgpu_autocorr_allreduce": (C.c_int, [vp, vp, C.c_uint64]),
     "tsdrgpu_zero": (C.c_int, [vp, vp, C.c_size_t]),
     "tsdrgpu_timer_start": (C.c_int, [vp]),
     "tsdrgpu_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
@@ -463,6 +469,31 @@ class PostProcess:
         return c, r
 
 
+class Comm:
+    """RCCL communicator for the sharded sweep (tsdrgpu_comm_*): one per rank, on the context's device."""
+
+    @staticmethod
+    def unique_id(ctx):
+        buf = (C.c_char * 128)()
+        ctx._ck(ctx.lib.tsdrgpu_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, world, rank, id128):
+        self.ctx = ctx
+        h = vp()
+        ctx._ck(ctx.lib.tsdrgpu_comm_create(ctx.h, C.byref(h), int(world), int(rank), C.c_char_p(id128)))
+        self.h = h
+        self.world, self.rank = world, rank
+
+    def allreduce_f64(self, d_ptr, count, lane=0):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_comm_allreduce_f64(self.h, d_ptr, int(count), int(lane)))
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.tsdrgpu_comm_destroy(self.h)
+        self.h = None
+
+
 class Autocorr:
     """frameratedetector numerics on the device (frameratedetector.c:26-126)."""
 
@@ -510,6 +541,10 @@ class Autocorr:
         p, n = vp(), C.c_int64()
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_device_plots(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def allreduce(self, comm, total_windows):
+        """per-lag sums of every rank -> global plots on every rank (RCCL from C, on this object's lane)"""
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_allreduce(self.h, comm.h, int(total_windows)))
 
     def finalize_sums(self, total_windows):
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_finalize_sums(self.h, total_windows))
