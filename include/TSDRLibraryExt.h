@@ -1,0 +1,49 @@
+/*
+ * TSDRLibraryExt.h — extensions of the tsdr_* API that only this (MI355X) implementation has.  They live
+ * behind their own symbols (tsdrx_*): the eighteen tsdr_* entry points of include/TSDRLibrary.h stay exactly the
+ * reference's, and a host that never calls anything here sees the reference's behaviour.
+ *
+ * What they are for: the two conversions that sit right next to the hot path in the reference —
+ * the sample-format decode inside the RawFile plugin (TSDRPlugin_RawFile/src/TSDRPlugin_RawFile.c:241-261) and the
+ * float -> packed RGB pixel loop inside the Java GUI's JNI shim (JavaGUI/jni/TSDRLibraryNDK.c:222-276) — run on the
+ * device here, so narrow samples cross PCIe as they are (2-4x fewer bytes in) and the per-pixel branch chain on the
+ * host disappears.
+ */
+#ifndef TSDR_LIBRARY_EXT_H_
+#define TSDR_LIBRARY_EXT_H_
+
+#include <stdint.h>
+
+#include "TSDRLibrary.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One reconstructed frame as width*height packed 0x00RRGGBB pixels, converted exactly like the JNI shim does
+ * (gray = (int)(v*255) for 0 < v <= 1, black/white outside, the PIXEL_SPECIAL_VALUE_* debug colours, pixels equal
+ * to PIXEL_SPECIAL_VALUE_TRANSPARENT keep the colour the previous frame of the same size left there).  The buffer
+ * is the library's and valid during the call. */
+typedef void (*tsdrx_readasync_rgb_function)(int32_t *pixels, int width, int height, void *ctx);
+
+/* tsdr_readasync with frames delivered through `cb` as packed RGB; `inverted` as the GUI's invert-colours option
+ * (Java_martin_tempest_core_TSDRLibrary_setInvertedColors).  Same blocking / error behaviour as tsdr_readasync. */
+int tsdrx_readasync_rgb(tsdr_lib_t *tsdr, tsdrx_readasync_rgb_function cb, void *ctx, int inverted);
+
+/* Sample formats of the optional raw plugin entry point, numbered like tsdrgpu_decode_samples:
+ *     int tsdrplugin_readasync_raw(tsdrplugin_readasync_raw_function cb, void *ctx);
+ * A source plugin that exports it (besides the ten mandatory tsdrplugin_* symbols) hands its blocks over in their
+ * native format; the library decodes them on the device bit-exactly like the RawFile plugin does on the host
+ * (double division, float store).  items_count counts values (two per IQ sample), like the float callback's.
+ * TSDR_GPU_RAW=0 makes the library ignore the entry point. */
+#define TSDRX_SAMPLE_FLOAT32 0
+#define TSDRX_SAMPLE_INT8 1
+#define TSDRX_SAMPLE_INT16 2
+#define TSDRX_SAMPLE_UINT8 3
+#define TSDRX_SAMPLE_UINT16 4
+typedef void (*tsdrplugin_readasync_raw_function)(const void *buf, uint64_t items_count, int sample_type, void *ctx, int64_t samples_dropped);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

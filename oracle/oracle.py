@@ -318,6 +318,25 @@ def ref():
     return r
 
 
+_REF_JNI = os.path.join(_HERE, "_ref", "libtsdr_ref_jni.so")
+_ref_jni = None
+
+
+def have_ref_jni():
+    return os.path.exists(_REF_JNI)
+
+
+def ref_jni():
+    """ctypes handle of the reference's JNI shim compiled behind oracle/jni_stub (its frame -> RGB pixel loop)."""
+    global _ref_jni
+    if _ref_jni is None:
+        r = C.CDLL(_REF_JNI)
+        _sig(r.ref_jni_frame_to_rgb, None, f32p, C.c_int, C.c_int, C.c_int, i32p)
+        _sig(r.ref_jni_reset, None)
+        _ref_jni = r
+    return _ref_jni
+
+
 def plot_populate(data, nwidth, scale=None):
     """PlotVisualizer.populateData: (visdata, lowest, highest, max_index); scale=None = unzoomed."""
     data = np.ascontiguousarray(data, np.float64)

@@ -17,10 +17,14 @@
  * /root/reference into oracle/_ref/ by oracle/Makefile (tests/test_oracle_vs_ref.py,
  * bit-exact) and against golden vectors produced by that build
  * (tests/golden/, script tests/golden/make_golden.py).
- * PARITY UNPINNED for two restatements of Java / JNI code, which cannot be built
- * here (no JDK): orc_plot_populate (PlotVisualizer.populateData) and
- * orc_frame_to_rgb (TSDRLibraryNDK.c pixel conversion); both are integer / max-only
- * loops and are cross-checked by independent formulations in tests/test_extras_cpu.py.
+ * orc_frame_to_rgb is pinned against the reference's JNI shim itself, compiled from
+ * JavaGUI/jni/TSDRLibraryNDK.c behind a stub jni.h (oracle/jni_stub, oracle/ref_shim_jni.c;
+ * tests/test_oracle_vs_ref.py::test_frame_to_rgb_*).
+ * PARITY UNPINNED for the restatements of JAVA code, which cannot be run here (no JVM):
+ * orc_plot_populate (PlotVisualizer.populateData) and the mode-detection logic
+ * (Main.java / VideoMode.java); they are integer / max-only / f64-division logic, checked
+ * against line-by-line transliterations in tests/test_extras_cpu.py and against committed
+ * fixtures (tests/golden/java_fixtures.json) derived from those.
  *
  * Build: gcc -O3 -fPIC -shared -ffp-contract=off (no fast-math; the reference
  * is built -O3 without fast-math, TempestSDR/makefile:21).

@@ -66,6 +66,7 @@ typedef struct {
 
 typedef struct {
     float *d; size_t cap;              /* F frames */
+    int32_t *d_rgb; size_t rgb_cap;    /* the same frames as packed RGB (tsdrx_readasync_rgb runs only) */
     tsdrgpu_pp_frameinfo_t *d_info;    /* F records */
     int info_cap;
     tsdrgpu_event_t *done, *last_dl;   /* batch computed (COMPUTE) / its last download queued (DOWNLOAD) */
@@ -75,6 +76,8 @@ typedef struct {
 typedef struct {
     float *h; size_t hcap;   /* pinned bounce buffer (used when the plugin's memory cannot be page-locked) */
     float *d; size_t dcap;   /* device copy of the block */
+    void *d_raw; size_t raw_cap; /* the block in the plugin's native sample format (tsdrplugin_readasync_raw), bytes */
+    int raw_type;            /* TSDRX_SAMPLE_*: != FLOAT32 means d_raw still has to be decoded into d */
     size_t nfloats;
     int64_t dropped;
     tsdrgpu_event_t *consumed; /* COMPUTE lane is done reading d */
@@ -120,6 +123,7 @@ struct engine {
     float *d_rs; size_t rs_cap; /* resampler scratch for the calls whose first pixels are skipped */
     out_buf_t out[NOUT];
     int out_next;
+    int32_t *d_rgb_state; size_t rgb_state_cap; /* the viewer's pixel buffer: transparent pixels keep the previous frame's colour */
 
     int64_t dev_difference; /* samples still to skip (process(), TSDRLibrary.c:284-295) */
     int64_t pix_difference; /* pixels still to skip (decimatingthread, TSDRLibrary.c:342-346) */
@@ -260,7 +264,12 @@ static int plugin_memory_pinned(struct engine *e, void *p, size_t n)
     return 1;
 }
 
-static void on_block(float *buf, uint64_t items, void *ctx, int64_t dropped)
+static size_t sample_bytes(int type)
+{
+    return (type == TSDRX_SAMPLE_INT8 || type == TSDRX_SAMPLE_UINT8) ? 1 : ((type == TSDRX_SAMPLE_INT16 || type == TSDRX_SAMPLE_UINT16) ? 2 : 4);
+}
+
+static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, int64_t dropped)
 {
     struct engine *e = (struct engine *)ctx;
     if (!e->t->running || (items & 1)) return;
@@ -277,27 +286,37 @@ static void on_block(float *buf, uint64_t items, void *ctx, int64_t dropped)
     pthread_mutex_unlock(&e->qm);
     int ok = 1;
     if (items) {
-        const size_t bytes = (size_t)items * sizeof(float);
+        const size_t bytes = (size_t)items * sample_bytes(type);
         if (s->consumed_valid) { tsdrgpu_event_sync(e->g, s->consumed); s->consumed_valid = 0; } /* long done in practice */
         if (s->dcap < items) {
             tsdrgpu_free(e->g, s->d);
             s->d = NULL; s->dcap = 0;
-            if (tsdrgpu_alloc(e->g, (void **)&s->d, bytes) == 0) s->dcap = items; else ok = 0;
+            if (tsdrgpu_alloc(e->g, (void **)&s->d, (size_t)items * sizeof(float)) == 0) s->dcap = items; else ok = 0;
+        }
+        void *dst = s->d;
+        if (type != TSDRX_SAMPLE_FLOAT32) { /* narrow samples cross PCIe as they are; the device thread decodes them */
+            if (ok && s->raw_cap < bytes) {
+                tsdrgpu_free(e->g, s->d_raw);
+                s->d_raw = NULL; s->raw_cap = 0;
+                if (tsdrgpu_alloc(e->g, &s->d_raw, bytes) == 0) s->raw_cap = bytes; else ok = 0;
+            }
+            dst = s->d_raw;
         }
         const void *src = buf;
-        if (ok && !plugin_memory_pinned(e, buf, bytes)) {
-            if (s->hcap < items) {
+        if (ok && !plugin_memory_pinned(e, (void *)buf, bytes)) {
+            if (s->hcap < items) { /* sized for float32, the widest format */
                 tsdrgpu_free_host(e->g, s->h);
                 s->h = NULL; s->hcap = 0;
-                if (tsdrgpu_alloc_host(e->g, (void **)&s->h, bytes) == 0) s->hcap = items; else ok = 0;
+                if (tsdrgpu_alloc_host(e->g, (void **)&s->h, (size_t)items * sizeof(float)) == 0) s->hcap = items; else ok = 0;
             }
             if (ok) { memcpy(s->h, buf, bytes); src = s->h; }
         }
         /* the plugin's buffer is ours only until we return: wait for the DMA (about 40 us for RawFile's 2 MB) */
         const double t1 = e->stats ? now_s() : 0.0;
-        if (ok) ok = tsdrgpu_upload_lane(e->g, s->d, src, bytes) == 0 && tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD) == 0;
+        if (ok) ok = tsdrgpu_upload_lane(e->g, dst, src, bytes) == 0 && tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD) == 0;
         if (e->stats) e->s_plugin_dma += now_s() - t1;
     }
+    s->raw_type = type;
     pthread_mutex_lock(&e->qm);
     if (!ok) { /* could not stage the block: count it as lost, like a full queue */
         e->pending_drop += (int64_t)(items / 2) + dropped;
@@ -312,6 +331,17 @@ static void on_block(float *buf, uint64_t items, void *ctx, int64_t dropped)
     pthread_cond_signal(&e->q_nonempty);
     pthread_mutex_unlock(&e->qm);
     if (e->stats) e->s_plugin_busy += now_s() - t0;
+}
+
+static void on_block(float *buf, uint64_t items, void *ctx, int64_t dropped) /* the tsdrplugin_readasync callback */
+{
+    on_block_any(buf, items, TSDRX_SAMPLE_FLOAT32, ctx, dropped);
+}
+
+static void on_block_raw(const void *buf, uint64_t items, int type, void *ctx, int64_t dropped) /* tsdrplugin_readasync_raw */
+{
+    if (type < TSDRX_SAMPLE_FLOAT32 || type > TSDRX_SAMPLE_UINT16) return;
+    on_block_any(buf, items, type, ctx, dropped);
 }
 
 /* ---- video thread ---------------------------------------------------------------- */
@@ -336,7 +366,8 @@ static void *video_thread(void *arg)
         if (arrived && t->running) {
             /* dsp.c:231-235: autogain values every 7th frame */
             if (f->announce_autogain) tsdr_announce_value(t, VALUE_ID_AUTOGAIN_VALUES, f->h_info->lastmin, f->h_info->lastmax);
-            e->cb(f->h, f->width, f->height, e->cbctx);
+            if (t->rgb_cb) t->rgb_cb((int32_t *)(void *)f->h, f->width, f->height, e->cbctx);
+            else e->cb(f->h, f->width, f->height, e->cbctx);
         }
         if (e->stats) { e->s_video_wait += t1 - t0; e->s_video_cb += now_s() - t1; }
         pthread_mutex_lock(&e->fm);
@@ -535,7 +566,8 @@ static void deliver_frames(struct engine *e, out_buf_t *ob, int F, int W, int H)
             s->cap = P;
         }
         if (!queued && tsdrgpu_lane_wait(e->g, TSDRGPU_LANE_DOWNLOAD, ob->done)) return;
-        if (tsdrgpu_download_lane(e->g, s->h, ob->d + (size_t)f * P, P * sizeof(float)) ||
+        const void *d_src = e->t->rgb_cb ? (const void *)(ob->d_rgb + (size_t)f * P) : (const void *)(ob->d + (size_t)f * P);
+        if (tsdrgpu_download_lane(e->g, s->h, d_src, P * sizeof(float)) ||
             tsdrgpu_download_lane(e->g, s->h_info, ob->d_info + f, sizeof(tsdrgpu_pp_frameinfo_t)) ||
             tsdrgpu_event_record(e->g, s->ready, TSDRGPU_LANE_DOWNLOAD))
             continue;
@@ -591,6 +623,28 @@ static void run_frames(struct engine *e)
         }
         tsdrgpu_pp_frameinfo_t info;
         if (!gpu_ok(e, tsdrgpu_postproc_run(e->pp, e->pix.d + e->pix.rd, F, W, H, &prm, ob->d, prm.pll ? &info : NULL), "postproc")) return;
+        if (t->rgb_cb) {
+            /* the JNI shim's pixel loop (TSDRLibraryNDK.c:222-276) on the device: frame after frame into the viewer's
+             * persistent pixel buffer (transparent pixels keep their colour), a copy of which goes home */
+            if (e->rgb_state_cap < P) {
+                tsdrgpu_sync(e->g);
+                tsdrgpu_free(e->g, e->d_rgb_state);
+                e->d_rgb_state = NULL; e->rgb_state_cap = 0;
+                if (tsdrgpu_alloc(e->g, (void **)&e->d_rgb_state, P * sizeof(int32_t))) return;
+                e->rgb_state_cap = P;
+            }
+            if (ob->rgb_cap < P * (size_t)F) {
+                tsdrgpu_sync(e->g);
+                tsdrgpu_free(e->g, ob->d_rgb);
+                ob->d_rgb = NULL; ob->rgb_cap = 0;
+                if (tsdrgpu_alloc(e->g, (void **)&ob->d_rgb, P * (size_t)MAX_FRAME_BATCH * sizeof(int32_t))) return;
+                ob->rgb_cap = P * (size_t)MAX_FRAME_BATCH;
+            }
+            for (int f = 0; f < F; f++)
+                if (!gpu_ok(e, tsdrgpu_frame_to_rgb(e->g, ob->d + (size_t)f * P, e->d_rgb_state, (int64_t)P, t->rgb_inverted), "frame_to_rgb") ||
+                    !gpu_ok(e, tsdrgpu_copy(e->g, ob->d_rgb + (size_t)f * P, e->d_rgb_state, P * sizeof(int32_t)), "rgb copy"))
+                    return;
+        }
         if (!gpu_ok(e, tsdrgpu_postproc_info_pack(e->pp, ob->d_info, F), "info") ||
             !gpu_ok(e, tsdrgpu_event_record(e->g, ob->done, TSDRGPU_LANE_COMPUTE), "event"))
             return;
@@ -748,6 +802,10 @@ static void process_block(struct engine *e, in_slot_t *slot)
     tsdr_lib_t *t = e->t;
     const float *d_blk = slot->d;
     const size_t nfloats = slot->nfloats;
+    /* TSDRPlugin_RawFile.c:241-261 on the device, bit-exact (double division, float store) */
+    if (nfloats && slot->raw_type != TSDRX_SAMPLE_FLOAT32 &&
+        !gpu_ok(e, tsdrgpu_decode_samples(e->g, slot->d_raw, slot->raw_type, slot->d, (int64_t)nfloats), "decode"))
+        return;
     const int64_t dropped = slot->dropped;
     const size_t size2 = nfloats / 2;
 
@@ -888,7 +946,11 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     pthread_create(&th_video, NULL, video_thread, e);
     pthread_create(&th_plot, NULL, plot_thread, e);
 
-    const int status = t->plugin.readasync(on_block, e); /* blocks until tsdr_stop / plugin failure */
+    /* blocks until tsdr_stop / plugin failure; a plugin that offers its blocks in their native sample format
+     * (TSDRLibraryExt.h) is taken up on it unless TSDR_GPU_RAW=0 */
+    const char *rawenv = getenv("TSDR_GPU_RAW");
+    const int use_raw = t->plugin.readasync_raw && !(rawenv && rawenv[0] == '0');
+    const int status = use_raw ? t->plugin.readasync_raw(on_block_raw, e) : t->plugin.readasync(on_block, e);
 
     t->running = 0;
     pthread_join(th_dev, NULL);
@@ -918,6 +980,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     for (int i = 0; i < NSLOT; i++) {
         tsdrgpu_free_host(e->g, e->slot[i].h);
         tsdrgpu_free(e->g, e->slot[i].d);
+        tsdrgpu_free(e->g, e->slot[i].d_raw);
         tsdrgpu_event_destroy(e->g, e->slot[i].consumed);
     }
     for (int i = 0; i < NFRAMEQ; i++) {
@@ -927,6 +990,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     }
     for (int i = 0; i < NOUT; i++) {
         tsdrgpu_free(e->g, e->out[i].d);
+        tsdrgpu_free(e->g, e->out[i].d_rgb);
         tsdrgpu_free(e->g, e->out[i].d_info);
         tsdrgpu_event_destroy(e->g, e->out[i].done);
         tsdrgpu_event_destroy(e->g, e->out[i].last_dl);
@@ -937,6 +1001,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     tsdrgpu_event_destroy(e->g, e->plot_ready);
     tsdrgpu_event_destroy(e->g, e->det_read);
     tsdrgpu_free(e->g, e->d_rs);
+    tsdrgpu_free(e->g, e->d_rgb_state);
     tsdrgpu_free(e->g, e->d_super_out);
     stream_free(e, &e->iq); stream_free(e, &e->det); stream_free(e, &e->pix);
     if (e->ac) tsdrgpu_autocorr_destroy(e->ac);

@@ -37,6 +37,7 @@ int plugin_host_load(plugin_host_t *p, const char *path)
             return TSDR_ERR_PLUGIN;
         }
     }
+    p->readasync_raw = (int (*)(tsdrplugin_readasync_raw_function, void *))dlsym(p->dl, "tsdrplugin_readasync_raw"); /* optional */
     p->loaded = 1;
     return TSDR_OK;
 }

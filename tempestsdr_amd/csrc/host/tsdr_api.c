@@ -246,7 +246,7 @@ int tsdr_stop(tsdr_lib_t *t) /* TSDRLibrary.c:213-224 */
     return plugin_result(t, status);
 }
 
-int tsdr_readasync(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx) /* TSDRLibrary.c:467-536 */
+static int readasync_common(tsdr_lib_t *t, tsdr_readasync_function cb, tsdrx_readasync_rgb_function rgb_cb, int inverted, void *ctx)
 {
     pthread_mutex_lock(&t->lock);
     if (t->nativerunning || t->running) {
@@ -258,6 +258,8 @@ int tsdr_readasync(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx) /* TSDR
         return tsdr_set_error(t, TSDR_ERR_PLUGIN, "Please load a working plugin first!");
     }
     tsdr_reset(t);
+    t->rgb_cb = rgb_cb;
+    t->rgb_inverted = inverted;
     t->nativerunning = 1;
     t->running = 1;
     pthread_mutex_unlock(&t->lock);
@@ -279,6 +281,19 @@ int tsdr_readasync(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx) /* TSDR
     pthread_mutex_unlock(&t->lock);
     return status;
 }
+
+int tsdr_readasync(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx) /* TSDRLibrary.c:467-536 */
+{
+    return readasync_common(t, cb, NULL, 0, ctx);
+}
+
+#pragma GCC visibility push(default)
+int tsdrx_readasync_rgb(tsdr_lib_t *t, tsdrx_readasync_rgb_function cb, void *ctx, int inverted) /* TSDRLibraryExt.h */
+{
+    if (!cb) return tsdr_set_error(t, TSDR_WRONG_VIDEOPARAMS, "tsdrx_readasync_rgb needs a callback");
+    return readasync_common(t, NULL, cb, inverted ? 1 : 0, ctx);
+}
+#pragma GCC visibility pop
 
 /* dsp.c:321-324,354-368 */
 static uint64_t drop_comp(const int block, const int dropped)

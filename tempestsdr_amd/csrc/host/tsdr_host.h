@@ -11,6 +11,7 @@
 /* the library is built with -fvisibility=hidden: only the tsdr_* API is exported */
 #pragma GCC visibility push(default)
 #include "TSDRLibrary.h"
+#include "TSDRLibraryExt.h"
 #pragma GCC visibility pop
 #include "tsdrgpu.h"
 
@@ -31,6 +32,7 @@ typedef struct plugin_host {
     char *(*getlasterrortext)(void);
     int (*readasync)(tsdrplugin_readasync_function, void *);
     void (*cleanup)(void);
+    int (*readasync_raw)(tsdrplugin_readasync_raw_function, void *); /* optional extension, NULL when absent */
 } plugin_host_t;
 
 int plugin_host_load(plugin_host_t *p, const char *path); /* TSDR_OK / TSDR_INCOMPATIBLE_PLUGIN / TSDR_ERR_PLUGIN */
@@ -68,6 +70,10 @@ struct tsdr_lib {
 
     volatile int detector_purge; /* frameratedetector_flushcachedestimation */
     struct engine *eng;
+
+    /* TSDRLibraryExt.h: frames as packed RGB for this run (NULL: float frames through the tsdr_readasync callback) */
+    tsdrx_readasync_rgb_function rgb_cb;
+    int rgb_inverted;
 };
 
 void tsdr_geometry_update(tsdr_lib_t *t, uint32_t samplerate); /* set_internal_samplerate */

@@ -21,6 +21,8 @@ MEM_PLUGIN = os.path.join(ROOT, "tempestsdr_amd", "libTSDRPlugin_Mem.so")
 
 from tempestsdr_amd.tsdrlib import FRAME_CB, VALUE_CB, PLOT_CB, TSDR_SYMBOLS, load as _load  # noqa: E402,F401
 
+RGB_CB = C.CFUNCTYPE(None, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p)
+
 
 def build_test_plugin():
     if not os.path.exists(PLUGIN) or os.path.getmtime(PLUGIN) < os.path.getmtime(PLUGIN_SRC):
@@ -55,6 +57,12 @@ class Session:
             with self.lock:
                 self.plots.append((pid, offset, a, rate))
 
+        def on_rgb(buf, w, h, ctx):
+            a = np.ctypeslib.as_array(buf, shape=(w * h,)).copy()
+            with self.lock:
+                self.frames.append((w, h, a))
+
+        self._rgb_cb = RGB_CB(on_rgb)
         self._cbs = (FRAME_CB(on_frame), VALUE_CB(on_value), PLOT_CB(on_plot))
         self.h = C.c_void_p()
         self.lib.tsdr_init(C.byref(self.h), self._cbs[1], self._cbs[2], None)
@@ -65,9 +73,14 @@ class Session:
         e = self.lib.tsdr_getlasterrortext(self.h)
         return e.decode() if e else None
 
-    def start(self):
+    def start(self, rgb=None):
+        """rgb: None = float frames through tsdr_readasync; 0 / 1 = packed RGB through tsdrx_readasync_rgb (inverted = rgb)"""
         def run():
-            self.status = self.lib.tsdr_readasync(self.h, self._cbs[0], None)
+            if rgb is None:
+                self.status = self.lib.tsdr_readasync(self.h, self._cbs[0], None)
+            else:
+                self.lib.tsdrx_readasync_rgb.argtypes = [C.c_void_p, RGB_CB, C.c_void_p, C.c_int]
+                self.status = self.lib.tsdrx_readasync_rgb(self.h, self._rgb_cb, None, int(rgb))
         self.thread = threading.Thread(target=run)
         self.thread.start()
 

@@ -54,7 +54,7 @@ def match_in_order(got, want):
     return hits
 
 
-def run_session(plugin, params, setup=None, nframes=8, during=None, timeout=40, height=H, refresh=FV):
+def run_session(plugin, params, setup=None, nframes=8, during=None, timeout=40, height=H, refresh=FV, rgb=None):
     s = hu.Session()
     assert s.lib.tsdr_loadplugin(s.h, plugin.encode(), params.encode()) == 0, s.err()
     assert s.lib.tsdr_setbasefreq(s.h, 400_000_000) == 0
@@ -62,7 +62,7 @@ def run_session(plugin, params, setup=None, nframes=8, during=None, timeout=40, 
     assert s.lib.tsdr_setresolution(s.h, height, refresh) == 0
     if setup:
         setup(s)
-    s.start()
+    s.start(rgb)
     ok = s.wait_frames(nframes, timeout)
     if during:
         during(s)
@@ -416,6 +416,56 @@ def test_pipeline_mem_plugin_matches_oracle(orc, iq_file, monkeypatch, zerocopy)
     frame_plots = [p for p in s.plots if p[0] == 0]
     assert frame_plots and np.array_equal(frame_plots[0][2], ac.frame)
     s.close()
+
+
+@pytest.mark.parametrize("inverted", [0, 1])
+def test_extension_rgb_delivery_matches_the_jni_conversion(orc, iq_file, inverted):
+    """tsdrx_readasync_rgb (include/TSDRLibraryExt.h): frames arrive as packed 0x00RRGGBB, converted on the device;
+    each equals the oracle's frame pushed through the oracle's restatement of the JNI shim's pixel loop (pinned against
+    the compiled shim in tests/test_oracle_vs_ref.py), green sync lines (512.0 -> 0x00FF00) included."""
+    path, iq = iq_file
+    geo = orc.geometry(FS, H, FV)
+    want = []
+    buf = np.zeros(geo.width * H, np.int32)
+    for fr in oracle_frames(orc, iq, geo):
+        orc.lib.orc_frame_to_rgb(fr, buf, fr.size, inverted)
+        want.append(buf.copy())
+    s, ok, rc = run_session(hu.build_test_plugin(), f"{path} {FS} {BLOCK} 8000", nframes=len(want) - 3, timeout=20, rgb=inverted)
+    assert ok and rc == 0 and s.status == 0, s.err()
+    assert all(a.dtype == np.int32 for (_, _, a) in s.frames)
+    hits = match_in_order(s.frames, want)
+    assert hits[0] == 0 and len(hits) >= len(want) - 4
+    assert any((a == 0x00FF00).any() for (_, _, a) in s.frames)  # the sync detector's green lines made it through
+    s.close()
+
+
+@pytest.mark.parametrize("fmt,dtype,scale", [("int16", np.int16, 20000.0), ("int8", np.int8, 100.0), ("uint8", np.uint8, 100.0)])
+def test_extension_raw_sample_formats(orc, tmp_path, monkeypatch, fmt, dtype, scale):
+    """tsdrplugin_readasync_raw (include/TSDRLibraryExt.h): the in-memory source hands int16 / int8 / uint8 IQ over as
+    it is, the library decodes on the device (TSDRPlugin_RawFile.c:241-261 arithmetic).  Frames equal the oracle's
+    on the RawFile-decoded stream — and equal what the same plugin delivers through the plain float callback with
+    TSDR_GPU_RAW=0 (host-side conversion like RawFile's)."""
+    n = 14 * (BLOCK // 2)
+    iqf = synth.synth_iq(FS, "640x480", 60.0, n, seed=0x5EED0001)
+    if dtype == np.uint8:
+        raw = np.clip(np.round(iqf * scale) + 128, 0, 255).astype(np.uint8)
+        tid = 3
+    else:
+        raw = np.clip(np.round(iqf * scale), np.iinfo(dtype).min, np.iinfo(dtype).max).astype(dtype)
+        tid = 2 if dtype == np.int16 else 1
+    path = tmp_path / f"iq.{fmt}"
+    raw.tofile(path)
+    decoded = np.empty(raw.size, np.float32)
+    orc.lib.orc_decode_samples(raw.ctypes.data, tid, decoded, raw.size)  # pinned against the RawFile plugin binary
+    geo = orc.geometry(FS, H, FV)
+    want = oracle_frames(orc, decoded, geo)
+    for use_raw in ("1", "0"):
+        monkeypatch.setenv("TSDR_GPU_RAW", use_raw)
+        s, ok, rc = run_session(hu.MEM_PLUGIN, f"{path} {FS} {BLOCK} 1 6000 {fmt}", nframes=len(want) - 3, timeout=20)
+        assert ok and rc == 0 and s.status == 0, s.err()
+        hits = match_in_order(s.frames, want)
+        assert hits[0] == 0 and len(hits) >= len(want) - 4, use_raw
+        s.close()
 
 
 def test_pipeline_free_running_source(orc, iq_file):

@@ -232,3 +232,65 @@ def test_dropped_shift(orc, ref, block):
         diff_m = orc.lib.orc_dropped_shift_with(diff_m, block, s)
         ref.dsp_dropped_compensation_shift_with(C.byref(diff_r), block, s)
         assert diff_m == diff_r.value
+
+
+# ---------------------------------------------------------------------------
+# f3: frame -> packed RGB.  The reference is the JNI shim's pixel loop (JavaGUI/jni/TSDRLibraryNDK.c:222-276),
+# compiled here from its own source behind oracle/jni_stub/jni.h and driven through its frame callback read_async().
+# ---------------------------------------------------------------------------
+def _rgb_frame(rng, n):
+    v = rng.random(n).astype(np.float32) * np.float32(1.6) - np.float32(0.3)  # below 0, inside (0,1], above 1
+    idx = rng.choice(n, size=min(n, 64), replace=False)
+    special = np.array([256.0, 512.0, 1024.0, 2048.0, 0.0, 1.0, -0.0, np.nextafter(np.float32(1.0), np.float32(2.0)),
+                        255.9999 / 255.0, 1e-30, np.inf, -np.inf, 300.0, 2047.0, 2049.0, 0.5], np.float32)
+    v[idx] = special[np.arange(idx.size) % special.size]
+    return v
+
+
+@pytest.mark.parametrize("inverted", [0, 1])
+def test_frame_to_rgb_equals_the_reference_jni_loop(orc, inverted):
+    if not orc.have_ref_jni():
+        pytest.skip("oracle/_ref/libtsdr_ref_jni.so not built (no /root/reference on this box)")
+    jni = orc.ref_jni()
+    jni.ref_jni_reset()
+    rng = np.random.default_rng(40 + inverted)
+    prev_ref = prev_orc = None
+    for (w, h) in [(64, 48), (64, 48), (507, 525), (507, 525), (33, 7)]:  # a repeated size keeps the viewer's buffer
+        n = w * h
+        frame = _rgb_frame(rng, n)
+        got_ref = np.zeros(n, np.int32)
+        jni.ref_jni_frame_to_rgb(frame, w, h, inverted, got_ref)
+        # the oracle converts into a caller buffer: transparent pixels keep what it holds, which for the GUI is the
+        # previous frame of the same size (a fresh, malloc'ed buffer after a size change: those pixels are undefined
+        # in the reference, so they are excluded from the comparison for the first frame of a size)
+        if prev_orc is not None and prev_orc.size == n:
+            buf = prev_orc.copy()
+            defined = np.ones(n, bool)
+        else:
+            buf = np.zeros(n, np.int32)
+            defined = frame != np.float32(2048.0)
+        orc.lib.orc_frame_to_rgb(frame, buf, n, inverted)
+        assert np.array_equal(buf[defined], got_ref[defined])
+        # carry the REFERENCE's buffer forward so that undefined pixels cannot leak into the next comparison
+        prev_orc = got_ref.copy()
+        prev_ref = got_ref
+
+
+def test_frame_to_rgb_every_gray_level(orc):
+    """(int)(v*255.0f) over a fine sweep of (0, 1]: every one of the 256 levels and their boundaries."""
+    if not orc.have_ref_jni():
+        pytest.skip("oracle/_ref/libtsdr_ref_jni.so not built")
+    jni = orc.ref_jni()
+    jni.ref_jni_reset()
+    k = np.arange(1, 256 * 4096 + 1, dtype=np.float64) / (256 * 4096)
+    frame = k.astype(np.float32)
+    edges = (np.arange(1, 256, dtype=np.float32) / np.float32(255.0))
+    frame = np.concatenate([frame, edges, np.nextafter(edges, np.float32(0)), np.nextafter(edges, np.float32(2))]).astype(np.float32)
+    n = frame.size
+    for inverted in (0, 1):
+        a = np.zeros(n, np.int32)
+        b = np.zeros(n, np.int32)
+        jni.ref_jni_frame_to_rgb(frame, n, 1, inverted, a)
+        orc.lib.orc_frame_to_rgb(frame, b, n, inverted)
+        assert np.array_equal(a, b)
+        assert len(np.unique(a & 255)) == 256
