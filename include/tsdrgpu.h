@@ -222,6 +222,17 @@ int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsdrgpu_pp_fra
 int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width, int height,
                                   const tsdrgpu_pp_params_t *params, const float *d_fmin, const float *d_fmax,
                                   float *d_out);
+/* Row-band sharding of the frame path across GPUs: this rank holds rows [y0, y0+rows) of every
+ * frame (d_band: nframes * rows * width floats), y0 a multiple of 32.  _band_begin computes the band's statistics and
+ * exposes two small device buffers; the caller all-reduces them IN PLACE across the ranks — *d_xsum (n_xsum doubles)
+ * with ncclSum, *d_xmax (n_xmax floats) with ncclMax: tsdrgpu_comm_allreduce_f64 / tsdrgpu_comm_allreduce_f32max —
+ * and _band_finish runs the (replicated) autogain / sync-detector chain and the normalise / green-lines / IIR pass on
+ * the band's rows into d_out_band.  Library-default stage order, no autoshift, no PLL.  Frames are bit-identical to
+ * tsdrgpu_postproc_run's in its fast mode (tsdrgpu_postproc_set_exact_ties(pp, 0)); a one-band "sharding" needs no
+ * exchange at all.  Reference: dsp.c:41-110, syncdetector.c:171-225. */
+int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *d_band, int nframes, int width, int height, int y0, int rows,
+                                const tsdrgpu_pp_params_t *params, double **d_xsum, int64_t *n_xsum, float **d_xmax, int64_t *n_xmax);
+int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out_band, tsdrgpu_pp_frameinfo_t *h_info);
 /* The per-frame record of the last run, without a host synchronisation: packs nframes tsdrgpu_pp_frameinfo_t
  * into the caller's DEVICE buffer on the COMPUTE lane (download it on any lane behind an event). */
 int tsdrgpu_postproc_info_pack(tsdrgpu_postproc_t *pp, tsdrgpu_pp_frameinfo_t *d_info, int nframes);
@@ -307,6 +318,7 @@ int tsdrgpu_rccl_unique_id(void *id128);
 int tsdrgpu_comm_create(tsdrgpu_t *g, tsdrgpu_comm_t **out, int world, int rank, const void *id128);
 void tsdrgpu_comm_destroy(tsdrgpu_comm_t *c);
 int tsdrgpu_comm_allreduce_f64(tsdrgpu_comm_t *c, double *d_buf, int64_t count, int lane); /* in place, ncclSum */
+int tsdrgpu_comm_allreduce_f32max(tsdrgpu_comm_t *c, float *d_buf, int64_t count, int lane); /* in place, ncclMax */
 int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t *c, uint64_t total_windows);
 
 /* ---- a13/a14: super-bandwidth stitch --------------------------------------------- */

@@ -81,6 +81,14 @@ struct tsdrgpu_postproc {
     int pending;                // 1: begin() done, chain queued on the side stream; 2: begin() deferred everything;
                                 // 3: fused run (begin_minmax) queued completely, finish() only joins the streams
     const float *p_frames;
+    // row-band sharding (tsdrgpu_postproc_band_begin / _finish)
+    int band_y0, band_rows;     // this rank's rows [y0, y0 + rows) of every frame
+    int band_mode;              // launch_chain: strips come from the exchange, no literal re-collapse is possible
+    double *d_xsum;             // [F][3][W + H]: column sums of the band, row sums of its rows (zero elsewhere)
+    float *d_xmax;              // [F][4]: -min, max, pixel 0 of the frame (rank of band 0, else -inf), spare
+    float *d_v0;                // [F] pixel 0 of every frame after the exchange
+    ChainOut *d_chain_band;     // the chain record with dy relative to the band, for the pass
+    size_t cap_xsum, cap_xmax, cap_v0, cap_chain_band;
     const float *ext_fmin, *ext_fmax;  // per-frame min/max supplied by the caller (fused run), else null
     int p_F, p_W, p_H;
     tsdrgpu_pp_params_t p_prm;
@@ -1297,7 +1305,8 @@ extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
     (void)hipEventDestroy(pp->ev_stats);
     (void)hipEventDestroy(pp->ev_chain);
     void *bufs[] = {pp->d_state, pp->d_screen, pp->d_screen2, pp->d_dump, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
-                    pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain, pp->d_sflag, pp->d_exact};
+                    pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain, pp->d_sflag, pp->d_exact,
+                    pp->d_xsum, pp->d_xmax, pp->d_v0, pp->d_chain_band};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (pp->h_chain) (void)hipHostFree(pp->h_chain);
@@ -1402,28 +1411,37 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
         sc.blur = pp->d_work;
         sc.prefix = (double *)(pp->d_work + (((size_t)F * 2 * nmax + 1) & ~(size_t)1));
         sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
-        TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, strips_normalised,
-                    pp->d_sflag);
+        if (pp->band_mode) {
+            // row-band run: a rank holds only its rows, so the literal (raster-order) re-collapse of a strip is not
+            // available; every strip is taken from the exchanged f64 sums
+            HIP_TRY(g, hipMemsetAsync(pp->d_sflag, 0, sizeof(int) * (size_t)F * 2, st));
+        } else {
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, strips_normalised,
+                        pp->d_sflag);
+        }
         SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
         int *d_amb = pp->d_sflag + (size_t)F * 2, *d_fresh = d_amb + (size_t)F * 2, *d_redo = d_fresh + (size_t)F * 2;
         const int *const no_gate = nullptr;
         const unsigned exact_blocks = (unsigned)(((W + 63) / 64) > ((H + 63) / 64) ? ((W + 63) / 64) : ((H + 63) / 64));
         // run 1 as speculated; with exact ties on, run 2 (five empty launches unless needed) repeats the chain for a
         // batch in which some decision was a toss-up at the precision of the strips, those frames' strips made exact
-        const int runs = pp->exact_ties ? 2 : 1;
+        const int runs = (pp->exact_ties && !pp->band_mode) ? 2 : 1;
         for (int run = 0; run < runs; run++) {
             const int *gate = run ? d_redo : no_gate;
             const int *only = run ? d_fresh : no_gate;
             if (run) TSDR_LAUNCH(g, PROF_CHAIN, st, k_redo_prepare, 1, 256, 2 * F, d_amb, pp->d_sflag, d_redo, d_fresh);
-            TSDR_LAUNCH(g, PROF_CHAIN, st, k_exact_strips, dim3(exact_blocks, 2, F), 256, frames, fstride, W, H, pp->d_chain, strips_normalised,
-                        pp->d_sflag, pp->d_exact, nmax, gate, only);
-            KERNEL_CHECK(g, "k_exact_strips");
+            if (!pp->band_mode) {
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_exact_strips, dim3(exact_blocks, 2, F), 256, frames, fstride, W, H, pp->d_chain, strips_normalised,
+                            pp->d_sflag, pp->d_exact, nmax, gate, only);
+                KERNEL_CHECK(g, "k_exact_strips");
+            }
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
                         strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, gate);
             KERNEL_CHECK(g, "k_strip_prepare");
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, run ? pp->d_state + 1 : pp->d_state, spec, gate, only);
             KERNEL_CHECK(g, "k_sync_search");
-            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1, pp->exact_ties ? d_amb : (int *)nullptr, gate);
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, H, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1,
+                        (pp->exact_ties && !pp->band_mode) ? d_amb : (int *)nullptr, gate);
         }
         KERNEL_CHECK(g, "k_sync_chain");
     }
@@ -1711,6 +1729,134 @@ extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsd
     const int lines = (!prm->autoshift && a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
     int rc;
     if ((rc = launch_pass(pp, PASS_NORMALISE | map | lines | PASS_IIR, pp->p_frames, Ps, d_out, Ps, F, W, H, a))) return rc;
+    if (h_info) return pp_copy_info(pp, F, h_info);
+    return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Row-band sharding of the frame path (dsp.c:41-110, syncdetector.c:171-225).  Temporal sharding is
+// impossible (IIR state, autogain, sync state are frame-to-frame recurrences) but rows shard: rank r holds rows
+// [y0, y0+rows) of every frame, its IIR state and its part of the output.  What a frame needs from the other ranks is
+// tiny: min / max / pixel 0 (autogain, dsp.c:50-66) and the two collapsed strips (dsp.c:96-110) — column sums add up
+// over the bands, row sums are concatenated (added here with zeros elsewhere, so one sum all-reduce does both).
+// begin: band statistics -> exchange buffers; the CALLER all-reduces them in place (sum for d_xsum, max for d_xmax:
+// tsdrgpu_comm_allreduce_f64 / _f32max over RCCL); finish: every rank runs the (tiny, replicated) chain on the
+// identical strips and the normalise / lines / IIR pass on its rows.  With bands that start on multiples of 32 rows
+// the tile partial sums are the single-GPU run's, f64 sums of <= a few hundred f32 partials are exact, so strips, sync
+// decisions and therefore frames are bit-identical to the single-GPU run in its fast mode (no literal re-collapse of
+// toss-up strips: that walks a column through every band in order).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_band_pack(int F, int W, int Htot, int y0, int rows, const double *__restrict__ strip_x,
+                                                   const double *__restrict__ strip_y, const float *__restrict__ fmin_,
+                                                   const float *__restrict__ fmax_, const float *__restrict__ frames, long long fstride,
+                                                   double *__restrict__ xsum, float *__restrict__ xmax)
+{
+    const int f = blockIdx.z, q = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W + Htot) {
+        double v;
+        if (i < W) v = strip_x[((long long)f * 3 + q) * W + i];
+        else {
+            const int y = i - W;
+            v = (y >= y0 && y < y0 + rows) ? strip_y[((long long)f * 3 + q) * rows + (y - y0)] : 0.0;
+        }
+        xsum[((long long)f * 3 + q) * (W + Htot) + i] = v;
+    }
+    if (i == 0 && q == 0) {
+        xmax[f * 4 + 0] = -fmin_[f];
+        xmax[f * 4 + 1] = fmax_[f];
+        xmax[f * 4 + 2] = (y0 == 0) ? frames[(long long)f * fstride] : -INFINITY;  // dsp.c:50-51: v[0] seeds min and max
+        xmax[f * 4 + 3] = -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_band_unpack(int F, int W, int Htot, const double *__restrict__ xsum, const float *__restrict__ xmax,
+                                                     double *__restrict__ strip_x, double *__restrict__ strip_y, float *__restrict__ fmin_,
+                                                     float *__restrict__ fmax_, float *__restrict__ v0)
+{
+    const int f = blockIdx.z, q = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W + Htot) {
+        const double v = xsum[((long long)f * 3 + q) * (W + Htot) + i];
+        if (i < W) strip_x[((long long)f * 3 + q) * W + i] = v;
+        else strip_y[((long long)f * 3 + q) * Htot + (i - W)] = v;
+    }
+    if (i == 0 && q == 0) {
+        fmin_[f] = -xmax[f * 4 + 0];
+        fmax_[f] = xmax[f * 4 + 1];
+        v0[f] = xmax[f * 4 + 2];
+    }
+}
+
+__global__ void k_band_chain(const ChainOut *__restrict__ chain, ChainOut *__restrict__ out, int F, int y0)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    ChainOut c = chain[f];
+    c.dy -= y0;  // the pass compares band-local row numbers
+    out[f] = c;
+}
+
+extern "C" int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *d_band, int F, int W, int Htot, int y0, int rows,
+                                           const tsdrgpu_pp_params_t *prm, double **d_xsum, int64_t *n_xsum, float **d_xmax, int64_t *n_xmax)
+{
+    if (!pp || !d_band || !prm || F <= 0 || W <= 0 || Htot <= 0 || y0 < 0 || rows <= 0 || y0 + rows > Htot)
+        return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_begin", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    if (pp->pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_begin", "a split run is already open");
+    if (prm->lowpass_before_sync || prm->autogain_after_proc || prm->autoshift || prm->pll)
+        return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_begin",
+                         "row bands support the library-default stage order without autoshift (the 2-D roll needs every row) and without the PLL");
+    if (y0 % TILE_H) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_begin", "a band must start on a multiple of 32 rows");
+    int rc;
+    if ((rc = pp_prepare(pp, F, W, Htot, prm))) return rc;
+    if ((rc = ensure(g, &pp->d_xsum, &pp->cap_xsum, (size_t)F * 3 * (W + Htot)))) return rc;
+    if ((rc = ensure(g, &pp->d_xmax, &pp->cap_xmax, (size_t)F * 4))) return rc;
+    if ((rc = ensure(g, &pp->d_v0, &pp->cap_v0, (size_t)F))) return rc;
+    if ((rc = ensure(g, &pp->d_chain_band, &pp->cap_chain_band, (size_t)F))) return rc;
+    const long long Pb = (long long)W * rows;
+    if ((rc = launch_stats(pp, d_band, Pb, F, W, rows, 1))) return rc;  // strips of the band: [F][3][W] and [F][3][rows]
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, g->stream, k_band_pack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, y0, rows, pp->d_strip_x, pp->d_strip_y,
+                pp->d_fmin, pp->d_fmax, d_band, Pb, pp->d_xsum, pp->d_xmax);
+    KERNEL_CHECK(g, "k_band_pack");
+    pp->p_frames = d_band;
+    pp->p_F = F; pp->p_W = W; pp->p_H = Htot;
+    pp->p_prm = *prm;
+    pp->band_y0 = y0;
+    pp->band_rows = rows;
+    pp->pending = 4;
+    if (d_xsum) *d_xsum = pp->d_xsum;
+    if (n_xsum) *n_xsum = (int64_t)F * 3 * (W + Htot);
+    if (d_xmax) *d_xmax = pp->d_xmax;
+    if (n_xmax) *n_xmax = (int64_t)F * 4;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out_band, tsdrgpu_pp_frameinfo_t *h_info)
+{
+    if (!pp || !d_out_band) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_finish", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    if (pp->pending != 4) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_finish", "no band run is open");
+    pp->pending = 0;
+    const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H, y0 = pp->band_y0, rows = pp->band_rows;
+    const tsdrgpu_pp_params_t *prm = &pp->p_prm;
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, g->stream, k_band_unpack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_xmax, pp->d_strip_x,
+                pp->d_strip_y, pp->d_fmin, pp->d_fmax, pp->d_v0);
+    KERNEL_CHECK(g, "k_band_unpack");
+    pp->band_mode = 1;
+    int rc = launch_chain(pp, pp->d_v0, 1, F, W, Htot, 1, 1, 1, prm);  // "frames" = pixel 0 of every frame, stride 1
+    pp->band_mode = 0;
+    if (rc) return rc;
+    TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_band_chain, (F + 63) / 64, 64, pp->d_chain, pp->d_chain_band, F, y0);
+    KERNEL_CHECK(g, "k_band_chain");
+    const float a = prm->motionblur;
+    const int lines = (a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+    const long long Pb = (long long)W * rows;
+    ChainOut *full = pp->d_chain;
+    pp->d_chain = pp->d_chain_band;  // what the pass reads
+    rc = launch_pass(pp, PASS_NORMALISE | lines | PASS_IIR, pp->p_frames, Pb, d_out_band, Pb, F, W, rows, a);
+    pp->d_chain = full;
+    if (rc) return rc;
     if (h_info) return pp_copy_info(pp, F, h_info);
     return TSDRGPU_OK;
 }

@@ -112,6 +112,18 @@ extern "C" int tsdrgpu_comm_allreduce_f64(tsdrgpu_comm_t *c, double *d_buf, int6
     return TSDRGPU_OK;
 }
 
+extern "C" int tsdrgpu_comm_allreduce_f32max(tsdrgpu_comm_t *c, float *d_buf, int64_t count, int lane)
+{
+    if (!c || !d_buf || count < 0) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = c->g;
+    const RcclApi *r = rccl();
+    if (!r) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_comm_allreduce_f32max", "librccl.so.1 not found");
+    hipStream_t st = lane == TSDRGPU_LANE_SIDE ? g->stream2 : g->stream;
+    const ncclResult_t rc = r->AllReduce(d_buf, d_buf, (size_t)count, 7 /* ncclFloat32 */, 2 /* ncclMax */, c->comm, st);
+    if (rc != ncclSuccess_) return tsdr_fail(g, TSDRGPU_EHIP, "ncclAllReduce", r->GetErrorString(rc));
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t *c, uint64_t total_windows)
 {
     if (!ac || !c || total_windows == 0) return TSDRGPU_EINVAL;

@@ -78,6 +78,10 @@ _SIGS = {
     "tsdrgpu_host_unregister": (C.c_int, [vp, vp]),
     "tsdrgpu_bind_thread": (C.c_int, [vp]),
     "tsdrgpu_postproc_info_pack": (C.c_int, [vp, vp, C.c_int]),
+    "tsdrgpu_postproc_band_begin": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_int64),
+                                              C.POINTER(vp), C.POINTER(C.c_int64)]),
+    "tsdrgpu_postproc_band_finish": (C.c_int, [vp, vp, vp]),
+    "tsdrgpu_comm_allreduce_f32max": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
     "tsdrgpu_autocorr_plots_async": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_lane": (C.c_int, [vp]),
     "tsdrgpu_rccl_unique_id": (C.c_int, [vp]),
@@ -462,6 +466,21 @@ class PostProcess:
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_finish(self.h, d_out.at(out_offset), info))
         return list(info) if want_info else None
 
+    def band_begin(self, d_band, nframes, width, height, y0, rows, motionblur=0.0, lowpasscoeff=0.1, superres=0, frames_offset=0):
+        """Row-band sharding, first half: statistics of rows [y0, y0+rows); returns (xsum_ptr, n_doubles, xmax_ptr,
+        n_floats): device buffers the caller all-reduces in place (sum / max) across the ranks."""
+        prm = PPParams(0, 0, 0, 0, superres, motionblur, lowpasscoeff)
+        self._nframes = nframes
+        ps, ns, pm, nm = vp(), C.c_int64(), vp(), C.c_int64()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_begin(self.h, d_band.at(frames_offset), nframes, width, height, y0, rows, C.byref(prm),
+                                                              C.byref(ps), C.byref(ns), C.byref(pm), C.byref(nm)))
+        return ps.value, ns.value, pm.value, nm.value
+
+    def band_finish(self, d_out_band, want_info=True, out_offset=0):
+        info = (PPFrameInfo * self._nframes)() if want_info else None
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_finish(self.h, d_out_band.at(out_offset), info))
+        return list(info) if want_info else None
+
     def strips(self, width, height):
         c = np.empty(width, np.float32)
         r = np.empty(height, np.float32)
@@ -484,6 +503,9 @@ class Comm:
         ctx._ck(ctx.lib.tsdrgpu_comm_create(ctx.h, C.byref(h), int(world), int(rank), C.c_char_p(id128)))
         self.h = h
         self.world, self.rank = world, rank
+
+    def allreduce_f32max(self, d_ptr, count, lane=0):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_comm_allreduce_f32max(self.h, d_ptr, int(count), int(lane)))
 
     def allreduce_f64(self, d_ptr, count, lane=0):
         self.ctx._ck(self.ctx.lib.tsdrgpu_comm_allreduce_f64(self.h, d_ptr, int(count), int(lane)))
