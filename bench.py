@@ -382,6 +382,35 @@ def main():
         prof = g.profile_end()
     frames_done = frames_timed
 
+    # side metric: the super-bandwidth stitch (superb_ondataready, superbandwidth.c:121-152) of 4 hops x 10 frames
+    superb = None
+    if rank == 0 and world == 1 and not args.no_profile and not args.force_dist and args.config == 2:
+        try:
+            sif = int(fs / fv)
+            gathered = 10 * sif
+            per = 1 << (gathered.bit_length() - 1)
+            d_hops = [DevPtr(iq[2 * k * gathered:2 * (k + 1) * gathered].clone()) for k in range(4)]
+            d_st = DevPtr(torch.empty(2 * 4 * per, dtype=torch.float32, device=dev))
+            offs, total = g.superb_stitch(d_hops, gathered, sif, d_st)  # warm-up (allocates the context's scratch)
+            for k in range(4):  # the stitch leaves spectra in the hop buffers: restore the samples
+                d_hops[k].t.copy_(iq[2 * k * gathered:2 * (k + 1) * gathered])
+            torch.cuda.synchronize()
+            tsb = time.perf_counter()
+            offs, total = g.superb_stitch(d_hops, gathered, sif, d_st)  # synchronises (the offsets steer the rotation)
+            tsb = time.perf_counter() - tsb
+            bfl = 1 << ((((2 * per) // sif) * sif).bit_length() - 1)
+            bn = bfl // 2
+            # abs-diff of 4 hops (16 bn each), 1 + 3 forward and 3 inverse transforms of bn (16 bn each at one pass per
+            # transform), 4 rotations and 4 hop transforms of `per` (16 per each), the stitch transform of 4 per
+            alg = 16.0 * bn * 4 + 16.0 * bn * 7 + 16.0 * per * 8 + 16.0 * 4 * per
+            superb = {"ms_per_stitch": round(tsb * 1e3, 3), "hops": 4, "samples_per_hop": per, "correlated_samples": bn,
+                      "hop_offsets_floats": [int(o) for o in offs], "alg_bytes": int(alg),
+                      "achieved_GBs": round(alg / tsb / 1e9, 1), "frac": round(alg / tsb / 1e9 / HBM_PEAK_GBS, 4),
+                      "note": "one call incl. its host synchronisation; bytes at one HBM pass per transform"}
+            del d_hops, d_st
+        except Exception as ex:
+            superb = {"error": repr(ex)}
+
     redo_stats = None
     if rank == 0:
         try:
@@ -508,7 +537,7 @@ def main():
             if dom == "autocorrelation":
                 roofline = {"bound": "hbm", "kernel": "autocorrelation group: " + "+".join(ac_group),
                             "achieved": autocorr["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": autocorr["frac"],
-                            "traffic": sum(traffic_all.get(k, 0) or 0 for k in ac_group) or None,
+                            "traffic": int(sum((traffic_all.get(k, 0) or 0) * per_pass(k)[1] for k in ac_group)) or None,
                             "avg_launch_ms": round(ac_ms, 4), "alg_bytes_per_launch": int(ac_bytes_pass),
                             "launch": f"one pass = {nwin} windows = {round(ac_launches)} launches of the group (SURVEY 8(d) gives "
                                       "bytes per window for the group, not per kernel)"}
@@ -577,6 +606,7 @@ def main():
             # Main.java:1233-1277) applied to one plot update per pass
             "sweep": sweep,
             "e2e": e2e,
+            "superbandwidth": superb,
             "exact_autocorr": exact_ac,
             "sync_redo_last_batch": redo_stats,
             "device": g.device_name(),

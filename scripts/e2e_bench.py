@@ -46,11 +46,11 @@ def main():
     out = {"config": f"{args.fs/1e6:g} MS/s float32 IQ recording of {n/args.fs:.3f} s replayed free-running, h={args.height}, fv={args.fv}",
            "host_cores": os.cpu_count()}
 
-    def leg(name, lib, plugin, params, env=None, free=True):
+    def leg(name, lib, plugin, params, env=None, free=True, setup=None):
         old = {k: os.environ.get(k) for k in (env or {})}
         os.environ.update(env or {})
         try:
-            r = tsdrlib.throughput_run(lib, plugin, params, args.height, args.fv, args.seconds, free=free)
+            r = tsdrlib.throughput_run(lib, plugin, params, args.height, args.fv, args.seconds, free=free, setup=setup)
         finally:
             for k, v in old.items():
                 if v is None:
@@ -64,6 +64,19 @@ def main():
     leg("mi355x_mem_plugin", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0")
     leg("mi355x_mem_plugin_fast_modes", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0", {"TSDR_GPU_EXACT": "0"})
     leg("mi355x_mem_plugin_bounce_buffers", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0", {"TSDR_GPU_ZEROCOPY": "0"})
+    # PARAM_INT_FRAMERATE_PLL (1): one frame per launch group and one host round trip per frame (the nudge feeds back)
+    leg("mi355x_mem_plugin_pll_on", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0",
+        setup=lambda lib, h: lib.tsdr_setparameter_int(h, 1, 1))
+    # int16 recording of the same stream: half the bytes in (tsdrplugin_readasync_raw, decoded on the device)
+    path16 = "/tmp/e2e_iq.s16"
+    import numpy as np
+    with open(path, "rb") as fin, open(path16, "wb") as fout:
+        while True:
+            a = np.fromfile(fin, np.float32, 1 << 22)
+            if a.size == 0:
+                break
+            np.clip(np.round(a * 20000.0), -32768, 32767).astype(np.int16).tofile(fout)
+    leg("mi355x_mem_plugin_int16_raw", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path16} {args.fs} {block} 0 0 int16")
     if os.path.exists(rawfile):
         leg("mi355x_rawfile_plugin", tsdrlib.LIB, rawfile, f"{path} {args.fs} float")
         if args.reference and os.path.exists(reflib):

@@ -1,0 +1,15 @@
+#!/bin/bash
+# full evidence run: GPU suite, driver-style bench, kernel trace, PMC traffic, SQ counters
+set -u
+O=gpurun_out/${1:-r2full}; mkdir -p $O
+R=$GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?" | tee $O/summary.txt; tail -n 3 $O/tests.log
+timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary.txt
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/summary.txt
+bash scripts/gpu_prof.sh ${1:-r2full}/trace > /dev/null 2>&1
+cp $O/trace/kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+bash scripts/pmc_collect.sh ${1:-r2full}/pmc > $O/pmc.log 2>&1
+bash scripts/pmc_sq.sh ${1:-r2full}/sq > $O/sq.txt 2>&1
+python scripts/show_bench.py $O/bench.json | cut -c1-1200
+cat $O/pmc/summary.txt | head -40
+cat $O/sq.txt | tail -25

@@ -31,7 +31,12 @@ def load(dirpath, counter):
 
 def short(name):
     m = re.match(r"(?:void )?(k_[A-Za-z0-9_]+)", name)
-    return m.group(1) if m else None
+    if not m:
+        return None
+    k = m.group(1)
+    if k == "k_ac_cols":  # one kernel template, two trips: <log2 N1, input mode, LAST>
+        k += "_trip3" if re.search(r"k_ac_cols<[^>]*true>", name) else "_trip1"
+    return k
 
 
 def main():
@@ -70,16 +75,24 @@ def main():
         out[k] = {"launches": r["launches"], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                   "hbm_bytes_per_launch": fb + wb}
         print(f"{k:24s} {r['launches']:8d} {fb / 1e6:16.1f} {wb / 1e6:16.1f} {(fb + wb) / 1e6:16.1f}")
+    if "k_ac_cols_trip1" in out and "k_ac_cols_trip3" in out:  # the profiler stage of bench.py covers both trips
+        a, b = out["k_ac_cols_trip1"], out["k_ac_cols_trip3"]
+        n_l = a["launches"] + b["launches"]
+        out["k_ac_cols"] = {"launches": n_l,
+                            "fetch_bytes_per_launch": (a["fetch_bytes_per_launch"] * a["launches"] + b["fetch_bytes_per_launch"] * b["launches"]) / n_l,
+                            "write_bytes_per_launch": (a["write_bytes_per_launch"] * a["launches"] + b["write_bytes_per_launch"] * b["launches"]) / n_l}
+        out["k_ac_cols"]["hbm_bytes_per_launch"] = out["k_ac_cols"]["fetch_bytes_per_launch"] + out["k_ac_cols"]["write_bytes_per_launch"]
     res = {"fetch_factor": ff, "write_factor": wf, "unit": "bytes per launch", "kernels": out}
     if len(sys.argv) > 2:
         json.dump(res, open(sys.argv[2], "w"), indent=1)
     if len(sys.argv) > 3:
         # the flat form bench.py reads for roofline.traffic: kernel -> HBM bytes per launch
         flat = {k: int(round(v["hbm_bytes_per_launch"])) for k, v in out.items()}
+        flat["_source"] = os.environ.get("PMC_SOURCE", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_collect.sh), not collected live")
         flat["_note"] = (f"HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units), "
                          f"FETCH_SIZE x{ff:.3f} and WRITE_SIZE x{wf:.3f} calibrated on k_demod_vec4 (known 8 B read + 4 B "
-                         "written per sample); bench workload: 1 s of 100 MS/s IQ per step (60 frames; 17 windows transformed "
-                         "6+6+5 per launch); scripts/pmc_collect.sh")
+                         "written per sample); bench workload: 1 s of 100 MS/s IQ per pass (60 frames; 17 windows transformed "
+                         "6+6+5 per launch); k_ac_cols = launch-weighted mean of its two trips; scripts/pmc_collect.sh")
         json.dump(flat, open(sys.argv[3], "w"), indent=1)
     return res
 

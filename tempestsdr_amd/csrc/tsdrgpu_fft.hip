@@ -1123,27 +1123,23 @@ __global__ __launch_bounds__(256) void k_abs_diff(const float2 *__restrict__ z, 
     out[i] = make_float2(cur - prev, 0.f);
 }
 
-// A * conj(B)-style product of fft_crosscorrelation (fft.c:80-89), in place in a
-__global__ __launch_bounds__(256) void k_mul_conj(float2 *__restrict__ a, const float2 *__restrict__ b, unsigned n)
+// superb_bestfit's peak search (superbandwidth.c:100-116): first maximum of |.| over n points of each of
+// gridDim.y correlations (z + y*stride), in two stages like the plots' argmax: SB_ARG_BLOCKS workgroups per
+// correlation, then one wave each; the lowest index wins ties.
+#define SB_ARG_BLOCKS 256
+__global__ __launch_bounds__(256) void k_argmax_abs_partial(const float2 *__restrict__ z, long long stride, unsigned n, float *__restrict__ pval,
+                                                            int *__restrict__ pidx)
 {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float2 x = a[i], y = b[i];
-    a[i] = make_float2(x.x * y.x + x.y * y.y, x.x * y.y - x.y * y.x);
-}
-
-// superb_bestfit's peak search (superbandwidth.c:100-116): first maximum of |.|
-__global__ __launch_bounds__(1024) void k_argmax_abs(const float2 *__restrict__ z, unsigned n, int *__restrict__ out_floats)
-{
+    const float2 *zb = z + (long long)blockIdx.y * stride;
     float best = -1.f;
     int at = 0x7fffffff;
-    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
-        const float2 c = z[i];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float2 c = zb[i];
         const float v = sqrtf(c.x * c.x + c.y * c.y);
-        if (v > best) { best = v; at = (int)i; }
+        if (v > best) { best = v; at = (int)i; }  // i ascending per thread
     }
-    __shared__ float sb[16];
-    __shared__ int si[16];
+    __shared__ float sb[4];
+    __shared__ int si[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_down(best, o, 64);
@@ -1153,10 +1149,39 @@ __global__ __launch_bounds__(1024) void k_argmax_abs(const float2 *__restrict__ 
     if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = at; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; w++)
+        for (int w = 1; w < 4; w++)
             if (sb[w] > best || (sb[w] == best && si[w] < at)) { best = sb[w]; at = si[w]; }
-        *out_floats = 2 * at;  // the reference returns the offset in floats
+        pval[blockIdx.y * SB_ARG_BLOCKS + blockIdx.x] = best;
+        pidx[blockIdx.y * SB_ARG_BLOCKS + blockIdx.x] = at;
     }
+}
+
+__global__ __launch_bounds__(64) void k_argmax_abs_final(const float *__restrict__ pval, const int *__restrict__ pidx, int *__restrict__ out_floats)
+{
+    float best = -1.f;
+    int at = 0x7fffffff;
+    for (int b = threadIdx.x; b < SB_ARG_BLOCKS; b += 64) {
+        const float ob = pval[blockIdx.x * SB_ARG_BLOCKS + b];
+        const int oi = pidx[blockIdx.x * SB_ARG_BLOCKS + b];
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(at, o, 64);
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+    if (threadIdx.x == 0) out_floats[blockIdx.x] = 2 * at;  // the reference returns the offset in floats
+}
+
+// fft_crosscorrelation's product (fft.c:80-89) for a batch: b[y][i] <- a[i] (x) b[y][i], a shared by the batch
+__global__ __launch_bounds__(256) void k_mul_conj_batch(const float2 *__restrict__ a, float2 *__restrict__ b, unsigned n)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float2 *bb = b + (long long)blockIdx.y * n;
+    const float2 x = a[i], y = bb[i];
+    bb[i] = make_float2(x.x * y.x + x.y * y.y, x.x * y.y - x.y * y.x);
 }
 
 // circular left rotation by *off floats (superbandwidth.c:135-137)
@@ -1177,6 +1202,21 @@ static uint32_t pow2_floor(uint32_t v)  // fft_getrealsize, fft.c:5-11
     return 1u << m;
 }
 
+// Scratch of the stitch, kept in the context between calls (one stitch per 4-hop cycle, always the same size).
+static int superb_scratch(tsdrgpu_t *g, size_t bytes, char **out)
+{
+    if (g->superb_ws_bytes < bytes) {
+        HIP_TRY(g, hipStreamSynchronize(g->stream));
+        if (g->superb_ws) (void)hipFree(g->superb_ws);
+        g->superb_ws = nullptr;
+        g->superb_ws_bytes = 0;
+        if (hipMalloc(&g->superb_ws, bytes) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_superb_stitch", "work buffers");
+        g->superb_ws_bytes = bytes;
+    }
+    *out = (char *)g->superb_ws;
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered, int samples_in_frame,
                                      float *d_out, int32_t *h_offsets, uint32_t *h_total)
 {
@@ -1190,57 +1230,57 @@ extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nho
     if (bsize < 2) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_superb_stitch", "hop shorter than one frame");
     const uint32_t bfl = pow2_floor((uint32_t)bsize);
     const uint32_t bn = bfl / 2;  // complex samples cross-correlated
+    const uint32_t nfft = pow2_floor(total);  // fft_perform truncates, fft.c:101-105
+    const int nb = nhops - 1;              // correlations against hop 0
 
-    float2 *w = nullptr;  // [A bn][B bn][tmp1 max][tmp2 max]
-    const size_t big = per > bn ? per : bn;
-    int *d_off = nullptr;
-    if (hipMalloc(&w, sizeof(float2) * (2 * (size_t)bn + 4 * big)) != hipSuccess || hipMalloc(&d_off, sizeof(int) * nhops) != hipSuccess) {
-        if (w) (void)hipFree(w);
-        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_superb_stitch", "work buffers");
-    }
-    float2 *A = w, *B = w + bn, *T1 = w + 2 * (size_t)bn, *T2 = T1 + big, *T3 = T2 + big, *T4 = T3 + big;
+    // [A bn][FA 2 bn][B nb bn][FB 2 nb bn][R total][S 2 total][BIG 2 nfft] float2, then offsets and argmax partials
+    const size_t f2 = (size_t)bn * 3 + (size_t)bn * nb * 3 + (size_t)total * 3 + (size_t)nfft * 2;
+    const size_t bytes = f2 * sizeof(float2) + sizeof(int) * (size_t)nhops + (sizeof(float) + sizeof(int)) * (size_t)SB_ARG_BLOCKS * (nb > 0 ? nb : 1);
+    char *ws = nullptr;
+    int rc = superb_scratch(g, bytes + 64, &ws);
+    if (rc) return rc;
+    float2 *A = (float2 *)ws, *FA = A + bn, *B = FA + 2 * (size_t)bn, *FB = B + (size_t)bn * nb, *R = FB + 2 * (size_t)bn * nb;
+    float2 *S = R + total, *BIG = S + 2 * (size_t)total;
+    int *d_off = (int *)(BIG + 2 * (size_t)nfft);
+    float *pval = (float *)(d_off + nhops);
+    int *pidx = (int *)(pval + (size_t)SB_ARG_BLOCKS * (nb > 0 ? nb : 1));
     hipStream_t st = g->stream;
-    (void)hipMemsetAsync(d_off, 0, sizeof(int) * nhops, st);
+    HIP_TRY(g, hipMemsetAsync(d_off, 0, sizeof(int) * nhops, st));
 
-    float2 *spec0 = nullptr;
-    for (int i = 1; i < nhops; i++) {
+    if (nb > 0) {
+        // complex_to_abs_diff of every hop (superbandwidth.c:67-81), then ONE forward transform of hop 0's and one
+        // batched transform of the others', the products, one batched inverse transform, the peaks
         TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_hops[0], A, bn);
-        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_hops[i], B, bn);
-        float2 *fa = run_fft(g, A, 0, bn, T1, T2, bn, 1, 0, false, 1.0f / (float)bn);
-        float2 *fb = run_fft(g, B, 0, bn, T3, T4, bn, 1, 0, false, 1.0f / (float)bn);
-        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_mul_conj, (bn + 255) / 256, 256, fa, fb, bn);
-        float2 *other = (fa == T1) ? T2 : T1;
-        float2 *xc = run_fft(g, fa, 0, bn, fa, other, bn, 1, 1, false, 1.0f);
-        TSDR_LAUNCH(g, PROF_ARGMAX, st, k_argmax_abs, 1, 1024, xc, bn, d_off + i);
-        // rotate hop i, then forward FFT of `per` points back into the hop buffer
-        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_rotate, (nfl + 255) / 256, 256, d_hops[i], (float *)T1, nfl, d_off + i);
-        float2 *sp = run_fft(g, T1, 0, per, T1, T2, per, 1, 0, false, 1.0f / (float)per);
-        (void)hipMemcpyAsync(d_hops[i], sp, sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
+        for (int i = 1; i < nhops; i++)
+            TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_hops[i], B + (size_t)(i - 1) * bn, bn);
+        KERNEL_CHECK(g, "k_abs_diff");
+        float2 *fa = run_fft(g, A, 0, bn, FA, FA + bn, bn, 1, 0, false, 1.0f / (float)bn);
+        float2 *fb = run_fft(g, B, 0, bn, FB, FB + (size_t)bn * nb, bn, nb, 0, false, 1.0f / (float)bn);
+        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_mul_conj_batch, dim3((bn + 255) / 256, nb), 256, fa, fb, bn);
+        KERNEL_CHECK(g, "k_mul_conj_batch");
+        float2 *other = (fb == FB) ? FB + (size_t)bn * nb : FB;
+        float2 *xc = run_fft(g, fb, 0, bn, fb, other, bn, nb, 1, false, 1.0f);
+        TSDR_LAUNCH(g, PROF_ARGMAX, st, k_argmax_abs_partial, dim3(SB_ARG_BLOCKS, nb), 256, xc, (long long)bn, bn, pval, pidx);
+        TSDR_LAUNCH(g, PROF_ARGMAX, st, k_argmax_abs_final, nb, 64, pval, pidx, d_off + 1);
+        KERNEL_CHECK(g, "k_argmax_abs");
     }
-    {
-        (void)hipMemcpyAsync(T1, d_hops[0], sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
-        spec0 = run_fft(g, T1, 0, per, T1, T2, per, 1, 0, false, 1.0f / (float)per);
-        (void)hipMemcpyAsync(d_hops[0], spec0, sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
-    }
-    // concatenate the spectra in hop order, no fftshift (superbandwidth.c:143-144)
+    // rotate every hop by its offset (hop 0: none) into one contiguous buffer, one batched forward transform:
+    // the result IS the concatenation of the spectra in hop order, no fftshift (superbandwidth.c:135-144)
     for (int i = 0; i < nhops; i++)
-        (void)hipMemcpyAsync(d_out + (size_t)i * per * 2, d_hops[i], sizeof(float2) * per, hipMemcpyDeviceToDevice, st);
-    // inverse FFT over the largest power of two <= total (fft_perform truncates, fft.c:101-105)
-    const uint32_t nfft = pow2_floor(total);
-    float2 *big2 = nullptr;
-    hipError_t e = hipMalloc(&big2, sizeof(float2) * (size_t)nfft * 2);
-    if (e == hipSuccess) {
-        float2 *res = run_fft(g, d_out, 0, nfft, big2, big2 + nfft, nfft, 1, 1, false, 1.0f);
-        (void)hipMemcpyAsync(d_out, res, sizeof(float2) * nfft, hipMemcpyDeviceToDevice, st);
-    }
-    if (e == hipSuccess) e = hipGetLastError();
-    if (h_offsets && e == hipSuccess) e = hipMemcpyAsync(h_offsets, d_off, sizeof(int) * nhops, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    else (void)hipStreamSynchronize(st);
-    (void)hipFree(w);
-    (void)hipFree(d_off);
-    if (big2) (void)hipFree(big2);
-    if (e != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_superb_stitch", hipGetErrorString(e));
+        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_rotate, (nfl + 255) / 256, 256, d_hops[i], (float *)(R + (size_t)i * per), nfl, d_off + i);
+    KERNEL_CHECK(g, "k_rotate");
+    float2 *sp = run_fft(g, R, 0, per, S, S + total, per, nhops, 0, false, 1.0f / (float)per);
+    KERNEL_CHECK(g, "hop transforms");
+    for (int i = 0; i < nhops; i++)  // the reference leaves every hop buffer holding its spectrum
+        HIP_TRY(g, hipMemcpyAsync(d_hops[i], sp + (size_t)i * per, sizeof(float2) * per, hipMemcpyDeviceToDevice, st));
+    // inverse transform over the largest power of two <= total; what lies beyond keeps the spectra
+    if (total > nfft)
+        HIP_TRY(g, hipMemcpyAsync(d_out + 2 * (size_t)nfft, sp + nfft, sizeof(float2) * (size_t)(total - nfft), hipMemcpyDeviceToDevice, st));
+    float2 *res = run_fft(g, sp, 0, nfft, BIG, BIG + nfft, nfft, 1, 1, false, 1.0f);
+    KERNEL_CHECK(g, "stitch transform");
+    HIP_TRY(g, hipMemcpyAsync(d_out, res, sizeof(float2) * (size_t)nfft, hipMemcpyDeviceToDevice, st));
+    if (h_offsets) HIP_TRY(g, hipMemcpyAsync(h_offsets, d_off, sizeof(int) * nhops, hipMemcpyDeviceToHost, st));
+    HIP_TRY(g, hipStreamSynchronize(st));
     if (h_total) *h_total = total;
     return TSDRGPU_OK;
 }

@@ -48,6 +48,8 @@ struct tsdrgpu {
     // scratch kept between calls of tsdrgpu_fft (grown on demand)
     void *fft_ws;
     size_t fft_ws_bytes;
+    void *superb_ws;    // scratch of tsdrgpu_superb_stitch (grown on demand)
+    size_t superb_ws_bytes;
     void *fftx_tw;      // twiddle table of the last tsdrgpu_fft_exact size (double2[n-1])
     uint32_t fftx_n;
     // profiler
