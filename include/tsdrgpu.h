@@ -61,14 +61,15 @@ int tsdrgpu_copy2(tsdrgpu_t *g, void *d_dst1, void *d_dst2, const void *d_src, s
 int tsdrgpu_zero(tsdrgpu_t *g, void *d_ptr, size_t bytes);
 
 /* ---- lanes and events: what a streaming host needs to overlap PCIe copies with compute ------------
- * A context owns four in-order queues ("lanes"): COMPUTE (the stream every kernel entry point above and below
- * uses), SIDE (the high-priority side stream: sync-detector chain, asynchronous autocorrelation), UPLOAD and
- * DOWNLOAD (copy engines).  Nothing orders two lanes except events.  All of this is thread safe as long as each
+ * A context owns five in-order queues ("lanes"): COMPUTE (the stream every kernel entry point above and below
+ * uses), SIDE (high priority: the sync detector's short chain kernels), BACKGROUND (low priority: an asynchronous
+ * autocorrelation), UPLOAD and DOWNLOAD (copy engines).  Nothing orders two lanes except events.  All of this is thread safe as long as each
  * lane is fed by one thread at a time (the engine: the plugin's thread feeds UPLOAD, the device thread the rest). */
 #define TSDRGPU_LANE_COMPUTE 0
 #define TSDRGPU_LANE_SIDE 1
 #define TSDRGPU_LANE_UPLOAD 2
 #define TSDRGPU_LANE_DOWNLOAD 3
+#define TSDRGPU_LANE_BACKGROUND 4 /* lowest priority: where tsdrgpu_autocorr_set_async puts the detector, to fill the gaps of the frame path */
 typedef struct tsdrgpu_event tsdrgpu_event_t;
 int tsdrgpu_event_create(tsdrgpu_t *g, tsdrgpu_event_t **out);
 void tsdrgpu_event_destroy(tsdrgpu_t *g, tsdrgpu_event_t *ev);
@@ -264,9 +265,9 @@ int tsdrgpu_autocorr_geometry(tsdrgpu_autocorr_t *ac, int32_t *frame_lo, int32_t
  * the sums, then tsdrgpu_autocorr_finalize_sums). */
 int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, int64_t stride,
                          int nwindows, int mode);
-/* on != 0: this object's work is queued on the context's side stream, so it
- * overlaps the frame path; each run still waits for everything queued on the
- * main stream before it.  tsdrgpu_sync() waits for both streams. */
+/* on != 0: this object's work is queued on the context's BACKGROUND lane (lowest priority), so it overlaps the
+ * frame path and fills its gaps; each run still waits for everything queued on the COMPUTE lane before it.
+ * tsdrgpu_sync() waits for the COMPUTE, SIDE and BACKGROUND lanes. */
 int tsdrgpu_autocorr_set_async(tsdrgpu_autocorr_t *ac, int on);
 /* Exact mode.  The default autocorrelation is a different FFT algorithm than the reference's and agrees with it
  * to ~1e-6 of the plot maximum; where a plot holds exact mathematical ties (R[j] == R[N-j] inside the 8 MS/s
@@ -285,7 +286,7 @@ int tsdrgpu_autocorr_set_plan(tsdrgpu_autocorr_t *ac, int trips);
 int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line,
                            uint64_t *h_calls); /* syncs */
 /* the same copies queued on the object's lane without waiting: h_* must be pinned and stay valid until an event
- * recorded on that lane (COMPUTE, or SIDE after tsdrgpu_autocorr_set_async) behind this call has completed */
+ * recorded on that lane (tsdrgpu_autocorr_lane) behind this call has completed */
 int tsdrgpu_autocorr_plots_async(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line, uint64_t *h_calls);
 /* device plots: frame_len + line_len doubles, contiguous (frame first) */
 int tsdrgpu_autocorr_device_plots(tsdrgpu_autocorr_t *ac, double **d_plots, int64_t *count);
@@ -300,7 +301,7 @@ int tsdrgpu_autocorr_argmax_result(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, i
 /* the raw correlation of the LAST window run (2*n floats), for stage tests */
 int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **d_corr, uint32_t *n);
 
-int tsdrgpu_autocorr_lane(tsdrgpu_autocorr_t *ac); /* TSDRGPU_LANE_COMPUTE, or _SIDE after tsdrgpu_autocorr_set_async */
+int tsdrgpu_autocorr_lane(tsdrgpu_autocorr_t *ac); /* TSDRGPU_LANE_COMPUTE, or _BACKGROUND after tsdrgpu_autocorr_set_async */
 
 /* ---- the sweep across GPUs — one process per GPU, one exchange over RCCL / xGMI ------------------
  * Capture windows are independent; the reference only forms their running mean (accummulate,

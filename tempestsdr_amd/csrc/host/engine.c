@@ -4,7 +4,7 @@
  * postprocessingthread -> videodecodingthread through three float ring buffers,
  * with frameratedetector_thread and super_thread on the side
  * (TempestSDR/src/TSDRLibrary.c:264-418, frameratedetector.c:128-187,
- * superbandwidth.c:154-254).  Here four host threads feed four device queues
+ * superbandwidth.c:154-254).  Here four host threads feed five device queues
  * ("lanes", include/tsdrgpu.h) that only events order, so PCIe copies in both
  * directions overlap the kernels:
  *
@@ -15,8 +15,8 @@
  *   device thread   queues, without ever waiting for the device in steady state:
  *                   slot -> sample streams, fused demod+resample straight into the pixel
  *                   stream, batched frame post-processing into a ring of output buffers
- *                   (COMPUTE lane), the frame-rate detector (SIDE lane), the frames' and
- *                   plots' way back to pinned memory (DOWNLOAD / SIDE lane)
+ *                   (COMPUTE lane), the frame-rate detector (BACKGROUND lane), the frames' and
+ *                   plots' way back to pinned memory (DOWNLOAD / BACKGROUND lane)
  *   video thread    waits for a frame's download event, then the frame callback
  *                   (reference: videodecodingthread)
  *   plot thread     waits for the plots' event, then plot + value callbacks
@@ -452,7 +452,7 @@ static void detector_rebuild(struct engine *e, uint32_t fs)
      * the detected mode are bit-identical to the CPU library's (0.25 ms per 100 MS/s window against 56 ms of
      * signal).  TSDR_GPU_EXACT_AUTOCORR=0 / TSDR_GPU_EXACT=0 select the fast transform (plots within 1e-4*max). */
     if (exact_wanted("TSDR_GPU_EXACT_AUTOCORR")) (void)tsdrgpu_autocorr_set_exact(e->ac, 1);
-    (void)tsdrgpu_autocorr_set_async(e->ac, 1); /* SIDE lane: beside the frame path */
+    (void)tsdrgpu_autocorr_set_async(e->ac, 1); /* BACKGROUND lane: beside the frame path */
     plot_msg_t nm;
     memset(&nm, 0, sizeof(nm));
     uint32_t n = 0;
@@ -512,8 +512,8 @@ static void run_detector(struct engine *e, uint32_t fs)
         if (!gpu_ok(e, tsdrgpu_autocorr_run(e->ac, e->det.d + e->det.rd, 1, capture, 1, 0), "autocorr")) return;
         e->det.rd += (size_t)capture * 2;
         e->n_windows++;
-        /* the window is read on the SIDE lane; the COMPUTE lane must not recycle that memory before (process_block) */
-        if (tsdrgpu_event_record(e->g, e->det_read, TSDRGPU_LANE_SIDE) == 0) e->det_read_valid = 1;
+        /* the window is read on the detector's lane; the COMPUTE lane must not recycle that memory before (process_block) */
+        if (tsdrgpu_event_record(e->g, e->det_read, tsdrgpu_autocorr_lane(e->ac)) == 0) e->det_read_valid = 1;
         else tsdrgpu_sync(e->g);
         if (t->params_int[PARAM_AUTOCORR_DUMP]) {
             t->params_int[PARAM_AUTOCORR_DUMP] = 0;
@@ -529,7 +529,7 @@ static void run_detector(struct engine *e, uint32_t fs)
         if (!busy) {
             uint64_t calls = 0;
             if (tsdrgpu_autocorr_plots_async(e->ac, e->plot.h_frame, e->plot.h_line, &calls) == 0 &&
-                tsdrgpu_event_record(e->g, e->plot_ready, TSDRGPU_LANE_SIDE) == 0) {
+                tsdrgpu_event_record(e->g, e->plot_ready, tsdrgpu_autocorr_lane(e->ac)) == 0) {
                 pthread_mutex_lock(&e->pm);
                 e->plot.calls = calls;
                 e->plot_pending = 1;

@@ -26,6 +26,7 @@ extern "C" int tsdrgpu_create(tsdrgpu_t **out, int device)
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&g->prop, device) != hipSuccess ||
         hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&g->bg, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithFlags(&g->up, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&g->down, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&g->fork, hipEventDisableTiming) != hipSuccess ||
@@ -43,6 +44,8 @@ extern "C" void tsdrgpu_destroy(tsdrgpu_t *g)
     hipSetDevice(g->device);
     hipStreamSynchronize(g->stream);
     hipStreamSynchronize(g->stream2);
+    hipStreamSynchronize(g->bg);
+    hipStreamDestroy(g->bg);
     hipStreamSynchronize(g->up);
     hipStreamSynchronize(g->down);
     hipStreamDestroy(g->up);
@@ -71,6 +74,7 @@ extern "C" int tsdrgpu_sync(tsdrgpu_t *g)
     if (!g) return TSDRGPU_EINVAL;
     HIP_TRY(g, hipStreamSynchronize(g->stream));
     HIP_TRY(g, hipStreamSynchronize(g->stream2));
+    HIP_TRY(g, hipStreamSynchronize(g->bg));
     return TSDRGPU_OK;
 }
 
@@ -163,16 +167,18 @@ extern "C" int tsdrgpu_zero(tsdrgpu_t *g, void *d_ptr, size_t bytes)
     return TSDRGPU_OK;
 }
 // ---- lanes and events -------------------------------------------------------------------------------
-static hipStream_t lane_stream(tsdrgpu_t *g, int lane)
+hipStream_t tsdr_lane_stream(tsdrgpu_t *g, int lane)
 {
     switch (lane) {
         case TSDRGPU_LANE_COMPUTE: return g->stream;
         case TSDRGPU_LANE_SIDE: return g->stream2;
+        case TSDRGPU_LANE_BACKGROUND: return g->bg;
         case TSDRGPU_LANE_UPLOAD: return g->up;
         case TSDRGPU_LANE_DOWNLOAD: return g->down;
     }
     return nullptr;
 }
+static hipStream_t lane_stream(tsdrgpu_t *g, int lane) { return tsdr_lane_stream(g, lane); }
 extern "C" int tsdrgpu_bind_thread(tsdrgpu_t *g)
 {
     if (!g) return TSDRGPU_EINVAL;
@@ -306,6 +312,7 @@ extern "C" int tsdrgpu_profile_begin(tsdrgpu_t *g)
     if (!g) return TSDRGPU_EINVAL;
     HIP_TRY(g, hipStreamSynchronize(g->stream));
     HIP_TRY(g, hipStreamSynchronize(g->stream2));
+    HIP_TRY(g, hipStreamSynchronize(g->bg));
     g->nspans = 0;
     g->prof_on = 1;
     return TSDRGPU_OK;
@@ -317,6 +324,7 @@ extern "C" int tsdrgpu_profile_end(tsdrgpu_t *g, tsdrgpu_profile_entry_t *h_entr
     g->prof_on = 0;
     HIP_TRY(g, hipStreamSynchronize(g->stream));
     HIP_TRY(g, hipStreamSynchronize(g->stream2));
+    HIP_TRY(g, hipStreamSynchronize(g->bg));
     double total[PROF_COUNT] = {0};
     int launches[PROF_COUNT] = {0};
     for (int i = 0; i < g->nspans; i++) {

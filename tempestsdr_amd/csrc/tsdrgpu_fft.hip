@@ -31,7 +31,7 @@ struct tsdrgpu_autocorr {
     int arg_pending;
     double *d_pval;  // argmax partials
     int *d_pidx;
-    hipStream_t st;  // g->stream, or g->stream2 when set asynchronous
+    hipStream_t st;  // g->stream, or g->bg (the background lane) when set asynchronous
     int plan5;       // tsdrgpu_autocorr_set_plan: 1 = the five-trip Stockham plan even where the three-trip one applies
     // exact mode (tsdrgpu_autocorr_set_exact, tsdrgpu_fftx.hip)
     int exact;
@@ -827,6 +827,7 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
     if (!ac) return;
     (void)hipStreamSynchronize(ac->g->stream);
     (void)hipStreamSynchronize(ac->g->stream2);
+    (void)hipStreamSynchronize(ac->g->bg);
     (void)hipFree(ac->d_plots);
     (void)hipFree(ac->d_a);
     (void)hipFree(ac->d_b);
@@ -876,6 +877,7 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     if (ac->cap_windows < sub) {
         (void)hipStreamSynchronize(g->stream);
         (void)hipStreamSynchronize(g->stream2);
+        (void)hipStreamSynchronize(g->bg);
         (void)hipFree(ac->d_a);
         (void)hipFree(ac->d_b);
         ac->d_a = ac->d_b = nullptr;
@@ -1090,11 +1092,11 @@ extern "C" int tsdrgpu_autocorr_set_async(tsdrgpu_autocorr_t *ac, int on)
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     HIP_TRY(g, hipStreamSynchronize(ac->st));
-    ac->st = on ? g->stream2 : g->stream;
+    ac->st = on ? g->bg : g->stream;
     return TSDRGPU_OK;
 }
 
-extern "C" int tsdrgpu_autocorr_lane(tsdrgpu_autocorr_t *ac) { return (ac && ac->st == ac->g->stream2) ? TSDRGPU_LANE_SIDE : TSDRGPU_LANE_COMPUTE; }
+extern "C" int tsdrgpu_autocorr_lane(tsdrgpu_autocorr_t *ac) { return (ac && ac->st == ac->g->bg) ? TSDRGPU_LANE_BACKGROUND : TSDRGPU_LANE_COMPUTE; }
 
 extern "C" int tsdrgpu_autocorr_set_plan(tsdrgpu_autocorr_t *ac, int trips)
 {

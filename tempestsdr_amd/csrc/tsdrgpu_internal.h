@@ -41,6 +41,7 @@ struct tsdrgpu {
     hipStream_t stream;
     hipStream_t stream2;  // side stream: the autocorrelation can run beside the frame path
     hipStream_t up, down; // copy lanes (tsdrgpu_upload_lane / tsdrgpu_download_lane)
+    hipStream_t bg;       // background lane, lowest priority: an asynchronous autocorrelation fills the gaps of the frame path
     hipEvent_t fork;      // orders stream2 behind what is already queued on `stream`
     hipEvent_t t0, t1;
     char err[512];
@@ -62,6 +63,7 @@ struct tsdrgpu {
 // stop event (hipExtLaunchKernelGGL), so per-kernel durations are measured without extra barrier
 // packets between launches; with it off this is a plain launch.
 void prof_pair(tsdrgpu_t *g, int stage, hipEvent_t *a, hipEvent_t *b);
+hipStream_t tsdr_lane_stream(tsdrgpu_t *g, int lane);
 #define TSDR_LAUNCH(g_, stage_, stream_, kernel_, grid_, block_, ...)                                        \
     do {                                                                                                    \
         hipEvent_t pa_ = nullptr, pb_ = nullptr;                                                            \

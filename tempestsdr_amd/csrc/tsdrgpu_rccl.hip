@@ -106,7 +106,8 @@ extern "C" int tsdrgpu_comm_allreduce_f64(tsdrgpu_comm_t *c, double *d_buf, int6
     tsdrgpu_t *g = c->g;
     const RcclApi *r = rccl();
     if (!r) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_comm_allreduce_f64", "librccl.so.1 not found");
-    hipStream_t st = lane == TSDRGPU_LANE_SIDE ? g->stream2 : g->stream;
+    hipStream_t st = tsdr_lane_stream(g, lane);
+    if (!st) return tsdr_fail(g, TSDRGPU_EINVAL, "allreduce", "bad lane");
     const ncclResult_t rc = r->AllReduce(d_buf, d_buf, (size_t)count, ncclFloat64_, ncclSum_, c->comm, st);
     if (rc != ncclSuccess_) return tsdr_fail(g, TSDRGPU_EHIP, "ncclAllReduce", r->GetErrorString(rc));
     return TSDRGPU_OK;
@@ -118,7 +119,8 @@ extern "C" int tsdrgpu_comm_allreduce_f32max(tsdrgpu_comm_t *c, float *d_buf, in
     tsdrgpu_t *g = c->g;
     const RcclApi *r = rccl();
     if (!r) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_comm_allreduce_f32max", "librccl.so.1 not found");
-    hipStream_t st = lane == TSDRGPU_LANE_SIDE ? g->stream2 : g->stream;
+    hipStream_t st = tsdr_lane_stream(g, lane);
+    if (!st) return tsdr_fail(g, TSDRGPU_EINVAL, "allreduce", "bad lane");
     const ncclResult_t rc = r->AllReduce(d_buf, d_buf, (size_t)count, 7 /* ncclFloat32 */, 2 /* ncclMax */, c->comm, st);
     if (rc != ncclSuccess_) return tsdr_fail(g, TSDRGPU_EHIP, "ncclAllReduce", r->GetErrorString(rc));
     return TSDRGPU_OK;
