@@ -67,6 +67,13 @@ def synth_iq_torch(fs, mode, fv, nsamples, start, seed, device, noise=0.02):
     return out
 
 
+class _DevArray:
+    """A raw device buffer of doubles seen by torch (torch.as_tensor reads __cuda_array_interface__)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
 class DevPtr:
     """Adapter: a torch tensor seen as a tsdrgpu DeviceArray (pointer + offsets)."""
 
@@ -189,6 +196,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (sums + all-reduce + finalize) even with one rank; used to "
                          "exercise the RCCL path on a 1-GPU box")
+    ap.add_argument("--torch-collective", action="store_true",
+                    help="skip the library's own RCCL communicator and take the torch.distributed safety net (testing)")
     ap.add_argument("--fuse", action="store_true",
                     help="fused run: min/max from the resampler (frame tracking) and the sync detector's sums from the "
                          "normalise/IIR pass instead of a separate statistics pass (k_frame_stats).  Moves 12P instead of "
@@ -255,10 +264,29 @@ def main():
         # RCCL from C (tsdrgpu_rccl.hip): the all-reduce is queued by the library on the autocorrelation's own lane,
         # ordered with its kernels, no host synchronisation.  torch.distributed only ships the 128-byte id (and
         # provides the barrier / max-over-ranks of the timing contract).
-        ident = [gpu.Comm.unique_id(g) if rank == 0 else None]
+        comm_err = None
+        try:
+            ident = [gpu.Comm.unique_id(g) if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001 (reported in the JSON line)
+            ident, comm_err = [None], repr(e)
         if world > 1:
             dist.broadcast_object_list(ident, src=0)
-        comm = gpu.Comm(g, world, rank, ident[0])
+        if ident[0] is not None and not args.torch_collective:
+            try:
+                comm = gpu.Comm(g, world, rank, ident[0])
+            except Exception as e:  # noqa: BLE001
+                comm_err = repr(e)
+        # safety net: if the library's own communicator cannot be set up on this node, the same all-reduce goes
+        # through torch.distributed (also RCCL) on the plot buffer, with a host synchronisation either side, and
+        # the JSON line says so ("collective")
+        agreed = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if not int(agreed.item()):
+            if comm is not None:
+                comm.destroy()
+                comm = None
+            print(f"[bench rank {rank}] tsdrgpu_comm_create unavailable ({comm_err}); using torch.distributed", file=sys.stderr)
+            plots_t = torch.as_tensor(_DevArray(plots_ptr, plots_n), device=dev)
     my_windows = len(range(rank, nwin, world)) if strong else nwin
     total_windows = nwin if strong else nwin * world
 
@@ -327,7 +355,13 @@ def main():
         if sharded:
             # ncclAllReduce(ncclDouble, ncclSum) over xGMI of the per-lag |R| sums of every rank's windows, in place in the
             # library's plot buffer, then the division by the global window count
-            ac.allreduce(comm, total_windows)
+            if comm is not None:
+                ac.allreduce(comm, total_windows)
+            else:
+                g.sync()
+                dist.all_reduce(plots_t)
+                torch.cuda.synchronize()
+                ac.finalize_sums(total_windows)
         # every pass ends with a plot update: the argmax is queued behind the pass and collected one pass later,
         # so the host keeps queueing while the device works (one device sync per STEP)
         if arg_pending[0]:
@@ -586,6 +620,9 @@ def main():
             "frames_per_s": round(frames_total / (world if strong else 1) / dt, 1),
             "realtime_factor": round(total_samples / dt / fs / (1 if strong else world), 2),
             "roofline": roofline,
+            "collective": (None if not sharded else
+                           "ncclAllReduce(f64 sum) queued by the library (tsdrgpu_autocorr_allreduce) on the autocorrelation lane"
+                           if comm is not None else "torch.distributed all_reduce (library communicator unavailable on this node)"),
             "kernels": kernels,
             "frame_path": {"kernels_ms_per_pass": round(frame_ms, 4),
                            "achieved_GBs": round(frame_bytes_pass / (frame_ms * 1e-3) / 1e9, 1) if frame_ms else None,

@@ -1,0 +1,15 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r2q; mkdir -p $O
+run() { tag=$1; shift; env "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e > $O/$tag.json 2> $O/$tag.err; python - <<PY
+import json
+try:
+    d=json.loads([l for l in open("$O/$tag.json") if l.startswith("{")][0])
+    print("$tag", d["value"], d["ms_per_pass"], {k:v for k,v in d["stage_ms_per_pass"].items() if v>0.02})
+except Exception as e:
+    print("$tag failed", e); print(open("$O/$tag.err").read()[-1500:])
+PY
+}
+timeout 1500 python -m pytest tests/test_gpu_postproc.py tests/test_gpu_soak.py tests/test_gpu_bands.py tests/test_gpu_demod_resample.py tests/test_gpu_edges.py tests/test_gpu_extras.py tests/test_gpu_host_pipeline.py -x -q -m gpu > $O/pytest.log 2>&1; grep -E "passed|failed|error" $O/pytest.log | tail -3
+run new A=1
+run new2 A=1

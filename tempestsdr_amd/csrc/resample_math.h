@@ -140,13 +140,6 @@ TSDR_HD bool rs_area_pixel(const RsGeom &g, unsigned p, double contrib_in, In in
 // (`pid`, `contrib`) is known in closed form — and replay the loop body
 // (dsp.c:280-303) literally over the handful of samples that touch the group.
 // lo/hi/him1 and the demodulated sample are computed once per sample.
-// v[] must be pre-filled with 0 (pixels the reference never stores).
-// A thread's share of the work: pixels [p0, p0+NPIX) of the chunk (clipped to
-// [0, n_out)).  Instead of evaluating each pixel on its own, jump into the
-// reference's loop at the sample that stores the first pixel — its state there
-// (`pid`, `contrib`) is known in closed form — and replay the loop body
-// (dsp.c:280-303) literally over the handful of samples that touch the group.
-// lo/hi/him1 and the demodulated sample are computed once per sample.
 // put(k, value) receives pixel p0+k; pixels the reference never stores are not
 // reported (the caller pre-fills zeros).  `ipix` shadows the double `pix` so
 // that the group-window tests are integer compares.
@@ -184,6 +177,45 @@ TSDR_HD void rs_area_group(const RsGeom &g, int p0, int n_out, double contrib_in
         else
             contrib += g.r * val;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Sample-parallel form (k_rs_area_up).  One lane per INPUT sample: sample id
+// stores exactly the pixels [pix_in(id), pix_in(id+1)) — branch A of the loop
+// body (dsp.c:288-292) stores the first of them when it fires, branch B
+// (dsp.c:294-297) the rest as copies of the sample — and then adds one tail term
+// to contrib (dsp.c:299-302).  Everything but contrib depends on id alone, and
+// contrib on entry is 0.0 + tail(id-1) whenever sample id-1 fired branch A (with
+// r >= 1 practically always), so a lane needs three values from its left
+// neighbour: pix_in(id) (= the neighbour's pnext), whether the neighbour fired,
+// and its tail term.  When the neighbour did not fire, rs_contrib_before replays
+// the chain.  The expressions are the loop body's own.
+// ---------------------------------------------------------------------------
+struct RsUpGeom {
+    double lo, hi, him1;
+    double pnext;  // pix when the sample is done = pix_in(id+1)
+};
+
+TSDR_HD RsUpGeom rs_up_geom(const RsGeom &g, int id)
+{
+    RsUpGeom a;
+    a.lo = (double)id * g.r + g.o;
+    a.hi = a.lo + g.r;
+    a.him1 = a.lo + g.r - 1.0;
+    a.pnext = rs_first_not_below(a.him1);
+    return a;
+}
+// branch A taken?  pin = pix on entry
+TSDR_HD bool rs_up_fired(const RsUpGeom &a, double pin) { return pin < a.lo && pin < a.him1; }
+// the term dsp.c:299-302 adds after the stores (pix == pnext there)
+TSDR_HD double rs_up_tail(const RsGeom &g, const RsUpGeom &a, double val)
+{
+    return (a.pnext < a.hi && a.pnext > a.lo) ? (a.hi - a.pnext) * val : g.r * val;
+}
+// the straddling pixel's value (dsp.c:289)
+TSDR_HD float rs_up_first(const RsUpGeom &a, double pin, double contrib, double val)
+{
+    return (float)(contrib + val * (1.0 - a.lo + pin));
 }
 
 // nearest-neighbour branch, dsp.c:274-276

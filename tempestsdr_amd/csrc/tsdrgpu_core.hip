@@ -715,6 +715,113 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_rs_area_up: the same resampler, one lane per INPUT sample (resample_math.h, "sample-parallel form").
+// k_rs_area replays the loop body per 8-pixel group, which costs ~60 VALU instructions per pixel in branchy,
+// divergent code (the kernel was issue-bound at half the HBM rate).  Here every per-sample expression is
+// evaluated once, branch free, and the three values a lane needs from the previous sample arrive through a
+// DPP wave shift: lane l of a wave holds sample base + l - 2, lanes 0 and 1 are ghosts that only feed lane 2.
+// A workgroup (4 waves x `rounds` x 62 samples) writes its pixels [pix_in(sA), pix_in(sB)) into an LDS tile laid
+// out with the output's 16-byte phase, then stores the tile with dwordx4.  Used when 1 <= r <= 8 (the
+// reference's geometry always upsamples by ~2) and frame tracking is off; anything else runs k_rs_area.
+// ---------------------------------------------------------------------------
+#define RSU_LANES 62     // samples per wave and round
+#define RSU_BATCH 4     // rounds whose loads are in flight together
+#define RSU_TILE 2048    // pixels per workgroup the host may plan for (+8 floats of slack in LDS)
+__device__ __forceinline__ int rsu_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ double rsu_shr1(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = rsu_shr1((int)(b & 0xffffffffLL)), hi = rsu_shr1((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+template <bool IQ>
+__global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ chunks, double r, double rinv, const float *__restrict__ in,
+                                                    const double *__restrict__ cin, float *__restrict__ out, int rounds, int maxc)
+{
+    const RsChunk ch = chunks[blockIdx.y];
+    RsGeom g;
+    g.r = r;
+    g.rinv = rinv;
+    g.o = ch.o;
+    g.size = ch.size;
+    const int size = (int)ch.size, n_out = (int)ch.n_out;
+    const int S = 4 * RSU_LANES * rounds;
+    const int sA = (int)blockIdx.x * S;
+    if (sA >= size || n_out <= 0) return;
+    const int sB = (sA + S < size) ? sA + S : size;
+    const int PA = (int)rs_pix_in(g, sA);
+    int PE = (int)rs_pix_in(g, sB);                  // end of what the samples [sA, sB) store
+    PE = PE < n_out ? PE : n_out;
+    const int PB = (sB >= size) ? n_out : PE;        // end of what this workgroup writes (zeros behind PE)
+    if (PA >= PB) return;
+    float *dst = out + ch.out_off;
+    const int mis = (int)((((uintptr_t)(dst + PA)) >> 2) & 3);  // phase of pixel PA inside its 16-byte group
+    __shared__ float4 tile4[(RSU_TILE + 8) / 4];
+    float *tile = reinterpret_cast<float *>(tile4);
+    if (PB - PA + mis > RSU_TILE + 8) __builtin_trap();  // the host plans `rounds` so that this cannot happen
+
+    SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
+    const double c_in = cin[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int toff = mis - PA;
+    // rounds go in batches of RSU_BATCH: all of a batch's samples are requested before the first one is used
+    for (int j0 = 0; j0 < rounds; j0 += RSU_BATCH) {
+        float vfs[RSU_BATCH];
+#pragma unroll
+        for (int jj = 0; jj < RSU_BATCH; jj++) {
+            const int id = sA + (wave * rounds + j0 + jj) * RSU_LANES + lane - 2;
+            const int idc = id < 0 ? 0 : (id >= size ? size - 1 : id);
+            vfs[jj] = ld(idc);
+        }
+#pragma unroll
+        for (int jj = 0; jj < RSU_BATCH; jj++) {
+            const int base = sA + (wave * rounds + j0 + jj) * RSU_LANES;
+            if (j0 + jj >= rounds || base >= sB) break;  // wave-uniform
+            const int id = base + lane - 2;
+            const RsUpGeom a = rs_up_geom(g, id);
+            const int pnext = (int)a.pnext;
+            const float vf = vfs[jj];
+            const double val = (double)vf;
+            const double tail = rs_up_tail(g, a, val);
+            int pin = rsu_shr1(pnext);
+            pin = (id <= 0) ? 0 : pin;
+            const double pind = (double)pin;
+            const bool fired = rs_up_fired(a, pind);
+            const int fired_prev = rsu_shr1(fired ? 1 : 0);
+            const double tail_prev = rsu_shr1(tail);
+            double contrib = 0.0 + tail_prev;
+            if (id == 0) contrib = c_in;
+            const bool real = lane >= 2 && id < sB;
+            if (real && fired && id > 0 && !fired_prev) contrib = rs_contrib_before(g, id, c_in, ld);  // the exception when r >= 1
+            const float first = rs_up_first(a, pind, contrib, val);
+            const int cnt = real ? pnext - pin : 0;
+            for (int c = 0; c < maxc; c++) {
+                const int p = pin + c;
+                if (c < cnt && p < PE) tile[p + toff] = (c == 0 && fired) ? first : vf;
+            }
+        }
+    }
+    __syncthreads();
+    const int ngroups = (PB - PA + mis + 3) >> 2;
+    for (int grp = threadIdx.x; grp < ngroups; grp += 256) {
+        const int p0 = PA - mis + 4 * grp;
+        float4 q = tile4[grp];
+        float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (p0 + k >= PE) v[k] = 0.0f;  // pixels the reference's loop never stores
+        if (p0 >= PA && p0 + 4 <= PB) {
+            *reinterpret_cast<float4 *>(dst + p0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (p0 + k >= PA && p0 + k < PB) dst[p0 + k] = v[k];
+        }
+    }
+}
+
 // Frame tracking, second stage: one workgroup per frame touched by the call folds the records of
 // the workgroups whose span overlaps it (chunk range from the host), joins frame 0 with the
 // incomplete frame carried from the previous call and leaves the call's last, incomplete frame
@@ -989,7 +1096,18 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
                 rs->cap_frames = ntouched + 16;
             }
         }
-        if (max_out) {
+        // sample-parallel kernel whenever the ratio upsamples moderately (the reference's geometry: r ~ 2) and no
+        // frame tracking is wanted; `rounds` keeps a workgroup's pixels inside its LDS tile
+        static const int force_old = getenv("TSDRGPU_RS_GROUPS") ? 1 : 0;
+        const bool up_kernel = !track && !force_old && r >= 1.0 && r <= 8.0;
+        if (max_out && up_kernel) {
+            int rounds = (int)((RSU_TILE - 4) / (4.0 * RSU_LANES * r));
+            if (rounds < 1) rounds = 1;
+            const int maxc = (int)r + 2;
+            dim3 gridu(ceil_div_u(chunk, (unsigned)(4 * RSU_LANES * rounds)), (unsigned)nchunks);
+            if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<true>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, rounds, maxc);
+            else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<false>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, rounds, maxc);
+        } else if (max_out) {
             if (track) {
                 if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<true, true>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, d_cf, P, rs->d_slots);
                 else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<false, true>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, d_cf, P, rs->d_slots);

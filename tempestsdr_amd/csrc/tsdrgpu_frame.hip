@@ -99,6 +99,11 @@ struct tsdrgpu_postproc {
 // Wave w takes rows w, w+4, ...; lane l takes columns l, l+64, l+128, l+192 of
 // the tile, so every load instruction covers 256 contiguous bytes.
 // ---------------------------------------------------------------------------
+// frames are W*H floats apart and rows W floats, so a frame or row base is only 4-byte aligned in general: these
+// vector types say so, and gfx950 (unaligned access mode) still moves them with one dwordx2 / dwordx4 instruction
+typedef float float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float float4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
     float lo = INFINITY, hi = -INFINITY;
 
     // phase 1: issue all of this wave's loads (8 rows x 4 columns per lane) before touching them,
-    // so that 32 requests per lane are in flight
+    // so that 32 requests per lane are in flight (one dwordx4 per row measured 4 % slower here)
     constexpr int ROWS = TILE_H / 4;
     float val[ROWS][4];
 #pragma unroll
@@ -155,6 +160,41 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
     // sums are only reduced and written when the tile holds any (tflag), which saves two thirds of the
     // partial-sum traffic; k_frame_reduce reads them under the same flag.
     float prs[ROWS], prc[ROWS];
+    // a wave whose 32 x 256 pixels are all inside the frame and hold no sentinel (the rule, decided with one
+    // max3 per two pixels and a ballot) only needs the plain sums and min/max: same additions in the same
+    // order as the general form below, whose sentinel accumulators would all stay zero
+    bool plain = (x0 + TILE_W <= W) && (y0 + TILE_H <= H);  // workgroup-uniform
+    if (plain) {
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            m = fmaxf(fmaxf(m, fabsf(val[r][0])), fabsf(val[r][1]));
+            m = fmaxf(fmaxf(m, fabsf(val[r][2])), fabsf(val[r][3]));
+        }
+        plain = __builtin_amdgcn_ballot_w64(m > 250.0f) == 0ull;  // wave-uniform
+    }
+    if (plain) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            float rns = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float v = val[r][j];
+                cns[j] += v;
+                rns += v;
+            }
+            lo = fminf(fminf(lo, val[r][0]), val[r][1]);
+            lo = fminf(fminf(lo, val[r][2]), val[r][3]);
+            hi = fmaxf(fmaxf(hi, val[r][0]), val[r][1]);
+            hi = fmaxf(fmaxf(hi, val[r][2]), val[r][3]);
+            prs[r] = 0.f;
+            prc[r] = 0.f;
+            if (want_strips) {
+                rns = wave_sum(rns);
+                if (lane == 0) rowp[((long long)(f * tiles_x + tx) * 3) * H + (y0 + wave + 4 * r)] = rns;
+            }
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int y = y0 + wave + 4 * r;
@@ -180,6 +220,7 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
             rns = wave_sum(rns);
             if (lane == 0) rowp[((long long)(f * tiles_x + tx) * 3) * H + y] = rns;
         }
+    }
     }
     const int tile_sent = __syncthreads_or((cc[0] + cc[1] + cc[2] + cc[3]) != 0.f);
     if (want_strips && tile_sent) {
@@ -970,9 +1011,8 @@ __global__ __launch_bounds__(SYNC_T) void k_sync_chain(int F, int W, int H, Stri
 #define PASS_IIR 8
 
 template <int VW> struct VecT;
-template <> struct VecT<1> { typedef float type; };
-template <> struct VecT<2> { typedef float2 type; };
-template <> struct VecT<4> { typedef float4 type; };
+template <> struct VecT<2> { typedef float2_a4 type; };
+template <> struct VecT<4> { typedef float4_a4 type; };
 
 __device__ __forceinline__ float pass_one(int flags, float v, float &s, float a, double one_minus_a, float lastmin, float span,
                                           bool on_line)
@@ -1024,9 +1064,8 @@ __global__ __launch_bounds__(256) void k_frame_pass(const float *__restrict__ sr
             float v[VW];
             if (!(FLAGS & PASS_ROLL) && VW > 1 && full) {
                 const vec_t t = *reinterpret_cast<const vec_t *>(in + p0);
-                const float *tp = reinterpret_cast<const float *>(&t);
 #pragma unroll
-                for (int k = 0; k < VW; k++) v[k] = tp[k];
+                for (int k = 0; k < VW; k++) v[k] = t[k];
             } else {
 #pragma unroll
                 for (int k = 0; k < VW; k++) {
@@ -1043,9 +1082,8 @@ __global__ __launch_bounds__(256) void k_frame_pass(const float *__restrict__ sr
             for (int k = 0; k < VW; k++) v[k] = pass_one(FLAGS, v[k], s[k], a, one_minus_a, lastmin, span, x[k] == dx || y[k] == dy);
             if (VW > 1 && full) {
                 vec_t t;
-                float *tp = reinterpret_cast<float *>(&t);
 #pragma unroll
-                for (int k = 0; k < VW; k++) tp[k] = v[k];
+                for (int k = 0; k < VW; k++) t[k] = v[k];
                 *reinterpret_cast<vec_t *>(outp + p0) = t;
             } else {
 #pragma unroll
@@ -1260,7 +1298,7 @@ static pass_fn pick_pass_vw(int flags)
 
 static pass_fn pick_pass(int flags, int vw)
 {
-    return vw == 4 ? pick_pass_vw<4>(flags) : (vw == 2 ? pick_pass_vw<2>(flags) : pick_pass_vw<1>(flags));
+    return vw == 4 ? pick_pass_vw<4>(flags) : nullptr;
 }
 
 // ---------------------------------------------------------------------------
@@ -1452,11 +1490,9 @@ static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long
                        int F, int W, int H, float a)
 {
     tsdrgpu_t *g = pp->g;
-    // widest vector access every frame of both buffers is aligned for
-    int vw = 4;
-    while (vw > 1 && ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)pp->d_screen)) % (vw * sizeof(float)) != 0 ||
-                      (F > 1 && (sstride % vw != 0 || dstride % vw != 0))))
-        vw >>= 1;
+    // four pixels per lane (one dwordx4 per frame; the vector types only claim float alignment)
+    const int vw = 4;
+    (void)sstride;
     pass_fn fn = pick_pass(flags, vw);
     if (!fn) return tsdr_fail(g, TSDRGPU_EINVAL, "k_frame_pass", "unsupported flag combination");
     const long long P = (long long)W * H;

@@ -23,6 +23,8 @@ def emu():
     lib.emu_resample_chunk.restype = C.c_uint
     lib.emu_resample_chunk.argtypes = [f32p, C.c_uint, C.c_double, C.c_double, C.c_double, C.c_double, f32p,
                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.emu_resample_chunk_up.restype = C.c_uint
+    lib.emu_resample_chunk_up.argtypes = [f32p, C.c_uint, C.c_double, C.c_double, C.c_double, C.c_double, f32p]
     return lib
 
 
@@ -50,3 +52,26 @@ def test_closed_form_equals_sequential_loop(orc, emu, up, down, sizes):
         assert np.all(out[k:n] == 0.0)  # pixels the reference's loop never stores
         assert (co.value, oo.value) == (rs.st.contrib, rs.st.offset)
         con, off = co.value, oo.value
+
+
+@pytest.mark.parametrize("up,down,sizes", CASES + [(1.0000001, 1.0, [5000] * 3), (8.0, 1.0, [300, 301]), (2.5, 1.0, [1, 2, 1, 700]),
+                                                   (1481 * 2 * 1125 * 60.0, 100e6, [166666] * 2), (4.0, 3.0, [999] * 4)])
+def test_sample_parallel_form_equals_sequential_loop(orc, emu, up, down, sizes):
+    """k_rs_area_up's lane scheme (one lane per input sample, neighbour values through a wave shift).  It is only
+    dispatched for r >= 1, but it is exact for every ratio (the chain replay covers neighbours that did not fire)."""
+    rng = np.random.default_rng(6)
+    rs = orc.Resampler()
+    con, off = 0.0, 0.0
+    slow_total = 0
+    for s in sizes:
+        x = (rng.random(s).astype(np.float32) - np.float32(0.25))  # negative samples too (real-valued input)
+        want = rs.process(x, up, down)
+        out = np.full(want.size + 4, -7.0, np.float32)
+        slow_total += emu.emu_resample_chunk_up(x, s, up, down, off, con, out)
+        k = min(rs.last_emitted, want.size)
+        assert np.array_equal(out[:k], want[:k])
+        assert np.all(out[k:want.size] == 0.0)
+        assert np.all(out[want.size:] == -7.0)
+        con, off = rs.st.contrib, rs.st.offset
+    if up / down >= 1.0:
+        assert slow_total <= len(sizes)  # the chain replay is the exception when upsampling
