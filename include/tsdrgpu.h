@@ -58,6 +58,8 @@ int tsdrgpu_upload(tsdrgpu_t *g, void *d_dst, const void *h_src, size_t bytes);
 int tsdrgpu_download(tsdrgpu_t *g, void *h_dst, const void *d_src, size_t bytes);
 int tsdrgpu_copy(tsdrgpu_t *g, void *d_dst, const void *d_src, size_t bytes);
 int tsdrgpu_copy2(tsdrgpu_t *g, void *d_dst1, void *d_dst2, const void *d_src, size_t bytes); /* one launch, two destinations */
+/* n (<= 32) device blocks appended back to back to d_dst1 and, if not NULL, d_dst2, in one launch on the COMPUTE lane */
+int tsdrgpu_gather2(tsdrgpu_t *g, void *d_dst1, void *d_dst2, const void *const *d_srcs, const size_t *bytes, int n);
 int tsdrgpu_zero(tsdrgpu_t *g, void *d_ptr, size_t bytes);
 
 /* ---- lanes and events: what a streaming host needs to overlap PCIe copies with compute ------------

@@ -10,6 +10,10 @@ except Exception as e:
     print("$tag failed", e); print(open("$O/$tag.err").read()[-1500:])
 PY
 }
-timeout 1500 python -m pytest tests/test_gpu_postproc.py tests/test_gpu_soak.py tests/test_gpu_bands.py tests/test_gpu_demod_resample.py tests/test_gpu_edges.py tests/test_gpu_extras.py tests/test_gpu_host_pipeline.py -x -q -m gpu > $O/pytest.log 2>&1; grep -E "passed|failed|error" $O/pytest.log | tail -3
-run new A=1
-run new2 A=1
+run pad0 A=1
+run pad16 TSDRGPU_AC_PAD=16
+run pad32 TSDRGPU_AC_PAD=32
+run pad64 TSDRGPU_AC_PAD=64
+run pad8 TSDRGPU_AC_PAD=8
+run pad0b A=1
+TSDRGPU_AC_PAD=32 timeout 900 python -m pytest tests/test_gpu_autocorr.py -x -q -m gpu > $O/pytest.log 2>&1; grep -E "passed|failed|error" $O/pytest.log | tail -3

@@ -34,9 +34,9 @@
 
 #include "tsdr_host.h"
 
-#define NSLOT 8            /* input blocks in flight */
-#define NFRAMEQ 8          /* frames on their way to / waiting for the video callback */
-#define NOUT 3             /* post-processed batches whose frames may still be downloading */
+#define NSLOT 32           /* input blocks in flight: when the host is slow the backlog turns into bigger batches */
+#define NFRAMEQ 16         /* frames on their way to / waiting for the video callback */
+#define NOUT 6             /* post-processed batches whose frames may still be downloading */
 #define MAX_FRAME_BATCH 16
 #define MAX_HOSTREG 512    /* page-locked ranges of plugin memory */
 #define NORMALISATION_LOWPASS_COEFF (0.1f) /* TSDRLibrary.c:37 */
@@ -62,15 +62,20 @@ typedef struct {
     tsdrgpu_pp_frameinfo_t *h_info; /* pinned; the frame's post-processing record */
     int announce_autogain;
     tsdrgpu_event_t *ready; /* recorded on the DOWNLOAD lane behind the frame's copies */
+    /* what the download thread needs: where the frame and its record live on the device, and the batch they belong to */
+    const void *d_src;
+    const tsdrgpu_pp_frameinfo_t *d_info_src;
+    struct out_buf *ob;
 } frame_slot_t;
 
-typedef struct {
+typedef struct out_buf {
     float *d; size_t cap;              /* F frames */
     int32_t *d_rgb; size_t rgb_cap;    /* the same frames as packed RGB (tsdrx_readasync_rgb runs only) */
     tsdrgpu_pp_frameinfo_t *d_info;    /* F records */
     int info_cap;
-    tsdrgpu_event_t *done, *last_dl;   /* batch computed (COMPUTE) / its last download queued (DOWNLOAD) */
+    tsdrgpu_event_t *done, *last_dl;   /* batch computed (COMPUTE) / its latest download (DOWNLOAD) */
     int busy;
+    int pending;                       /* frames of the batch whose download is not queued yet (under fm) */
 } out_buf_t;
 
 typedef struct {
@@ -102,7 +107,7 @@ struct engine {
     tsdrgpu_autocorr_t *ac;
     uint32_t ac_rate, ac_failed_rate;
     uint32_t ac_capture;
-    tsdrgpu_event_t *det_read; /* SIDE lane is done reading the detector's sample stream */
+    tsdrgpu_event_t *det_read; /* the detector's lane (when it has its own) is done reading the detector's sample stream */
     int det_read_valid;
 
     /* input queue */
@@ -131,9 +136,10 @@ struct engine {
 
     /* video delivery */
     frame_slot_t fq[NFRAMEQ];
-    int fq_head, fq_count;
+    int fq_head, fq_count, fq_issued;  /* fq_issued of the fq_count queued frames have their download on the DOWNLOAD lane */
     pthread_mutex_t fm;
-    pthread_cond_t f_nonempty;
+    pthread_cond_t f_nonempty;         /* a download was queued (video thread) */
+    pthread_cond_t f_queued;           /* a frame was queued (download thread) / a batch has no download pending (device thread) */
 
     /* plot delivery: one message in flight; its geometry travels with it (the detector may be rebuilt for a
      * new sample rate while the host still looks at the previous plots) */
@@ -149,7 +155,14 @@ struct engine {
     int stats;
     double t_start;
     double s_plugin_busy, s_plugin_dma, s_dev_busy, s_dev_wait_out, s_video_wait, s_video_cb;
+    double s_dev_blocks, s_dev_rs, s_dev_frames, s_dev_det; /* device thread: appending blocks / resampler / frame path / detector */
     long n_blocks, n_blocks_lost, n_frames_made, n_frames_lost, n_batches, n_resample_calls, n_windows;
+
+    /* blocks of the current look at the queue that go to both sample streams with one launch (gather_flush) */
+    const void *g_src[32];
+    size_t g_bytes[32];
+    int gn;
+    float *g_det, *g_iq;
 
     /* super-bandwidth */
     int super_state, super_hop, super_gathered, super_to_gather, super_frame, super_to_pause;
@@ -200,7 +213,9 @@ static int stream_reserve(struct engine *e, devstream_t *s, size_t extra)
         s->rd = 0; s->wr = live;
         return 1;
     }
-    size_t cap = need * 2 + 4096;
+    /* generous: a stream is compacted (its live part copied to the twin) every time the write position reaches the
+     * end, so the slack behind the live part sets how often that copy happens (HBM is not the scarce resource) */
+    size_t cap = need * 4 + ((size_t)16 << 20);
     float *n1 = NULL, *n2 = NULL;
     if (tsdrgpu_alloc(e->g, (void **)&n1, cap * sizeof(float)) || tsdrgpu_alloc(e->g, (void **)&n2, cap * sizeof(float))) {
         tsdrgpu_free(e->g, n1);
@@ -352,7 +367,7 @@ static void *video_thread(void *arg)
     tsdrgpu_bind_thread(e->g);
     pthread_mutex_lock(&e->fm);
     while (e->alive || e->fq_count) {
-        if (!e->fq_count) {
+        if (!e->fq_issued) {
             struct timespec ts;
             deadline_ms(&ts, 30);
             pthread_cond_timedwait(&e->f_nonempty, &e->fm, &ts);
@@ -373,6 +388,44 @@ static void *video_thread(void *arg)
         pthread_mutex_lock(&e->fm);
         e->fq_head = (e->fq_head + 1) % NFRAMEQ;
         e->fq_count--;
+        e->fq_issued--;
+    }
+    pthread_mutex_unlock(&e->fm);
+    return NULL;
+}
+
+/* ---- download thread ---------------------------------------------------------------- */
+/* Waits ON THE HOST for a batch to be computed and only then queues its frames' way home.  Letting the DOWNLOAD lane
+ * wait on the device instead (hipStreamWaitEvent) parks a barrier packet in that lane's hardware queue until the batch
+ * is done, and a parked barrier slows the COMPUTE lane's own queue down — measured on MI355X: every kernel of the
+ * frame path took ~40 us longer and the engine ran at 1.8 instead of 5 GS/s, depending on which hardware queues the
+ * lanes happened to get. */
+static void *download_thread(void *arg)
+{
+    struct engine *e = (struct engine *)arg;
+    tsdrgpu_bind_thread(e->g);
+    pthread_mutex_lock(&e->fm);
+    while (e->alive || e->fq_issued < e->fq_count) {
+        if (e->fq_issued == e->fq_count) {
+            struct timespec ts;
+            deadline_ms(&ts, 30);
+            pthread_cond_timedwait(&e->f_queued, &e->fm, &ts);
+            continue;
+        }
+        frame_slot_t *s = &e->fq[(e->fq_head + e->fq_issued) % NFRAMEQ];
+        pthread_mutex_unlock(&e->fm);
+        out_buf_t *ob = s->ob;
+        tsdrgpu_event_sync(e->g, ob->done);
+        const size_t P = (size_t)s->width * s->height;
+        (void)tsdrgpu_download_lane(e->g, s->h, s->d_src, P * sizeof(float));
+        (void)tsdrgpu_download_lane(e->g, s->h_info, s->d_info_src, sizeof(tsdrgpu_pp_frameinfo_t));
+        (void)tsdrgpu_event_record(e->g, s->ready, TSDRGPU_LANE_DOWNLOAD);
+        (void)tsdrgpu_event_record(e->g, ob->last_dl, TSDRGPU_LANE_DOWNLOAD);
+        pthread_mutex_lock(&e->fm);
+        e->fq_issued++;
+        ob->pending--;
+        pthread_cond_signal(&e->f_nonempty);
+        if (!ob->pending) pthread_cond_broadcast(&e->f_queued);
     }
     pthread_mutex_unlock(&e->fm);
     return NULL;
@@ -452,7 +505,15 @@ static void detector_rebuild(struct engine *e, uint32_t fs)
      * the detected mode are bit-identical to the CPU library's (0.25 ms per 100 MS/s window against 56 ms of
      * signal).  TSDR_GPU_EXACT_AUTOCORR=0 / TSDR_GPU_EXACT=0 select the fast transform (plots within 1e-4*max). */
     if (exact_wanted("TSDR_GPU_EXACT_AUTOCORR")) (void)tsdrgpu_autocorr_set_exact(e->ac, 1);
-    (void)tsdrgpu_autocorr_set_async(e->ac, 1); /* BACKGROUND lane: beside the frame path */
+    /* The detector's transforms run in line on the COMPUTE lane.  On its own (BACKGROUND) lane they would overlap the
+     * frame path, but every window then needs two device-side waits between the lanes, and a barrier packet parked in
+     * one hardware queue slows the other queues of the process down (see download_thread): measured 1.8-2.4 GS/s
+     * against 4-5 GS/s, depending on which hardware queues the lanes were given.  TSDR_GPU_DETECTOR_LANE=background
+     * opts back in. */
+    {
+        const char *lane = getenv("TSDR_GPU_DETECTOR_LANE");
+        (void)tsdrgpu_autocorr_set_async(e->ac, lane && lane[0] == 'b');
+    }
     plot_msg_t nm;
     memset(&nm, 0, sizeof(nm));
     uint32_t n = 0;
@@ -513,8 +574,10 @@ static void run_detector(struct engine *e, uint32_t fs)
         e->det.rd += (size_t)capture * 2;
         e->n_windows++;
         /* the window is read on the detector's lane; the COMPUTE lane must not recycle that memory before (process_block) */
-        if (tsdrgpu_event_record(e->g, e->det_read, tsdrgpu_autocorr_lane(e->ac)) == 0) e->det_read_valid = 1;
-        else tsdrgpu_sync(e->g);
+        if (tsdrgpu_autocorr_lane(e->ac) != TSDRGPU_LANE_COMPUTE) { /* (in line, the lane's own order does it) */
+            if (tsdrgpu_event_record(e->g, e->det_read, tsdrgpu_autocorr_lane(e->ac)) == 0) e->det_read_valid = 1;
+            else tsdrgpu_sync(e->g);
+        }
         if (t->params_int[PARAM_AUTOCORR_DUMP]) {
             t->params_int[PARAM_AUTOCORR_DUMP] = 0;
             dump_autocorr(e);
@@ -540,13 +603,12 @@ static void run_detector(struct engine *e, uint32_t fs)
     }
 }
 
-/* Queues the way back of a batch's frames: DOWNLOAD lane behind the batch's COMPUTE event, one pinned slot and one
- * event per frame; the video thread picks a frame up when its event has fired.  A full queue drops the frame (the
- * viewer is slower than the stream), like the reference's lossy video ring. */
+/* Hands a batch's frames to the download thread: one pinned slot and one event per frame; the video thread picks a
+ * frame up when its event has fired.  A full queue drops the frame (the viewer is slower than the stream), like the
+ * reference's lossy video ring. */
 static void deliver_frames(struct engine *e, out_buf_t *ob, int F, int W, int H)
 {
     const size_t P = (size_t)W * H;
-    int queued = 0;
     for (int f = 0; f < F; f++) {
         const int announce = e->pp_runs++ > AUTOGAIN_REPORT_EVERY_FRAMES;
         if (announce) e->pp_runs = 0;
@@ -565,21 +627,18 @@ static void deliver_frames(struct engine *e, out_buf_t *ob, int F, int W, int H)
             if (tsdrgpu_alloc_host(e->g, (void **)&s->h, P * sizeof(float))) continue;
             s->cap = P;
         }
-        if (!queued && tsdrgpu_lane_wait(e->g, TSDRGPU_LANE_DOWNLOAD, ob->done)) return;
-        const void *d_src = e->t->rgb_cb ? (const void *)(ob->d_rgb + (size_t)f * P) : (const void *)(ob->d + (size_t)f * P);
-        if (tsdrgpu_download_lane(e->g, s->h, d_src, P * sizeof(float)) ||
-            tsdrgpu_download_lane(e->g, s->h_info, ob->d_info + f, sizeof(tsdrgpu_pp_frameinfo_t)) ||
-            tsdrgpu_event_record(e->g, s->ready, TSDRGPU_LANE_DOWNLOAD))
-            continue;
-        queued++;
+        s->d_src = e->t->rgb_cb ? (const void *)(ob->d_rgb + (size_t)f * P) : (const void *)(ob->d + (size_t)f * P);
+        s->d_info_src = ob->d_info + f;
+        s->ob = ob;
         s->width = W; s->height = H;
         s->announce_autogain = announce;
         pthread_mutex_lock(&e->fm);
         e->fq_count++;
-        pthread_cond_signal(&e->f_nonempty);
+        ob->pending++;
+        ob->busy = 1;
+        pthread_cond_broadcast(&e->f_queued);
         pthread_mutex_unlock(&e->fm);
     }
-    if (queued && tsdrgpu_event_record(e->g, ob->last_dl, TSDRGPU_LANE_DOWNLOAD) == 0) ob->busy = 1;
 }
 
 static void run_frames(struct engine *e)
@@ -608,6 +667,13 @@ static void run_frames(struct engine *e)
         e->out_next = (e->out_next + 1) % NOUT;
         if (ob->busy) { /* its frames have left the device? */
             const double t0 = e->stats ? now_s() : 0.0;
+            pthread_mutex_lock(&e->fm);
+            while (ob->pending && e->alive) {
+                struct timespec ts;
+                deadline_ms(&ts, 30);
+                pthread_cond_timedwait(&e->f_queued, &e->fm, &ts);
+            }
+            pthread_mutex_unlock(&e->fm);
             tsdrgpu_event_sync(e->g, ob->last_dl);
             ob->busy = 0;
             if (e->stats) e->s_dev_wait_out += now_s() - t0;
@@ -717,7 +783,9 @@ static void run_resampler(struct engine *e)
         const int so = t->syncoffset;
         t->syncoffset = 0;
         e->pix_difference = drop_shift_with(e->pix_difference, (uint32_t)totalpixels, -(int64_t)so);
+        const double tf = e->stats ? now_s() : 0.0;
         run_frames(e);
+        if (e->stats) e->s_dev_frames += now_s() - tf;
     }
 }
 
@@ -796,6 +864,14 @@ static int super_feed(struct engine *e, const float *d_blk, size_t nfloats, int6
     return 0;
 }
 
+/* the blocks collected by process_block go behind each other into the detector's and the resampler's stream */
+static void gather_flush(struct engine *e)
+{
+    if (!e->gn) return;
+    gpu_ok(e, tsdrgpu_gather2(e->g, e->g_det, e->g_iq, e->g_src, e->g_bytes, e->gn), "append");
+    e->gn = 0;
+}
+
 /* One plugin block, already on the device (slot->d): everything below only queues work. */
 static void process_block(struct engine *e, in_slot_t *slot)
 {
@@ -810,6 +886,7 @@ static void process_block(struct engine *e, in_slot_t *slot)
     const size_t size2 = nfloats / 2;
 
     if (t->params_int[PARAM_AUTOCORR_SUPERRESOLUTION]) { /* TSDRLibrary.c:271-279 */
+        gather_flush(e);
         if (!e->iq_is_mag) { e->iq.rd = e->iq.wr = 0; e->det.rd = e->det.wr = 0; e->iq_is_mag = 1; }
         uint32_t total = 0;
         if (nfloats && super_feed(e, d_blk, nfloats, dropped, &total)) {
@@ -819,6 +896,7 @@ static void process_block(struct engine *e, in_slot_t *slot)
         }
     } else {
         if (e->iq_is_mag || e->super_state != SUPER_STOPPED) { /* superb_stop, superbandwidth.c:256-264 */
+            gather_flush(e);
             super_reset(e);
             if (t->plugin.loaded) t->plugin.setbasefreq(t->centfreq);
             pthread_mutex_lock(&t->lock);
@@ -837,14 +915,20 @@ static void process_block(struct engine *e, in_slot_t *slot)
             tsdrgpu_lane_wait(e->g, TSDRGPU_LANE_COMPUTE, e->det_read);
             e->det_read_valid = 0;
         }
+        const int usual = plots_on && dropped == 0 && !drop_all && nfloats && e->dev_difference == 0;
+        /* anything but another usual block ends the run of blocks that one launch appends; so does a stream that has
+         * to be compacted or grown first (stream_reserve may move it) */
+        if (!usual || e->det.wr + nfloats > e->det.cap || e->iq.wr + nfloats > e->iq.cap) gather_flush(e);
         if (plots_on && dropped != 0) e->det.rd = e->det.wr = 0;
-        if (plots_on && dropped == 0 && !drop_all && nfloats && e->dev_difference == 0 && stream_reserve(e, &e->det, nfloats) &&
-            stream_reserve(e, &e->iq, nfloats)) {
-            /* the usual block — nothing lost, nothing to skip — goes to both streams in one launch */
-            if (gpu_ok(e, tsdrgpu_copy2(e->g, e->det.d + e->det.wr, e->iq.d + e->iq.wr, d_blk, nfloats * sizeof(float)), "append")) {
-                e->det.wr += nfloats;
-                e->iq.wr += nfloats;
-            }
+        if (usual && stream_reserve(e, &e->det, nfloats) && stream_reserve(e, &e->iq, nfloats)) {
+            /* the usual block — nothing lost, nothing to skip — goes to both streams, together with its neighbours */
+            if (!e->gn) { e->g_det = e->det.d + e->det.wr; e->g_iq = e->iq.d + e->iq.wr; }
+            e->g_src[e->gn] = d_blk;
+            e->g_bytes[e->gn] = nfloats * sizeof(float);
+            e->gn++;
+            e->det.wr += nfloats;
+            e->iq.wr += nfloats;
+            if (e->gn == 32) gather_flush(e);
         } else {
             if (plots_on && dropped == 0 && !drop_all && nfloats && !stream_append(e, &e->det, d_blk, nfloats)) e->det.rd = e->det.wr = 0;
             /* dsp_dropped_compensation_add, dsp.c:326-346 */
@@ -852,9 +936,6 @@ static void process_block(struct engine *e, in_slot_t *slot)
             else if (stream_append(e, &e->iq, d_blk + 2 * e->dev_difference, nfloats - 2 * (size_t)e->dev_difference)) e->dev_difference = 0;
         }
     }
-    /* the plugin thread may refill this slot once the COMPUTE lane has read it */
-    if (nfloats && tsdrgpu_event_record(e->g, slot->consumed, TSDRGPU_LANE_COMPUTE) == 0) slot->consumed_valid = 1;
-    else if (nfloats) tsdrgpu_sync(e->g);
 }
 
 static void *device_thread(void *arg)
@@ -877,13 +958,29 @@ static void *device_thread(void *arg)
         pthread_mutex_unlock(&e->qm);
         const double t0 = e->stats ? now_s() : 0.0;
         for (int i = 0; i < n; i++) process_block(e, &e->slot[(head + i) % NSLOT]);
+        gather_flush(e);
+        /* the plugin thread may refill these slots once the COMPUTE lane has read them */
+        for (int i = 0; i < n; i++) {
+            in_slot_t *sl = &e->slot[(head + i) % NSLOT];
+            if (!sl->nfloats) continue;
+            if (tsdrgpu_event_record(e->g, sl->consumed, TSDRGPU_LANE_COMPUTE) == 0) sl->consumed_valid = 1;
+            else tsdrgpu_sync(e->g);
+        }
         pthread_mutex_lock(&e->qm);
         e->q_head = (e->q_head + n) % NSLOT;
         e->q_count -= n;
         pthread_mutex_unlock(&e->qm);
+        const double t1 = e->stats ? now_s() : 0.0;
         run_resampler(e);
+        const double t2 = e->stats ? now_s() : 0.0;
         run_detector(e, t->samplerate);
-        if (e->stats) e->s_dev_busy += now_s() - t0;
+        if (e->stats) {
+            const double t3 = now_s();
+            e->s_dev_busy += t3 - t0;
+            e->s_dev_blocks += t1 - t0;
+            e->s_dev_rs += t2 - t1; /* includes the frame path, which run_resampler drives */
+            e->s_dev_det += t3 - t2;
+        }
     }
     return NULL;
 }
@@ -933,7 +1030,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
         e->zero_copy = !(z && z[0] == '0');
     }
     pthread_mutex_init(&e->qm, NULL); pthread_cond_init(&e->q_nonempty, NULL);
-    pthread_mutex_init(&e->fm, NULL); pthread_cond_init(&e->f_nonempty, NULL);
+    pthread_mutex_init(&e->fm, NULL); pthread_cond_init(&e->f_nonempty, NULL); pthread_cond_init(&e->f_queued, NULL);
     pthread_mutex_init(&e->pm, NULL); pthread_cond_init(&e->p_nonempty, NULL);
     e->alive = 1;
     t->eng = e;
@@ -941,9 +1038,10 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     t->detector_purge = 1;
     t->params_int[PARAM_AUTOCORR_PLOTS_RESET] = 2;
 
-    pthread_t th_dev, th_video, th_plot;
+    pthread_t th_dev, th_video, th_plot, th_down;
     pthread_create(&th_dev, NULL, device_thread, e);
     pthread_create(&th_video, NULL, video_thread, e);
+    pthread_create(&th_down, NULL, download_thread, e);
     pthread_create(&th_plot, NULL, plot_thread, e);
 
     /* blocks until tsdr_stop / plugin failure; a plugin that offers its blocks in their native sample format
@@ -955,8 +1053,9 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     t->running = 0;
     pthread_join(th_dev, NULL);
     e->alive = 0;
-    pthread_mutex_lock(&e->fm); pthread_cond_broadcast(&e->f_nonempty); pthread_mutex_unlock(&e->fm);
+    pthread_mutex_lock(&e->fm); pthread_cond_broadcast(&e->f_nonempty); pthread_cond_broadcast(&e->f_queued); pthread_mutex_unlock(&e->fm);
     pthread_mutex_lock(&e->pm); pthread_cond_broadcast(&e->p_nonempty); pthread_mutex_unlock(&e->pm);
+    pthread_join(th_down, NULL);
     pthread_join(th_video, NULL);
     pthread_join(th_plot, NULL);
 
@@ -966,10 +1065,12 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
                 "tsdr stats: %.2f s | blocks in %ld lost %ld | frames made %ld lost-to-viewer %ld in %ld batches | resample calls %ld | windows %ld | "
                 "page-locked ranges %d\n"
                 "tsdr stats: plugin thread busy %.0f%% (DMA wait %.0f%%) | device thread busy %.0f%% (waiting for output buffers %.0f%%) | "
-                "video thread: waiting for frames %.0f%%, in the callback %.0f%%\n",
+                "video thread: waiting for frames %.0f%%, in the callback %.0f%%\n"
+                "tsdr stats: device thread: appending blocks %.0f%% | resampler %.0f%% | frame path %.0f%% | detector %.0f%%\n",
                 T, e->n_blocks, e->n_blocks_lost, e->n_frames_made, e->n_frames_lost, e->n_batches, e->n_resample_calls, e->n_windows, e->nreg,
                 100 * e->s_plugin_busy / T, 100 * e->s_plugin_dma / T, 100 * e->s_dev_busy / T, 100 * e->s_dev_wait_out / T,
-                100 * e->s_video_wait / T, 100 * e->s_video_cb / T);
+                100 * e->s_video_wait / T, 100 * e->s_video_cb / T,
+                100 * e->s_dev_blocks / T, 100 * (e->s_dev_rs - e->s_dev_frames) / T, 100 * e->s_dev_frames / T, 100 * e->s_dev_det / T);
     }
     tsdrgpu_bind_thread(e->g);
     tsdrgpu_sync(e->g);
@@ -1009,7 +1110,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     tsdrgpu_resampler_destroy(e->rs);
     tsdrgpu_destroy(e->g);
     pthread_mutex_destroy(&e->qm); pthread_cond_destroy(&e->q_nonempty);
-    pthread_mutex_destroy(&e->fm); pthread_cond_destroy(&e->f_nonempty);
+    pthread_mutex_destroy(&e->fm); pthread_cond_destroy(&e->f_nonempty); pthread_cond_destroy(&e->f_queued);
     pthread_mutex_destroy(&e->pm); pthread_cond_destroy(&e->p_nonempty);
     t->eng = NULL;
     free(e);

@@ -160,6 +160,63 @@ extern "C" int tsdrgpu_copy2(tsdrgpu_t *g, void *d_dst1, void *d_dst2, const voi
     KERNEL_CHECK(g, "k_copy2");
     return TSDRGPU_OK;
 }
+// n source blocks, back to back, into two destinations with ONE launch (the streaming engine appends every block the
+// source queued since the last look to both sample streams; one launch per block made the COMPUTE lane launch bound)
+#define GATHER_MAX 32
+struct GatherArgs {
+    const float *src[GATHER_MAX];
+    long long off[GATHER_MAX + 1];  // floats: block b lands at dst + off[b]
+};
+__global__ __launch_bounds__(256) void k_gather2(GatherArgs a, float *__restrict__ d1, float *__restrict__ d2)
+{
+    const int b = blockIdx.y;
+    const float *__restrict__ src = a.src[b];
+    const long long n = a.off[b + 1] - a.off[b];
+    float *o1 = d1 + a.off[b];
+    float *o2 = d2 ? d2 + a.off[b] : nullptr;
+    const bool vec = ((((uintptr_t)src) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 15) == 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long done = 0;
+    if (vec) {
+        const long long nq = n / 4;
+        for (long long i = first; i < nq; i += stride) {
+            const float4 v = reinterpret_cast<const float4 *>(src)[i];
+            reinterpret_cast<float4 *>(o1)[i] = v;
+            if (o2) reinterpret_cast<float4 *>(o2)[i] = v;
+        }
+        done = nq * 4;
+    }
+    for (long long i = done + first; i < n; i += stride) {
+        const float v = src[i];
+        o1[i] = v;
+        if (o2) o2[i] = v;
+    }
+}
+extern "C" int tsdrgpu_gather2(tsdrgpu_t *g, void *d_dst1, void *d_dst2, const void *const *d_srcs, const size_t *bytes, int n)
+{
+    if (!g || !d_dst1 || !d_srcs || !bytes || n < 0 || n > GATHER_MAX) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_gather2", "bad argument") : TSDRGPU_EINVAL;
+    if (n == 0) return TSDRGPU_OK;
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    long long off = 0, longest = 0;
+    for (int b = 0; b < n; b++) {
+        if (!d_srcs[b] || (bytes[b] & 3)) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_gather2", "block sizes must be multiples of 4");
+        a.src[b] = (const float *)d_srcs[b];
+        a.off[b] = off;
+        const long long nf = (long long)(bytes[b] / 4);
+        off += nf;
+        if (nf > longest) longest = nf;
+    }
+    a.off[n] = off;
+    if (off == 0) return TSDRGPU_OK;
+    long long blocks = (longest / 4 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_gather2, dim3((unsigned)blocks, (unsigned)n), 256, a, (float *)d_dst1, (float *)d_dst2);
+    KERNEL_CHECK(g, "k_gather2");
+    return TSDRGPU_OK;
+}
 extern "C" int tsdrgpu_zero(tsdrgpu_t *g, void *d_ptr, size_t bytes)
 {
     if (!g) return TSDRGPU_EINVAL;
