@@ -290,6 +290,9 @@ int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_li
 /* the same copies queued on the object's lane without waiting: h_* must be pinned and stay valid until an event
  * recorded on that lane (tsdrgpu_autocorr_lane) behind this call has completed */
 int tsdrgpu_autocorr_plots_async(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line, uint64_t *h_calls);
+/* a device-side copy (frame plot first, then the line plot) taken on the object's lane by a kernel; copy it home on
+ * another lane once an event recorded behind this call has fired (the streaming engine's plot thread does) */
+int tsdrgpu_autocorr_plots_snapshot(tsdrgpu_autocorr_t *ac, const double **d_snapshot, uint64_t *h_calls);
 /* device plots: frame_len + line_len doubles, contiguous (frame first) */
 int tsdrgpu_autocorr_device_plots(tsdrgpu_autocorr_t *ac, double **d_plots, int64_t *count);
 int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t total_windows);

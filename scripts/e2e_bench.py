@@ -46,17 +46,12 @@ def main():
     out = {"config": f"{args.fs/1e6:g} MS/s float32 IQ recording of {n/args.fs:.3f} s replayed free-running, h={args.height}, fv={args.fv}",
            "host_cores": os.cpu_count()}
 
-    def leg(name, lib, plugin, params, env=None, free=True, setup=None):
-        old = {k: os.environ.get(k) for k in (env or {})}
-        os.environ.update(env or {})
-        try:
-            r = tsdrlib.throughput_run(lib, plugin, params, args.height, args.fv, args.seconds, free=free, setup=setup)
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+    def leg(name, lib, plugin, params, env=None, free=True, set_int=()):
+        # every leg in a process of its own, like a host application (and so that no leg inherits another's runtime state)
+        e = {"TSDR_GPU_STATS": "1"}
+        e.update(env or {})
+        r = tsdrlib.throughput_subprocess(lib, plugin, params, args.height, args.fv, args.seconds, env=e, set_int=set_int, free=free)
+        print(r.pop("stderr_tail", ""), file=sys.stderr)
         r["effective_Msps"] = r["frames_per_s"] * S / 1e6
         out[name] = r
         print(name, json.dumps(r), file=sys.stderr, flush=True)
@@ -66,7 +61,7 @@ def main():
     leg("mi355x_mem_plugin_bounce_buffers", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0", {"TSDR_GPU_ZEROCOPY": "0"})
     # PARAM_INT_FRAMERATE_PLL (1): one frame per launch group and one host round trip per frame (the nudge feeds back)
     leg("mi355x_mem_plugin_pll_on", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0",
-        setup=lambda lib, h: lib.tsdr_setparameter_int(h, 1, 1))
+        set_int=[(1, 1)])
     # int16 recording of the same stream: half the bytes in (tsdrplugin_readasync_raw, decoded on the device)
     path16 = "/tmp/e2e_iq.s16"
     import numpy as np

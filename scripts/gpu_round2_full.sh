@@ -13,3 +13,5 @@ bash scripts/pmc_sq.sh ${1:-r2full}/sq > $O/sq.txt 2>&1
 python scripts/show_bench.py $O/bench.json | cut -c1-1200
 cat $O/pmc/summary.txt | head -40
 cat $O/sq.txt | tail -25
+timeout 600 python scripts/e2e_bench.py --reference > $O/e2e.json 2> $O/e2e.txt; echo "e2e rc=$?" | tee -a $O/summary.txt
+grep -E "^(mi355x|reference)" $O/e2e.txt | cut -c1-200

@@ -1,6 +1,7 @@
 // Micro-benchmark: how long does a chain of tiny dependent kernels take on one stream while other engines of the
 // device are busy (H2D / D2H DMA on their own streams, a long kernel on another stream)?
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -68,6 +69,22 @@ int main(int argc, char **argv)
         double t2 = now();
         for (int i = 0; i < 300; i++) { hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, st, p); CK(hipStreamSynchronize(st)); }
         double d1 = (now() - t2) / 300;
+        {   // hipExtLaunchKernelGGL with null start/stop events (what TSDR_LAUNCH expands to)
+            double t3 = now();
+            for (int i = 0; i < N; i++) hipExtLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, st, nullptr, nullptr, 0, p);
+            CK(hipStreamSynchronize(st));
+            double dx = (now() - t3) / N;
+            // kernels alternating with small async device-to-device copies and small pinned host-to-device copies
+            t3 = now();
+            for (int i = 0; i < N; i++) {
+                hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, st, p);
+                if ((i & 3) == 0) CK(hipMemcpyAsync(g_dev + 4096, g_dev, 1024, hipMemcpyDeviceToDevice, st));
+                if ((i & 3) == 2) CK(hipMemcpyAsync(g_dev + 8192, g_host, 2048, hipMemcpyHostToDevice, st));
+            }
+            CK(hipStreamSynchronize(st));
+            double dy = (now() - t3) / N;
+            printf("%-14s hipExtLaunch chain: %.2f us/kernel; kernels + small D2D/H2D copies every other: %.2f us/kernel\n", names[c], dx * 1e6, dy * 1e6);
+        }
         {   // the same chain with an event recorded after every kernel (what the engine's slot / batch bookkeeping does)
             hipEvent_t ev[8]; for (int i = 0; i < 8; i++) CK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
             hipStream_t other; CK(hipStreamCreateWithFlags(&other, hipStreamNonBlocking));

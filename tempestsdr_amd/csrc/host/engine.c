@@ -93,6 +93,7 @@ typedef struct {
     int32_t flo, flen, llo, llen;
     uint32_t rate;
     double *h_frame, *h_line; /* pinned */
+    const double *d_snapshot; /* the plots on the device (frame first), complete when plot_ready has fired */
     uint64_t calls;
 } plot_msg_t;
 
@@ -144,7 +145,7 @@ struct engine {
     /* plot delivery: one message in flight; its geometry travels with it (the detector may be rebuilt for a
      * new sample rate while the host still looks at the previous plots) */
     plot_msg_t plot;
-    tsdrgpu_event_t *plot_ready;
+    tsdrgpu_event_t *plot_ready, *plot_home; /* snapshot taken (detector's lane) / copied to the host (DOWNLOAD lane) */
     int plot_pending, plot_reset_announce, plot_dumped_announce;
     pthread_mutex_t pm;
     pthread_cond_t p_nonempty;
@@ -451,7 +452,12 @@ static void *plot_thread(void *arg)
         pthread_mutex_unlock(&e->pm);
         if (reset) tsdr_announce_value(t, VALUE_ID_AUTOCORRECT_RESET, 0, 0);
         if (dumped) tsdr_announce_value(t, VALUE_ID_AUTOCORRECT_DUMPED, 0, 0);
-        if (plots && tsdrgpu_event_sync(e->g, e->plot_ready) == 0) {
+        /* the snapshot is complete once plot_ready has fired; its way home is queued here, on the DOWNLOAD lane, so
+         * that the detector's lane never waits for a copy engine */
+        if (plots && tsdrgpu_event_sync(e->g, e->plot_ready) == 0 &&
+            tsdrgpu_download_lane(e->g, e->plot.h_frame, e->plot.d_snapshot, sizeof(double) * (size_t)e->plot.flen) == 0 &&
+            tsdrgpu_download_lane(e->g, e->plot.h_line, e->plot.d_snapshot + e->plot.flen, sizeof(double) * (size_t)e->plot.llen) == 0 &&
+            tsdrgpu_event_record(e->g, e->plot_home, TSDRGPU_LANE_DOWNLOAD) == 0 && tsdrgpu_event_sync(e->g, e->plot_home) == 0) {
             const plot_msg_t *m = &e->plot;
             tsdr_on_plot_ready_callback pcb = t->plotready_callback;
             if (pcb) { /* frameratedetector.c:121-124 */
@@ -493,6 +499,15 @@ static void dump_autocorr(struct engine *e) /* dump_autocorrect, frameratedetect
 
 static void detector_rebuild(struct engine *e, uint32_t fs)
 {
+    /* the plot thread may still be copying the old detector's snapshot home */
+    pthread_mutex_lock(&e->pm);
+    while (e->plot_pending && e->alive) {
+        pthread_mutex_unlock(&e->pm);
+        struct timespec ts = {0, 1000000};
+        nanosleep(&ts, NULL);
+        pthread_mutex_lock(&e->pm);
+    }
+    pthread_mutex_unlock(&e->pm);
     if (e->ac) tsdrgpu_autocorr_destroy(e->ac);
     e->ac = NULL;
     e->ac_rate = 0;
@@ -591,10 +606,12 @@ static void run_detector(struct engine *e, uint32_t fs)
         pthread_mutex_unlock(&e->pm);
         if (!busy) {
             uint64_t calls = 0;
-            if (tsdrgpu_autocorr_plots_async(e->ac, e->plot.h_frame, e->plot.h_line, &calls) == 0 &&
+            const double *snap = NULL;
+            if (tsdrgpu_autocorr_plots_snapshot(e->ac, &snap, &calls) == 0 &&
                 tsdrgpu_event_record(e->g, e->plot_ready, tsdrgpu_autocorr_lane(e->ac)) == 0) {
                 pthread_mutex_lock(&e->pm);
                 e->plot.calls = calls;
+                e->plot.d_snapshot = snap;
                 e->plot_pending = 1;
                 pthread_cond_signal(&e->p_nonempty);
                 pthread_mutex_unlock(&e->pm);
@@ -997,7 +1014,8 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     const char *env = getenv("TSDR_GPU_DEVICE");
     if (env) dev = atoi(env);
     int ok = tsdrgpu_create(&e->g, dev) == 0 && tsdrgpu_resampler_create(e->g, &e->rs) == 0 && tsdrgpu_postproc_create(e->g, &e->pp) == 0 &&
-             tsdrgpu_event_create(e->g, &e->plot_ready) == 0 && tsdrgpu_event_create(e->g, &e->det_read) == 0;
+             tsdrgpu_event_create(e->g, &e->plot_ready) == 0 && tsdrgpu_event_create(e->g, &e->plot_home) == 0 &&
+             tsdrgpu_event_create(e->g, &e->det_read) == 0;
     for (int i = 0; ok && i < NSLOT; i++) ok = tsdrgpu_event_create(e->g, &e->slot[i].consumed) == 0;
     for (int i = 0; ok && i < NFRAMEQ; i++)
         ok = tsdrgpu_event_create(e->g, &e->fq[i].ready) == 0 && tsdrgpu_alloc_host(e->g, (void **)&e->fq[i].h_info, sizeof(tsdrgpu_pp_frameinfo_t)) == 0;
@@ -1007,7 +1025,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
             for (int i = 0; i < NSLOT; i++) tsdrgpu_event_destroy(e->g, e->slot[i].consumed);
             for (int i = 0; i < NFRAMEQ; i++) { tsdrgpu_event_destroy(e->g, e->fq[i].ready); tsdrgpu_free_host(e->g, e->fq[i].h_info); }
             for (int i = 0; i < NOUT; i++) { tsdrgpu_event_destroy(e->g, e->out[i].done); tsdrgpu_event_destroy(e->g, e->out[i].last_dl); }
-            tsdrgpu_event_destroy(e->g, e->plot_ready);
+            tsdrgpu_event_destroy(e->g, e->plot_ready); tsdrgpu_event_destroy(e->g, e->plot_home);
             tsdrgpu_event_destroy(e->g, e->det_read);
             if (e->pp) tsdrgpu_postproc_destroy(e->pp);
             if (e->rs) tsdrgpu_resampler_destroy(e->rs);
@@ -1099,7 +1117,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     for (int i = 0; i < SUPER_HOPS; i++) tsdrgpu_free(e->g, e->d_hops[i]);
     tsdrgpu_free_host(e->g, e->plot.h_frame);
     tsdrgpu_free_host(e->g, e->plot.h_line);
-    tsdrgpu_event_destroy(e->g, e->plot_ready);
+    tsdrgpu_event_destroy(e->g, e->plot_ready); tsdrgpu_event_destroy(e->g, e->plot_home);
     tsdrgpu_event_destroy(e->g, e->det_read);
     tsdrgpu_free(e->g, e->d_rs);
     tsdrgpu_free(e->g, e->d_rgb_state);

@@ -7,6 +7,15 @@
 // ---------------------------------------------------------------------------
 // context / memory
 // ---------------------------------------------------------------------------
+// The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 by default).  The streaming
+// engine keeps three lanes busy at once (COMPUTE, UPLOAD, DOWNLOAD); measured on MI355X through the tsdr_* API it
+// sustains 5.0-5.1 GS/s when they share two hardware queues and 3.6 GS/s (1.8-2.4 before the host-side waits of
+// engine.c) when each lane has a queue of its own: with more queues active, the command processor's switching between
+// them adds tens of microseconds to every small kernel of the frame path.  So, unless the host application has
+// chosen a value itself, the library asks for two before the runtime starts (the variable is read when the runtime
+// initialises, i.e. at the process's first HIP call).
+__attribute__((constructor)) static void tsdrgpu_runtime_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "2", 0); }
+
 extern "C" int tsdrgpu_create(tsdrgpu_t **out, int device)
 {
     if (!out) return TSDRGPU_EINVAL;

@@ -21,6 +21,7 @@ struct tsdrgpu_autocorr {
     uint32_t capture, n;
     uint64_t calls;
     double *d_plots;   // frame_len + line_len
+    double *d_snapshot;  // tsdrgpu_autocorr_plots_snapshot
     float2 *d_a, *d_b; // ping-pong work buffers, cap_windows * n/2 complex each (packed real transform)
     int cap_windows;
     float2 *d_last;    // packed correlation of the last window run (n/2 complex = n reals)
@@ -829,6 +830,7 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
     (void)hipStreamSynchronize(ac->g->stream2);
     (void)hipStreamSynchronize(ac->g->bg);
     (void)hipFree(ac->d_plots);
+    (void)hipFree(ac->d_snapshot);
     (void)hipFree(ac->d_a);
     (void)hipFree(ac->d_b);
     (void)hipFree(ac->d_expand);
@@ -990,6 +992,22 @@ extern "C" int tsdrgpu_autocorr_plots_async(tsdrgpu_autocorr_t *ac, double *h_fr
     if (h_frame) HIP_TRY(g, hipMemcpyAsync(h_frame, ac->d_plots, sizeof(double) * ac->frame_len, hipMemcpyDeviceToHost, ac->st));
     if (h_line) HIP_TRY(g, hipMemcpyAsync(h_line, ac->d_plots + ac->frame_len, sizeof(double) * ac->line_len, hipMemcpyDeviceToHost, ac->st));
     if (h_calls) *h_calls = ac->calls;  // host-side count: known without the device
+    return TSDRGPU_OK;
+}
+
+// A device-side copy of the plots as they are at this point of the object's lane (a kernel, not a DMA: the lane never
+// waits for a copy engine).  Whoever wants them on the host copies the snapshot on a lane of its own once an event
+// recorded behind this call has fired.
+extern "C" int tsdrgpu_autocorr_plots_snapshot(tsdrgpu_autocorr_t *ac, const double **d_snapshot, uint64_t *h_calls)
+{
+    if (!ac || !d_snapshot) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    const size_t L = (size_t)ac->frame_len + ac->line_len;
+    if (!ac->d_snapshot && hipMalloc(&ac->d_snapshot, sizeof(double) * L) != hipSuccess)
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_plots_snapshot", "snapshot");
+    HIP_TRY(g, hipMemcpyAsync(ac->d_snapshot, ac->d_plots, sizeof(double) * L, hipMemcpyDeviceToDevice, ac->st));
+    *d_snapshot = ac->d_snapshot;
+    if (h_calls) *h_calls = ac->calls;
     return TSDRGPU_OK;
 }
 

@@ -84,6 +84,7 @@ _SIGS = {
     "tsdrgpu_postproc_band_finish": (C.c_int, [vp, vp, vp]),
     "tsdrgpu_comm_allreduce_f32max": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
     "tsdrgpu_autocorr_plots_async": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
+    "tsdrgpu_autocorr_plots_snapshot": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_lane": (C.c_int, [vp]),
     "tsdrgpu_rccl_unique_id": (C.c_int, [vp]),
     "tsdrgpu_comm_create": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, vp]),

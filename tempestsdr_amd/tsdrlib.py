@@ -90,3 +90,32 @@ def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, set
         lib.tsdr_free(C.byref(h))
     return {"frames_per_s": (f1 - f0) / (t1 - t0), "plots_per_s": (p1 - p0) / (t1 - t0), "width": cnt["w"], "height": cnt["h"],
             "status": status.get("rc")}
+
+
+def throughput_subprocess(libpath, plugin, params, height, fv, seconds, env=None, timeout=120, set_int=(), free=True):
+    """throughput_run in a process of its own — what a host application is: the library there picks the HIP runtime
+    settings it wants (tsdrgpu_core.hip: two hardware queues) instead of inheriting the caller's."""
+    import json
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.pop("GPU_MAX_HW_QUEUES", None)
+    e.update(env or {})
+    extra = ["free" if free else "nofree"] + [str(v) for pair in set_int for v in pair]  # tsdr_setparameter_int(id, value) pairs
+    out = subprocess.run([sys.executable, "-m", "tempestsdr_amd.tsdrlib", libpath, plugin, params, str(height), str(fv), str(seconds)] + extra,
+                         env=e, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        raise RuntimeError(f"throughput run failed ({out.returncode}): {out.stderr[-500:]}")
+    r = json.loads(lines[-1])
+    r["stderr_tail"] = out.stderr[-2000:]
+    return r
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    a = sys.argv[1:]
+    pairs = [(int(a[i]), int(a[i + 1])) for i in range(7, len(a) - 1, 2)]
+    print(json.dumps(throughput_run(a[0], a[1], a[2], int(a[3]), float(a[4]), float(a[5]), free=(len(a) < 7 or a[6] == "free"),
+                                    setup=(lambda lib, h: [lib.tsdr_setparameter_int(h, i, v) for i, v in pairs]) if pairs else None)))
