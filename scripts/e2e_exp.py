@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of engine knobs through the tsdr_* API (experiment helper)."""
+"""A/B of engine knobs through the tsdr_* API: usage e2e_exp.py '[["name","f32"|"i16",{"ENV":"value",...}],...]' — the legs
+run one after the other in THIS process (so that first / later engines of a process can be compared); PARAM_ID=n in a
+leg's environment sets tsdr_setparameter_int(n, 1) for it."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,24 +29,6 @@ def leg(name, params, env):
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
     print(name, round(r["frames_per_s"] * S / 1e6, 1), "MS/s", flush=True)
-if os.environ.get("DUMMY"):
-    from tempestsdr_amd import gpu
-    g0 = gpu.TsdrGpu(0)
-    g0.sync()
-    if os.environ["DUMMY"] == "close":
-        g0.close()
-    print("dummy context", os.environ["DUMMY"], flush=True)
-if os.environ.get("BURN"):
-    import time
-    from tempestsdr_amd import gpu
-    g = gpu.TsdrGpu(0)
-    x = g.to_device(np.zeros(1 << 26, np.float32)); y = g.to_device(np.zeros(1 << 25, np.float32))
-    t0 = time.time(); n = 0
-    while time.time() - t0 < 3.0:
-        for _ in range(50): g._ck(g.lib.tsdrgpu_am_demod(g.h, x.ptr, y.ptr, 1 << 25))
-        g.sync(); n += 50
-    print("burn: ", n, "demod launches of 32M samples", flush=True)
-    g.close()
 f32 = f"{path} {fs} {block} 0 0"; i16 = f"{path16} {fs} {block} 0 0 int16"
 for name, params, env in json.loads(sys.argv[1]):
     leg(name, f32 if params == "f32" else i16, env)
