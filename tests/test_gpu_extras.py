@@ -128,3 +128,59 @@ def test_plot_columns_on_autocorr_plot(orc):
     got = g.plot_columns(p + 8 * f.size, l.size, 800)
     want = orc.plot_populate(l, 800)
     assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+
+
+def test_gather2_appends_blocks_back_to_back():
+    """tsdrgpu_gather2: n device blocks (ragged sizes, aligned and misaligned sources / destinations) land behind each
+    other in both destinations; one destination may be left out.  Byte-exact."""
+    import ctypes as C
+    g = ctx()
+    rng = np.random.default_rng(12)
+    sizes = [524288, 4, 1000003, 8, 262145, 12, 65536] + [4096] * 25  # 32 blocks = the most one launch takes
+    srcs, host = [], []
+    for i, n in enumerate(sizes):
+        h = rng.random(n + 3).astype(np.float32)
+        d = g.to_device(h)
+        srcs.append((d, i % 3))  # element offset 0..2 into the allocation: 4-byte aligned sources too
+        host.append(h[i % 3:i % 3 + n])
+    want = np.concatenate(host)
+    for dst_off, second in ((0, True), (1, True), (0, False)):
+        d1 = g.empty(want.size + 8)
+        d2 = g.empty(want.size + 8)
+        d1.zero()
+        d2.zero()
+        ptrs = (C.c_void_p * len(sizes))(*[d.at(o) for d, o in srcs])
+        nbytes = (C.c_size_t * len(sizes))(*[4 * n for n in sizes])
+        g._ck(g.lib.tsdrgpu_gather2(g.h, d1.at(dst_off), d2.at(dst_off) if second else None, ptrs, nbytes, len(sizes)))
+        g.sync()
+        a = d1.download()
+        assert np.array_equal(a[dst_off:dst_off + want.size], want) and not a[:dst_off].any() and not a[dst_off + want.size:].any()
+        b = d2.download()
+        if second:
+            assert np.array_equal(b, a)
+        else:
+            assert not b.any()
+    # bad arguments are refused, nothing is launched
+    ptrs = (C.c_void_p * 1)(srcs[0][0].ptr)
+    nb = (C.c_size_t * 1)(6)
+    assert g.lib.tsdrgpu_gather2(g.h, d1.ptr, None, ptrs, nb, 1) != 0
+    assert g.lib.tsdrgpu_gather2(g.h, d1.ptr, None, ptrs, nb, 33) != 0
+
+
+def test_autocorr_plots_snapshot_is_a_device_copy_of_the_plots():
+    import ctypes as C
+    from tempestsdr_amd import gpu
+    g = ctx()
+    ac = gpu.Autocorr(g, 8_000_000)
+    rng = np.random.default_rng(3)
+    x = rng.random(2 * ac.capture).astype(np.float32)
+    ac.run(g.to_device(x), 0, ac.capture, 2)
+    f, l, calls = ac.plots()
+    snap, n = C.c_void_p(), C.c_uint64()
+    g._ck(g.lib.tsdrgpu_autocorr_plots_snapshot(ac.h, C.byref(snap), C.byref(n)))
+    g.sync()
+    out = np.empty(f.size + l.size, np.float64)
+    g._ck(g.lib.tsdrgpu_download(g.h, out.ctypes.data, snap.value, out.nbytes))
+    g.sync()
+    assert n.value == calls == 2
+    assert np.array_equal(out[:f.size], f) and np.array_equal(out[f.size:], l)
