@@ -348,6 +348,12 @@ int tsdrgpu_superb_stitch_exact(tsdrgpu_t *g, float *const *d_hops, int nhops, i
  * (2 per IQ sample).  Bit-exact with the plugin's double division + float store. */
 int tsdrgpu_decode_samples(tsdrgpu_t *g, const void *d_raw, int type, float *d_out, int64_t n);
 
+/* a3, on demand: dsp_autogain_t.snr of a frame as dsp_autogain_run would leave it (TempestSDR/src/dsp.c:69-93: mean over
+ * the non-sentinel sum / all pixels, deviations over every pixel).  The reference never reads the field (dsp.c:234 is
+ * commented out), so the post-processing run does not produce it; f64 tree sums, ~1e-12 relative to the sequential
+ * loop.  Synchronises. */
+int tsdrgpu_frame_snr(tsdrgpu_t *g, const float *d_frame, int64_t npixels, float *h_snr);
+
 /* f3: frame -> packed 0x00RRGGBB exactly like the JNI shim (JavaGUI/jni/TSDRLibraryNDK.c:222-276):
  * gray = (int)(v*255) for 0 < v <= 1, black/white outside, the PIXEL_SPECIAL_VALUE_* debug colours,
  * TRANSPARENT keeps the pixel d_rgb already holds; `inverted` as the GUI's invert option. */

@@ -77,6 +77,81 @@ __global__ __launch_bounds__(256) void k_frame_to_rgb(const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// dsp_autogain_t.snr (dsp.c:69-93): mean / stdev of a frame as dsp_autogain_run leaves it — the sum skips sentinel
+// pixels but divides by all of them, the deviations run over every pixel.  No caller of the reference reads it (its
+// report is commented out at dsp.c:234), so it is not part of the post-processing launch set: this is the on-demand
+// form.  f64 tree sums in a fixed order (deterministic); the reference adds sequentially, so the result agrees to
+// ~1e-12 relative, not bit for bit (tests: 1e-9).
+// ---------------------------------------------------------------------------
+#define SNR_BLOCKS 256
+__device__ __forceinline__ double snr_block_sum(double v, double *sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;  // the same value in every thread
+}
+__global__ __launch_bounds__(256) void k_snr_sum(const float *__restrict__ x, long long n, double *__restrict__ part)
+{
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)SNR_BLOCKS * 256) {
+        const float v = x[i];
+        if (!(v > 250.0 || v < -250)) s += (double)v;
+    }
+    s = snr_block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_snr_dev(const float *__restrict__ x, long long n, const double *__restrict__ part, double *__restrict__ part2)
+{
+    __shared__ double sh[4];
+    const double sum = snr_block_sum(part[threadIdx.x], sh);  // SNR_BLOCKS == blockDim.x
+    const double mean = sum / (double)n;
+    double s2 = 0.0, s1 = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)SNR_BLOCKS * 256) {
+        const double d = x[i] - mean;
+        s2 += d * d;
+        s1 += d;
+    }
+    s2 = snr_block_sum(s2, sh);
+    s1 = snr_block_sum(s1, sh);
+    if (threadIdx.x == 0) { part2[2 * blockIdx.x] = s2; part2[2 * blockIdx.x + 1] = s1; }
+}
+__global__ __launch_bounds__(256) void k_snr_final(long long n, const double *__restrict__ part, const double *__restrict__ part2, float *__restrict__ out)
+{
+    __shared__ double sh[4];
+    const double sum = snr_block_sum(part[threadIdx.x], sh);
+    const double s2 = snr_block_sum(part2[2 * threadIdx.x], sh);
+    const double s1 = snr_block_sum(part2[2 * threadIdx.x + 1], sh);
+    if (threadIdx.x == 0) {
+        const double mean = sum / (double)n;
+        const double stdev = sqrt((s2 - s1 * s1 / (double)n) / (double)(n - 1));
+        out[0] = (float)(mean / stdev);
+    }
+}
+extern "C" int tsdrgpu_frame_snr(tsdrgpu_t *g, const float *d_frame, int64_t npixels, float *h_snr)
+{
+    if (!g || !d_frame || npixels < 1 || !h_snr) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_frame_snr", "bad argument") : TSDRGPU_EINVAL;
+    double *d_part = nullptr;
+    if (hipMalloc(&d_part, sizeof(double) * (3 * SNR_BLOCKS + 1)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_frame_snr", "partials");
+    float *d_out = reinterpret_cast<float *>(d_part + 3 * SNR_BLOCKS);
+    TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_snr_sum, SNR_BLOCKS, 256, d_frame, (long long)npixels, d_part);
+    TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_snr_dev, SNR_BLOCKS, 256, d_frame, (long long)npixels, (const double *)d_part, d_part + SNR_BLOCKS);
+    TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_snr_final, 1, 256, (long long)npixels, (const double *)d_part, (const double *)(d_part + SNR_BLOCKS), d_out);
+    int rc = TSDRGPU_OK;
+    if (hipGetLastError() != hipSuccess) rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_frame_snr", "launch");
+    if (!rc && (hipMemcpyAsync(h_snr, d_out, sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+                hipStreamSynchronize(g->stream) != hipSuccess))
+        rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_frame_snr", "copy");
+    else if (rc) (void)hipStreamSynchronize(g->stream);
+    (void)hipFree(d_part);
+    return rc;
+}
+
 extern "C" int tsdrgpu_frame_to_rgb(tsdrgpu_t *g, const float *d_frame, int32_t *d_rgb, int64_t npixels, int inverted)
 {
     if (!g || !d_frame || !d_rgb || npixels < 0) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_frame_to_rgb", "bad argument") : TSDRGPU_EINVAL;

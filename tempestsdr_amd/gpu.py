@@ -64,6 +64,7 @@ _SIGS = {
     "tsdrgpu_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "tsdrgpu_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "tsdrgpu_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tsdrgpu_frame_snr": (C.c_int, [vp, vp, C.c_int64, C.POINTER(C.c_float)]),
     "tsdrgpu_copy2": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
     "tsdrgpu_gather2": (C.c_int, [vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int]),
     "tsdrgpu_event_create": (C.c_int, [vp, C.POINTER(vp)]),

@@ -184,3 +184,28 @@ def test_autocorr_plots_snapshot_is_a_device_copy_of_the_plots():
     g.sync()
     assert n.value == calls == 2
     assert np.array_equal(out[:f.size], f) and np.array_equal(out[f.size:], l)
+
+
+@pytest.mark.parametrize("n,sentinels", [(1, False), (2, False), (507 * 525, False), (2962 * 1125, True), (1033 * 806, True)])
+def test_frame_snr_matches_dsp_autogain_run(orc, n, sentinels):
+    """dsp_autogain_t.snr (dsp.c:69-93), the by-product the post-processing run leaves out: on demand, against the
+    oracle's (pinned) sequential f64 loop.  Tolerance 1e-9 relative: tree sums instead of a sequential sum."""
+    import ctypes as C
+    g = ctx()
+    rng = np.random.default_rng(n)
+    x = (rng.random(n).astype(np.float32) * np.float32(3.0) + np.float32(0.25))
+    if sentinels:
+        x[rng.integers(0, n, 50)] = np.float32(512.0)
+        x[rng.integers(0, n, 50)] = np.float32(-512.0)
+    ag = orc.Autogain()
+    orc.lib.orc_autogain_init(C.byref(ag))
+    out = np.empty(n, np.float32)
+    orc.lib.orc_autogain_run(C.byref(ag), n, x, out, np.float32(0.1))
+    got = C.c_float()
+    d_x = g.to_device(x)
+    g._ck(g.lib.tsdrgpu_frame_snr(g.h, d_x.ptr, n, C.byref(got)))
+    want = np.float32(ag.snr)
+    if np.isnan(want) or np.isinf(want):
+        assert np.isnan(got.value) == np.isnan(want) and np.isinf(got.value) == np.isinf(want)
+    else:
+        assert abs(got.value - want) <= 1e-9 * abs(want) + np.spacing(want)
