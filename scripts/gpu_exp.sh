@@ -10,9 +10,6 @@ except Exception as e:
     print("$tag failed", e); print(open("$O/$tag.err").read()[-1500:])
 PY
 }
-run base
-run fpl6 --frames-per-launch 6
-run fpl12 --frames-per-launch 12
-run fpl20 --frames-per-launch 20
-run overlap --overlap
-run base2
+run fuse_wave --fuse
+TSDRGPU_FUSE_TILE=1 run fuse_tile --fuse
+TSDRGPU_FUSE_TILE=1 timeout 900 python -m pytest tests/test_gpu_postproc.py -x -q -m gpu -k "fused or minmax or fuse" 2>&1 | tail -3
