@@ -764,11 +764,22 @@ static void run_resampler(struct engine *e)
         const size_t have = (e->iq.wr - e->iq.rd) / per;
         int nchunks = (int)(have / (size_t)chunk);
         if (nchunks <= 0) break;
-        /* while pixels are being skipped or a manual shift is pending go chunk by chunk like the reference;
-         * with the PLL on as well, because a frame completed by this chunk may nudge the refresh rate, which
-         * the next chunk's ratio must already see */
-        if (e->pix_difference != 0 || t->syncoffset != 0 || t->params_int[PARAM_INT_FRAMERATE_PLL]) nchunks = 1;
+        /* while pixels are being skipped or a manual shift is pending go chunk by chunk like the reference */
+        if (e->pix_difference != 0 || t->syncoffset != 0) nchunks = 1;
         else if (nchunks > 40) nchunks = 40;
+        if (nchunks > 1 && t->params_int[PARAM_INT_FRAMERATE_PLL]) {
+            /* PLL on: a frame completed by a chunk may nudge the refresh rate, which the NEXT chunk's ratio must already
+             * see (TSDRLibrary.c:335-340 re-reads the geometry per chunk) — so one call takes the chunks up to and
+             * including the one that completes the frame being filled, no further */
+            const size_t pending = e->pix.wr - e->pix.rd;
+            int k = 1;
+            while (k < nchunks) {
+                const int64_t c = tsdrgpu_resample_count(e->rs, (uint32_t)chunk, k, up, down);
+                if (c < 0 || pending + (size_t)c >= (size_t)totalpixels) break;
+                k++;
+            }
+            nchunks = k;
+        }
         const int64_t count = tsdrgpu_resample_count(e->rs, (uint32_t)chunk, nchunks, up, down);
         if (count < 0) return;
         e->n_resample_calls++;
