@@ -1,4 +1,15 @@
 #!/bin/bash
 set -u
-timeout 900 python -m pytest tests/test_gpu_host_pipeline.py -x -q -m gpu 2>&1 | tail -2
-timeout 300 python scripts/e2e_exp.py '[["pll_on","f32",{"PARAM_ID":"1"}]]' 2>&1 | grep -E "MS/s|tsdr stats"
+O=gpurun_out/r2q; mkdir -p $O
+run() { tag=$1; shift; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e "$@" > $O/$tag.json 2> $O/$tag.err; python - <<PY
+import json
+try:
+    d=json.loads([l for l in open("$O/$tag.json") if l.startswith("{")][0])
+    print("$tag", d["value"], d["ms_per_pass"], {k:v for k,v in d["stage_ms_per_pass"].items() if v>0.02}, d["autocorrelation"]["frac"])
+except Exception as e:
+    print("$tag failed", e); print(open("$O/$tag.err").read()[-1500:])
+PY
+}
+run a
+run b
+timeout 900 python -m pytest tests/test_gpu_autocorr.py tests/test_gpu_distributed.py -x -q -m gpu 2>&1 | tail -2

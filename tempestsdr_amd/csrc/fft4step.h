@@ -196,17 +196,17 @@ __device__ __forceinline__ float2 ac4_load(const void *__restrict__ base, long l
         const float *x = (const float *)base;
         return make_float2(x[2 * at], x[2 * at + 1]);
     }
-    const float2 *x = (const float2 *)base;
-    float2 a, b;
-    if (al16) {
-        const float4 t = *reinterpret_cast<const float4 *>(x + 2 * at);
-        a = make_float2(t.x, t.y);
-        b = make_float2(t.z, t.w);
-    } else {
-        a = x[2 * at];
-        b = x[2 * at + 1];
-    }
+    // two IQ samples = 16 bytes; a window starts on an 8-byte boundary only (capture lengths are odd), and gfx950
+    // moves an under-aligned dwordx4 in one instruction all the same
+    (void)al16;
+#if defined(__HIPCC__)
+    typedef float float4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    const float4_a8 t = *reinterpret_cast<const float4_a8 *>((const float2 *)base + 2 * at);
+    return make_float2(sqrtf(t[0] * t[0] + t[1] * t[1]), sqrtf(t[2] * t[2] + t[3] * t[3]));
+#else  // tests/emu: the same two samples
+    const float2 a = ((const float2 *)base)[2 * at], b = ((const float2 *)base)[2 * at + 1];
     return make_float2(sqrtf(a.x * a.x + a.y * a.y), sqrtf(b.x * b.x + b.y * b.y));
+#endif
 }
 
 // rtw[i] = w_nh^(ebase + estep i), i < 16

@@ -12,7 +12,7 @@
 #include "tsdrgpu_internal.h"
 #include "fft4step.h"
 
-#define AC_SUBBATCH 8
+#define AC_SUBBATCH 9
 
 struct tsdrgpu_autocorr {
     tsdrgpu_t *g;
@@ -681,8 +681,9 @@ __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ co
     double acc = plots[i];
     for (int w = 0; w < nwindows; w++) {
         // r[lag] of window w (real: the packed inverse transform has no imaginary residue)
-        const double re = corr[(long long)w * n + lag];
-        const double now = sqrt(re * re);
+        // sqrt(re*re + im*im) with im == 0 (frameratedetector.c:41-44): the square of a float is exact in f64 and the
+        // correctly rounded root of an exact square is exact, so this is |re| bit for bit
+        const double now = fabs((double)corr[(long long)w * n + lag]);
         if (mode == 0) {
             const unsigned long long calls = calls_before + w + 1;
             acc = (acc * (double)(calls - 1) + now) / (double)calls;
@@ -873,8 +874,11 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     if (nwindows == 0) return TSDRGPU_OK;
     tsdrgpu_t *g = ac->g;
     if (nwindows > 65535) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "too many windows in one call");
-    // windows are transformed AC_SUBBATCH at a time: 8 x 2 x 16 MB of ping-pong buffers stay inside the
-    // 256 MB Infinity Cache between passes (measured 12 % faster than 16+ windows per launch)
+    // windows are transformed at most AC_SUBBATCH at a time.  A launch of the three-trip plan is only ~3 rounds of
+    // resident workgroups per 6 windows, so every launch pays a ramp and a drain: measured at 17 windows per pass,
+    // 6+6+5 -> group at 0.565 of the roofline, 9+8 -> 0.585, one launch of 17 -> 0.62 — but a caller's small kernels on
+    // another lane (the sync chain in bench.py's split run) then find free CUs less often (0.31 -> 0.49 ms) and become
+    // the critical path; 9 is where the whole pass is fastest
     const int sub = nwindows < AC_SUBBATCH ? nwindows : AC_SUBBATCH;
     if (ac->cap_windows < sub) {
         (void)hipStreamSynchronize(g->stream);
@@ -911,7 +915,7 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     float2 *corr = nullptr;
     int last_count = 0;
     const int parts = (nwindows + AC_SUBBATCH - 1) / AC_SUBBATCH;
-    const int per_part = (nwindows + parts - 1) / parts;  // equal sub-batches (17 -> 6,6,5)
+    const int per_part = (nwindows + parts - 1) / parts;  // equal sub-batches (17 -> 9,8)
     for (int w0 = 0; w0 < nwindows; w0 += per_part) {
         const int cnt = (nwindows - w0 < per_part) ? (nwindows - w0) : per_part;
         const float *src = d_in + (size_t)w0 * (size_t)stride * (in_is_iq ? 2 : 1);
