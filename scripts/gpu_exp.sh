@@ -12,4 +12,4 @@ PY
 }
 run a
 run b
-timeout 900 python -m pytest tests/test_gpu_autocorr.py tests/test_gpu_distributed.py -x -q -m gpu 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_autocorr.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -2

@@ -230,6 +230,11 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *_
     constexpr int R0 = G::R0, NP = G::NP, G0 = 16 / R0;
     __shared__ float2 L[N1 * C];
     __shared__ float2 twN[N1];
+    // C == 16 (column lengths >= 256): the powers (w_nh^(col Q))^i, i < 16, of the workgroup's 16 columns are shared by
+    // the 32 threads of a column — one accurate evaluation each instead of four evaluations and eleven products per
+    // thread (rows padded to 17 entries: sixteen columns' reads hit sixteen different bank pairs)
+    constexpr bool PTAB = (C == 16u);
+    __shared__ float2 ptw[PTAB ? 16 * 17 : 1];
     const unsigned N2 = nh / N1;
     const unsigned tid = threadIdx.x;
     const unsigned c = tid % C, q = tid / C;
@@ -243,6 +248,10 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *_
         float sn, cs;
         sincospif(-2.0f * (float)e / (float)N1, &sn, &cs);
         twN[e] = make_float2(cs, sn);
+    }
+    if (PTAB && tid < 256u) {
+        const unsigned cc = tid >> 4, i = tid & 15u;
+        ptw[cc * 17u + i] = tw_exact((tile * C + cc) * Q * i, nh - 1u, -2.0f / (float)nh);
     }
     const void *xb;
     bool al16 = false;
@@ -268,7 +277,15 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *_
     // the factors are w^(n2 q) * (w^(n2 Q))^i: five accurate evaluations and products of depth <= 4.
     if (LAST) {
         float2 rtw[16];
-        ac4_col_twiddles(rtw, col * Q, col * q, nh);
+        if (PTAB) {
+            __syncthreads();  // ptw[] complete (the loads above are in flight meanwhile)
+            const float2 rbase = tw_exact(col * q, nh - 1u, -2.0f / (float)nh);
+            rtw[0] = rbase;
+#pragma unroll
+            for (int i = 1; i < 16; i++) rtw[i] = cmul(rbase, ptw[c * 17u + (unsigned)i]);
+        } else {
+            ac4_col_twiddles(rtw, col * Q, col * q, nh);
+        }
 #pragma unroll
         for (int a = 0; a < G0; a++)
 #pragma unroll
@@ -307,7 +324,16 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *_
     constexpr int RL = (NP > 1) ? 16 : R0;  // radix of the last pass
     constexpr int GL = 16 / RL;
     float2 rtw[16];
-    if (!LAST) ac4_col_twiddles(rtw, col * Q, col * q, nh);
+    if (!LAST) {
+        if (PTAB) {  // (NP > 1 here: the passes' barriers lie between the table's writes and these reads)
+            const float2 rbase = tw_exact(col * q, nh - 1u, -2.0f / (float)nh);
+            rtw[0] = rbase;
+#pragma unroll
+            for (int i = 1; i < 16; i++) rtw[i] = cmul(rbase, ptw[c * 17u + (unsigned)i]);
+        } else {
+            ac4_col_twiddles(rtw, col * Q, col * q, nh);
+        }
+    }
 #pragma unroll
     for (int a = 0; a < GL; a++)
 #pragma unroll
