@@ -202,7 +202,10 @@ __device__ __forceinline__ float2 ac4_load(const void *__restrict__ base, long l
 #if defined(__HIPCC__)
     typedef float float4_a8 __attribute__((ext_vector_type(4), aligned(8)));
     const float4_a8 t = *reinterpret_cast<const float4_a8 *>((const float2 *)base + 2 * at);
-    return make_float2(sqrtf(t[0] * t[0] + t[1] * t[1]), sqrtf(t[2] * t[2] + t[3] * t[3]));
+    // am_demod (TSDRLibrary.c:244-262) inside the float32 transform, whose plots carry a 1e-4 tolerance: the hardware
+    // square root (1 ulp, one instruction) instead of the 15-instruction correctly rounded sequence — 32 of them per
+    // thread.  (The resampler's and the bit-exact detector's demodulation stay correctly rounded.)
+    return make_float2(AC_SQRT(t[0] * t[0] + t[1] * t[1]), AC_SQRT(t[2] * t[2] + t[3] * t[3]));
 #else  // tests/emu: the same two samples
     const float2 a = ((const float2 *)base)[2 * at], b = ((const float2 *)base)[2 * at + 1];
     return make_float2(sqrtf(a.x * a.x + a.y * a.y), sqrtf(b.x * b.x + b.y * b.y));
