@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 O=gpurun_out/r2q; mkdir -p $O
-run() { tag=$1; shift; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e "$@" > $O/$tag.json 2> $O/$tag.err; python - <<PY
+run() { tag=$1; dir=$2; (cd $dir && timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e) > $O/$tag.json 2> $O/$tag.err; python - <<PY
 import json
 try:
     d=json.loads([l for l in open("$O/$tag.json") if l.startswith("{")][0])
@@ -10,6 +10,6 @@ except Exception as e:
     print("$tag failed", e); print(open("$O/$tag.err").read()[-1500:])
 PY
 }
-run a
-run b
-timeout 900 python -m pytest tests/test_gpu_autocorr.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -2
+run new1 .; run new2 .
+timeout 1200 python -m pytest tests/test_gpu_postproc.py tests/test_gpu_soak.py tests/test_gpu_bands.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -2
+timeout 600 python scripts/fuzz_parity.py 60 91 2>&1 | tail -1
