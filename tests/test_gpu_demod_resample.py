@@ -79,10 +79,15 @@ def test_resample_library_geometry(orc, fs, h, fv, nearest, from_iq):
         assert con == ref_rs.st.contrib
 
 
-@pytest.mark.parametrize("r", [0.05, 0.37, 0.5, 0.999, 1.0, 1.5, 2.0, 3.25, 7.0])
-def test_resample_rates(orc, r):
+@pytest.mark.parametrize("chunk,nch", [(1013, 7), (166_666, 2), (1, 5), (62, 3), (249, 4)])
+@pytest.mark.parametrize("r", [0.05, 0.37, 0.5, 0.999, 1.0, 1.0000001, 1.5, 1.99935, 2.0, 3.25, 4.0 / 3.0, 7.0, 8.0, 8.0000001, 13.5])
+def test_resample_rates(orc, r, chunk, nch):
+    """every ratio class: below 1 and above 8 run the pixel-group kernel (k_rs_area), 1 <= r <= 8 the
+    sample-parallel one (k_rs_area_up; its workgroups take 1 to 8 rounds of 62 samples per wave depending on r),
+    chunk sizes around the kernels' 62-sample / 248-sample granularity"""
     g = ctx()
-    chunk, nch = 1013, 7
+    if chunk * nch * max(r, 1.0) > 4e6:
+        nch = 1
     mag = RNG.random(nch * chunk).astype(np.float32)
     ref_rs = orc.Resampler()
     want = []
