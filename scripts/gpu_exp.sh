@@ -1,14 +1,15 @@
 #!/bin/bash
-# same-box A/B: .tmp_old (baseline build) against the working tree, alternating
 set -u
 O=gpurun_out/r2q; mkdir -p $O
-run() { tag=$1; dir=$2; (cd $dir && timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e) > $O/$tag.json 2> $O/$tag.err; python - <<PY
+run() { tag=$1; shift; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e "$@" > $O/$tag.json 2> $O/$tag.err; python - <<PY
 import json
 try:
     d=json.loads([l for l in open("$O/$tag.json") if l.startswith("{")][0])
-    print("$tag", d["value"], d["ms_per_pass"], {k:v for k,v in d["stage_ms_per_pass"].items() if v>0.02}, d["autocorrelation"]["frac"])
+    print("$tag", d["value"], d["ms_per_pass"], {k:v for k,v in d["stage_ms_per_pass"].items() if v>0.02})
 except Exception as e:
     print("$tag failed", e); print(open("$O/$tag.err").read()[-1500:])
 PY
 }
-for i in 1 2 3; do run old$i .tmp_old; run new$i .; done
+run fuse --fuse
+TSDRGPU_DEBUG_NOMM=1 run fuse_nomm --fuse
+run base

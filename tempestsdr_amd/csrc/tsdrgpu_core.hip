@@ -802,9 +802,12 @@ __device__ __forceinline__ double rsu_shr1(double v)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
-template <bool IQ>
+// MM: frame tracking (tsdrgpu_resampler_track_frames) — every wave also leaves the min/max of the non-sentinel pixels it
+// wrote, split over the (at most two) frames the workgroup's span touches, exactly like k_rs_area (RsBlockMM).
+template <bool IQ, bool MM>
 __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ chunks, double r, double rinv, const float *__restrict__ in,
-                                                    const double *__restrict__ cin, float *__restrict__ out, int rounds, int maxc)
+                                                    const double *__restrict__ cin, float *__restrict__ out, int rounds, int maxc,
+                                                    const RsChunkFrame *__restrict__ cframes, long long P, RsBlockMM *__restrict__ slots)
 {
     const RsChunk ch = chunks[blockIdx.y];
     RsGeom g;
@@ -815,13 +818,33 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
     const int size = (int)ch.size, n_out = (int)ch.n_out;
     const int S = 4 * RSU_LANES * rounds;
     const int sA = (int)blockIdx.x * S;
-    if (sA >= size || n_out <= 0) return;
     const int sB = (sA + S < size) ? sA + S : size;
-    const int PA = (int)rs_pix_in(g, sA);
-    int PE = (int)rs_pix_in(g, sB);                  // end of what the samples [sA, sB) store
+    const int PA = (sA < size) ? (int)rs_pix_in(g, sA) : 0;
+    int PE = (sA < size) ? (int)rs_pix_in(g, sB) : 0;  // end of what the samples [sA, sB) store
     PE = PE < n_out ? PE : n_out;
     const int PB = (sB >= size) ? n_out : PE;        // end of what this workgroup writes (zeros behind PE)
-    if (PA >= PB) return;
+    if (sA >= size || n_out <= 0 || PA >= PB) {       // nothing to write
+        if (MM && (threadIdx.x & 63) == 63) {
+            RsBlockMM o;
+            o.f0 = -1;
+            o.mn0 = o.mn1 = INFINITY;
+            o.mx0 = o.mx1 = -INFINITY;
+            slots[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = o;
+        }
+        return;
+    }
+    // frame tracking: frame of the workgroup's first pixel (fb) and how many of its pixels still belong to it (up
+    // here, so that the record's load is long done when the copy-out needs it)
+    float mn0 = INFINITY, mx0 = -INFINITY, mn1 = INFINITY, mx1 = -INFINITY;
+    int fb = -1, to_b = 0x3fffffff;
+    if (MM) {
+        const RsChunkFrame cf = cframes[blockIdx.y];
+        long long remb;
+        rs_frame_of(P, cf.f, cf.rem, PA, &fb, &remb);
+        const long long tb = P - remb;
+        to_b = tb > 0x3fffffffLL ? 0x3fffffff : (int)tb;  // pixel p is in frame fb iff p - PA < to_b
+    }
+    const bool crosses = MM && PB - PA > to_b;  // uniform: the span reaches into frame fb + 1
     float *dst = out + ch.out_off;
     const int mis = (int)((((uintptr_t)(dst + PA)) >> 2) & 3);  // phase of pixel PA inside its 16-byte group
     __shared__ float4 tile4[(RSU_TILE + 8) / 4];
@@ -878,12 +901,44 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (p0 + k >= PE) v[k] = 0.0f;  // pixels the reference's loop never stores
-        if (p0 >= PA && p0 + 4 <= PB) {
+        const bool whole = p0 >= PA && p0 + 4 <= PB;
+        if (whole) {
             *reinterpret_cast<float4 *>(dst + p0) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (p0 + k >= PA && p0 + k < PB) dst[p0 + k] = v[k];
+        }
+        if (MM) {
+            // usual case: a whole group in a span that stays inside one frame, no sentinel among its pixels -> min/max
+            // of the four values
+            const float m = fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), M = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            if (whole && !crosses && !(M > 250.0f || m < -250.0f)) {
+                mn0 = fminf(mn0, m);
+                mx0 = fmaxf(mx0, M);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int p = p0 + k;
+                    const float val = v[k];
+                    const bool ok = p >= PA && p < PB && !((val > 250.0f) || (val < -250.0f));  // dsp.c:57
+                    const bool first = p - PA < to_b;
+                    mn0 = fminf(mn0, (ok && first) ? val : INFINITY);
+                    mx0 = fmaxf(mx0, (ok && first) ? val : -INFINITY);
+                    mn1 = fminf(mn1, (ok && !first) ? val : INFINITY);
+                    mx1 = fmaxf(mx1, (ok && !first) ? val : -INFINITY);
+                }
+            }
+        }
+    }
+    if (MM) {
+        mn0 = rs_wave_min(mn0); mx0 = rs_wave_max(mx0);
+        if (crosses) { mn1 = rs_wave_min(mn1); mx1 = rs_wave_max(mx1); }
+        if ((threadIdx.x & 63) == 63) {
+            RsBlockMM o;
+            o.f0 = fb;
+            o.mn0 = mn0; o.mx0 = mx0; o.mn1 = mn1; o.mx1 = mx1;
+            slots[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = o;
         }
     }
 }
@@ -1143,7 +1198,8 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
             }
         }
         if (track) {
-            const size_t nslots = (size_t)grid4.x * (size_t)nchunks * 4;
+            const unsigned gx_up = ceil_div_u(chunk, (unsigned)(4 * RSU_LANES));  // k_rs_area_up's widest grid (one round per wave)
+            const size_t nslots = (size_t)(grid4.x > gx_up ? grid4.x : gx_up) * (size_t)nchunks * 4;
             if (rs->cap_slots < nslots) {
                 (void)hipStreamSynchronize(g->stream);
                 hipFree(rs->d_slots);
@@ -1162,17 +1218,24 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
                 rs->cap_frames = ntouched + 16;
             }
         }
-        // sample-parallel kernel whenever the ratio upsamples moderately (the reference's geometry: r ~ 2) and no
-        // frame tracking is wanted; `rounds` keeps a workgroup's pixels inside its LDS tile
+        // sample-parallel kernel whenever the ratio upsamples moderately (the reference's geometry: r ~ 2); `rounds`
+        // keeps a workgroup's pixels inside its LDS tile
+        int mm_gx = (int)grid4.x;  // workgroups per chunk of whichever kernel writes the tracking records
         static const int force_old = getenv("TSDRGPU_RS_GROUPS") ? 1 : 0;
-        const bool up_kernel = !track && !force_old && r >= 1.0 && r <= 8.0;
+        const bool up_kernel = !force_old && r >= 1.0 && r <= 8.0;
         if (max_out && up_kernel) {
             int rounds = (int)((RSU_TILE - 4) / (4.0 * RSU_LANES * r));
             if (rounds < 1) rounds = 1;
             const int maxc = (int)r + 2;
             dim3 gridu(ceil_div_u(chunk, (unsigned)(4 * RSU_LANES * rounds)), (unsigned)nchunks);
-            if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<true>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, rounds, maxc);
-            else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<false>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, rounds, maxc);
+            mm_gx = (int)gridu.x;
+            if (track) {
+                if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<true, true>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, rounds, maxc, d_cf, P, rs->d_slots);
+                else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<false, true>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, rounds, maxc, d_cf, P, rs->d_slots);
+            } else {
+                if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<true, false>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, rounds, maxc, (const RsChunkFrame *)nullptr, 0LL, (RsBlockMM *)nullptr);
+                else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<false, false>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, rounds, maxc, (const RsChunkFrame *)nullptr, 0LL, (RsBlockMM *)nullptr);
+            }
         } else if (max_out) {
             if (track) {
                 if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area<true, true>), grid4, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_out, d_cf, P, rs->d_slots);
@@ -1184,7 +1247,7 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
         }
         KERNEL_CHECK(g, "k_rs_area");
         if (track && ntouched > 0) {
-            TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, k_rs_minmax, (unsigned)ntouched, 256, rs->d_slots, (int)grid4.x, d_rg, ntouched, ncomplete,
+            TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, k_rs_minmax, (unsigned)ntouched, 256, rs->d_slots, mm_gx, d_rg, ntouched, ncomplete,
                         rs->d_carry + 2 * rs->parity, rs->d_carry + 2 * (1 - rs->parity), rs->d_fmin, rs->d_fmax);
             KERNEL_CHECK(g, "k_rs_minmax");
             rs->parity = 1 - rs->parity;
