@@ -45,6 +45,7 @@ struct tsdrgpu_postproc {
     PpState *d_state;
     float *d_screen;   // dsp_postprocess_t.screenbuffer (IIR state)
     size_t cap_screen;
+    int *d_odd;        // k_frame_pass_par's "this batch needs the frame-by-frame form" flag
     float *d_screen2;  // second IIR buffer of the fused run (read one, write the other, swap)
     size_t cap_screen2;
     float *d_dump;     // where the fused pass's lanes outside the frame store (never read)
@@ -1031,9 +1032,11 @@ __device__ __forceinline__ float pass_one(int flags, float v, float &s, float a,
 template <int FLAGS, int VW>
 __global__ __launch_bounds__(256) void k_frame_pass(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
                                                     long long dstride, int F, int W, int H,
-                                                    const ChainOut *__restrict__ chain, float *__restrict__ screen, float a)
+                                                    const ChainOut *__restrict__ chain, float *__restrict__ screen, float a,
+                                                    const int *__restrict__ gate)
 {
     typedef typename VecT<VW>::type vec_t;
+    if (gate && !*gate) return;  // (the exact redo behind k_frame_pass_par: launched always, needed almost never)
     const int P = W * H;
     const double one_minus_a = 1.0 - a;
     const int ngroups = (P + VW - 1) / VW;
@@ -1097,6 +1100,93 @@ __global__ __launch_bounds__(256) void k_frame_pass(const float *__restrict__ sr
                 if (p0 + k < P) screen[p0 + k] = s[k];
         }
     }
+}
+
+// The same pass with one thread per FOUR PIXELS OF ONE FRAME: every frame is one contiguous stream (a thread of
+// k_frame_pass walks the F frames of its four pixels, 13 MB apart) — 0.327 -> 0.298 ms for 60 frames of 2962x1125.
+// For flag sets without the IIR, and for the IIR with motion blur 0: then s*a + v*(1-a) (dsp.c:29-32, f32*f32 in f32,
+// the rest in f64) is v itself whenever s is finite and v is not -0.0, so a frame's output does not depend on the
+// previous frame's, and the last frame's output is the new state.  The exceptions are caught, not assumed away: any
+// non-finite incoming state or output (a NaN sticks to its pixel for good in the reference) or a -0.0 output raises
+// *odd, and the frame-by-frame kernel, queued behind this one and gated on *odd, redoes the batch literally;
+// k_pass_state copies the last frame into the state only when *odd stayed 0.  grid (spans, F).
+template <int FLAGS>
+__global__ __launch_bounds__(256) void k_frame_pass_par(const float *__restrict__ src, long long sstride, float *__restrict__ dst,
+                                                        long long dstride, int W, int H, const ChainOut *__restrict__ chain,
+                                                        const float *__restrict__ screen, int *__restrict__ odd)
+{
+    typedef typename VecT<4>::type vec_t;
+    const int P = W * H;
+    const int ngroups = (P + 3) / 4;
+    const int f = blockIdx.y;
+    const unsigned gx = gridDim.x;
+    const unsigned lb = (gx % 8u == 0u) ? (blockIdx.x % 8u) * (gx / 8u) + blockIdx.x / 8u : blockIdx.x;
+    const float *in = src + (long long)f * sstride;
+    float *outp = dst + (long long)f * dstride;
+    int dx = 0, dy = 0;
+    float lastmin = 0.f, span = 1.f;
+    if (FLAGS & (PASS_ROLL | PASS_LINES)) { dx = chain[f].dx; dy = chain[f].dy; }
+    if (FLAGS & PASS_NORMALISE) { lastmin = chain[f].lastmin; span = chain[f].span; }
+    bool bad = false;
+    for (int grp = lb * blockDim.x + threadIdx.x; grp < ngroups; grp += gx * blockDim.x) {
+        const int p0 = grp * 4;
+        const bool full = (p0 + 4 <= P);
+        int x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
+        if (FLAGS & (PASS_ROLL | PASS_LINES)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int p = p0 + k;
+                y[k] = p / W;
+                x[k] = p - y[k] * W;
+            }
+        }
+        float v[4];
+        if (!(FLAGS & PASS_ROLL) && full) {
+            const vec_t t = *reinterpret_cast<const vec_t *>(in + p0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = t[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int sp = p0 + k;
+                if (FLAGS & PASS_ROLL) {
+                    int sx = x[k] + dx; if (sx >= W) sx -= W;
+                    int sy = y[k] + dy; if (sy >= H) sy -= H;
+                    sp = sy * W + sx;
+                }
+                v[k] = (p0 + k < P) ? in[sp] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float none = 0.f;
+            v[k] = pass_one(FLAGS & ~PASS_IIR, v[k], none, 0.f, 1.0, lastmin, span, x[k] == dx || y[k] == dy);
+            if (FLAGS & PASS_IIR) bad |= !(fabsf(v[k]) <= 3.4028234664e38f) || __float_as_uint(v[k]) == 0x80000000u;
+        }
+        if ((FLAGS & PASS_IIR) && f == 0) {  // the incoming state only has to be finite
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (p0 + k < P) bad |= !(fabsf(screen[p0 + k]) <= 3.4028234664e38f);
+        }
+        if (full) {
+            vec_t t;
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = v[k];
+            *reinterpret_cast<vec_t *>(outp + p0) = t;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (p0 + k < P) outp[p0 + k] = v[k];
+        }
+    }
+    if ((FLAGS & PASS_IIR) && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(odd, 1);
+}
+
+// the new IIR state behind k_frame_pass_par: the last frame's output, unless the batch has to be redone
+__global__ __launch_bounds__(256) void k_pass_state(const float *__restrict__ last, float *__restrict__ screen, int P, const int *__restrict__ odd)
+{
+    if (*odd) return;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) screen[p] = last[p];
 }
 
 // ---------------------------------------------------------------------------
@@ -1283,7 +1373,17 @@ __global__ __launch_bounds__(256) void k_fix_lines(const float *__restrict__ src
     screen_out[pix] = s;
 }
 
-typedef void (*pass_fn)(const float *, long long, float *, long long, int, int, int, const ChainOut *, float *, float);
+typedef void (*pass_fn)(const float *, long long, float *, long long, int, int, int, const ChainOut *, float *, float, const int *);
+typedef void (*pass_par_fn)(const float *, long long, float *, long long, int, int, const ChainOut *, const float *, int *);
+static pass_par_fn pick_pass_par(int flags)
+{
+    switch (flags) {
+#define CASE(f) case f: return k_frame_pass_par<f>;
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+#undef CASE
+    }
+    return nullptr;
+}
 
 template <int VW>
 static pass_fn pick_pass_vw(int flags)
@@ -1342,7 +1442,7 @@ extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
     (void)hipStreamSynchronize(pp->g->stream);
     (void)hipEventDestroy(pp->ev_stats);
     (void)hipEventDestroy(pp->ev_chain);
-    void *bufs[] = {pp->d_state, pp->d_screen, pp->d_screen2, pp->d_dump, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
+    void *bufs[] = {pp->d_state, pp->d_odd, pp->d_screen, pp->d_screen2, pp->d_dump, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
                     pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain, pp->d_sflag, pp->d_exact,
                     pp->d_xsum, pp->d_xmax, pp->d_v0, pp->d_chain_band};
     for (void *b : bufs)
@@ -1490,6 +1590,32 @@ static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long
                        int F, int W, int H, float a)
 {
     tsdrgpu_t *g = pp->g;
+    // one stream per frame instead of one walk over the frames per pixel group, whenever a frame's output does not
+    // depend on the previous one's (k_frame_pass_par) and the batch is long enough to pay for its three small launches
+    static const int serial_only = getenv("TSDRGPU_PASS_SERIAL") ? 1 : 0;
+    const bool iir = (flags & PASS_IIR) != 0;
+    const int *gate = nullptr;
+    if (!serial_only && F >= 8 && (!iir || a == 0.0f)) {
+        pass_par_fn pf = pick_pass_par(flags);
+        if (!pf) return tsdr_fail(g, TSDRGPU_EINVAL, "k_frame_pass_par", "unsupported flag combination");
+        if (iir) {
+            if (!pp->d_odd && hipMalloc(&pp->d_odd, sizeof(int)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "flag");
+            HIP_TRY(g, hipMemsetAsync(pp->d_odd, 0, sizeof(int), g->stream));
+        }
+        const long long P = (long long)W * H;
+        long long bx = ((P + 3) / 4 + 255) / 256;
+        const long long cap = (long long)g->prop.multiProcessorCount * 64 / (F < 64 ? F : 64) + 8;
+        if (bx > cap) bx = cap;
+        bx = (bx + 7) & ~7LL;  // a multiple of the 8 XCDs (the kernel's span order relies on it)
+        TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, pf, dim3((unsigned)bx, (unsigned)F), 256, src, sstride, dst, dstride, W, H, pp->d_chain,
+                    (const float *)pp->d_screen, pp->d_odd);
+        KERNEL_CHECK(g, "k_frame_pass_par");
+        if (!iir) return TSDRGPU_OK;
+        TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, k_pass_state, (unsigned)(g->prop.multiProcessorCount * 4), 256,
+                    (const float *)(dst + (long long)(F - 1) * dstride), pp->d_screen, (int)P, (const int *)pp->d_odd);
+        KERNEL_CHECK(g, "k_pass_state");
+        gate = pp->d_odd;  // ... and the literal form below only runs if the flag was raised
+    }
     // four pixels per lane (one dwordx4 per frame; the vector types only claim float alignment)
     const int vw = 4;
     (void)sstride;
@@ -1500,7 +1626,7 @@ static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long
     const long long cap = (long long)g->prop.multiProcessorCount * 16;
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7LL;  // a multiple of the 8 XCDs (the kernel's span order relies on it)
-    TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, fn, (unsigned)blocks, 256, src, sstride, dst, dstride, F, W, H, pp->d_chain, pp->d_screen, a);
+    TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, fn, (unsigned)blocks, 256, src, sstride, dst, dstride, F, W, H, pp->d_chain, pp->d_screen, a, gate);
     KERNEL_CHECK(g, "k_frame_pass");
     return TSDRGPU_OK;
 }
