@@ -537,6 +537,9 @@ def main():
                               "alg_bytes_per_launch": int(bytes_pass / n),
                               "achieved_GBs": round(bytes_pass / (ms * 1e-3) / 1e9, 1),
                               "frac": round(bytes_pass / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                if k == "k_frame_pass" and n > 1.5:
+                    kernels[k]["note"] = ("stage of three launches: k_frame_pass_par (the frame-parallel pass, motion blur 0) + "
+                                          "k_pass_state (new IIR state) + k_frame_pass gated on the device's redo flag (returns at once)")
         ac_group = [k for k in ("k_ac_cols", "k_ac_rows", "k_fft_lds", "k_ac_mid", "k_accumulate") if k in prof]
         ac_ms = sum(per_pass(k)[0] for k in ac_group)
         ac_launches = sum(per_pass(k)[1] for k in ac_group)
