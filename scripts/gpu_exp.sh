@@ -10,6 +10,5 @@ except Exception as e:
     print("$tag failed", e); print(open("$O/$tag.err").read()[-1500:])
 PY
 }
-timeout 900 python -m pytest tests/test_gpu_postproc.py tests/test_gpu_soak.py tests/test_gpu_bands.py -x -q -m gpu 2>&1 | tail -12 | cut -c1-200
-TSDRGPU_PASS_SERIAL=1 run serial; TSDRGPU_PASS_SERIAL=1 run serial2
-run par; run par2
+run base
+TSDRGPU_X_FUSED=1 run xfused
