@@ -10,5 +10,6 @@ except Exception as e:
     print("$tag failed", e); print(open("$O/$tag.err").read()[-1500:])
 PY
 }
-run base
-TSDRGPU_X_FUSED=1 run xfused
+run a; run b
+timeout 1200 python -m pytest tests/test_gpu_postproc.py tests/test_gpu_soak.py tests/test_gpu_bands.py tests/test_gpu_host_pipeline.py -x -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -3
+timeout 600 python scripts/fuzz_parity.py 300 555 2>&1 | tail -1

@@ -493,21 +493,39 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_flag(int W, int H, const doub
 // values one after the other (dsp.c:103-108).  That chain is short (a few thousand dependent adds); what costs is the
 // latency of the loads, so the frame is walked in tiles of 256 (along the sum) x 64 staged through LDS: all four waves
 // fetch tile k+1 (64 coalesced loads per lane in flight) while wave 0 sums tile k out of LDS.
-#define XS_LONG 256
+#define XS_ITEMS 16  // strips re-collapsed side by side
+#define XS_LONG 64   // terms per tile: 64 x 65 floats = 16.6 KB of LDS, so that a workgroup finds room beside the FFT trips' (2 x 70 KB per CU)
+#define XS_E (XS_LONG / 4)  // elements per thread and tile
 #define XS_WAVES 4
 __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ frames, long long fstride, int W, int H,
                                                       const ChainOut *__restrict__ chain, int strips_normalised,
                                                       const int *__restrict__ sflag, float *__restrict__ exact, int nmax,
-                                                      const int *__restrict__ redo, const int *__restrict__ only)
+                                                      const int *__restrict__ redo, const int *__restrict__ only, int nstrips)
 {
-    const int axis = blockIdx.y, f = blockIdx.z;
     if (redo && !*redo) return;
-    if (!sflag[f * 2 + axis]) return;
-    if (only && !only[f * 2 + axis]) return;  // second run: the first one already made this strip exact
+    // grid (blocks of 64 sums, XS_ITEMS): row j of the grid takes the j-th, (j + XS_ITEMS)-th ... flagged strip of the
+    // batch.  Almost every launch finds none: a grid with a row per (frame, axis) spent ~0.1 ms on the latency-bound
+    // chain dispatching thousands of workgroups (66 KB of LDS each, beside the FFT's) that returned at once.
+    const int lane_ = threadIdx.x & 63;
+    for (int target = blockIdx.y;; target += gridDim.y) {
+    int item = -1, seen = 0;
+    for (int base = 0; base < nstrips && item < 0; base += 64) {
+        const int i = base + lane_;
+        const bool on = i < nstrips && sflag[i] && (!only || only[i]);  // (second run: the first one already made the others exact)
+        unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+        const int n = __builtin_popcountll(m);
+        if (target < seen + n) {
+            for (int k = target - seen; k > 0; k--) m &= m - 1;
+            item = base + __builtin_ctzll(m);
+        }
+        seen += n;
+    }
+    if (item < 0) return;  // (workgroup-uniform: every wave sees the same flags)
+    const int axis = item & 1, f = item >> 1;
     const int nsum = axis == 0 ? W : H;   // how many sums this axis has
     const int nlong = axis == 0 ? H : W;  // how many terms each sum has
     const int s0 = blockIdx.x * 64;       // first sum of this workgroup
-    if (s0 >= nsum) return;
+    if (s0 >= nsum) continue;             // (this axis is the shorter one: on to the next strip)
     const float *src = frames + (long long)f * fstride;
     const float lastmin = chain[f].lastmin, span = chain[f].span;
     float *out = exact + ((long long)f * 2 + axis) * nmax;
@@ -515,7 +533,7 @@ __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ 
     // store of axis 1 and the walk of one thread down its column are conflict free
     __shared__ float tile[XS_LONG][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float v[64];
+    float v[XS_E];
     const int ntiles = (nlong + XS_LONG - 1) / XS_LONG;
     float acc = 0.f;
     // element i of a thread: axis 0: term t = wave + 4 i, sum s = lane          -> pixel (x = s0 + lane, y = t0 + t)
@@ -524,7 +542,7 @@ __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ 
     // loads first, unconditionally (indices clamped into the frame), so that all 64 are in flight together; the
     // normalisation and the inside-the-frame test follow
 #define XS_FETCH(t0_)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 64; i++) {                                                        \
+    _Pragma("unroll") for (int i = 0; i < XS_E; i++) {                                                        \
         const int t = axis == 0 ? wave + XS_WAVES * i : lane + 64 * (i >> 4);                               \
         const int sidx = axis == 0 ? lane : wave + XS_WAVES * (i & 15);                                     \
         int x = axis == 0 ? s0 + sidx : (t0_) + t, y = axis == 0 ? (t0_) + t : s0 + sidx;                   \
@@ -532,7 +550,7 @@ __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ 
         y = y < H ? y : H - 1;                                                                              \
         v[i] = src[(long long)y * W + x];                                                                   \
     }                                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 64; i++) {                                                        \
+    _Pragma("unroll") for (int i = 0; i < XS_E; i++) {                                                        \
         const int t = axis == 0 ? wave + XS_WAVES * i : lane + 64 * (i >> 4);                               \
         const int sidx = axis == 0 ? lane : wave + XS_WAVES * (i & 15);                                     \
         const int x = axis == 0 ? s0 + sidx : (t0_) + t, y = axis == 0 ? (t0_) + t : s0 + sidx;             \
@@ -543,7 +561,7 @@ __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ 
     XS_FETCH(0)
     for (int k = 0; k < ntiles; k++) {
 #pragma unroll
-        for (int i = 0; i < 64; i++) {
+        for (int i = 0; i < XS_E; i++) {
             const int t = axis == 0 ? wave + XS_WAVES * i : lane + 64 * (i >> 4);
             const int sidx = axis == 0 ? lane : wave + XS_WAVES * (i & 15);
             tile[t][sidx] = v[i];
@@ -572,6 +590,8 @@ __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ 
     }
 #undef XS_FETCH
     if (threadIdx.x < 64 && s0 + (int)threadIdx.x < nsum) out[s0 + threadIdx.x] = acc;
+    __syncthreads();  // the tile is free for the next strip
+    }
 }
 
 __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const double *__restrict__ strip_x,
@@ -1569,8 +1589,8 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
             const int *only = run ? d_fresh : no_gate;
             if (run) TSDR_LAUNCH(g, PROF_CHAIN, st, k_redo_prepare, 1, 256, 2 * F, d_amb, pp->d_sflag, d_redo, d_fresh);
             if (!pp->band_mode) {
-                TSDR_LAUNCH(g, PROF_CHAIN, st, k_exact_strips, dim3(exact_blocks, 2, F), 256, frames, fstride, W, H, pp->d_chain, strips_normalised,
-                            pp->d_sflag, pp->d_exact, nmax, gate, only);
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_exact_strips, dim3(exact_blocks, 2 * F < XS_ITEMS ? 2 * F : XS_ITEMS), 256, frames, fstride, W, H,
+                            pp->d_chain, strips_normalised, pp->d_sflag, pp->d_exact, nmax, gate, only, 2 * F);
                 KERNEL_CHECK(g, "k_exact_strips");
             }
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
