@@ -453,9 +453,23 @@ int staging_acquire(tsdrgpu_t *g, StagingRing *r, size_t bytes)
     }
     return s;
 }
+// A few kilobytes of chunk table per call: copied by a kernel that reads the pinned host buffer directly.  (As a
+// hipMemcpyAsync it went through a copy engine, and the kernels behind it in the lane started ~29 us later —
+// rocprofv3 timeline of bench.py, scripts/bench_gaps.py.)
+__global__ __launch_bounds__(256) void k_stage_copy(const unsigned *__restrict__ h, unsigned *__restrict__ d, unsigned n)
+{
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = h[i];
+}
 int staging_push(tsdrgpu_t *g, StagingRing *r, int slot, size_t bytes)
 {
-    HIP_TRY(g, hipMemcpyAsync(r->d[slot], r->h[slot], bytes, hipMemcpyHostToDevice, g->stream));
+    if (bytes > (1u << 20) || (bytes & 3)) {
+        HIP_TRY(g, hipMemcpyAsync(r->d[slot], r->h[slot], bytes, hipMemcpyHostToDevice, g->stream));
+        return TSDRGPU_OK;
+    }
+    const unsigned n = (unsigned)(bytes / 4);
+    hipLaunchKernelGGL(k_stage_copy, dim3((n + 255) / 256 < 64 ? (n + 255) / 256 : 64), dim3(256), 0, g->stream, (const unsigned *)r->h[slot],
+                       (unsigned *)r->d[slot], n);
+    HIP_TRY(g, hipGetLastError());
     return TSDRGPU_OK;
 }
 int staging_release(tsdrgpu_t *g, StagingRing *r, int slot)
