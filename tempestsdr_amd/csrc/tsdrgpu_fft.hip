@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void k_argmax_partial(const double *__restrict
 }
 
 __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ pval, const int *__restrict__ pidx, int frame_len,
-                                                     int line_len, int *__restrict__ out)
+                                                     int line_len, int *__restrict__ out, int *__restrict__ h_out)
 {
     const int plot = blockIdx.x;
     double best = -1.0;
@@ -750,7 +750,11 @@ __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ 
         const int oi = __shfl_down(at, o, 64);
         if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
     }
-    if (threadIdx.x == 0) out[plot] = ((plot == 0 ? frame_len : line_len) > 0) ? at : -1;
+    if (threadIdx.x == 0) {
+        const int r = ((plot == 0 ? frame_len : line_len) > 0) ? at : -1;
+        out[plot] = r;
+        if (h_out) h_out[plot] = r;  // pinned host memory: the result needs no copy engine, the lane no wait for one
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1041,9 +1045,8 @@ extern "C" int tsdrgpu_autocorr_argmax_async(tsdrgpu_autocorr_t *ac)
     tsdrgpu_t *g = ac->g;
     if (ac->arg_pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_argmax_async", "the previous result was not collected");
     TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_partial, dim3(ARGMAX_BLOCKS, 2), 256, ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_pidx);
-    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_final, 2, 64, ac->d_pval, ac->d_pidx, ac->frame_len, ac->line_len, ac->d_arg);
+    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_final, 2, 64, ac->d_pval, ac->d_pidx, ac->frame_len, ac->line_len, ac->d_arg, ac->h_arg);
     KERNEL_CHECK(g, "k_argmax");
-    HIP_TRY(g, hipMemcpyAsync(ac->h_arg, ac->d_arg, 2 * sizeof(int), hipMemcpyDeviceToHost, ac->st));
     HIP_TRY(g, hipEventRecord(ac->ev_arg, ac->st));
     ac->arg_pending = 1;
     return TSDRGPU_OK;
