@@ -161,16 +161,17 @@ def test_resample_full_size_properties(orc):
     assert np.array_equal(y1[:want.size], want)
 
 
+@pytest.mark.parametrize("up", [1.99935, 0.62, 9.3, 1.0, 8.0])  # sample-parallel kernel (1 <= r <= 8) and the pixel-group one
 @pytest.mark.parametrize("from_iq", [0, 1])
 @pytest.mark.parametrize("P,phase0", [(4096, 0), (5003, 4321), (43623, 17), (100_000, 99_999)])
-def test_resampler_frame_minmax_tracking(from_iq, P, phase0):
+def test_resampler_frame_minmax_tracking(from_iq, P, phase0, up):
     """tsdrgpu_resampler_track_frames: per-frame min/max of the emitted pixel stream, carried across calls,
     == numpy on the downloaded stream (order-independent reductions: exact), sentinels (|v| > 250) excluded."""
     g = ctx()
     rng = np.random.default_rng(P + from_iq)
     rs = gpu.Resampler(g)
     rs.track_frames(P, phase0)
-    up, down = 1.99935, 1.0
+    down = 1.0
     stream, got_mn, got_mx = [], [], []
     for call, (chunk, nchunks) in enumerate([(3333, 7), (1000, 1), (16667, 13), (50, 3), (7777, 40)]):
         n = chunk * nchunks
