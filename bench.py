@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
                     help="BASELINE.json configs index (0-based): 2 = 100 MS/s 1080p60 (the headline metric, default), "
                          "1 = 25 MS/s 1024x768, 4 = 200 MS/s 2160p with 15/16 motion blur (use --seconds 0.5)")
-    ap.add_argument("--passes", type=int, default=40,
+    ap.add_argument("--passes", type=int, default=50,
                     help="passes over the HBM-resident batch per step (a step = passes x seconds of signal), so that "
                          "the default 20-30 steps give a timed region of more than a second")
     ap.add_argument("--fast-sync", action="store_true",
