@@ -401,9 +401,23 @@ __device__ __forceinline__ void ac4_fft4096(float2 (&v)[16], float2 *Lr, unsigne
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 16; t++) v[t] = Lj[272 * t];
-    // pass 2, Ns = 256: w_4096^(t j) = w_256^(t (j >> 4)) * w_4096^(t (j & 15))
+    // pass 2, Ns = 256: w_4096^(t j), t < 16, as powers of b = w_4096^j = w_256^(j >> 4) * w_4096^(j & 15) — two table
+    // reads and 15 products of depth <= 4 instead of 30 reads and 30 products
+    {
+        float2 pw[16];
+        pw[1] = cmul(tw256[jh], tw4k[k]);
+        pw[2] = cmul(pw[1], pw[1]);
+        pw[3] = cmul(pw[2], pw[1]);
+        pw[4] = cmul(pw[2], pw[2]);
+        pw[5] = cmul(pw[4], pw[1]);
+        pw[6] = cmul(pw[4], pw[2]);
+        pw[7] = cmul(pw[4], pw[3]);
+        pw[8] = cmul(pw[4], pw[4]);
 #pragma unroll
-    for (int t = 1; t < 16; t++) v[t] = cmul(v[t], cmul(tw256[((unsigned)t * jh) & 255u], tw4k[(unsigned)t * k]));
+        for (int t = 9; t < 16; t++) pw[t] = cmul(pw[8], pw[t - 8]);
+#pragma unroll
+        for (int t = 1; t < 16; t++) v[t] = cmul(v[t], pw[t]);
+    }
     dft_reg<16>(v);
 }
 
