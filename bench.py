@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--fast-sync", action="store_true",
                     help="opt out of the contract-exact sync detector (tsdrgpu_postproc_set_exact_ties(0)); the default "
                          "— and what the library ships — redoes toss-up decisions with the reference's own strip sums")
+    ap.add_argument("--uncertified", action="store_true",
+                    help="plain float32 autocorrelation without the argmax certificate / exact replay (round-2 behaviour)")
     ap.add_argument("--plan", type=int, default=3, choices=[3, 5], help="autocorrelation transform plan (trips over HBM)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the whole-library leg (tsdr_* API, in-memory source plugin, PCIe both ways) that is run "
@@ -250,16 +252,26 @@ def main():
     rs = gpu.Resampler(g)
     pp = gpu.PostProcess(g)
     pp.set_exact_ties(not args.fast_sync)
-    ac = gpu.Autocorr(g, fs)
-    ac.set_plan(args.plan)
+    # The detector in its CERTIFIED mode — what tsdr_readasync ships (host/engine.c): float32 three-trip transforms, an
+    # argmax certificate per plot update, an exact replay of the epoch when the certificate fails.  One epoch = one pass
+    # (reset, 17 windows, plot update).  The windows live in the HBM-resident stream, so the caller retains them (mode 2:
+    # no copy); two objects alternate so that a pass's certificate is read one pass later, without stalling the queue.
+    acs = []
+    for _ in range(2):
+        a_ = gpu.Autocorr(g, fs)
+        a_.set_plan(args.plan)
+        if not args.uncertified:
+            a_.set_certify(2)
+        acs.append(a_)
+    ac = acs[0]
     nwin = nsamples // ac.capture
     max_pix = int(nsamples * (up / down)) + 64 + P  # + a carried partial frame
     pix = torch.empty(max_pix, dtype=torch.float32, device=dev)
     frames_cap = max_pix // P + 1
     out = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
     d_pix, d_out = DevPtr(pix), DevPtr(out)
-    plots_ptr, plots_n = ac.device_plots()
     comm = None
+    plots_ts = {}
     if sharded:
         # RCCL from C (tsdrgpu_rccl.hip): the all-reduce is queued by the library on the autocorrelation's own lane,
         # ordered with its kernels, no host synchronisation.  torch.distributed only ships the 128-byte id (and
@@ -286,28 +298,59 @@ def main():
                 comm.destroy()
                 comm = None
             print(f"[bench rank {rank}] tsdrgpu_comm_create unavailable ({comm_err}); using torch.distributed", file=sys.stderr)
-            plots_t = torch.as_tensor(_DevArray(plots_ptr, plots_n), device=dev)
+            for a_ in acs:  # (+ 1: the accumulated lag-0 value behind the plots sums like the lags)
+                pp_, pn_ = a_.device_plots()
+                plots_ts[id(a_)] = torch.as_tensor(_DevArray(pp_, pn_ + 1), device=dev)
     my_windows = len(range(rank, nwin, world)) if strong else nwin
     total_windows = nwin if strong else nwin * world
 
     carry = 0  # pixels left over from the previous step (a frame straddling two batches)
     frames_done = 0
 
-    ac.set_async(args.overlap)
+    for a_ in acs:
+        a_.set_async(args.overlap)
     if args.frames_per_launch <= 0 and not args.no_split and args.fuse:
         rs.track_frames(P, 0)  # per-frame min/max out of the resampler (the batch starts on a frame boundary)
 
-    def run_autocorr():
-        if not sharded:
-            ac.run(d_iq, 1, ac.capture, nwin, mode=0)
-        elif strong:  # windows rank, rank + world, ... of the one stream
-            ac.reset()
-            ac.run(d_iq, 1, ac.capture * world, my_windows, mode=1, in_offset=2 * rank * ac.capture)
-        else:
-            ac.reset()
-            ac.run(d_iq, 1, ac.capture, nwin, mode=1)
+    pass_no = [0]
+    promoted_passes = [0]
 
-    arg_pending = [False]
+    def run_autocorr():
+        a = acs[pass_no[0] % 2]
+        a.reset()  # a pass is an epoch: its plot update is the mean over this pass's windows
+        if not sharded:
+            a.run(d_iq, 1, a.capture, nwin, mode=0)
+        elif strong:  # windows rank, rank + world, ... of the one stream
+            a.run(d_iq, 1, a.capture * world, my_windows, mode=1, in_offset=2 * rank * a.capture)
+        else:
+            a.run(d_iq, 1, a.capture, nwin, mode=1)
+
+    def exchange(a):
+        # ncclAllReduce(ncclDouble, ncclSum) over xGMI of the per-lag |R| sums of every rank's windows, in place in the
+        # library's plot buffer, then the division by the global window count
+        if comm is not None:
+            a.allreduce(comm, total_windows)
+        else:
+            g.sync()
+            dist.all_reduce(plots_ts[id(a)])
+            torch.cuda.synchronize()
+            a.finalize_sums(total_windows)
+
+    def settle(a, fi_li):
+        """The contract's half of a plot update: an argmax that is not certified is replaced by the argmax of the epoch
+        replayed in the reference's arithmetic (every rank decides alike: the plots are identical after the exchange)."""
+        if args.uncertified:
+            return fi_li
+        c = a.certificate()
+        if c.frame_certified and c.line_certified:
+            return fi_li
+        promoted_passes[0] += 1
+        a.promote()
+        if sharded:
+            exchange(a)
+        return a.argmax()
+
+    arg_pending = [None]
 
     def step():
         for _ in range(args.passes - 1):
@@ -352,27 +395,21 @@ def main():
                 g._ck(g.lib.tsdrgpu_copy(g.h, d_pix.at(0), d_pix.at(F * P), rem * 4))
             carry = rem
             frames_done += F
+        a = acs[pass_no[0] % 2]
+        pass_no[0] += 1
         if sharded:
-            # ncclAllReduce(ncclDouble, ncclSum) over xGMI of the per-lag |R| sums of every rank's windows, in place in the
-            # library's plot buffer, then the division by the global window count
-            if comm is not None:
-                ac.allreduce(comm, total_windows)
-            else:
-                g.sync()
-                dist.all_reduce(plots_t)
-                torch.cuda.synchronize()
-                ac.finalize_sums(total_windows)
-        # every pass ends with a plot update: the argmax is queued behind the pass and collected one pass later,
-        # so the host keeps queueing while the device works (one device sync per STEP)
-        if arg_pending[0]:
-            ac.argmax_result()
-            arg_pending[0] = False
+            exchange(a)
+        # every pass ends with a plot update: the argmax (+ its certificate) is queued behind the pass and collected one
+        # pass later, so the host keeps queueing while the device works (one device sync per STEP)
+        if arg_pending[0] is not None:
+            settle(arg_pending[0], arg_pending[0].argmax_result())
+            arg_pending[0] = None
         if not last:
-            ac.argmax_async()
-            arg_pending[0] = True
+            a.argmax_async()
+            arg_pending[0] = a
             return None
-        fi_li = ac.argmax()  # waits for the side stream
-        g.sync()             # and the frames of this step
+        fi_li = settle(a, a.argmax())  # waits for the autocorrelation's lane
+        g.sync()                       # and the frames of this step
         return fi_li
 
     def barrier():
@@ -468,7 +505,8 @@ def main():
         tx = time.perf_counter() - tx
         exact_ac = {"windows_per_s": round(reps * nwin / tx, 1), "ms_per_window": round(tx / (reps * nwin) * 1e3, 4),
                     "realtime_factor": round(reps * nwin * acx.capture / tx / fs, 1),
-                    "note": "tsdrgpu_autocorr_set_exact: plots bit-identical to fft.c; the engine's default detector"}
+                    "note": "tsdrgpu_autocorr_set_exact: plots bit-identical to fft.c; what a certified epoch is replayed "
+                            "through when its argmax certificate fails"}
         acx.destroy()
 
     # side metric: the product path end to end — libTSDRLibrary.so behind the tsdr_* API, fed by the in-memory source
@@ -620,8 +658,13 @@ def main():
                        "stage_order": "library default (autogain, sync, IIR)",
                        "sync_detector": "fast (toss-ups not redone)" if args.fast_sync else
                                         "contract-exact: toss-up decisions redone with the reference's own strip sums (library default)",
-                       "autocorrelation": f"float32 transform, {trips.split(' ')[0]}-trip plan (the engine's default detector "
-                                          "uses the bit-exact form, see exact_autocorr)"},
+                       "autocorrelation": (f"float32 transform, {trips.split(' ')[0]}-trip plan, uncertified (--uncertified)" if args.uncertified else
+                                           f"CERTIFIED float32 transform, {trips.split(' ')[0]}-trip plan — the engine's default detector mode "
+                                           "(tsdrgpu_autocorr_set_certify): every plot update carries an argmax certificate (best - runner-up > "
+                                           "8e-6 * R[0], computed in the argmax kernels); an epoch whose certificate fails is replayed in the "
+                                           "reference's own FFT arithmetic (bit-identical plots).  One epoch = one pass; windows retained by the "
+                                           "caller (mode 2: the stream is HBM-resident; the engine retains copies, mode 1)"),
+                       "autocorr_epochs_replayed_exact": promoted_passes[0]},
             "ms_per_pass": round(ms_pass, 4),
             "step_ms": {"min": round(srt[0] * 1e3, 3), "median": round(srt[len(srt) // 2] * 1e3, 3), "max": round(srt[-1] * 1e3, 3),
                         "timed_region_s": round(dt, 3)},

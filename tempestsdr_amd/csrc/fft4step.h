@@ -131,7 +131,8 @@ __device__ __forceinline__ void tw_powers(float2 (&pw)[M], unsigned e1, unsigned
 
 // Output filter of a transform's last pass: when `on`, only outputs whose index lies in one of two
 // ranges are stored (the autocorrelation reads nothing but its two lag windows, frameratedetector.c:
-// 115-118), except for transform `full_b` of the batch, which is stored whole.
+// 115-118) plus point 0 (lag 0, the scale of the argmax certificate), except for transform `full_b`
+// of the batch, which is stored whole.
 struct FftKeep {
     int on;
     int full_b;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *_
             if (!LAST) o = cmul(o, rtw[a + GL * u]);
             if (LAST) {
                 o.y = -o.y;
-                if (keep.on && (int)b != keep.full_b && !((m >= keep.lo0 && m < keep.hi0) || (m >= keep.lo1 && m < keep.hi1))) continue;
+                if (keep.on && (int)b != keep.full_b && !((m >= keep.lo0 && m < keep.hi0) || (m >= keep.lo1 && m < keep.hi1) || m == 0u)) continue;
             }
             yb[m] = o;
         }

@@ -95,6 +95,8 @@ typedef struct {
     double *h_frame, *h_line; /* pinned */
     const double *d_snapshot; /* the plots on the device (frame first), complete when plot_ready has fired */
     uint64_t calls;
+    int certify;              /* an argmax + certificate was queued in front of the snapshot on `ac` */
+    tsdrgpu_autocorr_t *ac;
 } plot_msg_t;
 
 struct engine {
@@ -110,6 +112,9 @@ struct engine {
     uint32_t ac_capture;
     tsdrgpu_event_t *det_read; /* the detector's lane (when it has its own) is done reading the detector's sample stream */
     int det_read_valid;
+    int ac_certified;          /* the detector runs in its certified mode (default): plots leave only with a certificate */
+    volatile int det_promote;  /* plot thread -> device thread: the last plot's argmax was not certified, replay the epoch exactly */
+    long n_promotions, n_plots_held;
 
     /* input queue */
     in_slot_t slot[NSLOT];
@@ -454,7 +459,20 @@ static void *plot_thread(void *arg)
         if (dumped) tsdr_announce_value(t, VALUE_ID_AUTOCORRECT_DUMPED, 0, 0);
         /* the snapshot is complete once plot_ready has fired; its way home is queued here, on the DOWNLOAD lane, so
          * that the detector's lane never waits for a copy engine */
-        if (plots && tsdrgpu_event_sync(e->g, e->plot_ready) == 0 &&
+        int deliver = plots && tsdrgpu_event_sync(e->g, e->plot_ready) == 0;
+        if (deliver && e->plot.certify) {
+            /* certified mode: the argmax kernels ran in front of the snapshot.  A plot whose argmax is not provably the
+             * reference's does not leave: the device thread replays the epoch exactly and publishes that plot instead */
+            int32_t fi, li;
+            tsdrgpu_ac_certificate_t c;
+            if (tsdrgpu_autocorr_argmax_result(e->plot.ac, &fi, &li) == 0 && tsdrgpu_autocorr_certificate(e->plot.ac, &c) == 0 &&
+                !(c.frame_certified && c.line_certified)) {
+                deliver = 0;
+                e->n_plots_held++;
+                e->det_promote = 1;
+            }
+        }
+        if (deliver &&
             tsdrgpu_download_lane(e->g, e->plot.h_frame, e->plot.d_snapshot, sizeof(double) * (size_t)e->plot.flen) == 0 &&
             tsdrgpu_download_lane(e->g, e->plot.h_line, e->plot.d_snapshot + e->plot.flen, sizeof(double) * (size_t)e->plot.llen) == 0 &&
             tsdrgpu_event_record(e->g, e->plot_home, TSDRGPU_LANE_DOWNLOAD) == 0 && tsdrgpu_event_sync(e->g, e->plot_home) == 0) {
@@ -516,10 +534,29 @@ static void detector_rebuild(struct engine *e, uint32_t fs)
         e->ac_failed_rate = fs;
         return;
     }
-    /* The frame-rate detector runs in the reference's own FFT arithmetic by default: plots, their argmax and so
-     * the detected mode are bit-identical to the CPU library's (0.25 ms per 100 MS/s window against 56 ms of
-     * signal).  TSDR_GPU_EXACT_AUTOCORR=0 / TSDR_GPU_EXACT=0 select the fast transform (plots within 1e-4*max). */
-    if (exact_wanted("TSDR_GPU_EXACT_AUTOCORR")) (void)tsdrgpu_autocorr_set_exact(e->ac, 1);
+    /* Detector mode.  Default: CERTIFIED — the float32 three-trip transform; every plot that leaves carries an argmax
+     * certificate (tsdrgpu_autocorr_set_certify), and an epoch whose certificate fails is replayed in the reference's own
+     * FFT arithmetic before its plot is delivered, so the argmax the host takes (PlotVisualizer.java:233-236) is always
+     * the CPU library's; such an epoch (and any epoch that outgrows the retention ring, TSDR_GPU_AUTOCORR_RETAIN_MB,
+     * default 1024) continues bit-identical.  TSDR_GPU_AUTOCORR=exact (or TSDR_GPU_EXACT_AUTOCORR=1 / TSDR_GPU_EXACT=1): every window in the
+     * reference's arithmetic, plots bit-identical always.  TSDR_GPU_AUTOCORR=fast (or TSDR_GPU_EXACT_AUTOCORR=0 /
+     * TSDR_GPU_EXACT=0): plain float32 form, plots within 1e-4*max, no guarantee on ties. */
+    {
+        const char *m = getenv("TSDR_GPU_AUTOCORR"), *one = getenv("TSDR_GPU_EXACT_AUTOCORR"), *all = getenv("TSDR_GPU_EXACT");
+        int mode = 1; /* 0 fast, 1 certified, 2 exact */
+        if (m && m[0]) mode = m[0] == 'e' ? 2 : (m[0] == 'f' ? 0 : 1);
+        else if (one && one[0]) mode = one[0] != '0' ? 2 : 0;
+        else if (all && all[0]) mode = all[0] != '0' ? 2 : 0;
+        e->ac_certified = 0;
+        if (mode == 2) (void)tsdrgpu_autocorr_set_exact(e->ac, 1);
+        else if (mode == 1) {
+            const char *mb = getenv("TSDR_GPU_AUTOCORR_RETAIN_MB");
+            const size_t bytes = (mb && atol(mb) > 0) ? (size_t)atol(mb) << 20 : 0;
+            if (tsdrgpu_autocorr_set_certify(e->ac, 1, bytes) == 0) e->ac_certified = 1;
+            else (void)tsdrgpu_autocorr_set_exact(e->ac, 1); /* no room for the ring: the exact form needs none */
+        }
+    }
+    e->det_promote = 0;
     /* The detector's transforms run in line on the COMPUTE lane.  On its own (BACKGROUND) lane they would overlap the
      * frame path, but every window then needs two device-side waits between the lanes, and a barrier packet parked in
      * one hardware queue slows the other queues of the process down (see download_thread): measured 1.8-2.4 GS/s
@@ -559,6 +596,33 @@ static void detector_rebuild(struct engine *e, uint32_t fs)
     e->ac_failed_rate = 0;
 }
 
+/* A plot update: snapshot of the plots on the detector's lane (in certified mode behind the argmax kernels that
+ * produce the certificate), picked up by the plot thread.  Skipped while the host still shows the previous one. */
+static void publish_plot(struct engine *e)
+{
+    pthread_mutex_lock(&e->pm);
+    const int busy = e->plot_pending;
+    pthread_mutex_unlock(&e->pm);
+    if (busy) return;
+    uint64_t calls = 0;
+    const double *snap = NULL;
+    const int certify = e->ac_certified && tsdrgpu_autocorr_argmax_async(e->ac) == 0;
+    if (tsdrgpu_autocorr_plots_snapshot(e->ac, &snap, &calls) == 0 &&
+        tsdrgpu_event_record(e->g, e->plot_ready, tsdrgpu_autocorr_lane(e->ac)) == 0) {
+        pthread_mutex_lock(&e->pm);
+        e->plot.calls = calls;
+        e->plot.d_snapshot = snap;
+        e->plot.certify = certify;
+        e->plot.ac = e->ac;
+        e->plot_pending = 1;
+        pthread_cond_signal(&e->p_nonempty);
+        pthread_mutex_unlock(&e->pm);
+    } else if (certify) {
+        int32_t a, b;
+        (void)tsdrgpu_autocorr_argmax_result(e->ac, &a, &b); /* nobody will collect it */
+    }
+}
+
 static void run_detector(struct engine *e, uint32_t fs)
 {
     tsdr_lib_t *t = e->t;
@@ -569,15 +633,29 @@ static void run_detector(struct engine *e, uint32_t fs)
         if (!e->ac) { e->det.rd = e->det.wr = 0; return; }
     }
     const uint32_t capture = e->ac_capture;
+    if (e->det_promote) { /* the plot thread held a plot back: its epoch once more, in the reference's arithmetic */
+        pthread_mutex_lock(&e->pm);
+        const int busy = e->plot_pending; /* (the plot thread clears it right after raising the request) */
+        pthread_mutex_unlock(&e->pm);
+        if (!busy) {
+            e->det_promote = 0;
+            if (gpu_ok(e, tsdrgpu_autocorr_promote(e->ac), "autocorr promote")) {
+                e->n_promotions++;
+                publish_plot(e);
+            }
+        }
+    }
     while ((e->det.wr - e->det.rd) / 2 >= capture && t->running) {
         if (t->detector_purge) { /* frameratedetector.c:171-176 */
             t->detector_purge = 0;
             tsdrgpu_autocorr_reset(e->ac);
+            e->det_promote = 0;
         }
         if (t->params_int[PARAM_AUTOCORR_PLOTS_RESET]) { /* frameratedetector.c:97-104 */
             const uint32_t orig = t->params_int[PARAM_AUTOCORR_PLOTS_RESET];
             t->params_int[PARAM_AUTOCORR_PLOTS_RESET] = 0;
             tsdrgpu_autocorr_reset(e->ac);
+            e->det_promote = 0;
             if (orig == 1) {
                 pthread_mutex_lock(&e->pm);
                 e->plot_reset_announce = 1;
@@ -601,22 +679,7 @@ static void run_detector(struct engine *e, uint32_t fs)
             pthread_cond_signal(&e->p_nonempty);
             pthread_mutex_unlock(&e->pm);
         }
-        pthread_mutex_lock(&e->pm);
-        const int busy = e->plot_pending; /* host still showing the previous plot: skip this update */
-        pthread_mutex_unlock(&e->pm);
-        if (!busy) {
-            uint64_t calls = 0;
-            const double *snap = NULL;
-            if (tsdrgpu_autocorr_plots_snapshot(e->ac, &snap, &calls) == 0 &&
-                tsdrgpu_event_record(e->g, e->plot_ready, tsdrgpu_autocorr_lane(e->ac)) == 0) {
-                pthread_mutex_lock(&e->pm);
-                e->plot.calls = calls;
-                e->plot.d_snapshot = snap;
-                e->plot_pending = 1;
-                pthread_cond_signal(&e->p_nonempty);
-                pthread_mutex_unlock(&e->pm);
-            }
-        }
+        publish_plot(e);
     }
 }
 
@@ -1095,11 +1158,13 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
                 "page-locked ranges %d\n"
                 "tsdr stats: plugin thread busy %.0f%% (DMA wait %.0f%%) | device thread busy %.0f%% (waiting for output buffers %.0f%%) | "
                 "video thread: waiting for frames %.0f%%, in the callback %.0f%%\n"
-                "tsdr stats: device thread: appending blocks %.0f%% | resampler %.0f%% | frame path %.0f%% | detector %.0f%%\n",
+                "tsdr stats: device thread: appending blocks %.0f%% | resampler %.0f%% | frame path %.0f%% | detector %.0f%%\n"
+                "tsdr stats: detector %s | plots held back for an exact replay %ld | epochs replayed %ld\n",
                 T, e->n_blocks, e->n_blocks_lost, e->n_frames_made, e->n_frames_lost, e->n_batches, e->n_resample_calls, e->n_windows, e->nreg,
                 100 * e->s_plugin_busy / T, 100 * e->s_plugin_dma / T, 100 * e->s_dev_busy / T, 100 * e->s_dev_wait_out / T,
                 100 * e->s_video_wait / T, 100 * e->s_video_cb / T,
-                100 * e->s_dev_blocks / T, 100 * (e->s_dev_rs - e->s_dev_frames) / T, 100 * e->s_dev_frames / T, 100 * e->s_dev_det / T);
+                100 * e->s_dev_blocks / T, 100 * (e->s_dev_rs - e->s_dev_frames) / T, 100 * e->s_dev_frames / T, 100 * e->s_dev_det / T,
+                e->ac_certified ? "certified (float32 + argmax certificate)" : "exact or plain (TSDR_GPU_AUTOCORR)", e->n_plots_held, e->n_promotions);
     }
     tsdrgpu_bind_thread(e->g);
     tsdrgpu_sync(e->g);

@@ -14,23 +14,42 @@
 
 #define AC_SUBBATCH 9
 
+// one tsdrgpu_autocorr_run call of the current epoch, as the certified mode remembers it for an exact replay
+struct AcLogRec {
+    const float *src;
+    int is_iq;
+    long long stride;
+    int nwindows;
+    int mode;
+};
+
+// what k_argmax_final leaves in pinned memory: the argmax pair and its certificate
+struct AcArgHost {
+    int idx[2];
+    int certified[2];
+    double best[2], second[2];
+    double r0, margin;
+};
+
 struct tsdrgpu_autocorr {
     tsdrgpu_t *g;
     uint32_t samplerate;
     int32_t frame_lo, frame_len, line_lo, line_len;
     uint32_t capture, n;
     uint64_t calls;
-    double *d_plots;   // frame_len + line_len
+    double *d_plots;   // frame_len + line_len, + 1: the accumulated lag-0 value (scale of the certificate)
     double *d_snapshot;  // tsdrgpu_autocorr_plots_snapshot
     float2 *d_a, *d_b; // ping-pong work buffers, cap_windows * n/2 complex each (packed real transform)
     int cap_windows;
-    float2 *d_last;    // packed correlation of the last window run (n/2 complex = n reals)
+    float2 *d_last;    // packed correlation of the last window run (n/2 complex = n reals), or n complex (last_exact)
+    int last_exact;
     float2 *d_expand;  // the same unpacked to n complex values, made on demand
-    int *d_arg;
-    int *h_arg;
-    hipEvent_t ev_arg;  // recorded behind the copy of d_arg to h_arg
+    AcArgHost *d_arg;
+    AcArgHost *h_arg;
+    AcArgHost res;      // the last collected result
+    hipEvent_t ev_arg;  // recorded behind the kernel that writes h_arg
     int arg_pending;
-    double *d_pval;  // argmax partials
+    double *d_pval, *d_psec;  // argmax partials: best and runner-up values
     int *d_pidx;
     hipStream_t st;  // g->stream, or g->bg (the background lane) when set asynchronous
     int plan5;       // tsdrgpu_autocorr_set_plan: 1 = the five-trip Stockham plan even where the three-trip one applies
@@ -39,6 +58,14 @@ struct tsdrgpu_autocorr {
     double2 *d_tw;   // the reference's twiddle recurrence values, n-1 entries
     float2 *d_xz;    // AC_XBATCH windows of n complex points
     float *d_xmag;   // and of n magnitudes
+    // certified mode (tsdrgpu_autocorr_set_certify)
+    int certify;       // 0 off, 1 windows retained by the library (ring), 2 retained by the caller
+    int epoch_exact;   // this epoch (since the last reset) was promoted: its windows run in the exact form
+    int promotions;    // epochs promoted so far (diagnostics)
+    AcLogRec *log;
+    int log_count, log_cap;
+    float *d_ring;     // certify == 1: ring_cap windows of n magnitudes
+    int ring_cap, ring_count;
 };
 #define AC_XBATCH 4
 
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(256) void k_fft_lds(const void *__restrict__ xin, l
 #pragma unroll
             for (int k2 = 0; k2 < 16; k2++) {
                 const unsigned o = o0 + (q + R1 * k2) * Ns;
-                if ((o >= keep.lo0 && o < keep.hi0) || (o >= keep.lo1 && o < keep.hi1)) yo[(long long)(q + R1 * k2) * Ns] = w[k2];
+                if ((o >= keep.lo0 && o < keep.hi0) || (o >= keep.lo1 && o < keep.hi1) || o == 0u) yo[(long long)(q + R1 * k2) * Ns] = w[k2];
             }
         } else {
 #pragma unroll
@@ -676,8 +703,9 @@ __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ co
                                                     unsigned long long calls_before, int mode)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= frame_len + line_len) return;
-    const int lag = (i < frame_len) ? (frame_lo + i) : (line_lo + (i - frame_len));
+    if (i > frame_len + line_len) return;
+    // entry frame_len + line_len accumulates lag 0 the same way: the scale of the argmax certificate
+    const int lag = (i < frame_len) ? (frame_lo + i) : (i < frame_len + line_len ? line_lo + (i - frame_len) : 0);
     double acc = plots[i];
     for (int w = 0; w < nwindows; w++) {
         // r[lag] of window w (real: the packed inverse transform has no imaginary residue)
@@ -701,59 +729,89 @@ __global__ void k_scale_plots(double *plots, int count, double divisor)
 }
 
 // argmax with lowest-index tie-break (PlotVisualizer.java:233-236), two stages:
-// ARGMAX_BLOCKS workgroups per plot (enough to pull 5 MB of lags at memory speed), then one wave per plot
+// ARGMAX_BLOCKS workgroups per plot (enough to pull 5 MB of lags at memory speed), then one wave per plot.
+// Beside the maximum the reduction carries the RUNNER-UP value (the largest value at any other lag; equal to the
+// maximum when the maximum is attained twice): the certificate of tsdrgpu_autocorr_certificate compares their
+// distance with the bound on what separates this plot from the reference's.
 #define ARGMAX_BLOCKS 512
+struct ArgTop {
+    double best, second;
+    int at;
+};
+__device__ __forceinline__ void argtop_merge(ArgTop &a, double ob, double os, int oi)
+{
+    const double lo = a.best < ob ? a.best : ob;  // the loser of the two maxima is a runner-up candidate
+    double sec = a.second > os ? a.second : os;
+    sec = sec > lo ? sec : lo;
+    if (ob > a.best || (ob == a.best && oi < a.at)) { a.best = ob; a.at = oi; }
+    a.second = sec;
+}
+__device__ __forceinline__ void argtop_wave(ArgTop &a)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(a.best, o, 64);
+        const double os = __shfl_down(a.second, o, 64);
+        const int oi = __shfl_down(a.at, o, 64);
+        argtop_merge(a, ob, os, oi);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_argmax_partial(const double *__restrict__ plots, int frame_len, int line_len,
-                                                        double *__restrict__ pval, int *__restrict__ pidx)
+                                                        double *__restrict__ pval, double *__restrict__ psec, int *__restrict__ pidx)
 {
     const int plot = blockIdx.y;
     const double *p = plot == 0 ? plots : plots + frame_len;
     const int len = plot == 0 ? frame_len : line_len;
-    double best = -1.0;
-    int at = 0x7fffffff;
+    ArgTop a = {-1.0, -1.0, 0x7fffffff};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
         const double v = p[i];
-        if (v > best) { best = v; at = i; }  // i ascending per thread
+        if (v > a.best) { a.second = a.best; a.best = v; a.at = i; }  // i ascending per thread
+        else if (v > a.second) a.second = v;
     }
-    __shared__ double sb[4];
+    __shared__ double sb[4], ss[4];
     __shared__ int si[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_down(best, o, 64);
-        const int oi = __shfl_down(at, o, 64);
-        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
-    }
-    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = at; }
+    argtop_wave(a);
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = a.best; ss[threadIdx.x >> 6] = a.second; si[threadIdx.x >> 6] = a.at; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++)
-            if (sb[w] > best || (sb[w] == best && si[w] < at)) { best = sb[w]; at = si[w]; }
-        pval[plot * ARGMAX_BLOCKS + blockIdx.x] = best;
-        pidx[plot * ARGMAX_BLOCKS + blockIdx.x] = at;
+        for (int w = 1; w < 4; w++) argtop_merge(a, sb[w], ss[w], si[w]);
+        pval[plot * ARGMAX_BLOCKS + blockIdx.x] = a.best;
+        psec[plot * ARGMAX_BLOCKS + blockIdx.x] = a.second;
+        pidx[plot * ARGMAX_BLOCKS + blockIdx.x] = a.at;
     }
 }
 
-__global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ pval, const int *__restrict__ pidx, int frame_len,
-                                                     int line_len, int *__restrict__ out, int *__restrict__ h_out)
+// kappa: see TSDRGPU_AC_CERT_KAPPA (include/tsdrgpu.h); exact_epoch: the plots are the reference's own bits
+__global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ pval, const double *__restrict__ psec,
+                                                     const int *__restrict__ pidx, const double *__restrict__ plots, int frame_len,
+                                                     int line_len, double kappa, int exact_epoch, AcArgHost *__restrict__ out,
+                                                     AcArgHost *__restrict__ h_out)
 {
     const int plot = blockIdx.x;
-    double best = -1.0;
-    int at = 0x7fffffff;
-    for (int b = threadIdx.x; b < ARGMAX_BLOCKS; b += 64) {
-        const double ob = pval[plot * ARGMAX_BLOCKS + b];
-        const int oi = pidx[plot * ARGMAX_BLOCKS + b];
-        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_down(best, o, 64);
-        const int oi = __shfl_down(at, o, 64);
-        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
-    }
+    ArgTop a = {-1.0, -1.0, 0x7fffffff};
+    for (int b = threadIdx.x; b < ARGMAX_BLOCKS; b += 64)
+        argtop_merge(a, pval[plot * ARGMAX_BLOCKS + b], psec[plot * ARGMAX_BLOCKS + b], pidx[plot * ARGMAX_BLOCKS + b]);
+    argtop_wave(a);
     if (threadIdx.x == 0) {
-        const int r = ((plot == 0 ? frame_len : line_len) > 0) ? at : -1;
-        out[plot] = r;
-        if (h_out) h_out[plot] = r;  // pinned host memory: the result needs no copy engine, the lane no wait for one
+        const int len = plot == 0 ? frame_len : line_len;
+        const int r = len > 0 ? a.at : -1;
+        const double r0 = plots[frame_len + line_len];
+        const double margin = kappa * r0;
+        // a plot of one lag has no runner-up (second stays -1); NaNs compare false and leave the plot uncertified
+        const int ok = exact_epoch || len <= 1 || (a.best - a.second > margin);
+        out->idx[plot] = r;
+        out->certified[plot] = ok;
+        out->best[plot] = a.best;
+        out->second[plot] = a.second;
+        if (plot == 0) { out->r0 = r0; out->margin = margin; }
+        if (h_out) {  // pinned host memory: the result needs no copy engine, the lane no wait for one
+            h_out->idx[plot] = r;
+            h_out->certified[plot] = ok;
+            h_out->best[plot] = a.best;
+            h_out->second[plot] = a.second;
+            if (plot == 0) { h_out->r0 = r0; h_out->margin = margin; }
+        }
     }
 }
 
@@ -815,14 +873,22 @@ extern "C" int tsdrgpu_autocorr_create(tsdrgpu_t *g, tsdrgpu_autocorr_t **out, u
         free(ac);
         return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_create", "sample rate too low for the lag windows");
     }
-    if (hipMalloc(&ac->d_plots, sizeof(double) * L) != hipSuccess || hipMalloc(&ac->d_arg, 2 * sizeof(int)) != hipSuccess ||
+    if (hipMalloc(&ac->d_plots, sizeof(double) * (L + 1)) != hipSuccess || hipMalloc(&ac->d_arg, sizeof(AcArgHost)) != hipSuccess ||
         hipMalloc(&ac->d_pval, 2 * ARGMAX_BLOCKS * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ac->d_psec, 2 * ARGMAX_BLOCKS * sizeof(double)) != hipSuccess ||
         hipMalloc(&ac->d_pidx, 2 * ARGMAX_BLOCKS * sizeof(int)) != hipSuccess ||
-        hipHostMalloc(&ac->h_arg, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&ac->h_arg, sizeof(AcArgHost), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ac->ev_arg, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(ac->d_plots);
+        (void)hipFree(ac->d_arg);
+        (void)hipFree(ac->d_pval);
+        (void)hipFree(ac->d_psec);
+        (void)hipFree(ac->d_pidx);
+        if (ac->h_arg) (void)hipHostFree(ac->h_arg);
         free(ac);
         return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_create", "plots");
     }
+    memset(ac->h_arg, 0, sizeof(AcArgHost));
     ac->st = g->stream;
     *out = ac;
     return tsdrgpu_autocorr_reset(ac);
@@ -841,12 +907,15 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
     (void)hipFree(ac->d_expand);
     (void)hipFree(ac->d_arg);
     (void)hipFree(ac->d_pval);
+    (void)hipFree(ac->d_psec);
     (void)hipFree(ac->d_pidx);
     (void)hipHostFree(ac->h_arg);
     (void)hipEventDestroy(ac->ev_arg);
     (void)hipFree(ac->d_tw);
     (void)hipFree(ac->d_xz);
     (void)hipFree(ac->d_xmag);
+    (void)hipFree(ac->d_ring);
+    free(ac->log);
     free(ac);
 }
 
@@ -855,7 +924,11 @@ extern "C" int tsdrgpu_autocorr_reset(tsdrgpu_autocorr_t *ac)
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     ac->calls = 0;  // extbuffer "cleartozero" semantics, extbuffer.c:68-81
-    HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len), ac->st));
+    // a new epoch: back to the float32 transform, nothing retained
+    ac->epoch_exact = 0;
+    ac->log_count = 0;
+    ac->ring_count = 0;
+    HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len + 1), ac->st));
     return TSDRGPU_OK;
 }
 
@@ -872,12 +945,47 @@ extern "C" int tsdrgpu_autocorr_geometry(tsdrgpu_autocorr_t *ac, int32_t *frame_
     return TSDRGPU_OK;
 }
 
-extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, int64_t stride, int nwindows, int mode)
+// the exact form's resources: the twiddle table (built on the host, once per object) and AC_XBATCH windows of work space
+static int ac_ensure_exact(tsdrgpu_autocorr_t *ac)
 {
-    if (!ac || !d_in || nwindows < 0 || stride < 0) return ac ? tsdr_fail(ac->g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "bad argument") : TSDRGPU_EINVAL;
-    if (nwindows == 0) return TSDRGPU_OK;
     tsdrgpu_t *g = ac->g;
-    if (nwindows > 65535) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "too many windows in one call");
+    if (ac->d_tw) return TSDRGPU_OK;
+    int rc = fftx_build_table(g, ac->n, &ac->d_tw);
+    if (rc) return rc;
+    if (hipMalloc(&ac->d_xz, sizeof(float2) * (size_t)ac->n * AC_XBATCH) != hipSuccess ||
+        hipMalloc(&ac->d_xmag, sizeof(float) * (size_t)ac->n * AC_XBATCH) != hipSuccess) {
+        (void)hipFree(ac->d_xz);
+        (void)hipFree(ac->d_tw);
+        ac->d_xz = nullptr;
+        ac->d_tw = nullptr;
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr", "work buffers of the exact form");
+    }
+    return TSDRGPU_OK;
+}
+
+// `nwindows` windows in the reference's own arithmetic (tsdrgpu_fftx.hip), accumulated into the plots
+static int ac_run_exact(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, long long stride, int nwindows, int mode)
+{
+    tsdrgpu_t *g = ac->g;
+    int rc = ac_ensure_exact(ac);
+    if (rc) return rc;
+    for (int w0 = 0; w0 < nwindows; w0 += AC_XBATCH) {
+        const int cnt = nwindows - w0 < AC_XBATCH ? nwindows - w0 : AC_XBATCH;
+        const float *src = d_in + (size_t)w0 * (size_t)stride * (in_is_iq ? 2 : 1);
+        rc = fftx_autocorr(g, ac->st, src, in_is_iq, stride, cnt, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag, ac->frame_lo, ac->frame_len,
+                           ac->line_lo, ac->line_len, ac->d_plots, (unsigned long long)(ac->calls + w0), mode);
+        if (rc) return rc;
+        ac->d_last = ac->d_xz + (size_t)(cnt - 1) * ac->n;  // the whole complex correlation of the last window
+        ac->last_exact = 1;
+    }
+    ac->calls += (uint64_t)nwindows;
+    return TSDRGPU_OK;
+}
+
+// `nwindows` windows through the float32 transform (three-trip plan where it applies), accumulated into the plots
+static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, long long stride, int nwindows, int mode)
+{
+    tsdrgpu_t *g = ac->g;
     // windows are transformed at most AC_SUBBATCH at a time.  A launch of the three-trip plan is only ~3 rounds of
     // resident workgroups per 6 windows, so every launch pays a ramp and a drain: measured at 17 windows per pass,
     // 6+6+5 -> group at 0.565 of the roofline, 9+8 -> 0.585, one launch of 17 -> 0.62 — but a caller's small kernels on
@@ -897,25 +1005,8 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
             return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_run", "work buffers");
         ac->cap_windows = AC_SUBBATCH;
     }
-    if (ac->st != g->stream) {
-        // side stream: everything already queued on the main stream (e.g. the producer of d_in) comes first
-        HIP_TRY(g, hipEventRecord(g->fork, g->stream));
-        HIP_TRY(g, hipStreamWaitEvent(ac->st, g->fork, 0));
-    }
-    if (ac->exact) {
-        for (int w0 = 0; w0 < nwindows; w0 += AC_XBATCH) {
-            const int cnt = nwindows - w0 < AC_XBATCH ? nwindows - w0 : AC_XBATCH;
-            const float *src = d_in + (size_t)w0 * (size_t)stride * (in_is_iq ? 2 : 1);
-            const int rc = fftx_autocorr(g, ac->st, src, in_is_iq, stride, cnt, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag, ac->frame_lo, ac->frame_len,
-                                         ac->line_lo, ac->line_len, ac->d_plots, (unsigned long long)(ac->calls + w0), mode);
-            if (rc) return rc;
-            ac->d_last = ac->d_xz + (size_t)(cnt - 1) * ac->n;  // the whole complex correlation of the last window
-        }
-        ac->calls += (uint64_t)nwindows;
-        return TSDRGPU_OK;
-    }
     const uint32_t nh = ac->n / 2;
-    const int L = ac->frame_len + ac->line_len;
+    const int L = ac->frame_len + ac->line_len + 1;  // + the lag-0 entry
     float2 *corr = nullptr;
     int last_count = 0;
     const int parts = (nwindows + AC_SUBBATCH - 1) / AC_SUBBATCH;
@@ -929,8 +1020,8 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
         const unsigned Ns_last = nh / R_last;
         const bool fused = nh >= 4096 && plan.count >= 2 && Ns_last >= 2u * (2048u / R_last);
         float2 *corr_;
-        // lags stored by the last pass: complex point m holds lags 2m, 2m+1; the call's final window is stored
-        // whole for tsdrgpu_autocorr_last_corr
+        // lags stored by the last pass: complex point m holds lags 2m, 2m+1 (point 0, i.e. lag 0, always); the call's
+        // final window is stored whole for tsdrgpu_autocorr_last_corr
         FftKeep keep;
         keep.on = 1;
         keep.full_b = (w0 + cnt == nwindows) ? cnt - 1 : -1;
@@ -979,7 +1070,69 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     const int nwindows_last = last_count;
     ac->calls += (uint64_t)nwindows;
     ac->d_last = corr + (size_t)(nwindows_last - 1) * nh;
+    ac->last_exact = 0;
     return TSDRGPU_OK;
+}
+
+// Replays the epoch's windows (every run since the last reset) in the reference's own arithmetic: the plots then hold
+// what an exact run of the same calls would have left, and the rest of the epoch runs exact.
+extern "C" int tsdrgpu_autocorr_promote(tsdrgpu_autocorr_t *ac)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    if (!ac->certify) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_promote", "certified mode is off (tsdrgpu_autocorr_set_certify)");
+    if (ac->epoch_exact || ac->exact) return TSDRGPU_OK;
+    int rc = ac_ensure_exact(ac);
+    if (rc) return rc;
+    HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len + 1), ac->st));
+    ac->calls = 0;
+    ac->epoch_exact = 1;
+    ac->promotions++;
+    for (int i = 0; i < ac->log_count; i++) {
+        const AcLogRec &r = ac->log[i];
+        if ((rc = ac_run_exact(ac, r.src, r.is_iq, r.stride, r.nwindows, r.mode))) return rc;
+    }
+    ac->log_count = 0;
+    ac->ring_count = 0;  // the ring's windows are read by the replay queued above; later runs of this epoch do not retain
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, int64_t stride, int nwindows, int mode)
+{
+    if (!ac || !d_in || nwindows < 0 || stride < 0) return ac ? tsdr_fail(ac->g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "bad argument") : TSDRGPU_EINVAL;
+    if (nwindows == 0) return TSDRGPU_OK;
+    tsdrgpu_t *g = ac->g;
+    if (nwindows > 65535) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "too many windows in one call");
+    if (ac->st != g->stream) {
+        // side stream: everything already queued on the main stream (e.g. the producer of d_in) comes first
+        HIP_TRY(g, hipEventRecord(g->fork, g->stream));
+        HIP_TRY(g, hipStreamWaitEvent(ac->st, g->fork, 0));
+    }
+    if (ac->exact || ac->epoch_exact) return ac_run_exact(ac, d_in, in_is_iq, stride, nwindows, mode);
+    if (!ac->certify) return ac_run_fast(ac, d_in, in_is_iq, stride, nwindows, mode);
+    int rc;
+    if (ac->certify == 2) {
+        // the caller keeps the windows: remember where they are
+        if (ac->log_count >= ac->log_cap) {  // an epoch of more calls than the log holds continues in the exact form
+            if ((rc = tsdrgpu_autocorr_promote(ac))) return rc;
+            return ac_run_exact(ac, d_in, in_is_iq, stride, nwindows, mode);
+        }
+        const AcLogRec r = {d_in, in_is_iq, (long long)stride, nwindows, mode};
+        ac->log[ac->log_count++] = r;
+        return ac_run_fast(ac, d_in, in_is_iq, stride, nwindows, mode);
+    }
+    // the library keeps them: the first n samples of every window, demodulated, into the ring; the float32 transform
+    // then reads the ring.  An epoch that outgrows the ring is replayed exactly once and continues in the exact form.
+    if (ac->ring_count + nwindows > ac->ring_cap || ac->log_count >= ac->log_cap) {
+        if ((rc = tsdrgpu_autocorr_promote(ac))) return rc;
+        return ac_run_exact(ac, d_in, in_is_iq, stride, nwindows, mode);
+    }
+    float *slot = ac->d_ring + (size_t)ac->ring_count * ac->n;
+    if ((rc = fftx_retain(g, ac->st, d_in, in_is_iq, (long long)stride, nwindows, ac->n, slot))) return rc;
+    const AcLogRec r = {slot, 0, (long long)ac->n, nwindows, mode};
+    ac->log[ac->log_count++] = r;
+    ac->ring_count += nwindows;
+    return ac_run_fast(ac, slot, 0, (long long)ac->n, nwindows, mode);
 }
 
 extern "C" int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line, uint64_t *h_calls)
@@ -1010,7 +1163,7 @@ extern "C" int tsdrgpu_autocorr_plots_snapshot(tsdrgpu_autocorr_t *ac, const dou
 {
     if (!ac || !d_snapshot) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
-    const size_t L = (size_t)ac->frame_len + ac->line_len;
+    const size_t L = (size_t)ac->frame_len + ac->line_len;  // (the lag-0 entry behind them stays on the device)
     if (!ac->d_snapshot && hipMalloc(&ac->d_snapshot, sizeof(double) * L) != hipSuccess)
         return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_plots_snapshot", "snapshot");
     HIP_TRY(g, hipMemcpyAsync(ac->d_snapshot, ac->d_plots, sizeof(double) * L, hipMemcpyDeviceToDevice, ac->st));
@@ -1031,21 +1184,23 @@ extern "C" int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t t
 {
     if (!ac || total_windows == 0) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
-    const int L = ac->frame_len + ac->line_len;
+    const int L = ac->frame_len + ac->line_len + 1;  // the lag-0 entry scales with the plots
     TSDR_LAUNCH(g, PROF_ACCUMULATE, ac->st, k_scale_plots, (L + 255) / 256, 256, ac->d_plots, L, (double)total_windows);
     KERNEL_CHECK(g, "k_scale_plots");
     ac->calls = total_windows;
     return TSDRGPU_OK;
 }
 
-// queue the two-stage argmax of the current plots and the copy of its result to pinned memory
+// queue the two-stage argmax of the current plots; its last kernel writes the result and the certificate to pinned memory
 extern "C" int tsdrgpu_autocorr_argmax_async(tsdrgpu_autocorr_t *ac)
 {
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     if (ac->arg_pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_argmax_async", "the previous result was not collected");
-    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_partial, dim3(ARGMAX_BLOCKS, 2), 256, ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_pidx);
-    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_final, 2, 64, ac->d_pval, ac->d_pidx, ac->frame_len, ac->line_len, ac->d_arg, ac->h_arg);
+    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_partial, dim3(ARGMAX_BLOCKS, 2), 256, ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_psec,
+                ac->d_pidx);
+    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_final, 2, 64, ac->d_pval, ac->d_psec, ac->d_pidx, ac->d_plots, ac->frame_len, ac->line_len,
+                (double)TSDRGPU_AC_CERT_KAPPA, (ac->exact || ac->epoch_exact) ? 1 : 0, ac->d_arg, ac->h_arg);
     KERNEL_CHECK(g, "k_argmax");
     HIP_TRY(g, hipEventRecord(ac->ev_arg, ac->st));
     ac->arg_pending = 1;
@@ -1059,8 +1214,9 @@ extern "C" int tsdrgpu_autocorr_argmax_result(tsdrgpu_autocorr_t *ac, int32_t *f
     if (!ac->arg_pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_argmax_result", "no argmax was queued");
     HIP_TRY(g, hipEventSynchronize(ac->ev_arg));
     ac->arg_pending = 0;
-    if (frame_idx) *frame_idx = ac->h_arg[0];
-    if (line_idx) *line_idx = ac->h_arg[1];
+    ac->res = *ac->h_arg;
+    if (frame_idx) *frame_idx = ac->res.idx[0];
+    if (line_idx) *line_idx = ac->res.idx[1];
     return TSDRGPU_OK;
 }
 
@@ -1071,11 +1227,61 @@ extern "C" int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_id
     return tsdrgpu_autocorr_argmax_result(ac, frame_idx, line_idx);
 }
 
+extern "C" int tsdrgpu_autocorr_certificate(tsdrgpu_autocorr_t *ac, tsdrgpu_ac_certificate_t *out)
+{
+    if (!ac || !out) return TSDRGPU_EINVAL;
+    memset(out, 0, sizeof(*out));
+    out->frame_certified = ac->res.certified[0];
+    out->line_certified = ac->res.certified[1];
+    out->frame_best = ac->res.best[0];
+    out->frame_runner_up = ac->res.second[0];
+    out->line_best = ac->res.best[1];
+    out->line_runner_up = ac->res.second[1];
+    out->r0 = ac->res.r0;
+    out->margin = ac->res.margin;
+    out->exact_epoch = (ac->exact || ac->epoch_exact) ? 1 : 0;
+    out->promotions = ac->promotions;
+    return TSDRGPU_OK;
+}
+
+// Certified argmax in one call: the argmax, and — when the certificate fails — the promotion of the epoch and the argmax
+// of the exact plots.  Synchronises.
+extern "C" int tsdrgpu_autocorr_argmax_certified(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, int32_t *line_idx, int *h_promoted)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    int32_t fi = -1, li = -1;
+    int rc = tsdrgpu_autocorr_argmax(ac, &fi, &li);
+    if (rc) return rc;
+    int promoted = 0;
+    if (ac->certify && !(ac->res.certified[0] && ac->res.certified[1])) {
+        if ((rc = tsdrgpu_autocorr_promote(ac))) return rc;
+        if ((rc = tsdrgpu_autocorr_argmax(ac, &fi, &li))) return rc;
+        promoted = 1;
+    }
+    if (frame_idx) *frame_idx = fi;
+    if (line_idx) *line_idx = li;
+    if (h_promoted) *h_promoted = promoted;
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **d_corr, uint32_t *n)
 {
     if (!ac || !ac->d_last) return TSDRGPU_ESTATE;
     tsdrgpu_t *g = ac->g;
-    if (ac->exact) {  // already n complex values
+    if (!ac->last_exact && ac->certify && ac->log_count > 0) {
+        // certified mode, epoch still in the float32 form: the last window once more in the reference's arithmetic, so that
+        // what a host dumps (dump_autocorrect, frameratedetector.c:64-85) is the reference's bits
+        const AcLogRec &r = ac->log[ac->log_count - 1];
+        int rc = ac_ensure_exact(ac);
+        if (rc) return rc;
+        const float *src = r.src + (size_t)(r.nwindows - 1) * (size_t)r.stride * (r.is_iq ? 2 : 1);
+        if ((rc = fftx_correlate(g, ac->st, src, r.is_iq, r.stride, 1, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag))) return rc;
+        HIP_TRY(g, hipStreamSynchronize(ac->st));
+        if (d_corr) *d_corr = (const float *)ac->d_xz;
+        if (n) *n = ac->n;
+        return TSDRGPU_OK;
+    }
+    if (ac->last_exact) {  // already n complex values
         HIP_TRY(g, hipStreamSynchronize(ac->st));
         if (d_corr) *d_corr = (const float *)ac->d_last;
         if (n) *n = ac->n;
@@ -1097,18 +1303,54 @@ extern "C" int tsdrgpu_autocorr_set_exact(tsdrgpu_autocorr_t *ac, int on)
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     HIP_TRY(g, hipStreamSynchronize(ac->st));
-    if (on && !ac->d_tw) {
-        int rc = fftx_build_table(g, ac->n, &ac->d_tw);
+    if (on) {
+        const int rc = ac_ensure_exact(ac);
         if (rc) return rc;
-        if (hipMalloc(&ac->d_xz, sizeof(float2) * (size_t)ac->n * AC_XBATCH) != hipSuccess ||
-            hipMalloc(&ac->d_xmag, sizeof(float) * (size_t)ac->n * AC_XBATCH) != hipSuccess) {
-            (void)hipFree(ac->d_xz);
-            ac->d_xz = nullptr;
-            return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_set_exact", "work buffers");
-        }
     }
     ac->exact = on ? 1 : 0;
     ac->d_last = nullptr;  // the last correlation is kept in the mode's own layout
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, size_t retain_bytes)
+{
+    if (!ac || mode < 0 || mode > 2) return ac ? tsdr_fail(ac->g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_set_certify", "mode must be 0, 1 or 2") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    HIP_TRY(g, hipStreamSynchronize(ac->st));
+    if (ac->log_count || ac->epoch_exact) {  // mid-epoch: what was run so far can no longer be replayed consistently
+        const int rc = tsdrgpu_autocorr_reset(ac);
+        if (rc) return rc;
+    }
+    (void)hipFree(ac->d_ring);
+    ac->d_ring = nullptr;
+    ac->ring_cap = ac->ring_count = 0;
+    free(ac->log);
+    ac->log = nullptr;
+    ac->log_cap = ac->log_count = 0;
+    ac->certify = 0;
+    if (!mode) return TSDRGPU_OK;
+    int rc = ac_ensure_exact(ac);  // the table is built on the host (tens of ms at 2^22): now, not at the first promotion
+    if (rc) return rc;
+    int cap = 1024;
+    if (mode == 1) {
+        if (retain_bytes == 0) retain_bytes = (size_t)1 << 30;
+        size_t w = retain_bytes / (sizeof(float) * (size_t)ac->n);
+        if (w < 1) w = 1;
+        if (w > 65535) w = 65535;
+        if (hipMalloc(&ac->d_ring, sizeof(float) * (size_t)ac->n * w) != hipSuccess)
+            return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_set_certify", "retention ring");
+        ac->ring_cap = (int)w;
+        if (cap < (int)w) cap = (int)w;
+    }
+    ac->log = (AcLogRec *)malloc(sizeof(AcLogRec) * (size_t)cap);
+    if (!ac->log) {
+        (void)hipFree(ac->d_ring);
+        ac->d_ring = nullptr;
+        ac->ring_cap = 0;
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_set_certify", "log");
+    }
+    ac->log_cap = cap;
+    ac->certify = mode;
     return TSDRGPU_OK;
 }
 

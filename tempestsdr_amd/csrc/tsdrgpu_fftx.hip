@@ -132,14 +132,15 @@ __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src
     }
 }
 
-// accummulate (frameratedetector.c:34-62) on the complex correlation, in window order
+// accummulate (frameratedetector.c:34-62) on the complex correlation, in window order.  Entry frame_len + line_len
+// of `plots` accumulates lag 0 the same way (the scale of the argmax certificate, tsdrgpu_autocorr_certificate).
 __global__ __launch_bounds__(256) void k_fftx_accumulate(const float2 *__restrict__ corr, unsigned n, int nwindows, int frame_lo,
                                                          int frame_len, int line_lo, int line_len, double *__restrict__ plots,
                                                          unsigned long long calls_before, int mode)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= frame_len + line_len) return;
-    const int lag = (i < frame_len) ? (frame_lo + i) : (line_lo + (i - frame_len));
+    if (i > frame_len + line_len) return;
+    const int lag = (i < frame_len) ? (frame_lo + i) : (i < frame_len + line_len ? line_lo + (i - frame_len) : 0);
     double acc = plots[i];
     for (int w = 0; w < nwindows; w++) {
         const float2 v = corr[(long long)w * n + lag];
@@ -153,6 +154,32 @@ __global__ __launch_bounds__(256) void k_fftx_accumulate(const float2 *__restric
         }
     }
     plots[i] = acc;
+}
+
+// The first n samples of `cnt` capture windows as the reference's detector sees them — am_demod
+// (TSDRLibrary.c:244-262) of interleaved IQ, or a copy of magnitudes — into a contiguous ring (n floats per
+// window): what tsdrgpu_autocorr_set_certify(1) retains so that an epoch can be replayed exactly.
+__global__ __launch_bounds__(256) void k_fftx_retain(const float *__restrict__ src, int is_iq, long long stride, unsigned n,
+                                                     float *__restrict__ dst)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long w = blockIdx.y;
+    float v;
+    if (is_iq) {
+        const float2 iq = ((const float2 *)src)[w * stride + i];
+        v = sqrtf(iq.x * iq.x + iq.y * iq.y);
+    } else {
+        v = src[w * stride + i];
+    }
+    dst[w * (long long)n + i] = v;
+}
+
+int fftx_retain(tsdrgpu_t *g, hipStream_t st, const float *src, int is_iq, long long stride, int cnt, uint32_t n, float *dst)
+{
+    TSDR_LAUNCH(g, PROF_DEMOD, st, k_fftx_retain, dim3((n + 255) / 256, cnt), 256, src, is_iq, stride, n, dst);
+    if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "exact FFT", "retain");
+    return TSDRGPU_OK;
 }
 
 // u[q] of every stage, exactly as fft.c:132-165 computes them while it runs
@@ -235,19 +262,27 @@ static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int sr
     return TSDRGPU_OK;
 }
 
-// fft_autocorrelation + accummulate for `cnt` windows, exactly.  z: cnt*n complex, mag: cnt*n floats.
-int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
-                  const double2 *d_tw, float2 *z, float *mag, int frame_lo, int frame_len, int line_lo, int line_len, double *d_plots,
-                  unsigned long long calls_before, int mode)
+// fft_autocorrelation for `cnt` windows, exactly: answer = IFFT( | FFT(x) / N | ), fft.c:49-64.
+// z: cnt*n complex (the result), mag: cnt*n floats.
+int fftx_correlate(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
+                   const double2 *d_tw, float2 *z, float *mag)
 {
     int m = 0;
     while ((1u << m) < n) m++;
     int rc;
     if (m == 0) return tsdr_fail(g, TSDRGPU_EINVAL, "exact FFT", "transform too short");
-    // answer = IFFT( | FFT(x) / N | ), fft.c:49-64
     if ((rc = fftx_transform(g, st, d_in, in_is_iq ? 1 : 0, stride, z, mag, n, m, cnt, d_tw, 0, 1))) return rc;
-    if ((rc = fftx_transform(g, st, mag, 0, (long long)n, z, mag, n, m, cnt, d_tw, 1, 0))) return rc;
-    const int L = frame_len + line_len;
+    return fftx_transform(g, st, mag, 0, (long long)n, z, mag, n, m, cnt, d_tw, 1, 0);
+}
+
+// fft_autocorrelation + accummulate for `cnt` windows, exactly.  z: cnt*n complex, mag: cnt*n floats.
+int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
+                  const double2 *d_tw, float2 *z, float *mag, int frame_lo, int frame_len, int line_lo, int line_len, double *d_plots,
+                  unsigned long long calls_before, int mode)
+{
+    const int rc = fftx_correlate(g, st, d_in, in_is_iq, stride, cnt, n, d_tw, z, mag);
+    if (rc) return rc;
+    const int L = frame_len + line_len + 1;  // + the lag-0 entry
     TSDR_LAUNCH(g, PROF_ACCUMULATE, st, k_fftx_accumulate, (L + 255) / 256, 256, z, n, cnt, frame_lo, frame_len, line_lo, line_len, d_plots,
                 calls_before, mode);
     if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "exact FFT", "accumulate");

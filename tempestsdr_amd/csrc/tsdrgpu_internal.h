@@ -121,4 +121,7 @@ int fftx_build_table(tsdrgpu_t *g, uint32_t n, double2 **d_tw);
 int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
                   const double2 *d_tw, float2 *z, float *mag, int frame_lo, int frame_len, int line_lo, int line_len, double *d_plots,
                   unsigned long long calls_before, int mode);
+int fftx_correlate(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
+                   const double2 *d_tw, float2 *z, float *mag);
+int fftx_retain(tsdrgpu_t *g, hipStream_t st, const float *src, int is_iq, long long stride, int cnt, uint32_t n, float *dst);
 int fftx_perform(tsdrgpu_t *g, hipStream_t st, const float2 *d_z, float2 *d_work, uint32_t n, const double2 *d_tw, int inverse);

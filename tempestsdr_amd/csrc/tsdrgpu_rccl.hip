@@ -133,7 +133,8 @@ extern "C" int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t
     int64_t count = 0;
     int rc = tsdrgpu_autocorr_device_plots(ac, &d_plots, &count);
     if (rc) return rc;
-    rc = tsdrgpu_comm_allreduce_f64(c, d_plots, count, tsdrgpu_autocorr_lane(ac));
+    // + 1: the accumulated lag-0 value behind the plots (the scale of the argmax certificate) sums like the lags
+    rc = tsdrgpu_comm_allreduce_f64(c, d_plots, count + 1, tsdrgpu_autocorr_lane(ac));
     if (rc) return rc;
     return tsdrgpu_autocorr_finalize_sums(ac, total_windows);
 }

@@ -42,6 +42,13 @@ class PlotScale(C.Structure):
                 ("min_value", C.c_double), ("offset_px", C.c_int)]
 
 
+class AcCertificate(C.Structure):
+    """tsdrgpu_ac_certificate_t: the argmax certificate of the certified autocorrelation mode."""
+    _fields_ = [("frame_certified", C.c_int), ("line_certified", C.c_int), ("exact_epoch", C.c_int), ("promotions", C.c_int),
+                ("frame_best", C.c_double), ("frame_runner_up", C.c_double), ("line_best", C.c_double),
+                ("line_runner_up", C.c_double), ("r0", C.c_double), ("margin", C.c_double)]
+
+
 class PPFrameInfo(C.Structure):
     _fields_ = [("lastmin", C.c_float), ("lastmax", C.c_float),
                 ("dx", C.c_int), ("vx", C.c_int), ("stripx", C.c_int),
@@ -137,6 +144,10 @@ _SIGS = {
     "tsdrgpu_autocorr_argmax_result": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdrgpu_autocorr_argmax": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdrgpu_autocorr_last_corr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]),
+    "tsdrgpu_autocorr_set_certify": (C.c_int, [vp, C.c_int, C.c_size_t]),
+    "tsdrgpu_autocorr_promote": (C.c_int, [vp]),
+    "tsdrgpu_autocorr_certificate": (C.c_int, [vp, vp]),
+    "tsdrgpu_autocorr_argmax_certified": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     "tsdrgpu_superb_stitch": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     "tsdrgpu_superb_stitch_exact": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp,
@@ -582,6 +593,24 @@ class Autocorr:
     def set_exact(self, on=True):
         """The reference's own FFT arithmetic: plots / argmax / last_corr bit-identical (slower)."""
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_set_exact(self.h, int(on)))
+
+    def set_certify(self, mode=1, retain_bytes=0):
+        """Certified mode (tsdrgpu_autocorr_set_certify): 1 = the library retains the windows, 2 = the caller does."""
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_set_certify(self.h, int(mode), int(retain_bytes)))
+
+    def promote(self):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_promote(self.h))
+
+    def certificate(self):
+        c = AcCertificate()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_certificate(self.h, C.byref(c)))
+        return c
+
+    def argmax_certified(self):
+        """(frame_idx, line_idx, promoted): the argmax pair that is provably the reference's."""
+        a, b, p = C.c_int32(), C.c_int32(), C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_argmax_certified(self.h, C.byref(a), C.byref(b), C.byref(p)))
+        return a.value, b.value, p.value
 
     def set_plan(self, trips):
         """3: three-trip (four-step) transform plan where it applies (default); 5: the round-1 Stockham plan."""

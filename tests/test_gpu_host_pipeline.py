@@ -40,6 +40,22 @@ def oracle_frames(orc, mag_stream_iq, geo, cfg=(0.0, 0, 0, 0, 0), first_pixel=0)
     return out
 
 
+def oracle_plots(orc, iq, fs, calls):
+    """the oracle's running-mean plots after `calls` consecutive capture windows of the stream"""
+    ac = orc.Autocorr(fs)
+    cap = orc.capture_size(fs)
+    for k in range(calls):
+        ac.run(orc.am_demod(iq[2 * k * cap:2 * (k + 1) * cap]))
+    return ac
+
+
+def first_plot_calls(s):
+    """VALUE_ID_AUTOCORRECT_FRAMES_COUNT announced with the first plot pair (frameratedetector.c:121-126)"""
+    counts = [v for v in s.values if v[0] == 2]
+    assert counts and counts[0][2] >= 1.0
+    return int(counts[0][2])
+
+
 def match_in_order(got, want):
     """every delivered frame equals an oracle frame, in increasing order (the
     video queue may drop frames when the Python callback is slow)"""
@@ -97,21 +113,20 @@ def test_pipeline_matches_oracle(orc, iq_file, cfg):
     frame_plots = [p for p in s.plots if p[0] == 0]
     line_plots = [p for p in s.plots if p[0] == 1]
     assert frame_plots and line_plots
-    ac = orc.Autocorr(FS)
-    ac.run(orc.am_demod(iq)[:orc.capture_size(FS)])
+    # The library's default detector is the CERTIFIED mode.  At this rate the frame-lag window straddles N/2 and
+    # R[j] == R[N-j] mathematically, so no float32 plot can be certified: the first plot is held back, the epoch is
+    # replayed in the reference's own arithmetic and what is delivered — the running mean over the windows correlated
+    # by then — is the oracle's bit for bit, argmax across the tie included.
+    calls = first_plot_calls(s)
+    ac = oracle_plots(orc, iq, FS, calls)
     pid, off, vals, rate = frame_plots[0]
     assert (off, vals.size, rate) == (ac.flo, ac.flen, FS)
-    # the library's default is the contract-exact mode: the detector's transforms run in the reference's own
-    # arithmetic, so the plots and their argmax are the oracle's bit for bit — also across this rate's tie (the
-    # frame-lag window straddles N/2, and R[j] == R[N-j] mathematically, so rounding picks the winner)
     assert np.array_equal(vals, ac.frame) and np.array_equal(line_plots[0][2], ac.line)
     assert int(np.argmax(vals)) == int(np.argmax(ac.frame))
     lag = ac.flo + int(np.argmax(vals))
     n = orc.lib.orc_fft_getrealsize(orc.capture_size(FS))
     assert min(abs(lag - FS / 60.0), abs((n - lag) - FS / 60.0)) <= 1.0
     assert (line_plots[0][1], line_plots[0][2].size) == (ac.llo, ac.llen)
-    counts = [v for v in s.values if v[0] == 2]
-    assert counts and counts[0][2] == 1.0  # VALUE_ID_AUTOCORRECT_FRAMES_COUNT, first window
     assert any(v[0] == 3 for v in s.values) or len(s.frames) < 7  # autogain report every 7th frame
     s.close()
 
@@ -411,8 +426,7 @@ def test_pipeline_mem_plugin_matches_oracle(orc, iq_file, monkeypatch, zerocopy)
     assert ok and rc == 0 and s.status == 0, s.err()
     hits = match_in_order(s.frames, want)
     assert hits[0] == 0 and len(hits) >= len(want) - 4
-    ac = orc.Autocorr(FS)
-    ac.run(orc.am_demod(iq)[:orc.capture_size(FS)])
+    ac = oracle_plots(orc, iq, FS, first_plot_calls(s))  # (certified default: held back, replayed exactly — see above)
     frame_plots = [p for p in s.plots if p[0] == 0]
     assert frame_plots and np.array_equal(frame_plots[0][2], ac.frame)
     s.close()
@@ -505,11 +519,15 @@ def test_pipeline_fast_modes_opt_out(orc, iq_file, monkeypatch):
     s.close()
 
 
-def test_pipeline_headline_config_matches_oracle(orc, tmp_path):
+@pytest.mark.parametrize("detector", ["certified", "exact"])
+def test_pipeline_headline_config_matches_oracle(orc, tmp_path, monkeypatch, detector):
     """BASELINE configs[2] through the tsdr_* API: 0.3 s of the 100 MS/s 1080p60 stream (h = 1125 -> 2962x1125
     frames) in RawFile-sized blocks; every delivered frame is the oracle driver's bit for bit, in order from the
-    first, and the first plots (one 2^22-sample window) are the oracle's exactly, argmax included."""
+    first.  The detector runs in its default, CERTIFIED mode: on this raster the float32 plots carry a certificate,
+    so they leave as they are — within 1e-4*max of the oracle's with the IDENTICAL argmax lag in both plots (SURVEY
+    8(d)); with TSDR_GPU_AUTOCORR=exact they are the oracle's bits."""
     fs, h, fv = 100_000_000, 1125, 60.0
+    monkeypatch.setenv("TSDR_GPU_AUTOCORR", detector)
     geo = orc.geometry(fs, h, fv)
     assert (geo.width, geo.height) == (2962, 1125)
     nsamp = 114 * (BLOCK // 2)  # 0.299 s
@@ -528,14 +546,17 @@ def test_pipeline_headline_config_matches_oracle(orc, tmp_path):
     assert all((w_, h_) == (geo.width, h) for (w_, h_, _) in s.frames)
     hits = match_in_order(s.frames, want)
     assert hits[0] == 0 and len(hits) >= len(want) - 4
-    ac = orc.Autocorr(fs)
-    ac.run(orc.am_demod(iq[:2 * orc.capture_size(fs)]))
+    ac = oracle_plots(orc, iq, fs, first_plot_calls(s))
     frame_plots = [p for p in s.plots if p[0] == 0]
     line_plots = [p for p in s.plots if p[0] == 1]
     assert frame_plots and line_plots
     assert (frame_plots[0][1], frame_plots[0][3]) == (ac.flo, fs)
-    assert np.array_equal(frame_plots[0][2], ac.frame) and np.array_equal(line_plots[0][2], ac.line)
-    flag = ac.flo + int(np.argmax(frame_plots[0][2]))
+    fp, lp = frame_plots[0][2], line_plots[0][2]
+    if detector == "exact":
+        assert np.array_equal(fp, ac.frame) and np.array_equal(lp, ac.line)
+    assert np.max(np.abs(fp - ac.frame)) <= 1e-4 * np.max(ac.frame) and np.max(np.abs(lp - ac.line)) <= 1e-4 * np.max(ac.line)
+    assert int(np.argmax(fp)) == int(np.argmax(ac.frame)) and int(np.argmax(lp)) == int(np.argmax(ac.line))
+    flag = ac.flo + int(np.argmax(fp))
     assert abs(flag - fs / fv) <= 1.0  # detected frame lag = the true frame period
     s.close()
 
