@@ -43,6 +43,17 @@ int tsdrx_readasync_rgb(tsdr_lib_t *tsdr, tsdrx_readasync_rgb_function cb, void 
 #define TSDRX_SAMPLE_UINT16 4
 typedef void (*tsdrplugin_readasync_raw_function)(const void *buf, uint64_t items_count, int sample_type, void *ctx, int64_t samples_dropped);
 
+/* Optional plugin entry point:
+ *     int tsdrplugin_memory_stable(void);
+ * A source plugin that exports it and returns non-zero PROMISES that every buffer it hands to the callbacks lies in
+ * memory that stays allocated, mapped and at the same address from the moment it first appears until
+ * tsdrplugin_cleanup (or the next tsdrplugin_init) — a recording held in memory, one ring allocated at init.  Only
+ * then does the library page-lock the plugin's memory and DMA straight out of it (the ranges are unlocked after
+ * tsdrplugin_readasync has returned, before anything can call cleanup/init).  Without the promise every block is
+ * copied through the library's own pinned buffers, which is what the plugin ABI guarantees to be safe: the
+ * reference's plugins (RawFile, Mirics, SDRplay) free their buffer INSIDE tsdrplugin_readasync, before it returns.
+ * TSDR_GPU_ZEROCOPY=0 disables the direct path, =1 forces it for a plugin the user knows to be stable. */
+
 #ifdef __cplusplus
 }
 #endif

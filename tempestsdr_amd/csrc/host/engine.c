@@ -39,6 +39,7 @@
 #define NOUT 6             /* post-processed batches whose frames may still be downloading */
 #define MAX_FRAME_BATCH 16
 #define MAX_HOSTREG 512    /* page-locked ranges of plugin memory */
+#define MAX_HOSTREJ 16     /* ranges that could not be page-locked, remembered so that the call is not repeated */
 #define NORMALISATION_LOWPASS_COEFF (0.1f) /* TSDRLibrary.c:37 */
 #define FRAMES_TO_POLL (0.1)               /* TSDRLibrary.c:41 */
 #define AUTOGAIN_REPORT_EVERY_FRAMES (5)   /* dsp.c:20 */
@@ -126,6 +127,8 @@ struct engine {
     int zero_copy;
     struct { char *p; size_t n; } reg[MAX_HOSTREG];
     int nreg;
+    struct { char *p; size_t n; } rej[MAX_HOSTREJ]; /* ranges hipHostRegister refused */
+    int nrej;
 
     devstream_t iq;   /* samples for the resampler (interleaved IQ; magnitude in super mode) */
     int iq_is_mag;
@@ -263,9 +266,12 @@ static int ensure_dev(struct engine *e, float **buf, size_t *cap, size_t need)
 }
 
 /* ---- plugin thread -------------------------------------------------------------- */
-/* Is [p, p+n) page-locked for DMA?  Plugins hand over the same buffer (RawFile, UHD) or blocks of one region
- * (file replays) again and again, so ranges are registered on first sight and remembered; anything that cannot
- * be registered (or overlaps a registered range only partly) goes through the slot's pinned bounce buffer. */
+/* Is [p, p+n) page-locked for DMA?  Only asked for plugins whose memory is stable (tsdrplugin_memory_stable,
+ * include/TSDRLibraryExt.h: a range, once seen, stays allocated and mapped until after tsdrplugin_readasync has
+ * returned — which is when the ranges are unlocked again).  Such plugins hand over blocks of one region again and
+ * again, so ranges are registered on first sight and remembered; what cannot be registered is remembered too (the
+ * failing call is not repeated for every block), and anything that overlaps a known range only partly goes through
+ * the slot's pinned bounce buffer, like every block of a plugin that made no promise. */
 static int plugin_memory_pinned(struct engine *e, void *p, size_t n)
 {
     if (!e->zero_copy) return 0;
@@ -274,9 +280,12 @@ static int plugin_memory_pinned(struct engine *e, void *p, size_t n)
         if (c >= e->reg[i].p && c + n <= e->reg[i].p + e->reg[i].n) return 1;
         if (c < e->reg[i].p + e->reg[i].n && e->reg[i].p < c + n) return 0; /* partial overlap */
     }
+    for (int i = 0; i < e->nrej; i++)
+        if (c < e->rej[i].p + e->rej[i].n && e->rej[i].p < c + n) return 0; /* refused before */
     if (e->nreg == MAX_HOSTREG) return 0;
     if (tsdrgpu_host_register(e->g, p, n)) {
-        if (e->nreg == 0) e->zero_copy = 0; /* the very first attempt failed: this memory cannot be page-locked */
+        if (e->nreg == 0 || e->nrej == MAX_HOSTREJ) e->zero_copy = 0; /* this plugin's memory cannot be page-locked: stop trying */
+        else { e->rej[e->nrej].p = c; e->rej[e->nrej].n = n; e->nrej++; }
         return 0;
     }
     e->reg[e->nreg].p = c;
@@ -1117,9 +1126,11 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
         e->stats = st && st[0] == '1';
         e->t_start = now_s();
     }
-    {   /* TSDR_GPU_ZEROCOPY=0: always go through the pinned bounce buffers */
+    {   /* DMA straight out of the plugin's memory only when the plugin promises that it is stable
+         * (tsdrplugin_memory_stable, include/TSDRLibraryExt.h); TSDR_GPU_ZEROCOPY=0 / =1 override */
         const char *z = getenv("TSDR_GPU_ZEROCOPY");
-        e->zero_copy = !(z && z[0] == '0');
+        if (z && (z[0] == '0' || z[0] == '1')) e->zero_copy = z[0] == '1';
+        else e->zero_copy = t->plugin.memory_stable && t->plugin.memory_stable() != 0;
     }
     pthread_mutex_init(&e->qm, NULL); pthread_cond_init(&e->q_nonempty, NULL);
     pthread_mutex_init(&e->fm, NULL); pthread_cond_init(&e->f_nonempty, NULL); pthread_cond_init(&e->f_queued, NULL);
@@ -1171,7 +1182,10 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD);
     tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_DOWNLOAD);
     if (e->super_state != SUPER_STOPPED && t->plugin.loaded) t->plugin.setbasefreq(t->centfreq);
-    for (int i = 0; i < e->nreg; i++) tsdrgpu_host_unregister(e->g, e->reg[i].p); /* before the plugin frees its memory */
+    /* tsdrplugin_readasync has returned and every DMA out of the plugin's memory is complete (UPLOAD lane drained
+     * above): the ranges are unlocked now, before anything can reach tsdrplugin_cleanup / tsdrplugin_init — the memory
+     * of a plugin that promised stability (tsdrplugin_memory_stable) is still allocated here */
+    for (int i = 0; i < e->nreg; i++) tsdrgpu_host_unregister(e->g, e->reg[i].p);
     for (int i = 0; i < NSLOT; i++) {
         tsdrgpu_free_host(e->g, e->slot[i].h);
         tsdrgpu_free(e->g, e->slot[i].d);

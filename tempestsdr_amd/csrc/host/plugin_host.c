@@ -38,6 +38,7 @@ int plugin_host_load(plugin_host_t *p, const char *path)
         }
     }
     p->readasync_raw = (int (*)(tsdrplugin_readasync_raw_function, void *))dlsym(p->dl, "tsdrplugin_readasync_raw"); /* optional */
+    p->memory_stable = (int (*)(void))dlsym(p->dl, "tsdrplugin_memory_stable"); /* optional */
     p->loaded = 1;
     return TSDR_OK;
 }

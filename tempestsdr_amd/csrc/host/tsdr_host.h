@@ -33,6 +33,7 @@ typedef struct plugin_host {
     int (*readasync)(tsdrplugin_readasync_function, void *);
     void (*cleanup)(void);
     int (*readasync_raw)(tsdrplugin_readasync_raw_function, void *); /* optional extension, NULL when absent */
+    int (*memory_stable)(void);                                      /* optional extension (TSDRLibraryExt.h), NULL when absent */
 } plugin_host_t;
 
 int plugin_host_load(plugin_host_t *p, const char *path); /* TSDR_OK / TSDR_INCOMPATIBLE_PLUGIN / TSDR_ERR_PLUGIN */

@@ -25,6 +25,7 @@ static uint32_t g_rate;
 static long g_block = 524288, g_loops = 0, g_sleep = 0;
 static volatile int g_working;
 static void *g_data;
+static float *g_conv;   /* one block converted to float for the plain callback (narrow formats only) */
 static size_t g_floats; /* values (two per IQ sample) */
 static int g_type = TSDRX_SAMPLE_FLOAT32;
 static size_t g_elem = 4;
@@ -36,7 +37,9 @@ void tsdrplugin_getName(char *name) { strcpy(name, "TSDR in-memory IQ replay"); 
 static void unload(void)
 {
     free(g_data);
+    free(g_conv);
     g_data = NULL;
+    g_conv = NULL;
     g_floats = 0;
 }
 
@@ -80,8 +83,18 @@ int tsdrplugin_init(const char *params)
         return g_errcode = TSDR_PLUGIN_PARAMETERS_WRONG;
     }
     fclose(f);
+    /* everything the callbacks will ever point at exists from here until tsdrplugin_cleanup (tsdrplugin_memory_stable) */
+    if (g_type != TSDRX_SAMPLE_FLOAT32 && !(g_conv = (float *)malloc(sizeof(float) * (size_t)g_block))) {
+        unload();
+        snprintf(g_err, sizeof(g_err), "out of memory");
+        return g_errcode = TSDR_ERR_PLUGIN;
+    }
     return g_errcode = TSDR_OK;
 }
+
+/* include/TSDRLibraryExt.h: the recording (and the conversion block) stay where they are from tsdrplugin_init to
+ * tsdrplugin_cleanup, so the library may page-lock them and DMA straight out of them */
+TSDRPLUGIN_API int tsdrplugin_memory_stable(void) { return 1; }
 
 uint32_t tsdrplugin_setsamplerate(uint32_t rate) { (void)rate; return g_rate; }
 uint32_t tsdrplugin_getsamplerate(void) { return g_rate; }
@@ -117,11 +130,7 @@ int tsdrplugin_readasync(tsdrplugin_readasync_function cb, void *ctx)
     }
     g_working = 1;
     const size_t blocks = g_floats / (size_t)g_block;
-    float *conv = NULL; /* narrow formats: converted per block like TSDRPlugin_RawFile.c:241-261 */
-    if (g_type != TSDRX_SAMPLE_FLOAT32 && !(conv = (float *)malloc(sizeof(float) * (size_t)g_block))) {
-        snprintf(g_err, sizeof(g_err), "out of memory");
-        return g_errcode = TSDR_ERR_PLUGIN;
-    }
+    float *conv = g_conv; /* narrow formats: converted per block like TSDRPlugin_RawFile.c:241-261 */
     for (long pass = 0; g_working && (g_loops == 0 || pass < g_loops); pass++)
         for (size_t b = 0; b < blocks && g_working; b++) {
             const size_t at = b * (size_t)g_block;
@@ -139,6 +148,5 @@ int tsdrplugin_readasync(tsdrplugin_readasync_function cb, void *ctx)
             if (g_sleep > 0) usleep((useconds_t)g_sleep);
         }
     while (g_working) usleep(2000); /* idle like a live source until stopped */
-    free(conv);
     return g_errcode = TSDR_OK;
 }
