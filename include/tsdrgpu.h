@@ -18,7 +18,7 @@
  * autocorrelation windows per call.
  *
  * Return value: 0 (TSDRGPU_OK) or a negative TSDRGPU_E* code;
- * tsdrgpu_last_error() gives the text.  There is no CPU fallback: without a
+ * tsdrgpu_last_error() gives the text of the CALLING THREAD's last failing call.  There is no CPU fallback: without a
  * HIP device tsdrgpu_create() fails.
  */
 #ifndef TSDRGPU_H_

@@ -159,6 +159,8 @@ struct engine {
     pthread_cond_t p_nonempty;
 
     volatile int alive; /* delivery threads keep going */
+    volatile int failed; /* a device call failed: the session is being torn down (gpu_ok) */
+    char fail_msg[400];
 
     /* TSDR_GPU_STATS=1: where the host threads spend their time (printed to stderr when the run ends) */
     int stats;
@@ -190,10 +192,18 @@ static int exact_wanted(const char *name)
     return 1;
 }
 
+/* A failing device call ends the session: the first failure is remembered, the workers stop, the plugin is told to
+ * stop, and tsdr_readasync returns TSDR_CANNOT_OPEN_DEVICE with this text (the reference surfaces its failures the
+ * same way, through the return value of tsdr_readasync and tsdr_getlasterrortext).  Nothing is retried. */
 static int gpu_ok(struct engine *e, int rc, const char *what)
 {
     if (rc == 0) return 1;
-    fprintf(stderr, "tsdr: %s failed (%d): %s\n", what, rc, tsdrgpu_last_error(e->g));
+    if (!__sync_lock_test_and_set(&e->failed, 1)) {
+        snprintf(e->fail_msg, sizeof(e->fail_msg), "GPU stage '%s' failed (%d): %s", what, rc, tsdrgpu_last_error(e->g));
+        fprintf(stderr, "tsdr: %s\n", e->fail_msg);
+        e->t->running = 0;
+        if (e->t->plugin.loaded && e->t->plugin.stop) e->t->plugin.stop();
+    }
     return 0;
 }
 
@@ -226,11 +236,16 @@ static int stream_reserve(struct engine *e, devstream_t *s, size_t extra)
      * end, so the slack behind the live part sets how often that copy happens (HBM is not the scarce resource) */
     size_t cap = need * 4 + ((size_t)16 << 20);
     float *n1 = NULL, *n2 = NULL;
-    if (tsdrgpu_alloc(e->g, (void **)&n1, cap * sizeof(float)) || tsdrgpu_alloc(e->g, (void **)&n2, cap * sizeof(float))) {
+    if (!gpu_ok(e, tsdrgpu_alloc(e->g, (void **)&n1, cap * sizeof(float)), "stream buffer") ||
+        !gpu_ok(e, tsdrgpu_alloc(e->g, (void **)&n2, cap * sizeof(float)), "stream buffer")) {
         tsdrgpu_free(e->g, n1);
         return 0;
     }
-    if (live && !gpu_ok(e, tsdrgpu_copy(e->g, n1, s->d + s->rd, live * sizeof(float)), "grow")) return 0;
+    if (live && !gpu_ok(e, tsdrgpu_copy(e->g, n1, s->d + s->rd, live * sizeof(float)), "grow")) {
+        tsdrgpu_free(e->g, n1);
+        tsdrgpu_free(e->g, n2);
+        return 0;
+    }
     tsdrgpu_sync(e->g);
     tsdrgpu_free(e->g, s->d);
     tsdrgpu_free(e->g, s->d_alt);
@@ -1221,7 +1236,11 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     pthread_mutex_destroy(&e->fm); pthread_cond_destroy(&e->f_nonempty); pthread_cond_destroy(&e->f_queued);
     pthread_mutex_destroy(&e->pm); pthread_cond_destroy(&e->p_nonempty);
     t->eng = NULL;
+    const int failed = e->failed;
+    char fail_msg[400];
+    memcpy(fail_msg, e->fail_msg, sizeof(fail_msg));
     free(e);
+    if (failed) return tsdr_set_error(t, TSDR_CANNOT_OPEN_DEVICE, fail_msg);
     if (status != TSDR_OK) return tsdr_set_error(t, status, t->plugin.getlasterrortext());
     t->errormsg_code = TSDR_OK;
     return TSDR_OK;

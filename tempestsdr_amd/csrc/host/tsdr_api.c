@@ -66,6 +66,12 @@ void tsdr_init(tsdr_lib_t **out, tsdr_value_changed_callback callback, tsdr_on_p
     tsdr_lib_t *t = (tsdr_lib_t *)calloc(1, sizeof(*t));
     *out = t;
     if (!t) return;
+    {   /* Opt-in: TSDR_GPU_HW_QUEUES=n is forwarded to the HIP runtime as GPU_MAX_HW_QUEUES (read at the process's
+         * first HIP call; 2 is the streaming optimum, tsdrgpu_core.hip) unless the host chose a value itself.  Nothing
+         * is changed without it: a library must not reconfigure its host process behind its back. */
+        const char *q = getenv("TSDR_GPU_HW_QUEUES");
+        if (q && q[0] >= '1' && q[0] <= '9') setenv("GPU_MAX_HW_QUEUES", q, 0);
+    }
     t->callback = callback;
     t->plotready_callback = plotready_callback;
     t->callbackctx = ctx;

@@ -7,14 +7,21 @@
 // ---------------------------------------------------------------------------
 // context / memory
 // ---------------------------------------------------------------------------
-// The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 by default).  The streaming
-// engine keeps three lanes busy at once (COMPUTE, UPLOAD, DOWNLOAD); measured on MI355X through the tsdr_* API it
-// sustains 5.0-5.1 GS/s when they share two hardware queues and 3.6 GS/s (1.8-2.4 before the host-side waits of
-// engine.c) when each lane has a queue of its own: with more queues active, the command processor's switching between
-// them adds tens of microseconds to every small kernel of the frame path.  So, unless the host application has
-// chosen a value itself, the library asks for two before the runtime starts (the variable is read when the runtime
-// initialises, i.e. at the process's first HIP call).
-__attribute__((constructor)) static void tsdrgpu_runtime_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "2", 0); }
+// Hardware queues.  The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 by default,
+// read when the runtime initialises, i.e. at the process's first HIP call).  The streaming engine keeps three lanes
+// busy at once (COMPUTE, UPLOAD, DOWNLOAD); measured on MI355X through the tsdr_* API it sustains 5.0-5.1 GS/s when
+// they share two hardware queues and 1.8-3.6 GS/s when each lane has a queue of its own (with more queues active the
+// command processor's switching between them adds tens of microseconds to every small kernel of the frame path).
+// This library does NOT touch the process environment: a launcher that wants the streaming optimum exports
+// GPU_MAX_HW_QUEUES=2 before the process starts (tempestsdr_amd/tsdrlib.py and bench.py's e2e leg do), or sets
+// TSDR_GPU_HW_QUEUES=2, which libTSDRLibrary.so's tsdr_init forwards if the host has not chosen a value (host/tsdr_api.c).
+
+// the text of the calling thread's last failing call (the engine drives one context from five threads)
+char *tsdr_errbuf(void)
+{
+    static thread_local char buf[512];
+    return buf;
+}
 
 extern "C" int tsdrgpu_create(tsdrgpu_t **out, int device)
 {
@@ -75,7 +82,7 @@ extern "C" void tsdrgpu_destroy(tsdrgpu_t *g)
     free(g);
 }
 
-extern "C" const char *tsdrgpu_last_error(tsdrgpu_t *g) { return g ? g->err : "no context"; }
+extern "C" const char *tsdrgpu_last_error(tsdrgpu_t *g) { return g ? tsdr_errbuf() : "no context"; }
 extern "C" void *tsdrgpu_stream(tsdrgpu_t *g) { return g ? (void *)g->stream : nullptr; }
 
 extern "C" int tsdrgpu_sync(tsdrgpu_t *g)

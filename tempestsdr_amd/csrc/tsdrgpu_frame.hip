@@ -1615,7 +1615,10 @@ static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long
     static const int serial_only = getenv("TSDRGPU_PASS_SERIAL") ? 1 : 0;
     const bool iir = (flags & PASS_IIR) != 0;
     const int *gate = nullptr;
-    if (!serial_only && F >= 8 && (!iir || a == 0.0f)) {
+    // (with the IIR the frame-parallel form may be redone literally from `src` behind it, so `src` must still hold the
+    // raw frames then: a run whose output overlaps its input takes the literal form at once)
+    const bool overlap = (const float *)dst < src + (long long)F * sstride && src < (const float *)dst + (long long)F * dstride;
+    if (!serial_only && F >= 8 && (!iir || (a == 0.0f && !overlap))) {
         pass_par_fn pf = pick_pass_par(flags);
         if (!pf) return tsdr_fail(g, TSDRGPU_EINVAL, "k_frame_pass_par", "unsupported flag combination");
         if (iir) {

@@ -44,7 +44,6 @@ struct tsdrgpu {
     hipStream_t bg;       // background lane, lowest priority: an asynchronous autocorrelation fills the gaps of the frame path
     hipEvent_t fork;      // orders stream2 behind what is already queued on `stream`
     hipEvent_t t0, t1;
-    char err[512];
     hipDeviceProp_t prop;
     // scratch kept between calls of tsdrgpu_fft (grown on demand)
     void *fft_ws;
@@ -71,9 +70,12 @@ hipStream_t tsdr_lane_stream(tsdrgpu_t *g, int lane);
         hipExtLaunchKernelGGL(kernel_, dim3(grid_), dim3(block_), 0, (stream_), pa_, pb_, 0, __VA_ARGS__);  \
     } while (0)
 
+// Error text is kept per host thread (tsdrgpu_last_error returns the calling thread's): several threads may drive one
+// context, each on its own lane, and a failing call on one must not garble what another is reading.
+char *tsdr_errbuf(void);
 static inline int tsdr_fail(tsdrgpu_t *g, int code, const char *what, const char *detail)
 {
-    if (g) snprintf(g->err, sizeof(g->err), "%s: %s", what, detail ? detail : "");
+    if (g) snprintf(tsdr_errbuf(), 512, "%s: %s", what, detail ? detail : "");
     return code;
 }
 

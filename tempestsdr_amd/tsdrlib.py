@@ -93,13 +93,15 @@ def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, set
 
 
 def throughput_subprocess(libpath, plugin, params, height, fv, seconds, env=None, timeout=120, set_int=(), free=True):
-    """throughput_run in a process of its own — what a host application is: the library there picks the HIP runtime
-    settings it wants (tsdrgpu_core.hip: two hardware queues) instead of inheriting the caller's."""
+    """throughput_run in a process of its own — what a host application is — started with GPU_MAX_HW_QUEUES=2 like a
+    launcher script would (tsdrgpu_core.hip says why) instead of inheriting the caller's runtime state."""
     import json
     import subprocess
     import sys
     e = dict(os.environ)
-    e.pop("GPU_MAX_HW_QUEUES", None)
+    # the launcher's job (the library does not touch its host's environment): two hardware queues are the streaming
+    # optimum on MI355X (tsdrgpu_core.hip); a caller's env overrides
+    e["GPU_MAX_HW_QUEUES"] = "2"
     e.update(env or {})
     extra = ["free" if free else "nofree"] + [str(v) for pair in set_int for v in pair]  # tsdr_setparameter_int(id, value) pairs
     out = subprocess.run([sys.executable, "-m", "tempestsdr_amd.tsdrlib", libpath, plugin, params, str(height), str(fv), str(seconds)] + extra,

@@ -67,8 +67,8 @@ def test_three_trip_autocorrelation_matches_numpy(emu, logn1, iq, cnt):
 
 
 def test_three_trip_lag_window_filter(emu):
-    """Trip 3 stores only the two lag windows (complex point m holds lags 2m, 2m+1), except for the window
-    that is kept whole for tsdrgpu_autocorr_last_corr."""
+    """Trip 3 stores only the two lag windows (complex point m holds lags 2m, 2m+1) and point 0 (lag 0, the scale
+    of the argmax certificate), except for the window that is kept whole for tsdrgpu_autocorr_last_corr."""
     logn1, cnt = 4, 2
     nh = 4096 << logn1
     n = 2 * nh
@@ -84,5 +84,6 @@ def test_three_trip_lag_window_filter(emu):
     keep = np.zeros(nh, bool)
     keep[lo0:hi0] = True
     keep[lo1:hi1] = True
+    keep[0] = True
     assert np.array_equal(p0[keep], f0[keep]) and np.all(p0[~keep] == -7.0)
     assert np.array_equal(part[n:], full[n:])  # window 1 == full_b: stored whole

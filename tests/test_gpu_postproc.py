@@ -403,15 +403,19 @@ def test_exact_ties_resolve_a_toss_up(orc):
 
 @pytest.mark.parametrize("cfg", [(0, 0, 0, 0, 0.0), (1, 0, 0, 0, 0.0), (1, 1, 0, 0, 0.0), (0, 1, 1, 0, 0.0)])
 @pytest.mark.parametrize("negzero", [0, 1])
-def test_frame_parallel_pass_and_its_literal_redo(orc, cfg, negzero):
+@pytest.mark.parametrize("odd", [0, 1])
+def test_frame_parallel_pass_and_its_literal_redo(orc, cfg, negzero, odd):
     """Motion blur 0 and batches of >= 8 frames take the frame-parallel pass (k_frame_pass_par): a frame's output does
     not depend on the previous frame's as long as the IIR state is finite and no output is -0.0.  A -0.0 pixel (the
     reference's s*a + v*(1-a) turns it into +0.0 when it reaches the IIR unnormalised) must raise the flag, and the
     batch then comes out of the gated frame-by-frame kernel instead: the oracle's frames bit for bit either way, the
     sign of zero included.  (Non-finite samples raise the same flag; they are not driven through the whole chain here
-    because the reference's own float -> int conversions are undefined for them.)"""
+    because the reference's own float -> int conversions are undefined for them.)
+    odd = 1: frames of an odd number of pixels (511 x 131) in buffers that start one float past a 16-byte boundary —
+    both passes move a lane's four pixels as one dwordx4 that only claims float alignment, and gfx950's global memory
+    path takes it (the engine's pixel stream holds frames at such offsets all the time)."""
     g = ctx()
-    fs, h, fv = 2_000_000, 131, 60.0
+    fs, h, fv = (2_010_000 if odd else 2_000_000), 131, 60.0
     geo = orc.geometry(fs, h, fv)
     w = geo.width
     n = w * h
@@ -423,12 +427,13 @@ def test_frame_parallel_pass_and_its_literal_redo(orc, cfg, negzero):
     want, states, _ = run_orc(orc, frames, fs, h, fv, cfg)
     lbs, aap, ash, pll, mb = cfg
     pp = gpu.PostProcess(g)
-    d_in = g.to_device(np.concatenate(frames))
-    d_out = g.empty(len(frames) * n)
+    assert (n % 2 == 1) == bool(odd)
+    d_in = g.to_device(np.concatenate([np.zeros(odd, np.float32)] + frames))
+    d_out = g.empty(len(frames) * n + odd)
     infos = []
     for s, k in ((0, 4), (4, 12), (16, 8)):  # a short batch, then two that take the frame-parallel pass
-        infos += pp.run(d_in, k, w, h, d_out, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * n, out_offset=s * n)
-    got = d_out.download().reshape(len(frames), n)
+        infos += pp.run(d_in, k, w, h, d_out, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * n + odd, out_offset=s * n + odd)
+    got = d_out.download()[odd:].reshape(len(frames), n)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # bit patterns: the sign of zero too
     for k, (info, (si, sd)) in enumerate(zip(infos, states)):
         assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) == tuple(si[:7]), f"frame {k}"
