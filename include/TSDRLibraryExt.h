@@ -30,6 +30,17 @@ typedef void (*tsdrx_readasync_rgb_function)(int32_t *pixels, int width, int hei
  * (Java_martin_tempest_core_TSDRLibrary_setInvertedColors).  Same blocking / error behaviour as tsdr_readasync. */
 int tsdrx_readasync_rgb(tsdr_lib_t *tsdr, tsdrx_readasync_rgb_function cb, void *ctx, int inverted);
 
+/* Counters of the tsdr_readasync session that is running, or of the last one that ended: what went in, what came
+ * out, what the (lossy by design, like the reference's rings) queues dropped, and how the detector's certified mode
+ * fared.  A host that must not lose frames checks frames_lost_to_viewer == 0. */
+typedef struct tsdrx_stats {
+    int64_t blocks_in, blocks_lost;              /* plugin callbacks taken / dropped because the input queue was full */
+    int64_t frames_made, frames_lost_to_viewer;  /* frames post-processed / not delivered because the viewer was slower */
+    int64_t windows;                             /* capture windows correlated */
+    int64_t plots_held, epochs_replayed;         /* certified detector: plots held back / epochs replayed exactly */
+} tsdrx_stats_t;
+int tsdrx_get_stats(tsdr_lib_t *tsdr, tsdrx_stats_t *out);
+
 /* Sample formats of the optional raw plugin entry point, numbered like tsdrgpu_decode_samples:
  *     int tsdrplugin_readasync_raw(tsdrplugin_readasync_raw_function cb, void *ctx);
  * A source plugin that exports it (besides the ten mandatory tsdrplugin_* symbols) hands its blocks over in their

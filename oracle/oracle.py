@@ -299,6 +299,7 @@ def ref():
     _sig(r.ref_resampler_process, C.c_uint32, C.c_void_p, f32p, C.c_uint32, f32p, C.c_double,
          C.c_double, C.c_int)
     _sig(r.ref_accumulate, None, f64p, f32p, C.c_int, C.c_int, C.c_uint64)
+    _sig(r.ref_dump_autocorr, C.c_int, f32p, C.c_int, C.c_double)
     _sig(r.ref_superb_stitch, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
          C.c_int, C.c_uint32, f32p)
     # reference stage symbols that take plain pointers are called directly

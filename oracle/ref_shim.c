@@ -134,6 +134,21 @@ SHIM_API void ref_accumulate(double *acc, float *corr, int start, int length, ui
     accummulate(&out, &in, start, length);
 }
 
+/* ---- PARAM_AUTOCORR_DUMP: the reference's own autocorrelate() + dump_autocorrect() (frameratedetector.c:26-32,64-85)
+ * on one capture window; writes autocorr.csv into the current directory exactly like the library's detector thread ---- */
+void autocorrelate(extbuffer_t *buff, float *data, int size);
+void dump_autocorrect(extbuffer_t *rawiq, double samplerate);
+SHIM_API int ref_dump_autocorr(float *window, int size, double samplerate)
+{
+    extbuffer_t buf;
+    extbuffer_init(&buf);
+    autocorrelate(&buf, window, size);
+    if (!buf.valid) return -1;
+    dump_autocorrect(&buf, samplerate);
+    extbuffer_free(&buf);
+    return 0;
+}
+
 /* ---- super-bandwidth stitch on caller-provided hop buffers ---- */
 SHIM_API uint32_t ref_superb_stitch(tsdr_lib_t *t, float **hops, int nhops, int gathered,
                                     int samples_in_frame, uint32_t samplerate, float *out)

@@ -1101,6 +1101,17 @@ static void *device_thread(void *arg)
 }
 
 /* ---- entry ----------------------------------------------------------------------------- */
+void engine_stats(struct engine *e, tsdrx_stats_t *out)
+{
+    out->blocks_in = e->n_blocks;
+    out->blocks_lost = e->n_blocks_lost;
+    out->frames_made = e->n_frames_made;
+    out->frames_lost_to_viewer = e->n_frames_lost;
+    out->windows = e->n_windows;
+    out->plots_held = e->n_plots_held;
+    out->epochs_replayed = e->n_promotions;
+}
+
 int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
 {
     struct engine *e = (struct engine *)calloc(1, sizeof(*e));
@@ -1235,7 +1246,10 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     pthread_mutex_destroy(&e->qm); pthread_cond_destroy(&e->q_nonempty);
     pthread_mutex_destroy(&e->fm); pthread_cond_destroy(&e->f_nonempty); pthread_cond_destroy(&e->f_queued);
     pthread_mutex_destroy(&e->pm); pthread_cond_destroy(&e->p_nonempty);
+    pthread_mutex_lock(&t->lock); /* tsdrx_get_stats may be looking at the engine */
+    engine_stats(e, &t->last_stats);
     t->eng = NULL;
+    pthread_mutex_unlock(&t->lock);
     const int failed = e->failed;
     char fail_msg[400];
     memcpy(fail_msg, e->fail_msg, sizeof(fail_msg));

@@ -294,6 +294,17 @@ int tsdr_readasync(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx) /* TSDR
 }
 
 #pragma GCC visibility push(default)
+int tsdrx_get_stats(tsdr_lib_t *t, tsdrx_stats_t *out) /* TSDRLibraryExt.h */
+{
+    if (!t || !out) return TSDR_INVALID_PARAMETER;
+    pthread_mutex_lock(&t->lock);
+    struct engine *e = (struct engine *)t->eng;
+    if (e) engine_stats(e, out); /* (counters of other threads, read without their locks: a snapshot, not a barrier) */
+    else *out = t->last_stats;
+    pthread_mutex_unlock(&t->lock);
+    return TSDR_OK;
+}
+
 int tsdrx_readasync_rgb(tsdr_lib_t *t, tsdrx_readasync_rgb_function cb, void *ctx, int inverted) /* TSDRLibraryExt.h */
 {
     if (!cb) return tsdr_set_error(t, TSDR_WRONG_VIDEOPARAMS, "tsdrx_readasync_rgb needs a callback");

@@ -40,6 +40,7 @@ int plugin_host_load(plugin_host_t *p, const char *path); /* TSDR_OK / TSDR_INCO
 void plugin_host_close(plugin_host_t *p);
 
 struct engine;
+void engine_stats(struct engine *e, tsdrx_stats_t *out); /* counters of a running session */
 
 struct tsdr_lib {
     plugin_host_t plugin;
@@ -74,6 +75,7 @@ struct tsdr_lib {
 
     /* TSDRLibraryExt.h: frames as packed RGB for this run (NULL: float frames through the tsdr_readasync callback) */
     tsdrx_readasync_rgb_function rgb_cb;
+    tsdrx_stats_t last_stats; /* of the last session that ended (tsdrx_get_stats) */
     int rgb_inverted;
 };
 

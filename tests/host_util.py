@@ -24,6 +24,12 @@ from tempestsdr_amd.tsdrlib import FRAME_CB, VALUE_CB, PLOT_CB, TSDR_SYMBOLS, lo
 RGB_CB = C.CFUNCTYPE(None, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p)
 
 
+class Stats(C.Structure):
+    """tsdrx_stats_t (include/TSDRLibraryExt.h)"""
+    _fields_ = [(n, C.c_int64) for n in ("blocks_in", "blocks_lost", "frames_made", "frames_lost_to_viewer", "windows",
+                                          "plots_held", "epochs_replayed")]
+
+
 def build_test_plugin():
     if not os.path.exists(PLUGIN) or os.path.getmtime(PLUGIN) < os.path.getmtime(PLUGIN_SRC):
         subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-o", PLUGIN, PLUGIN_SRC],
@@ -94,6 +100,12 @@ class Session:
                 return False
             time.sleep(0.01)
         return False
+
+    def stats(self):
+        st = Stats()
+        self.lib.tsdrx_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        assert self.lib.tsdrx_get_stats(self.h, C.byref(st)) == 0
+        return st
 
     def stop(self):
         rc = self.lib.tsdr_stop(self.h)

@@ -26,7 +26,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("fs,nwin", [(8_000_000, 7), (25_000_000, 5)])
+# (100 MS/s, 17 windows: BASELINE configs[3], one second of the stream in windows of 2^22 samples)
+@pytest.mark.parametrize("fs,nwin", [(8_000_000, 7), (25_000_000, 5), (100_000_000, 17)])
 def test_two_ranks_on_one_device_match_the_running_mean(fs, nwin):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

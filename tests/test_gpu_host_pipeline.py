@@ -109,6 +109,11 @@ def test_pipeline_matches_oracle(orc, iq_file, cfg):
     assert all((w, h) == (geo.width, H) for (w, h, _) in s.frames)
     hits = match_in_order(s.frames, want)
     assert hits[0] == 0
+    # nothing was dropped on the way to this (fast) viewer, so the frames compared above are ALL the frames of the
+    # stream up to the last one delivered before the stop, not a lucky subset
+    st = s.stats()
+    assert st.blocks_lost == 0 and st.frames_lost_to_viewer == 0 and len(s.frames) <= st.frames_made
+    assert hits == list(range(len(hits)))
     # plots: first one == the oracle's first capture window
     frame_plots = [p for p in s.plots if p[0] == 0]
     line_plots = [p for p in s.plots if p[0] == 1]
@@ -426,6 +431,9 @@ def test_pipeline_mem_plugin_matches_oracle(orc, iq_file, monkeypatch, zerocopy)
     assert ok and rc == 0 and s.status == 0, s.err()
     hits = match_in_order(s.frames, want)
     assert hits[0] == 0 and len(hits) >= len(want) - 4
+    st = s.stats()
+    assert st.blocks_lost == 0 and st.frames_lost_to_viewer == 0 and hits == list(range(len(hits)))
+    assert st.plots_held >= 1 and st.epochs_replayed >= 1  # this rate's tie (see test_pipeline_matches_oracle)
     ac = oracle_plots(orc, iq, FS, first_plot_calls(s))  # (certified default: held back, replayed exactly — see above)
     frame_plots = [p for p in s.plots if p[0] == 0]
     assert frame_plots and np.array_equal(frame_plots[0][2], ac.frame)
@@ -546,6 +554,10 @@ def test_pipeline_headline_config_matches_oracle(orc, tmp_path, monkeypatch, det
     assert all((w_, h_) == (geo.width, h) for (w_, h_, _) in s.frames)
     hits = match_in_order(s.frames, want)
     assert hits[0] == 0 and len(hits) >= len(want) - 4
+    st = s.stats()
+    assert st.blocks_lost == 0 and st.frames_lost_to_viewer == 0 and hits == list(range(len(hits)))
+    if detector == "certified":
+        assert st.plots_held == 0 and st.epochs_replayed == 0  # the raster's plots carry their certificate
     ac = oracle_plots(orc, iq, fs, first_plot_calls(s))
     frame_plots = [p for p in s.plots if p[0] == 0]
     line_plots = [p for p in s.plots if p[0] == 1]
@@ -596,4 +608,69 @@ def test_pipeline_all_exact_modes(orc, iq_file, monkeypatch):
     ac.run(orc.am_demod(iq)[:orc.capture_size(FS)])
     frame_plots = [p for p in s.plots if p[0] == 0]
     assert frame_plots and np.array_equal(frame_plots[0][2], ac.frame)
+    s.close()
+
+
+def test_autocorr_dump_is_the_reference_file(orc, ref, iq_file, tmp_path, monkeypatch):
+    """PARAM_AUTOCORR_DUMP through tsdr_*: the autocorr.csv the library writes for the first capture window is, byte
+    for byte, the file the COMPILED REFERENCE's own autocorrelate() + dump_autocorrect() (frameratedetector.c:26-32,
+    64-85) write for that window — the detector's default (certified) mode hands the dump the correlation in the
+    reference's arithmetic — and VALUE_ID_AUTOCORRECT_DUMPED is announced."""
+    path, iq = iq_file
+    plugin = hu.build_test_plugin()
+    monkeypatch.chdir(tmp_path)
+
+    def setup(s):
+        s.lib.tsdr_setparameter_int(s.h, 8, 1)  # PARAM_AUTOCORR_DUMP
+
+    s, ok, rc = run_session(plugin, f"{path} {FS} {BLOCK} 8000", setup, nframes=8)
+    assert rc == 0 and s.status == 0, s.err()
+    assert any(v[0] == 5 for v in s.values)  # VALUE_ID_AUTOCORRECT_DUMPED
+    ours = (tmp_path / "autocorr.csv").read_bytes()
+    (tmp_path / "autocorr.csv").unlink()
+    cap = orc.capture_size(FS)
+    window = np.ascontiguousarray(orc.am_demod(iq[:2 * cap]))
+    assert ref.ref_dump_autocorr(window, cap, float(FS)) == 0
+    theirs = (tmp_path / "autocorr.csv").read_bytes()
+    assert len(theirs) > 1_000_000 and ours == theirs
+    s.close()
+
+
+def test_pipeline_config5_matches_oracle(orc, tmp_path):
+    """BASELINE configs[4] through the tsdr_* API: 0.15 s of the 200 MS/s 3840x2160@60 stream (h = 2250 -> 2962x2250
+    frames), motion blur 15/16 (the IIR equivalent of 16-frame averaging): every delivered frame is the oracle
+    driver's bit for bit, in order from the first, none lost; the first plots (2^23-sample windows) within 1e-4*max
+    with the identical argmax."""
+    fs, h, fv, mb = 200_000_000, 2250, 60.0, 0.9375
+    geo = orc.geometry(fs, h, fv)
+    assert (geo.width, geo.height) == (2962, 2250)
+    nsamp = 115 * (BLOCK // 2)  # 0.151 s
+    iq = np.empty(2 * nsamp, np.float32)
+    step = 1 << 22
+    for s0 in range(0, nsamp, step):
+        n = min(step, nsamp - s0)
+        iq[2 * s0:2 * (s0 + n)] = synth.synth_iq(fs, "3840x2160", fv, n, start=s0, seed=0x5EED0005)
+    path = tmp_path / "cfg5.f32"
+    iq.tofile(path)
+    want = oracle_frames(orc, iq, geo, cfg=(mb, 0, 0, 0, 0))
+    assert len(want) >= 8
+
+    def setup(s):
+        s.lib.tsdr_motionblur(s.h, mb)
+
+    plugin = hu.build_test_plugin()
+    s, ok, rc = run_session(plugin, f"{path} {fs} {BLOCK} 6000", setup, nframes=len(want), height=h, refresh=fv, timeout=90)
+    assert rc == 0 and s.status == 0, s.err()
+    assert all((w_, h_) == (geo.width, h) for (w_, h_, _) in s.frames)
+    hits = match_in_order(s.frames, want)
+    st = s.stats()
+    assert st.blocks_lost == 0 and st.frames_lost_to_viewer == 0
+    assert hits == list(range(len(hits))) and len(hits) >= len(want) - 1
+    frame_plots = [p for p in s.plots if p[0] == 0]
+    line_plots = [p for p in s.plots if p[0] == 1]
+    if frame_plots:  # 0.151 s holds one capture window of 11 272 727 samples
+        ac = oracle_plots(orc, iq, fs, first_plot_calls(s))
+        fp, lp = frame_plots[0][2], line_plots[0][2]
+        assert np.max(np.abs(fp - ac.frame)) <= 1e-4 * np.max(ac.frame) and np.max(np.abs(lp - ac.line)) <= 1e-4 * np.max(ac.line)
+        assert int(np.argmax(fp)) == int(np.argmax(ac.frame)) and int(np.argmax(lp)) == int(np.argmax(ac.line))
     s.close()

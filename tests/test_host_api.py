@@ -24,7 +24,7 @@ def test_exports_exactly_the_reference_tsdr_symbols(libs):
     ours = [s for s in exported if s.startswith("tsdr_")]
     assert ours == sorted(hu.TSDR_SYMBOLS)  # == `nm -D Release/dlls/LINUX/X64/libTSDRLibrary.so | grep tsdr_`
     # everything else the library exports is the extension API of include/TSDRLibraryExt.h, under its own prefix
-    assert [s for s in exported if not s.startswith("tsdr_")] == ["tsdrx_readasync_rgb"]
+    assert [s for s in exported if not s.startswith("tsdr_")] == ["tsdrx_get_stats", "tsdrx_readasync_rgb"]
     ref = "/root/reference/Release/dlls/LINUX/X64/libTSDRLibrary.so"
     if os.path.exists(ref):
         o = subprocess.run(["nm", "-D", "--defined-only", ref], capture_output=True, text=True, check=True).stdout
