@@ -177,6 +177,12 @@ def main():
     ap.add_argument("--fast-sync", action="store_true",
                     help="opt out of the contract-exact sync detector (tsdrgpu_postproc_set_exact_ties(0)); the default "
                          "— and what the library ships — redoes toss-up decisions with the reference's own strip sums")
+    ap.add_argument("--blur", type=float, default=None, help="motion blur coefficient (tsdr_motionblur) instead of the configuration's own")
+    ap.add_argument("--leg", action="store_true",
+                    help="a side leg of another bench.py run: the timed region, the per-kernel rooflines and nothing else")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the side legs run after the timed region at N=1 (configs[1], configs[4], motion blur 0.5, the "
+                         "reference's threaded pipeline on the host cores)")
     ap.add_argument("--uncertified", action="store_true",
                     help="plain float32 autocorrelation without the argmax certificate / exact replay (round-2 behaviour)")
     ap.add_argument("--plan", type=int, default=3, choices=[3, 5], help="autocorrelation transform plan (trips over HBM)")
@@ -235,6 +241,11 @@ def main():
                  4: (200_000_000, 2250, 60.0, "3840x2160", 0.9375,
                      "BASELINE configs[4]: 200 MS/s synthetic IQ, 3840x2160@60 raster, motion blur 15/16 (16-frame averaging)")}
     fs, h, fv, mode, blur, wl_name = WORKLOADS[args.config]
+    if args.blur is not None:
+        blur = args.blur
+        wl_name += f", motion blur {blur:g}"
+    if args.leg:
+        args.no_e2e = args.no_cpu_baseline = args.no_legs = True
     W = geometry(fs, h, fv)
     P = W * h
     chunk = int(0.1 * fs / fv)  # TSDRLibrary.c:335
@@ -455,7 +466,7 @@ def main():
 
     # side metric: the super-bandwidth stitch (superb_ondataready, superbandwidth.c:121-152) of 4 hops x 10 frames
     superb = None
-    if rank == 0 and world == 1 and not args.no_profile and not args.force_dist and args.config == 2:
+    if rank == 0 and world == 1 and not args.no_profile and not args.force_dist and args.config == 2 and not args.leg:
         try:
             sif = int(fs / fv)
             gathered = 10 * sif
@@ -492,7 +503,7 @@ def main():
 
     # side metric: the detector in the reference's own FFT arithmetic (what tsdr_readasync uses by default)
     exact_ac = None
-    if rank == 0 and not args.no_profile and not sharded:
+    if rank == 0 and not args.no_profile and not sharded and not args.leg:
         acx = gpu.Autocorr(g, fs)
         acx.set_exact(True)
         acx.run(d_iq, 1, acx.capture, min(nwin, 4), mode=0)  # builds the twiddle table, warms up
@@ -511,29 +522,86 @@ def main():
 
     # side metric: the product path end to end — libTSDRLibrary.so behind the tsdr_* API, fed by the in-memory source
     # plugin, every block DMA'd in, every frame DMA'd out to the frame callback (PCIe-inclusive; never `value`)
-    e2e = None
+    e2e, cpu_pipeline = None, None
     if rank == 0 and world == 1 and not args.no_e2e and not args.force_dist and args.config == 2:
+        from tempestsdr_amd import tsdrlib
+        block = 524288
+        ne2e = (min(nsamples, 30_000_000) // (block // 2)) * (block // 2)
+        path = "/tmp/tsdr_bench_e2e.f32"
         try:
-            from tempestsdr_amd import tsdrlib
-            block = 524288
-            ne2e = (min(nsamples, 30_000_000) // (block // 2)) * (block // 2)
-            path = "/tmp/tsdr_bench_e2e.f32"
             iq[:2 * ne2e].cpu().numpy().tofile(path)
-            # in a process of its own, like a host application: this one asked the HIP runtime for 8 hardware queues
-            # (above), the library on its own asks for 2 (tsdrgpu_core.hip explains why)
+            # in a process of its own, like a host application started by a launcher that exports GPU_MAX_HW_QUEUES=2
+            # (tsdrlib.throughput_subprocess; tsdrgpu_core.hip explains why) — this process asked for 8 (above)
             r = tsdrlib.throughput_subprocess(tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {fs} {block} 0 0", h, fv, 3.0,
                                               env={"TSDR_GPU_STATS": "1"})
-            os.unlink(path)
             e2e = {"effective_Msps": round(r["frames_per_s"] * (fs / fv) / 1e6, 1), "frames_per_s": round(r["frames_per_s"], 1),
                    "plots_per_s": round(r["plots_per_s"], 2), "frame": f"{r['width']}x{r['height']}", "status": r["status"],
                    "realtime_factor": round(r["frames_per_s"] / fv, 2),
                    "path": "tsdr_readasync (libTSDRLibrary.so), source = libTSDRPlugin_Mem.so replaying "
                            f"{ne2e / fs:.3f} s of the stream free-running in 2 MiB blocks; float32 IQ in and float32 frames out "
-                           "over PCIe, contract-exact modes (library defaults); frames counted at the frame callback; run in a "
-                           "process of its own",
+                           "over PCIe, library defaults (contract-exact sync detector, certified frame-rate detector); frames "
+                           "counted at the frame callback; run in a process of its own with GPU_MAX_HW_QUEUES=2",
                    "engine_stats": [ln for ln in r.get("stderr_tail", "").splitlines() if ln.startswith("tsdr stats")]}
         except Exception as ex:  # a reported side metric, never the headline
             e2e = {"error": repr(ex)}
+        # the reference's own threaded library (oracle/_ref/libtsdr_ref.so, compiled from its sources)
+        # fed by its own RawFile plugin rebuilt free-running (PERFORMANCE_BENCHMARK=1) on the host cores of this box —
+        # frames delivered to the callback x samples per frame; cores = the CPU time the process burnt / wall time
+        try:
+            reflib = os.path.join(ROOT, "oracle", "_ref", "libtsdr_ref.so")
+            rawfile = os.path.join(ROOT, "oracle", "_ref", "libTSDRPlugin_RawFile_bench.so")
+            if not args.no_cpu_baseline and os.path.exists(reflib) and os.path.exists(rawfile) and os.path.exists(path):
+                import resource
+                r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
+                t0p = time.perf_counter()
+                secs = 8.0
+                r = tsdrlib.throughput_subprocess(reflib, rawfile, f"{path} {fs} float", h, fv, secs, free=False, timeout=180)
+                wall = time.perf_counter() - t0p
+                r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+                cpu_s = (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)
+                cpu_pipeline = {"value": round(r["frames_per_s"] * (fs / fv) / 1e6, 2), "unit": "Msamples/s (effective: frames at the callback x samples per frame)",
+                                "frames_per_s": round(r["frames_per_s"], 2), "plots_per_s": round(r["plots_per_s"], 2),
+                                "cores_used": round(cpu_s / wall, 2), "cores_on_box": os.cpu_count(), "kind": "reference",
+                                "sample": f"{secs:g} s of wall clock: the reference's tsdr_* library with its plugin / decimator / post-processing / "
+                                          f"video / detector threads, RawFile plugin free-running over {ne2e / fs:.3f} s of the same 100 MS/s stream "
+                                          "(it drops what it cannot process, so frames at the callback, not samples read, are counted)"}
+        except Exception as ex:
+            cpu_pipeline = {"error": repr(ex)}
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+    # side legs (N=1, headline config): the same harness on the other BASELINE configurations and with the IIR active,
+    # each in a process of its own right here, so that the driver's record holds the numbers DESIGN.md quotes
+    legs = None
+    if rank == 0 and world == 1 and not args.no_legs and not args.force_dist and args.config == 2:
+        import subprocess
+
+        def leg(extra, label):
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), "--leg", "--gpus", "1", "--warmup", "2"] + extra
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+                line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+                if out.returncode != 0 or not line:
+                    return {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
+                d = json.loads(line[-1])
+                return {"workload": d["config"]["workload"], "value_Msps": d["value"], "frames_per_s": d["frames_per_s"],
+                        "realtime_factor": d["realtime_factor"], "ms_per_pass": d["ms_per_pass"], "passes_timed": d["steps"] * d["config"]["passes_per_step"],
+                        "frame_path_frac": (d.get("frame_path") or {}).get("frac"), "autocorrelation_frac": (d.get("autocorrelation") or {}).get("frac"),
+                        "whole_pass_frac": (d.get("whole_pass") or {}).get("frac"), "kernels": d.get("kernels"),
+                        "stage_ms_per_pass": d.get("stage_ms_per_pass"), "autocorr_epochs_replayed_exact": d["config"].get("autocorr_epochs_replayed_exact"),
+                        "command": "bench.py --leg " + " ".join(extra), "label": label}
+            except Exception as ex:  # noqa: BLE001
+                return {"error": repr(ex)}
+
+        legs = {
+            "configs[1]": leg(["--config", "1", "--steps", "4", "--passes", "100"], "25 MS/s, 1024x768@60 (1033x806 frames), 1 s batches"),
+            "configs[4]": leg(["--config", "4", "--steps", "4", "--passes", "25"], "200 MS/s, 3840x2160@60 (2962x2250 frames), motion blur 15/16, 1 s batches"),
+            "frame_path_blur": leg(["--config", "2", "--blur", "0.5", "--steps", "4", "--passes", "40"],
+                                   "the headline configuration with motion blur 0.5: the IIR is live, every batch takes the frame-by-frame "
+                                   "k_frame_pass (state in registers across the batch's frames: 8P bytes moved per frame = 8P credited)"),
+        }
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -694,6 +762,7 @@ def main():
             # Main.java:1233-1277) applied to one plot update per pass
             "sweep": sweep,
             "e2e": e2e,
+            "configs": legs,
             "superbandwidth": superb,
             "exact_autocorr": exact_ac,
             "sync_redo_last_batch": redo_stats,
@@ -705,6 +774,8 @@ def main():
                 host = iq[:2 * half].cpu().numpy()
                 res["cpu_baseline"] = cpu_baseline(host, fs, h, fv, nframes=int(half / S), nwindows=max(1, half // ac.capture))
                 res["cpu_baseline"]["cores_on_box"] = os.cpu_count()
+                if cpu_pipeline is not None:
+                    res["cpu_baseline"]["pipeline"] = cpu_pipeline
             except Exception as e:  # the baseline is a reported number, never the product path
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)

@@ -143,6 +143,18 @@ int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int in_is_iq, u
  * (the first one includes the pixels earlier calls contributed), and their number. */
 int tsdrgpu_resampler_track_frames(tsdrgpu_resampler_t *rs, int64_t frame_pixels, int64_t phase);
 int tsdrgpu_resampler_frame_minmax(tsdrgpu_resampler_t *rs, const float **d_min, const float **d_max, int *nframes);
+/* Row-band form (the frame path sharded over GPUs by rows).  The same `nchunks` calls of
+ * dsp_resample_process with the same carried state — every rank passes the same samples and ends with the same
+ * `offset` / `contrib` — but only the pixels of rows [y0, y0 + rows) of each width x height frame are computed and
+ * stored: frame j, counted from the frame the call's first pixel lies in, goes to d_band + j * rows * width.
+ * `phase` = pixels of that first frame which earlier calls produced (0 when the call starts on a frame boundary); the
+ * caller carries an incomplete last frame (slot *h_frames_touched - 1 when (phase + *h_n_out) % (width*height) != 0) into
+ * slot 0 of its next call.  *h_n_out = pixels the full call would have produced.  Area mode; values bit-identical to
+ * the corresponding pixels of tsdrgpu_resample's output (dsp.c:256-307 entered at each pixel group through the closed
+ * form of resample_math.h). */
+int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in, int in_is_iq, uint32_t chunk, int nchunks,
+                          double upsample_by, double downsample_by, int width, int height, int y0, int rows, int64_t phase,
+                          float *d_band, int64_t band_capacity_frames, int64_t *h_n_out, int *h_frames_touched);
 /* Pixel count the next `nchunks` calls would produce, without running them. */
 int64_t tsdrgpu_resample_count(tsdrgpu_resampler_t *rs, uint32_t chunk, int nchunks,
                                double upsample_by, double downsample_by);
@@ -230,12 +242,26 @@ int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float *d_frames,
  * exposes two small device buffers; the caller all-reduces them IN PLACE across the ranks — *d_xsum (n_xsum doubles)
  * with ncclSum, *d_xmax (n_xmax floats) with ncclMax: tsdrgpu_comm_allreduce_f64 / tsdrgpu_comm_allreduce_f32max —
  * and _band_finish runs the (replicated) autogain / sync-detector chain and the normalise / green-lines / IIR pass on
- * the band's rows into d_out_band.  Library-default stage order, no autoshift, no PLL.  Frames are bit-identical to
- * tsdrgpu_postproc_run's in its fast mode (tsdrgpu_postproc_set_exact_ties(pp, 0)); a one-band "sharding" needs no
- * exchange at all.  Reference: dsp.c:41-110, syncdetector.c:171-225. */
+ * the band's rows into d_out_band.  Library-default stage order, no autoshift, no PLL.  With _band_finish frames are
+ * bit-identical to tsdrgpu_postproc_run's in its fast mode (tsdrgpu_postproc_set_exact_ties(pp, 0)); with
+ * _band_advance (below) to its default, contract-exact mode; a one-band "sharding" needs no exchange at all.
+ * Reference: dsp.c:41-110, syncdetector.c:171-225. */
 int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *d_band, int nframes, int width, int height, int y0, int rows,
                                 const tsdrgpu_pp_params_t *params, double **d_xsum, int64_t *n_xsum, float **d_xmax, int64_t *n_xmax);
 int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out_band, tsdrgpu_pp_frameinfo_t *h_info);
+/* The contract-exact form of _band_finish (tsdrgpu_postproc_set_exact_ties, on by default): frames and per-frame
+ * records bit-identical to tsdrgpu_postproc_run in ITS default mode, i.e. to the reference.  The literal collapse of
+ * a strip (f32 additions in raster order, dsp.c:96-110) — needed where a strip holds exact ties and where a sync
+ * decision is a toss-up — walks every column through all bands from the top, so the bands take turns: call
+ *     do { tsdrgpu_postproc_band_advance(pp, d_out_band, band_index, nbands, &d_buf, &n, &more, h_info);
+ *          if (more) <sum all-reduce of d_buf[0..n) over the ranks, in place: tsdrgpu_comm_allreduce_f64>; } while (more);
+ * after the two all-reduces of _band_begin.  band_index = this rank's position in the order of the bands from the top
+ * row down (0 .. nbands-1, one band per rank).  Whether and how often `more` is raised follows from the exchanged
+ * strips alone, identically on every rank: not at all for an ordinary batch (then the call costs one host
+ * synchronisation more than _band_finish), nbands times for a batch with flagged strips, again nbands times if a
+ * decision was a toss-up.  Synchronises.  With exact ties off it is _band_finish. */
+int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_out_band, int band_index, int nbands, double **d_buf,
+                                  int64_t *n_buf, int *h_more, tsdrgpu_pp_frameinfo_t *h_info);
 /* The per-frame record of the last run, without a host synchronisation: packs nframes tsdrgpu_pp_frameinfo_t
  * into the caller's DEVICE buffer on the COMPUTE lane (download it on any lane behind an event). */
 int tsdrgpu_postproc_info_pack(tsdrgpu_postproc_t *pp, tsdrgpu_pp_frameinfo_t *d_info, int nframes);

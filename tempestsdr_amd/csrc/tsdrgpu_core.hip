@@ -803,6 +803,58 @@ __global__ __launch_bounds__(256) void k_rs_area(const RsChunk *__restrict__ chu
 }
 
 // ---------------------------------------------------------------------------
+// Row-band form (tsdrgpu_resample_band): the same chunks, but only the pixels of rows
+// [y0, y0 + rows) of every frame are computed and stored, into a band buffer that holds frame after frame of
+// rows*width pixels.  A band entry = the part of one chunk's output that falls into the band of one frame (a chunk is
+// shorter than a frame, so at most two per chunk).  Every thread enters the reference loop at its own pixel group
+// through the closed form (rs_area_group), exactly like k_rs_area, so the values are those of the full run bit for bit.
+// ---------------------------------------------------------------------------
+struct RsBandEntry {
+    int chunk;          // index into the chunk table
+    int p_lo, p_hi;     // chunk-relative pixels [p_lo, p_hi) of this entry
+    int pad;
+    long long dst_off;  // where pixel p_lo goes in the band buffer
+};
+
+template <bool IQ>
+__global__ __launch_bounds__(256) void k_rs_area_band(const RsChunk *__restrict__ chunks, const RsBandEntry *__restrict__ ents, double r,
+                                                      double rinv, const float *__restrict__ in, const double *__restrict__ cin,
+                                                      float *__restrict__ out)
+{
+    const RsBandEntry e = ents[blockIdx.y];
+    const RsChunk ch = chunks[e.chunk];
+    RsGeom g;
+    g.r = r;
+    g.rinv = rinv;
+    g.o = ch.o;
+    g.size = ch.size;
+    SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
+    const double c_in = cin[e.chunk];
+    float *dst = out + e.dst_off - e.p_lo;  // pixel p of the chunk goes to dst[p] (only p_lo <= p < p_hi is ever touched)
+    const int mis = (int)((((uintptr_t)dst) >> 2) & 3);
+    const int n_out = (int)ch.n_out;
+    const int g_lo = (e.p_lo + mis) / RS_NPIX, g_hi = (e.p_hi + mis + RS_NPIX - 1) / RS_NPIX;
+    __shared__ float stage[RS_NPIX][256];
+    for (int grp = g_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x); grp < g_hi; grp += (int)(gridDim.x * blockDim.x)) {
+        const int p0 = RS_NPIX * grp - mis;
+#pragma unroll
+        for (int k = 0; k < RS_NPIX; k++) stage[k][threadIdx.x] = 0.0f;
+        rs_area_group<RS_NPIX>(g, p0, n_out, c_in, ld, [&](int k, float val) { stage[k][threadIdx.x] = val; });
+        float v[RS_NPIX];
+#pragma unroll
+        for (int k = 0; k < RS_NPIX; k++) v[k] = stage[k][threadIdx.x];
+        if (p0 >= e.p_lo && p0 + RS_NPIX <= e.p_hi) {
+            *reinterpret_cast<float4 *>(dst + p0) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(dst + p0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < RS_NPIX; k++)
+                if (p0 + k >= e.p_lo && p0 + k < e.p_hi) dst[p0 + k] = v[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_rs_area_up: the same resampler, one lane per INPUT sample (resample_math.h, "sample-parallel form").
 // k_rs_area replays the loop body per 8-pixel group, which costs ~60 VALU instructions per pixel in branchy,
 // divergent code (the kernel was issue-bound at half the HBM rate).  Here every per-sample expression is
@@ -1282,5 +1334,90 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
     if (rc) return rc;
     rs->offset = new_offset;
     if (h_n_out) *h_n_out = total;
+    return TSDRGPU_OK;
+}
+
+// The row-band form of tsdrgpu_resample (include/tsdrgpu.h).  Chunk table, incoming-contrib chain and the carried state
+// are those of the full call; what differs is the pixels computed: per chunk at most two band entries.
+extern "C" int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in, int in_is_iq, uint32_t chunk, int nchunks, double up,
+                                     double down, int width, int height, int y0, int rows, int64_t phase, float *d_band,
+                                     int64_t band_capacity_frames, int64_t *h_n_out, int *h_frames_touched)
+{
+    if (!rs || !d_in || !d_band || chunk == 0 || nchunks < 0 || nchunks > 65535 || !(up > 0) || !(down > 0) || width <= 0 || height <= 0 ||
+        y0 < 0 || rows <= 0 || y0 + rows > height || phase < 0 || phase >= (int64_t)width * height)
+        return rs ? tsdr_fail(rs->g, TSDRGPU_EINVAL, "tsdrgpu_resample_band", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = rs->g;
+    if (rs->frame_pixels > 0) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_resample_band", "frame tracking is on");
+    if (h_n_out) *h_n_out = 0;
+    if (h_frames_touched) *h_frames_touched = 0;
+    if (nchunks == 0) return TSDRGPU_OK;
+    const long long P = (long long)width * height;
+    double probe = rs->offset;
+    const int64_t total = build_chunks(&probe, chunk, nchunks, up, down, nullptr);
+    const long long touched = total > 0 ? (phase + total + P - 1) / P : 0;
+    if (touched > band_capacity_frames) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resample_band", "band buffer too small");
+    const size_t tab_bytes = sizeof(RsChunk) * (size_t)nchunks;
+    const size_t ent_off = (tab_bytes + 15) & ~(size_t)15;
+    const size_t bytes = ent_off + sizeof(RsBandEntry) * (size_t)(2 * nchunks + 2);
+    const int slot = staging_acquire(g, &rs->ring, bytes);
+    if (slot < 0) return slot;
+    RsChunk *tab = (RsChunk *)rs->ring.h[slot];
+    RsBandEntry *ent = (RsBandEntry *)((char *)rs->ring.h[slot] + ent_off);
+    double new_offset = rs->offset;
+    build_chunks(&new_offset, chunk, nchunks, up, down, tab);
+    const long long b_lo = (long long)y0 * width, b_hi = (long long)(y0 + rows) * width, Pb = (long long)rows * width;
+    int nent = 0;
+    int max_span = 0;
+    for (int c = 0; c < nchunks; c++) {
+        const long long g0 = phase + tab[c].out_off, g1 = g0 + tab[c].n_out;  // pixels counted from the first frame's start
+        for (long long j = g0 / P; j * P < g1; j++) {
+            long long lo = j * P + b_lo, hi = j * P + b_hi;
+            if (lo < g0) lo = g0;
+            if (hi > g1) hi = g1;
+            if (lo >= hi) continue;
+            RsBandEntry e;
+            e.chunk = c;
+            e.p_lo = (int)(lo - g0);
+            e.p_hi = (int)(hi - g0);
+            e.pad = 0;
+            e.dst_off = j * Pb + (lo - j * P - b_lo);
+            ent[nent++] = e;
+            if (e.p_hi - e.p_lo > max_span) max_span = e.p_hi - e.p_lo;
+        }
+    }
+    int rc = staging_push(g, &rs->ring, slot, bytes);
+    if (rc) return rc;
+    const RsChunk *d_tab = (const RsChunk *)rs->ring.d[slot];
+    const RsBandEntry *d_ent = (const RsBandEntry *)((const char *)rs->ring.d[slot] + ent_off);
+    if (rs->cap_chunks < nchunks) {
+        hipFree(rs->d_cin); hipFree(rs->d_tail); hipFree(rs->d_need);
+        rs->d_cin = rs->d_tail = nullptr; rs->d_need = nullptr; rs->cap_chunks = 0;
+        const int cap = nchunks + 64;
+        if (hipMalloc(&rs->d_cin, sizeof(double) * cap) != hipSuccess || hipMalloc(&rs->d_tail, sizeof(double) * cap) != hipSuccess ||
+            hipMalloc(&rs->d_need, cap) != hipSuccess)
+            return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_resample_band", "chunk scratch");
+        rs->cap_chunks = cap;
+    }
+    const double r = up / down;
+    const unsigned tb = ceil_div_u((unsigned)nchunks, 128);
+    // the incoming contrib of every chunk (data dependent, a few samples per chunk): every band needs it
+    if (in_is_iq) {
+        TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, (k_rs_tail<true>), tb, 128, d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need);
+        TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, (k_rs_chain<true>), 1, 256, d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+    } else {
+        TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, (k_rs_tail<false>), tb, 128, d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need);
+        TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, (k_rs_chain<false>), 1, 256, d_tab, nchunks, r, 1.0 / r, d_in, rs->d_tail, rs->d_need, rs->d_cin, rs->d_contrib);
+    }
+    if (nent) {
+        dim3 grid(ceil_div_u((unsigned)max_span + 2 * RS_NPIX, 256 * RS_NPIX), (unsigned)nent);
+        if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_band<true>), grid, 256, d_tab, d_ent, r, 1.0 / r, d_in, rs->d_cin, d_band);
+        else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_band<false>), grid, 256, d_tab, d_ent, r, 1.0 / r, d_in, rs->d_cin, d_band);
+    }
+    KERNEL_CHECK(g, "k_rs_area_band");
+    rc = staging_release(g, &rs->ring, slot);
+    if (rc) return rc;
+    rs->offset = new_offset;
+    if (h_n_out) *h_n_out = total;
+    if (h_frames_touched) *h_frames_touched = (int)touched;
     return TSDRGPU_OK;
 }

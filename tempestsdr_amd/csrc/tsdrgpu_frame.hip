@@ -90,6 +90,13 @@ struct tsdrgpu_postproc {
     float *d_v0;                // [F] pixel 0 of every frame after the exchange
     ChainOut *d_chain_band;     // the chain record with dy relative to the band, for the pass
     size_t cap_xsum, cap_xmax, cap_v0, cap_chain_band;
+    // contract-exact band runs (tsdrgpu_postproc_band_advance): the literal strip collapse relayed band by band
+    int band_stage;             // 0 = after the first exchange; 1 = relay of round 0; 2 = run 0 done; 3 = relay of round 1; 4 = pass
+    int relay_step, relay_items;
+    int *d_items;               // the (frame*2 + axis) ids being relayed
+    int *h_flags;               // host copy of a flag array [2F]
+    double *d_relay;            // [items][nmax]: sums so far (f32 values carried as f64 through the sum all-reduce)
+    size_t cap_items, cap_hflags, cap_relay;
     const float *ext_fmin, *ext_fmax;  // per-frame min/max supplied by the caller (fused run), else null
     int p_F, p_W, p_H;
     tsdrgpu_pp_params_t p_prm;
@@ -1464,10 +1471,11 @@ extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
     (void)hipEventDestroy(pp->ev_chain);
     void *bufs[] = {pp->d_state, pp->d_odd, pp->d_screen, pp->d_screen2, pp->d_dump, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
                     pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain, pp->d_sflag, pp->d_exact,
-                    pp->d_xsum, pp->d_xmax, pp->d_v0, pp->d_chain_band};
+                    pp->d_xsum, pp->d_xmax, pp->d_v0, pp->d_chain_band, pp->d_items, pp->d_relay};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (pp->h_chain) (void)hipHostFree(pp->h_chain);
+    free(pp->h_flags);
     free(pp);
 }
 
@@ -2009,6 +2017,7 @@ extern "C" int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *
     pp->p_prm = *prm;
     pp->band_y0 = y0;
     pp->band_rows = rows;
+    pp->band_stage = 0;
     pp->pending = 4;
     if (d_xsum) *d_xsum = pp->d_xsum;
     if (n_xsum) *n_xsum = (int64_t)F * 3 * (W + Htot);
@@ -2044,6 +2053,207 @@ extern "C" int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out
     if (rc) return rc;
     if (h_info) return pp_copy_info(pp, F, h_info);
     return TSDRGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Contract-exact row bands.  The single-GPU run redoes the collapse of a strip literally — f32 additions in raster
+// order, dsp.c:96-110 — where the strip holds exact ties (k_strip_flag) and where a sync decision was a toss-up at the
+// precision of the f64 tile sums (k_sync_chain's margin test).  A column sum in that order runs through every band
+// from the top row to the bottom one, so the bands take turns: at step s the band with index s continues every
+// requested sum over its own rows from the values it received (a row sum lies in one band: that band forms it from
+// zero) while all other ranks contribute zeros, and one sum all-reduce hands the result on.  After as many steps as
+// there are bands every rank holds the reference's own strips for the requested (frame, axis) items and the replicated
+// chain goes on exactly like the single-GPU one (run 0, then run 1 for the toss-ups).  Which items are requested is
+// decided from the exchanged strips, identically on every rank, so the ranks agree on every collective without talking.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_band_relay(const int *__restrict__ items, int nmax, const float *__restrict__ band, long long fstride,
+                                                    int W, int rows, int y0, const ChainOut *__restrict__ chain, int strips_normalised,
+                                                    double *__restrict__ X)
+{
+    const int item = items[blockIdx.y];
+    const int axis = item & 1, f = item >> 1;
+    const float *src = band + (long long)f * fstride;
+    const float lastmin = chain[f].lastmin, span = chain[f].span;
+    double *x = X + (long long)blockIdx.y * nmax;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (axis == 0) {  // column i: continue down this band's rows
+        if (i >= W) return;
+        float acc = (float)x[i];
+        for (int y = 0; y < rows; y++) {
+            float val = src[(long long)y * W + i];
+            if (strips_normalised) val = (val > 250.0f || val < -250.0f) ? val : ((val - lastmin) / span);  // dsp.c:80-86
+            acc += val;
+        }
+        x[i] = (double)acc;
+    } else {  // row y0 + i: all of it lies in this band
+        if (i >= rows) return;
+        float acc = 0.f;
+        const float *row = src + (long long)i * W;
+        for (int c = 0; c < W; c++) {
+            float val = row[c];
+            if (strips_normalised) val = (val > 250.0f || val < -250.0f) ? val : ((val - lastmin) / span);
+            acc += val;
+        }
+        x[y0 + i] = (double)acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_band_relay_take(const int *__restrict__ items, int nmax, int W, int H, const double *__restrict__ X,
+                                                         float *__restrict__ exact)
+{
+    const int item = items[blockIdx.y];
+    const int n = (item & 1) ? H : W;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) exact[(long long)item * nmax + i] = (float)X[(long long)blockIdx.y * nmax + i];
+}
+
+// host copy of a [2F] device flag array -> the list of set entries on the device (rare path: synchronises)
+static int band_collect_items(tsdrgpu_postproc_t *pp, const int *d_flags, int count, int *nitems)
+{
+    tsdrgpu_t *g = pp->g;
+    int rc;
+    if (pp->cap_hflags < (size_t)count) {
+        free(pp->h_flags);
+        pp->h_flags = (int *)malloc(sizeof(int) * (size_t)count * 2);
+        pp->cap_hflags = pp->h_flags ? (size_t)count : 0;
+        if (!pp->h_flags) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "band flags");
+    }
+    if ((rc = ensure(g, &pp->d_items, &pp->cap_items, (size_t)count))) return rc;
+    HIP_TRY(g, hipMemcpyAsync(pp->h_flags, d_flags, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    int *list = pp->h_flags + count;
+    int n = 0;
+    for (int i = 0; i < count; i++)
+        if (pp->h_flags[i]) list[n++] = i;
+    if (n) {
+        HIP_TRY(g, hipMemcpyAsync(pp->d_items, list, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(g, hipStreamSynchronize(g->stream));  // `list` is reused
+    }
+    *nitems = n;
+    return TSDRGPU_OK;
+}
+
+// one relay step: this band's turn -> continue the sums, otherwise contribute zeros
+static int band_relay_step(tsdrgpu_postproc_t *pp, int band_index)
+{
+    tsdrgpu_t *g = pp->g;
+    const int W = pp->p_W, H = pp->p_H, nmax = W > H ? W : H;
+    const size_t bytes = sizeof(double) * (size_t)pp->relay_items * nmax;
+    // step 0 starts every sum at zero; a rank whose turn it is not adds nothing to the all-reduce; the rank whose turn
+    // it is continues from what the previous step's all-reduce left in the buffer
+    if (pp->relay_step != band_index || pp->relay_step == 0) HIP_TRY(g, hipMemsetAsync(pp->d_relay, 0, bytes, g->stream));
+    if (pp->relay_step == band_index) {
+        const int longest = W > pp->band_rows ? W : pp->band_rows;
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_band_relay, dim3((longest + 255) / 256, pp->relay_items), 256, pp->d_items, nmax, pp->p_frames,
+                    (long long)W * pp->band_rows, W, pp->band_rows, pp->band_y0, pp->d_chain, 1, pp->d_relay);
+        KERNEL_CHECK(g, "k_band_relay");
+    }
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_out_band, int band_index, int nbands, double **d_buf,
+                                             int64_t *n_buf, int *h_more, tsdrgpu_pp_frameinfo_t *h_info)
+{
+    if (!pp || !d_out_band || !h_more || nbands < 1 || band_index < 0 || band_index >= nbands)
+        return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_advance", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    if (pp->pending != 4) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_advance", "no band run is open");
+    const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H, y0 = pp->band_y0, rows = pp->band_rows;
+    const tsdrgpu_pp_params_t *prm = &pp->p_prm;
+    const int nmax = W > Htot ? W : Htot;
+    hipStream_t st = g->stream;
+    *h_more = 0;
+    int rc;
+    StripScratch sc;
+    sc.nmax = nmax;
+    sc.blur = pp->d_work;
+    sc.prefix = (double *)(pp->d_work + (((size_t)F * 2 * nmax + 1) & ~(size_t)1));
+    sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
+    SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
+    int *d_amb = pp->d_sflag + (size_t)F * 2, *d_fresh = d_amb + (size_t)F * 2, *d_redo = d_fresh + (size_t)F * 2;
+    const int *const no_gate = nullptr;
+    const int exact = pp->exact_ties;
+
+    for (;;) {
+        switch (pp->band_stage) {
+        case 0: {  // the exchanged statistics -> autogain recurrence, tie flags
+            TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_xmax,
+                        pp->d_strip_x, pp->d_strip_y, pp->d_fmin, pp->d_fmax, pp->d_v0);
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 1,
+                        prm->lowpasscoeff);
+            KERNEL_CHECK(g, "k_autogain_chain");
+            pp->relay_items = 0;
+            if (exact) {
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, 1, pp->d_sflag);
+                KERNEL_CHECK(g, "k_strip_flag");
+                if ((rc = band_collect_items(pp, pp->d_sflag, 2 * F, &pp->relay_items))) return rc;
+            } else {
+                HIP_TRY(g, hipMemsetAsync(pp->d_sflag, 0, sizeof(int) * (size_t)F * 2, st));
+            }
+            pp->relay_step = 0;
+            pp->band_stage = pp->relay_items ? 1 : 2;
+            break;
+        }
+        case 1:
+        case 3: {  // relay: one step per call, the caller all-reduces the buffer in between
+            if (pp->relay_step == 0 && (rc = ensure(g, &pp->d_relay, &pp->cap_relay, (size_t)pp->relay_items * nmax))) return rc;
+            if (pp->relay_step < nbands) {
+                if ((rc = band_relay_step(pp, band_index))) return rc;
+                pp->relay_step++;
+                if (d_buf) *d_buf = pp->d_relay;
+                if (n_buf) *n_buf = (int64_t)pp->relay_items * nmax;
+                *h_more = 1;
+                return TSDRGPU_OK;
+            }
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_band_relay_take, dim3((nmax + 255) / 256, pp->relay_items), 256, pp->d_items, nmax, W, Htot, pp->d_relay,
+                        pp->d_exact);
+            KERNEL_CHECK(g, "k_band_relay_take");
+            pp->band_stage = pp->band_stage == 1 ? 2 : 4;
+            if (pp->band_stage == 4) {  // run 1 of the chain: only the strips that changed, from the saved state
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, 1, pp->taps[0],
+                            pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, (const int *)d_redo);
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, Htot, sc, pp->d_state + 1, spec, (const int *)d_redo, (const int *)d_fresh);
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, Htot, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1, d_amb,
+                            (const int *)d_redo);
+                KERNEL_CHECK(g, "k_sync_chain");
+            }
+            break;
+        }
+        case 2: {  // run 0 of the chain; with exact ties on, its toss-ups are the second relay's items
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, 1, pp->taps[0],
+                        pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, no_gate);
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, Htot, sc, pp->d_state, spec, no_gate, no_gate);
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, Htot, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1,
+                        exact ? d_amb : (int *)nullptr, no_gate);
+            KERNEL_CHECK(g, "k_sync_chain");
+            pp->relay_items = 0;
+            if (exact) {
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_redo_prepare, 1, 256, 2 * F, d_amb, pp->d_sflag, d_redo, d_fresh);
+                KERNEL_CHECK(g, "k_redo_prepare");
+                if ((rc = band_collect_items(pp, d_fresh, 2 * F, &pp->relay_items))) return rc;
+            }
+            pp->relay_step = 0;
+            pp->band_stage = pp->relay_items ? 3 : 4;
+            break;
+        }
+        default: {  // the pass over this band's rows
+            pp->pending = 0;
+            pp->band_stage = 0;
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_band_chain, (F + 63) / 64, 64, pp->d_chain, pp->d_chain_band, F, y0);
+            KERNEL_CHECK(g, "k_band_chain");
+            const float a = prm->motionblur;
+            const int lines = (a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+            const long long Pb = (long long)W * rows;
+            ChainOut *full = pp->d_chain;
+            pp->d_chain = pp->d_chain_band;  // what the pass reads
+            rc = launch_pass(pp, PASS_NORMALISE | lines | PASS_IIR, pp->p_frames, Pb, d_out_band, Pb, F, W, rows, a);
+            pp->d_chain = full;
+            if (rc) return rc;
+            if (h_info) return pp_copy_info(pp, F, h_info);
+            return TSDRGPU_OK;
+        }
+        }
+    }
 }
 
 __global__ void k_info_pack(const ChainOut *__restrict__ chain, tsdrgpu_pp_frameinfo_t *__restrict__ out, int F)

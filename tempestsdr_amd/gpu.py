@@ -90,6 +90,9 @@ _SIGS = {
     "tsdrgpu_postproc_band_begin": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_int64),
                                               C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_postproc_band_finish": (C.c_int, [vp, vp, vp]),
+    "tsdrgpu_postproc_band_advance": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int), vp]),
+    "tsdrgpu_resample_band": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int64, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "tsdrgpu_comm_allreduce_f32max": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
     "tsdrgpu_autocorr_plots_async": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_plots_snapshot": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
@@ -398,6 +401,13 @@ class Resampler:
     def count(self, chunk, nchunks, up, down):
         return self.ctx.lib.tsdrgpu_resample_count(self.h, chunk, nchunks, up, down)
 
+    def process_band(self, d_in, in_is_iq, chunk, nchunks, up, down, width, height, y0, rows, phase, d_band, capacity_frames, in_offset=0):
+        """tsdrgpu_resample_band: only rows [y0, y0+rows) of every frame; returns (pixels of the full call, frames touched)."""
+        n, ft = C.c_int64(), C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_resample_band(self.h, d_in.at(in_offset), int(in_is_iq), chunk, nchunks, up, down, width, height, y0, rows,
+                                                        phase, d_band.at(0), capacity_frames, C.byref(n), C.byref(ft)))
+        return n.value, ft.value
+
     def process(self, d_in, in_is_iq, chunk, nchunks, up, down, nearest, d_out, in_offset=0, out_offset=0):
         n = C.c_int64()
         self.ctx._ck(self.ctx.lib.tsdrgpu_resample(self.h, d_in.at(in_offset), int(in_is_iq), chunk, nchunks, up,
@@ -494,6 +504,15 @@ class PostProcess:
         info = (PPFrameInfo * self._nframes)() if want_info else None
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_finish(self.h, d_out_band.at(out_offset), info))
         return list(info) if want_info else None
+
+    def band_advance(self, d_out_band, band_index, nbands, want_info=True, out_offset=0):
+        """Contract-exact second half of a band run, one step: returns (more, buf_ptr, n_doubles, infos).  While `more`,
+        the caller sum-all-reduces buf in place over the ranks and calls again (tsdrgpu_postproc_band_advance)."""
+        info = (PPFrameInfo * self._nframes)() if want_info else None
+        buf, n, more = vp(), C.c_int64(), C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_advance(self.h, d_out_band.at(out_offset), band_index, nbands, C.byref(buf), C.byref(n),
+                                                                C.byref(more), info))
+        return more.value, buf.value, n.value, (list(info) if (want_info and not more.value) else None)
 
     def strips(self, width, height):
         c = np.empty(width, np.float32)

@@ -1,0 +1,96 @@
+"""Worker of tests/test_gpu_distributed.py::test_row_bands_in_two_processes_equal_the_oracle: one rank of the frame path
+sharded by ROW BANDS, one process per rank, the HIP kernels in every rank.
+usage: band_worker.py <rank> <world> <port>
+
+Every rank receives the whole (seeded) IQ stream — in production every GPU is fed the same blocks — and owns rows
+[y0, y0 + rows) of every frame: tsdrgpu_resample_band produces only those rows, tsdrgpu_postproc_band_begin their
+statistics; the exchanges (sum / max all-reduce of the strip partials and extrema, then the relay of the literal strip
+collapse whenever tsdrgpu_postproc_band_advance asks for it) go through gloo on the host here, because the test box's
+ranks share ONE device, which RCCL refuses (production: tsdrgpu_comm_allreduce_f64 / _f32max over xGMI).  Rank 0 gathers
+the bands and compares the reassembled frames with the ORACLE's driver (am_demod -> dsp_resample_process per chunk ->
+dsp_post_process per frame), bit for bit, together with the sync / autogain state."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    rank, world, port = (int(a) for a in sys.argv[1:4])
+    import torch
+    import torch.distributed as dist
+    from tempestsdr_amd import gpu, synth
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = gpu.TsdrGpu(0)
+    fs, h, fv, blur = 8_000_000, 525, 60.0, 0.5
+    geo = orc.geometry(fs, h, fv)
+    W, P = geo.width, geo.width * h
+    chunk = orc.chunk_size(fs, fv)
+    calls = (27, 38)  # chunks per batch: frames straddle the batches
+    iq = synth.synth_iq(fs, "640x480", fv, sum(calls) * chunk, seed=0x5EED0007)
+    # one frame's worth of silence in the middle of the stream: blank frames, i.e. strips full of exact ties, whose
+    # literal collapse has to be relayed band by band
+    iq[2 * 30 * chunk:2 * 42 * chunk] = 0.0
+    edges = [0] + [32 * ((h * k // world) // 32) for k in range(1, world)] + [h]
+    y0, rows = edges[rank], edges[rank + 1] - edges[rank]
+    up, down = W * h * fv, float(fs)
+
+    def allreduce(ptr, n, dtype, op):
+        a = np.empty(n, dtype)
+        g._ck(g.lib.tsdrgpu_download(g.h, a.ctypes.data, ptr, a.nbytes))
+        g.sync()
+        t = torch.from_numpy(a)
+        dist.all_reduce(t, op=op)
+        g._ck(g.lib.tsdrgpu_upload(g.h, ptr, a.ctypes.data, a.nbytes))
+        g.sync()
+
+    d_iq = g.to_device(iq)
+    rs, pp = gpu.Resampler(g), gpu.PostProcess(g)
+    cap = 8
+    d_band, d_out = g.empty(cap * rows * W), g.empty(cap * rows * W)
+    outs, infos, relay_steps = [], [], 0
+    phase, done = 0, 0
+    for k in calls:
+        n, touched = rs.process_band(d_iq, 1, chunk, k, up, down, W, h, y0, rows, phase, d_band, cap, in_offset=2 * done * chunk)
+        F = (phase + n) // P
+        ps, ns, pm, nm = pp.band_begin(d_band, F, W, h, y0, rows, motionblur=blur)
+        allreduce(ps, ns, np.float64, dist.ReduceOp.SUM)
+        allreduce(pm, nm, np.float32, dist.ReduceOp.MAX)
+        while True:
+            more, buf, nb, info = pp.band_advance(d_out, rank, world)
+            if not more:
+                break
+            allreduce(buf, nb, np.float64, dist.ReduceOp.SUM)
+            relay_steps += 1
+        outs.append(d_out.download()[:F * rows * W].reshape(F, rows, W).copy())
+        infos += info
+        phase = (phase + n) % P
+        if phase:  # the incomplete frame goes on in slot 0 of the next call
+            g._ck(g.lib.tsdrgpu_copy(g.h, d_band.at(0), d_band.at(F * rows * W), rows * W * 4))
+        done += k
+    mine = np.concatenate(outs)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    ok = True
+    if rank == 0:
+        got = np.concatenate(gathered, axis=1)
+        pix, _ = orc.demod_resample_stream(iq, geo)
+        opp = orc.PostProcess(geo)
+        want = np.stack([opp.run(pix[j * P:(j + 1) * P].copy(), blur).reshape(h, W) for j in range(got.shape[0])])
+        same = np.array_equal(got, want)
+        si, _ = opp.state()
+        last = infos[-1]
+        state_ok = (last.dx, last.vx, last.stripx, last.dy, last.vy, last.stripy, last.locked) == tuple(si[:7])
+        print(f"frames {got.shape[0]} of {W}x{h} in {world} bands, relay steps {relay_steps}", flush=True)
+        print("bands equal the oracle:", bool(same and state_ok and relay_steps >= world), flush=True)
+        ok = bool(same and state_ok and relay_steps >= world)
+    g.close()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

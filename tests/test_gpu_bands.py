@@ -101,3 +101,151 @@ def test_band_exchange_over_rccl_one_rank():
     comm.destroy()
     with pytest.raises(gpu.TsdrGpuError):
         pp.band_begin(d_in, F, W, H, 16, 100)  # bands start on multiples of 32 rows
+
+
+# ---------------------------------------------------------------------------
+# contract-exact bands (tsdrgpu_postproc_band_advance) and the band resampler, against the ORACLE
+# ---------------------------------------------------------------------------
+def _sum_exchange(g, ptrs, n):
+    """sum all-reduce of the ranks' double buffers on the host (production: tsdrgpu_comm_allreduce_f64 over RCCL)"""
+    bufs = [np.empty(n, np.float64) for _ in ptrs]
+    for b, p in zip(bufs, ptrs):
+        g._ck(g.lib.tsdrgpu_download(g.h, b.ctypes.data, p, b.nbytes))
+    g.sync()
+    tot = np.sum(bufs, axis=0)
+    for p in ptrs:
+        g._ck(g.lib.tsdrgpu_upload(g.h, p, tot.ctypes.data, tot.nbytes))
+    g.sync()
+
+
+def _run_bands(g, pps, rows, fr, blur):
+    """one batch through the band protocol; returns (concatenated output, per-frame records, relay steps taken)"""
+    F, H, W = fr.shape
+    begun, d_bands, d_outs = [], [], []
+    for pp, (y0, n) in zip(pps, rows):
+        d_b = g.to_device(np.ascontiguousarray(fr[:, y0:y0 + n, :]).reshape(-1))
+        d_bands.append(d_b)
+        d_outs.append(g.empty(F * W * n))
+        begun.append(pp.band_begin(d_b, F, W, H, y0, n, motionblur=blur))
+    # the two all-reduces of _band_begin (sum of the strip partials, max of {-min, max, pixel 0})
+    ns, nm = begun[0][1], begun[0][3]
+    _sum_exchange(g, [b[0] for b in begun], ns)
+    m = [np.empty(nm, np.float32) for _ in begun]
+    for k, b in enumerate(begun):
+        g._ck(g.lib.tsdrgpu_download(g.h, m[k].ctypes.data, b[2], m[k].nbytes))
+    g.sync()
+    mm = np.maximum.reduce(m)
+    for b in begun:
+        g._ck(g.lib.tsdrgpu_upload(g.h, b[2], mm.ctypes.data, mm.nbytes))
+    g.sync()
+    steps, infos = 0, None
+    while True:
+        res = [pp.band_advance(d_o, k, len(pps)) for k, (pp, d_o) in enumerate(zip(pps, d_outs))]
+        mores = {r[0] for r in res}
+        assert len(mores) == 1, "every rank takes the same decision"
+        if not res[0][0]:
+            infos = [r[3] for r in res]
+            break
+        assert len({r[2] for r in res}) == 1
+        _sum_exchange(g, [r[1] for r in res], res[0][2])
+        steps += 1
+    outs = [d_o.download().reshape(F, n, W) for d_o, (_, n) in zip(d_outs, rows)]
+    for other in infos[1:]:  # every rank ends up with the same record
+        for a, b in zip(infos[0], other):
+            assert (a.lastmin, a.lastmax, a.dx, a.vx, a.stripx, a.dy, a.vy, a.stripy, a.locked, a.avg_speed) == \
+                   (b.lastmin, b.lastmax, b.dx, b.vx, b.stripx, b.dy, b.vy, b.stripy, b.locked, b.avg_speed)
+    return np.concatenate(outs, axis=1), infos[0], steps
+
+
+def _geo(orc, W, H):
+    geo = orc.Geometry()
+    geo.samplerate, geo.width, geo.height, geo.refreshrate = 8_000_000, W, H, 60.0
+    geo.pixelrate = W * H * 60.0
+    geo.pixeltimeoversampletime = geo.samplerate / geo.pixelrate
+    return geo
+
+
+@pytest.mark.parametrize("W,H,cuts,blur", [(507, 525, (160, 352), 0.0), (1033, 806, (416,), 0.5), (640, 420, (96, 224, 320), 0.9375)])
+def test_exact_row_bands_equal_the_oracle(orc, W, H, cuts, blur):
+    """2, 3 and 4 bands in the default, contract-exact mode against the ORACLE (dsp_post_process restated, pinned to the
+    compiled reference): frames bit for bit and the sync / autogain records, over batches that hold every kind of
+    strip — noisy rasters (toss-ups at most), a blank frame and a noiseless pattern (exact ties: the literal collapse
+    is relayed band by band), a sentinel.  State is carried from batch to batch."""
+    g = ctx()
+    rng = np.random.default_rng(3 * W + H)
+    edges = (0,) + tuple(cuts) + (H,)
+    rows = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
+    pps = [gpu.PostProcess(g) for _ in rows]
+    single = gpu.PostProcess(g)  # the single-GPU run in its default (exact) mode
+    opp = orc.PostProcess(_geo(orc, W, H))
+    total_steps = 0
+    for batch, F in enumerate((4, 9, 2)):
+        fr = _frames(rng, F, W, H, 10 * batch)
+        if batch == 0:
+            fr[1] = 0.25                                                # blank: every window position ties
+            y, x = np.mgrid[0:H, 0:W]
+            fr[2] = (0.3 + 0.5 * ((x // 40) % 2)).astype(np.float32)    # plateaus without noise: ties in both strips
+        if batch == 1:
+            fr[3, 5, 7] = 1024.0                                        # a sentinel pixel
+        want = np.stack([opp.run(fr[k].reshape(-1).copy(), blur, 0.1, 0, 0, 0, 0, 0).reshape(H, W) for k in range(F)])
+        d_full, d_out = g.to_device(fr.reshape(-1)), g.empty(F * W * H)
+        sinfo = single.run(d_full, F, W, H, d_out, motionblur=blur)
+        assert np.array_equal(d_out.download().reshape(F, H, W), want)
+        got, infos, steps = _run_bands(g, pps, rows, fr, blur)
+        total_steps += steps
+        assert steps % len(rows) == 0  # whole relays only
+        if batch == 0:
+            assert steps >= len(rows)  # the blank frame needed one
+        assert np.array_equal(got, want), (batch, int(np.sum(got != want)))
+        for a, b in zip(sinfo, infos):
+            assert (a.lastmin, a.lastmax, a.dx, a.vx, a.stripx, a.dy, a.vy, a.stripy, a.locked, a.avg_speed) == \
+                   (b.lastmin, b.lastmax, b.dx, b.vx, b.stripx, b.dy, b.vy, b.stripy, b.locked, b.avg_speed)
+    si, sd = opp.state()
+    last = infos[-1]
+    assert (last.dx, last.vx, last.stripx, last.dy, last.vy, last.stripy, last.locked) == tuple(si[:7])
+
+
+@pytest.mark.parametrize("fs,h,y0,rows", [(8_000_000, 525, 160, 192), (8_000_000, 525, 0, 525), (25_000_000, 806, 416, 390),
+                                          (2_000_000, 131, 32, 64), (7_000_000, 525, 352, 173)])
+def test_band_resampler_equals_the_oracle_stream(orc, fs, h, y0, rows):
+    """tsdrgpu_resample_band over several calls (frames straddle the calls; the incomplete frame is carried into slot 0):
+    every band row equals the same row of the ORACLE's pixel stream, bit for bit, and the carried state (offset, contrib)
+    is the full call's."""
+    from tempestsdr_amd import synth
+    g = ctx()
+    fv = 60.0
+    geo = orc.geometry(fs, h, fv)
+    W, P = geo.width, geo.width * h
+    chunk = orc.chunk_size(fs, fv)
+    nch = 47
+    mode = {525: "640x480", 806: "1024x768", 131: "640x480"}[h]
+    iq = synth.synth_iq(fs, mode, fv, nch * chunk, seed=0x5EED0002)
+    want, _ = orc.demod_resample_stream(iq, geo)
+    d_iq = g.to_device(iq)
+    up, down = W * h * fv, float(fs)
+    rs_band, rs_full = gpu.Resampler(g), gpu.Resampler(g)
+    cap = 8
+    d_band = g.empty(cap * rows * W)
+    frames = {}
+    phase, done_chunks, frame0 = 0, 0, 0
+    for k in (5, 1, 13, 10, 18):  # chunks per call
+        n, touched = rs_band.process_band(d_iq, 1, chunk, k, up, down, W, h, y0, rows, phase, d_band, cap, in_offset=2 * done_chunks * chunk)
+        assert n == rs_full.count(chunk, k, up, down) and touched == (phase + n + P - 1) // P
+        d_scratch = g.empty(n + 16)
+        assert rs_full.process(d_iq, 1, chunk, k, up, down, 0, d_scratch, in_offset=2 * done_chunks * chunk) == n
+        assert rs_band.state() == rs_full.state()
+        got = d_band.download().reshape(cap, rows, W)
+        complete = (phase + n) // P
+        for j in range(complete):
+            frames[frame0 + j] = got[j].copy()
+        phase = (phase + n) % P
+        if phase:  # the incomplete frame goes on in slot 0 of the next call
+            part = got[complete].reshape(-1).copy()
+            g._ck(g.lib.tsdrgpu_upload(g.h, d_band.at(0), part.ctypes.data, part.nbytes))
+            g.sync()
+        frame0 += complete
+        done_chunks += k
+    assert len(frames) >= 3
+    for j, fr in frames.items():
+        ref = want[j * P:(j + 1) * P].reshape(h, W)[y0:y0 + rows]
+        assert np.array_equal(fr, ref), (j, int(np.sum(fr != ref)))

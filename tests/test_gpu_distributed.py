@@ -38,6 +38,19 @@ def test_two_ranks_on_one_device_match_the_running_mean(fs, nwin):
     assert "merged plots equal the single-rank running mean: True" in outs[0]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_bands_in_two_processes_equal_the_oracle(world):
+    """SURVEY 8(e) row 2 end to end, one process per rank: band resampler -> band statistics -> exchanges -> relayed literal
+    collapse -> chain -> pass; the reassembled frames are the ORACLE's (tests/band_worker.py)."""
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "band_worker.py"), str(r), str(world), str(port)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "bands equal the oracle: True" in outs[0]
+
+
 def test_rccl_from_c_one_rank(orc):
     """tsdrgpu_rccl_unique_id / tsdrgpu_comm_create / tsdrgpu_autocorr_allreduce with a communicator of one rank:
     the ncclAllReduce is queued by the library on the autocorrelation's lane; sums + all-reduce + finalise equal
