@@ -74,6 +74,13 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
+class _DevArrayF(_DevArray):
+    """the same for floats"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
 class DevPtr:
     """Adapter: a torch tensor seen as a tsdrgpu DeviceArray (pointer + offsets)."""
 
@@ -177,6 +184,11 @@ def main():
     ap.add_argument("--fast-sync", action="store_true",
                     help="opt out of the contract-exact sync detector (tsdrgpu_postproc_set_exact_ties(0)); the default "
                          "— and what the library ships — redoes toss-up decisions with the reference's own strip sums")
+    ap.add_argument("--bands", action="store_true",
+                    help="N > 1 (or --force-dist): ONE stream, the frame path sharded by ROW BANDS (SURVEY 8(e) row 2: rank k owns "
+                         "rows [k H/N, (k+1) H/N) of every frame — band resampler, band statistics, sum/max all-reduce of the strip "
+                         "partials over RCCL, the replicated sync chain, the pass over the band) and the capture windows sharded by "
+                         "window (--scaling strong); what configs[4] names for 8 GPUs.  Contract-exact like the single-GPU run")
     ap.add_argument("--blur", type=float, default=None, help="motion blur coefficient (tsdr_motionblur) instead of the configuration's own")
     ap.add_argument("--leg", action="store_true",
                     help="a side leg of another bench.py run: the timed region, the per-kernel rooflines and nothing else")
@@ -231,6 +243,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     sharded = dist is not None  # autocorrelation as per-lag sums + all-reduce
+    if args.bands:
+        if not sharded:
+            ap.error("--bands needs N > 1 ranks (or --force-dist for the same code path on one GPU)")
+        args.scaling = "strong"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -281,6 +297,16 @@ def main():
     frames_cap = max_pix // P + 1
     out = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
     d_pix, d_out = DevPtr(pix), DevPtr(out)
+    band = None
+    if args.bands:
+        # bands start on multiples of 32 rows (the statistics tiles); the last one takes the remainder
+        edges = [0] + [32 * ((h * k // world) // 32) for k in range(1, world)] + [h]
+        band = {"y0": edges[rank], "rows": edges[rank + 1] - edges[rank], "phase": 0}
+        if min(b - a for a, b in zip(edges[:-1], edges[1:])) <= 0:
+            ap.error("too many ranks for this frame height")
+        band_cap = frames_cap + 1
+        d_band = DevPtr(torch.empty(band_cap * band["rows"] * W, dtype=torch.float32, device=dev))
+        d_out_band = DevPtr(torch.empty(band_cap * band["rows"] * W, dtype=torch.float32, device=dev))
     comm = None
     plots_ts = {}
     if sharded:
@@ -368,8 +394,46 @@ def main():
             one_pass(False)
         return one_pass(True)
 
+    relay_steps = [0]
+
+    def band_pass():
+        """the frame path of one pass on this rank's row band"""
+        nonlocal frames_done
+        y0, rows_b = band["y0"], band["rows"]
+        n, touched = rs.process_band(d_iq, 1, chunk, nchunks, up, down, W, h, y0, rows_b, band["phase"], d_band, band_cap)
+        F = (band["phase"] + n) // P
+        ps, ns, pm, nm = pp.band_begin(d_band, F, W, h, y0, rows_b, motionblur=blur)
+        if comm is not None:
+            comm.allreduce_f64(ps, ns)     # strip partials: column sums add up, row sums concatenate
+            comm.allreduce_f32max(pm, nm)  # {-min, max, pixel 0}
+        else:
+            g.sync()
+            dist.all_reduce(torch.as_tensor(_DevArray(ps, ns), device=dev))
+            mx = torch.as_tensor(_DevArrayF(pm, nm), device=dev)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
+        run_autocorr()  # behind the exchange: the tiny replicated chain then finds the device busy with the FFT trips
+        while True:
+            more, buf, nb, _ = pp.band_advance(d_out_band, rank, world, want_info=False)
+            if not more:
+                break
+            relay_steps[0] += 1
+            if comm is not None:
+                comm.allreduce_f64(buf, nb)
+            else:
+                g.sync()
+                dist.all_reduce(torch.as_tensor(_DevArray(buf, nb), device=dev))
+                torch.cuda.synchronize()
+        band["phase"] = (band["phase"] + n) % P
+        if band["phase"]:  # the incomplete frame goes on in slot 0 of the next pass
+            g._ck(g.lib.tsdrgpu_copy(g.h, d_band.at(0), d_band.at(F * rows_b * W), rows_b * W * 4))
+        frames_done += F
+
     def one_pass(last):
         nonlocal carry, frames_done
+        if band is not None:
+            band_pass()
+            return finish_pass(last)
         split = args.frames_per_launch <= 0 and not args.no_split
         fuse = split and args.fuse
         if not split:
@@ -406,6 +470,9 @@ def main():
                 g._ck(g.lib.tsdrgpu_copy(g.h, d_pix.at(0), d_pix.at(F * P), rem * 4))
             carry = rem
             frames_done += F
+        return finish_pass(last)
+
+    def finish_pass(last):
         a = acs[pass_no[0] % 2]
         pass_no[0] += 1
         if sharded:
@@ -632,9 +699,10 @@ def main():
         #   frame path 8S+16P per frame = resampler (8S+4P) + statistics (4P) + normalise/IIR pass (8P)
         # The autocorrelation has ONE figure, 28N+16L per window, for all of its kernels together, so it gets one
         # group entry: bytes per window x windows / (sum of its kernels' durations).
-        own = {"k_rs_area": (8.0 * S + 4.0 * P) * (nsamples / S),
-               "k_frame_stats": 4.0 * P * frames_pass,
-               "k_frame_pass": 8.0 * P * frames_pass}
+        bfrac = (band["rows"] / h) if band is not None else 1.0  # a band touches its share of samples and pixels
+        own = {"k_rs_area": (8.0 * S + 4.0 * P) * (nsamples / S) * bfrac,
+               "k_frame_stats": 4.0 * P * frames_pass * bfrac,
+               "k_frame_pass": 8.0 * P * frames_pass * bfrac}
         kernels = {}
         for k, bytes_pass in own.items():
             ms, n = per_pass(k)
@@ -666,7 +734,7 @@ def main():
         fused = chain_hidden and args.fuse
         frame_group = ("k_rs_tail+k_rs_chain", "k_rs_area", "k_frame_stats", "k_frame_pass") + (() if chain_hidden else ("k_frame_reduce", "k_chain"))
         frame_ms = sum(per_pass(k)[0] for k in frame_group)
-        frame_bytes_pass = (8.0 * S + 16.0 * P) * frames_pass
+        frame_bytes_pass = (8.0 * S + 16.0 * P) * frames_pass * bfrac
         stage_ms = {k: round(v[0] / np_, 4) for k, v in prof.items()}
 
         # the `roofline` object: the entry that takes the most time per pass (a kernel, or the autocorrelation group)
@@ -732,7 +800,14 @@ def main():
                                            "8e-6 * R[0], computed in the argmax kernels); an epoch whose certificate fails is replayed in the "
                                            "reference's own FFT arithmetic (bit-identical plots).  One epoch = one pass; windows retained by the "
                                            "caller (mode 2: the stream is HBM-resident; the engine retains copies, mode 1)"),
-                       "autocorr_epochs_replayed_exact": promoted_passes[0]},
+                       "autocorr_epochs_replayed_exact": promoted_passes[0],
+                       "row_bands": None if band is None else
+                                    {"bands": world, "this_rank_rows": [band["y0"], band["y0"] + band["rows"]], "of": h,
+                                     "exchange": "per batch: sum all-reduce of the strip partials (3 x (W+H) doubles per frame) + max all-reduce "
+                                                 "of {-min, max, pixel 0}; + one sum all-reduce per band for every relay of the literal strip "
+                                                 "collapse (ties / toss-ups)",
+                                     "relay_steps_in_this_run": relay_steps[0],
+                                     "note": "strong scaling of ONE stream: value = samples of the stream / time, frames_per_s = frames of the stream"}},
             "ms_per_pass": round(ms_pass, 4),
             "step_ms": {"min": round(srt[0] * 1e3, 3), "median": round(srt[len(srt) // 2] * 1e3, 3), "max": round(srt[-1] * 1e3, 3),
                         "timed_region_s": round(dt, 3)},
