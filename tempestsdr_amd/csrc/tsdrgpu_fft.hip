@@ -972,8 +972,10 @@ static int ac_run_exact(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq,
     for (int w0 = 0; w0 < nwindows; w0 += AC_XBATCH) {
         const int cnt = nwindows - w0 < AC_XBATCH ? nwindows - w0 : AC_XBATCH;
         const float *src = d_in + (size_t)w0 * (size_t)stride * (in_is_iq ? 2 : 1);
+        // (only the call's final window is stored whole: tsdrgpu_autocorr_last_corr; the others keep their lag windows)
         rc = fftx_autocorr(g, ac->st, src, in_is_iq, stride, cnt, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag, ac->frame_lo, ac->frame_len,
-                           ac->line_lo, ac->line_len, ac->d_plots, (unsigned long long)(ac->calls + w0), mode);
+                           ac->line_lo, ac->line_len, ac->d_plots, (unsigned long long)(ac->calls + w0), mode,
+                           (w0 + cnt == nwindows) ? cnt - 1 : -1);
         if (rc) return rc;
         ac->d_last = ac->d_xz + (size_t)(cnt - 1) * ac->n;  // the whole complex correlation of the last window
         ac->last_exact = 1;

@@ -132,6 +132,165 @@ __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same trips, specialised (round 3).  k_fftx_trip above is generic — runtime tile shape, one radix-2 stage per LDS
+// round trip, a twiddle load per butterfly — and ran at 0.06 of the HBM roofline.  k_fftx_fast keeps the arithmetic
+// bit for bit (the same f64 butterfly on f32 values, every stage's results rounded to f32) and changes how it is fed:
+//   * tile shape at compile time (L stages x 4096 >> L columns): index math is shifts and masks;
+//   * up to three stages per LDS round trip: a thread holds the 8 (4, 2) points of one radix-8 (4, 2) group, rounds
+//     them to f32 between the stages exactly as the LDS store did, and needs 7 (3, 1) twiddles for its 12 (4, 1)
+//     butterflies;
+//   * the windows of a batch that share a tile position run back to back on the same XCD (block -> (tile, window)
+//     map below), so the late stages' twiddles — 64 MB of f64 pairs at N = 2^22, every entry used by one butterfly per
+//     window — come from that XCD's L2 for all windows but the first;
+//   * the last trip of the inverse transform stores only what the detector reads (the two lag windows and lag 0),
+//     except for the window kept whole for tsdrgpu_autocorr_last_corr.
+// ---------------------------------------------------------------------------
+struct FftxKeep {
+    int on;       // 0: store everything
+    int full_w;   // window of the batch stored whole (-1: none)
+    unsigned lo0, hi0, lo1, hi1;  // lag ranges kept (point 0 always)
+};
+
+__device__ __forceinline__ void fftx_bfly(float2 &a, float2 &b, double2 u)
+{
+    const double tr = u.x * (double)b.x - u.y * (double)b.y;  // fft.c:153-154
+    const double ti = u.x * (double)b.y + u.y * (double)b.x;
+    const float2 na = make_float2((float)((double)a.x + tr), (float)((double)a.y + ti));
+    b = make_float2((float)((double)a.x - tr), (float)((double)a.y - ti));
+    a = na;
+}
+
+// K consecutive stages, local stages a .. a+K-1 of the tile, on the group of 2^K rows {base + (j << a)} of column c
+template <int K, bool FIRST>
+__device__ __forceinline__ void fftx_group(float2 *__restrict__ t, unsigned Cp, unsigned base, unsigned c, int a, int s0, unsigned colg,
+                                           const double2 *__restrict__ tw, int inverse)
+{
+    constexpr int NP = 1 << K;
+    float2 v[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) v[j] = t[(base + ((unsigned)j << a)) * Cp + c];
+    const unsigned low = base & ((1u << a) - 1u);  // the part of the row index below the group's stride
+#pragma unroll
+    for (int st = 0; st < K; st++) {
+        const int s = s0 + a + st;
+        const double2 *ts = tw + ((1ull << s) - 1ull);  // this stage's u[q], q < 2^s
+#pragma unroll
+        for (int jl = 0; jl < (1 << st); jl++) {
+            const unsigned rowlow = low + ((unsigned)jl << a);
+            const unsigned long long q = FIRST ? (unsigned long long)rowlow : (((unsigned long long)rowlow << s0) + colg);
+            double2 u = ts[q];
+            if (inverse) u.y = -u.y;  // the inverse recurrence yields exactly the conjugates
+#pragma unroll
+            for (int jh = 0; jh < (NP >> (st + 1)); jh++) {
+                const int j0 = (jh << (st + 1)) | jl;
+                fftx_bfly(v[j0], v[j0 | (1 << st)], u);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; j++) t[(base + ((unsigned)j << a)) * Cp + c] = v[j];
+}
+
+// all groups of one chunk of K stages starting at local stage a: 4096 >> K groups over 256 threads
+template <int K, int L, bool FIRST>
+__device__ __forceinline__ void fftx_chunk(float2 *__restrict__ t, int a, int s0, unsigned colbase, const double2 *__restrict__ tw, int inverse)
+{
+    constexpr unsigned C = 4096u >> L, Cp = C + 1u;
+    constexpr unsigned NG = 4096u >> K;
+#pragma unroll 1
+    for (unsigned gid = threadIdx.x; gid < NG; gid += 256u) {
+        const unsigned c = gid & (C - 1u), gb = gid / C;
+        const unsigned base = ((gb >> a) << (a + K)) | (gb & ((1u << a) - 1u));
+        fftx_group<K, FIRST>(t, Cp, base, c, a, s0, colbase + c, tw, inverse);
+    }
+    __syncthreads();
+}
+
+template <int L, bool FIRST>
+__global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src, int src_mode, long long src_stride, float2 *__restrict__ z,
+                                                   float *__restrict__ mag, unsigned n, int m, int s0, int batch,
+                                                   const double2 *__restrict__ tw, int inverse, int epilogue, float nf, FftxKeep keep)
+{
+    constexpr unsigned R = 1u << L, C = 4096u >> L, Cp = C + 1u;
+    constexpr int LOGC = 12 - L;
+    __shared__ float2 t[R * Cp];
+    const unsigned tid = threadIdx.x;
+    // block -> (tile, window): the `batch` windows of a tile follow each other on one XCD (blocks are dealt round-robin
+    // to the 8 XCDs), tiles advance in octets; the tile count is a multiple of 8 (n >= 2^15)
+    const unsigned per_oct = 8u * (unsigned)batch;
+    const unsigned oct = blockIdx.x / per_oct, rem = blockIdx.x % per_oct;
+    const unsigned w = rem >> 3, tile = oct * 8u + (rem & 7u);
+    float2 *zb = z + (long long)w * n;
+    unsigned colbase = 0, r0 = 0;
+    unsigned long long gbase = 0;
+    if (FIRST) {
+        // the rows of column r are the 2^L elements of bit-reversed block B = rev(r): source elements rev_L(row)*S + r
+        const unsigned S = n >> L;
+        r0 = tile * C;
+        const float *sb = src + (long long)w * src_stride * (src_mode == 0 ? 1 : 2);
+#pragma unroll 4
+        for (unsigned e = tid; e < 4096u; e += 256u) {
+            const unsigned row = e >> LOGC, c = e & (C - 1u);
+            const unsigned long long at = (unsigned long long)fftx_rev(row, L) * S + r0 + c;
+            float2 v;
+            if (src_mode == 2) v = ((const float2 *)sb)[at];
+            else if (src_mode == 1) {
+                const float2 iq = ((const float2 *)sb)[at];
+                v = make_float2(sqrtf(iq.x * iq.x + iq.y * iq.y), 0.f);  // am_demod, TSDRLibrary.c:244-262
+            } else v = make_float2(sb[at], 0.f);  // real_to_complex, fft.c:14-22
+            t[row * Cp + c] = v;
+        }
+    } else {
+        const unsigned per_group = (1u << s0) >> LOGC;  // tiles across one group's 2^s0 columns
+        const unsigned group = tile / per_group;
+        colbase = (tile % per_group) << LOGC;
+        gbase = ((unsigned long long)group << (s0 + L)) + colbase;
+#pragma unroll 4
+        for (unsigned e = tid; e < 4096u; e += 256u) {
+            const unsigned row = e >> LOGC, c = e & (C - 1u);
+            t[row * Cp + c] = zb[gbase + ((unsigned long long)row << s0) + c];
+        }
+    }
+    __syncthreads();
+    // L stages as chunks of 3, 3, rest
+    if (L >= 3) fftx_chunk<3, L, FIRST>(t, 0, s0, colbase, tw, inverse);
+    if (L >= 6) fftx_chunk<3, L, FIRST>(t, 3, s0, colbase, tw, inverse);
+    if (L == 5) fftx_chunk<2, L, FIRST>(t, 3, s0, colbase, tw, inverse);
+    if (L == 7) fftx_chunk<1, L, FIRST>(t, 6, s0, colbase, tw, inverse);
+    if (L == 8) fftx_chunk<2, L, FIRST>(t, 6, s0, colbase, tw, inverse);
+    const bool filter = keep.on && (int)w != keep.full_w;
+    if (FIRST) {
+        // column c is block B = rev_{m-L}(r0 + c): R contiguous results per block
+#pragma unroll 4
+        for (unsigned e = tid; e < 4096u; e += 256u) {
+            const unsigned c = e >> L, row = e & (R - 1u);
+            const unsigned long long B = fftx_rev(r0 + c, m - L);
+            float2 v = t[row * Cp + c];
+            const unsigned long long at = B * R + row;
+            if (epilogue == 1 || epilogue == 2) {
+                v.x = v.x / nf;
+                v.y = v.y / nf;
+            }
+            if (epilogue == 1) mag[(long long)w * n + at] = sqrtf(v.x * v.x + v.y * v.y);
+            else if (!filter || at == 0ull || (at >= keep.lo0 && at < keep.hi0) || (at >= keep.lo1 && at < keep.hi1)) zb[at] = v;
+        }
+    } else {
+#pragma unroll 4
+        for (unsigned e = tid; e < 4096u; e += 256u) {
+            const unsigned row = e >> LOGC, c = e & (C - 1u);
+            float2 v = t[row * Cp + c];
+            const unsigned long long at = gbase + ((unsigned long long)row << s0) + c;
+            if (epilogue == 1 || epilogue == 2) {
+                v.x = v.x / nf;
+                v.y = v.y / nf;
+            }
+            if (epilogue == 1) mag[(long long)w * n + at] = sqrtf(v.x * v.x + v.y * v.y);
+            else if (!filter || at == 0ull || (at >= keep.lo0 && at < keep.hi0) || (at >= keep.lo1 && at < keep.hi1)) zb[at] = v;
+        }
+    }
+}
+
 // accummulate (frameratedetector.c:34-62) on the complex correlation, in window order.  Entry frame_len + line_len
 // of `plots` accumulates lag 0 the same way (the scale of the argmax certificate, tsdrgpu_autocorr_certificate).
 __global__ __launch_bounds__(256) void k_fftx_accumulate(const float2 *__restrict__ corr, unsigned n, int nwindows, int frame_lo,
@@ -241,10 +400,27 @@ static int fftx_plan(int m, FftxTrip *trips)
     return count;
 }
 
-// One transform (forward: from `src`; inverse: from the real array `mag`) of `batch` windows into z.
-static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int src_mode, long long src_stride, float2 *z, float *mag,
-                          uint32_t n, int m, int batch, const double2 *d_tw, int inverse, int epilogue)
+static const FftxKeep FFTX_KEEP_ALL = {0, -1, 0u, 0u, 0u, 0u};
+
+template <bool FIRST>
+static bool fftx_launch_fast(tsdrgpu_t *g, hipStream_t st, int L, unsigned blocks, const float *src, int src_mode, long long src_stride, float2 *z,
+                             float *mag, uint32_t n, int m, int s0, int batch, const double2 *d_tw, int inverse, int epi, const FftxKeep &keep)
 {
+    switch (L) {
+        case 5: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<5, FIRST>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, (float)n, keep); return true;
+        case 6: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<6, FIRST>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, (float)n, keep); return true;
+        case 7: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<7, FIRST>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, (float)n, keep); return true;
+        case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<8, FIRST>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, (float)n, keep); return true;
+        default: return false;
+    }
+}
+
+// One transform (forward: from `src`; inverse: from the real array `mag`) of `batch` windows into z.  `keep` filters what
+// the LAST trip stores (the inverse transform of the autocorrelation); intermediate trips store everything.
+static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int src_mode, long long src_stride, float2 *z, float *mag,
+                          uint32_t n, int m, int batch, const double2 *d_tw, int inverse, int epilogue, const FftxKeep &keep = FFTX_KEEP_ALL)
+{
+    static const int generic_only = getenv("TSDRGPU_FFTX_GENERIC") ? 1 : 0;  // A/B switch: the round-2 kernel for every trip
     FftxTrip trips[8];
     const int nt = fftx_plan(m, trips);
     for (int k = 0; k < nt; k++) {
@@ -252,11 +428,23 @@ static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int sr
         const unsigned R = 1u << L;
         unsigned C = 4096u / R;
         const unsigned width = s0 == 0 ? (n >> L) : (1u << s0);  // columns available to a tile
-        if (C > width) C = width;
-        const unsigned tiles = n / (R * C);
-        const int epi = (k == nt - 1) ? epilogue : 0;
-        TSDR_LAUNCH(g, PROF_FFT_PASS, st, k_fftx_trip, dim3(tiles, batch), 256, src, src_mode, src_stride, z, mag, n, m, s0, L, (int)C, d_tw,
-                    inverse, epi, (float)n);
+        const bool last = k == nt - 1;
+        const int epi = last ? epilogue : 0;
+        // the specialised kernel wants full 4096-point tiles, a tile count that is a multiple of 8 and L in 5..8
+        const bool fast_ok = !generic_only && C <= width && n >= (1u << 15) && L >= 5 && L <= 8;
+        bool done = false;
+        if (fast_ok) {
+            const unsigned blocks = (n / 4096u) * (unsigned)batch;
+            const FftxKeep &kp = last ? keep : FFTX_KEEP_ALL;
+            done = s0 == 0 ? fftx_launch_fast<true>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, kp)
+                           : fftx_launch_fast<false>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, kp);
+        }
+        if (!done) {
+            if (C > width) C = width;
+            const unsigned tiles = n / (R * C);
+            TSDR_LAUNCH(g, PROF_FFT_PASS, st, k_fftx_trip, dim3(tiles, batch), 256, src, src_mode, src_stride, z, mag, n, m, s0, L, (int)C, d_tw,
+                        inverse, epi, (float)n);
+        }
     }
     if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "exact FFT", "launch");
     return TSDRGPU_OK;
@@ -264,23 +452,37 @@ static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int sr
 
 // fft_autocorrelation for `cnt` windows, exactly: answer = IFFT( | FFT(x) / N | ), fft.c:49-64.
 // z: cnt*n complex (the result), mag: cnt*n floats.
-int fftx_correlate(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
-                   const double2 *d_tw, float2 *z, float *mag)
+static int fftx_correlate_keep(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
+                               const double2 *d_tw, float2 *z, float *mag, const FftxKeep &keep)
 {
     int m = 0;
     while ((1u << m) < n) m++;
     int rc;
     if (m == 0) return tsdr_fail(g, TSDRGPU_EINVAL, "exact FFT", "transform too short");
     if ((rc = fftx_transform(g, st, d_in, in_is_iq ? 1 : 0, stride, z, mag, n, m, cnt, d_tw, 0, 1))) return rc;
-    return fftx_transform(g, st, mag, 0, (long long)n, z, mag, n, m, cnt, d_tw, 1, 0);
+    return fftx_transform(g, st, mag, 0, (long long)n, z, mag, n, m, cnt, d_tw, 1, 0, keep);
 }
 
-// fft_autocorrelation + accummulate for `cnt` windows, exactly.  z: cnt*n complex, mag: cnt*n floats.
+int fftx_correlate(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
+                   const double2 *d_tw, float2 *z, float *mag)
+{
+    return fftx_correlate_keep(g, st, d_in, in_is_iq, stride, cnt, n, d_tw, z, mag, FFTX_KEEP_ALL);
+}
+
+// fft_autocorrelation + accummulate for `cnt` windows, exactly.  z: cnt*n complex, mag: cnt*n floats.  Only the lag
+// windows (and lag 0) of the correlations are stored, except for window `full_w` of the batch (-1: none), kept whole.
 int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
                   const double2 *d_tw, float2 *z, float *mag, int frame_lo, int frame_len, int line_lo, int line_len, double *d_plots,
-                  unsigned long long calls_before, int mode)
+                  unsigned long long calls_before, int mode, int full_w)
 {
-    const int rc = fftx_correlate(g, st, d_in, in_is_iq, stride, cnt, n, d_tw, z, mag);
+    FftxKeep keep;
+    keep.on = 1;
+    keep.full_w = full_w;
+    keep.lo0 = (unsigned)frame_lo;
+    keep.hi0 = (unsigned)(frame_lo + frame_len);
+    keep.lo1 = (unsigned)line_lo;
+    keep.hi1 = (unsigned)(line_lo + line_len);
+    const int rc = fftx_correlate_keep(g, st, d_in, in_is_iq, stride, cnt, n, d_tw, z, mag, keep);
     if (rc) return rc;
     const int L = frame_len + line_len + 1;  // + the lag-0 entry
     TSDR_LAUNCH(g, PROF_ACCUMULATE, st, k_fftx_accumulate, (L + 255) / 256, 256, z, n, cnt, frame_lo, frame_len, line_lo, line_len, d_plots,

@@ -122,7 +122,7 @@ struct FftPlan;
 int fftx_build_table(tsdrgpu_t *g, uint32_t n, double2 **d_tw);
 int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
                   const double2 *d_tw, float2 *z, float *mag, int frame_lo, int frame_len, int line_lo, int line_len, double *d_plots,
-                  unsigned long long calls_before, int mode);
+                  unsigned long long calls_before, int mode, int full_w);
 int fftx_correlate(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
                    const double2 *d_tw, float2 *z, float *mag);
 int fftx_retain(tsdrgpu_t *g, hipStream_t st, const float *src, int is_iq, long long stride, int cnt, uint32_t n, float *dst);
