@@ -67,7 +67,17 @@ struct tsdrgpu_autocorr {
     float *d_ring;     // certify == 1: ring_cap windows of n magnitudes
     int ring_cap, ring_count;
 };
-#define AC_XBATCH 4
+// windows per launch of the exact form (TSDRGPU_XBATCH overrides: 1..16)
+static int ac_xbatch()
+{
+    static const int v = [] {
+        const char *e = getenv("TSDRGPU_XBATCH");
+        const int n = e ? atoi(e) : 4;
+        return n < 1 ? 1 : (n > 16 ? 16 : n);
+    }();
+    return v;
+}
+#define AC_XBATCH (ac_xbatch())
 
 // (register DFTs, twiddle helpers and the three-trip autocorrelation kernels: fft4step.h)
 template <int IN_MODE>

@@ -161,56 +161,76 @@ __device__ __forceinline__ void fftx_bfly(float2 &a, float2 &b, double2 u)
     a = na;
 }
 
-// K consecutive stages, local stages a .. a+K-1 of the tile, on the group of 2^K rows {base + (j << a)} of column c
-template <int K, bool FIRST>
-__device__ __forceinline__ void fftx_group(float2 *__restrict__ t, unsigned Cp, unsigned base, unsigned c, int a, int s0, unsigned colg,
-                                           const double2 *__restrict__ tw, int inverse)
+// K consecutive stages, local stages a .. a+K-1 of the tile, on groups of 2^K rows {base + (j << a)} of column c.
+// U groups side by side (their loads in flight together, their butterflies interleaved): the rows of group u
+template <int K, bool FIRST, int U, bool INV>
+__device__ __forceinline__ void fftx_groups(float2 *__restrict__ t, unsigned Cp, const unsigned (&base)[U], const unsigned (&c)[U], int a, int s0,
+                                            unsigned colbase, const double2 *__restrict__ tw)
 {
     constexpr int NP = 1 << K;
-    float2 v[NP];
+    float2 v[U][NP];
 #pragma unroll
-    for (int j = 0; j < NP; j++) v[j] = t[(base + ((unsigned)j << a)) * Cp + c];
-    const unsigned low = base & ((1u << a) - 1u);  // the part of the row index below the group's stride
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int j = 0; j < NP; j++) v[u][j] = t[(base[u] + ((unsigned)j << a)) * Cp + c[u]];
 #pragma unroll
     for (int st = 0; st < K; st++) {
         const int s = s0 + a + st;
-        const double2 *ts = tw + ((1ull << s) - 1ull);  // this stage's u[q], q < 2^s
+        const unsigned sbase = (1u << s) - 1u;  // this stage's u[q], q < 2^s, start here (the whole table has n - 1 < 2^32 entries)
+        double2 w[U][1 << (K - 1)];
 #pragma unroll
-        for (int jl = 0; jl < (1 << st); jl++) {
-            const unsigned rowlow = low + ((unsigned)jl << a);
-            const unsigned long long q = FIRST ? (unsigned long long)rowlow : (((unsigned long long)rowlow << s0) + colg);
-            double2 u = ts[q];
-            if (inverse) u.y = -u.y;  // the inverse recurrence yields exactly the conjugates
+        for (int u = 0; u < U; u++) {
+            const unsigned low = base[u] & ((1u << a) - 1u);
 #pragma unroll
-            for (int jh = 0; jh < (NP >> (st + 1)); jh++) {
-                const int j0 = (jh << (st + 1)) | jl;
-                fftx_bfly(v[j0], v[j0 | (1 << st)], u);
+            for (int jl = 0; jl < (1 << st); jl++) {
+                const unsigned rowlow = low + ((unsigned)jl << a);
+                const unsigned q = sbase + (FIRST ? rowlow : ((rowlow << s0) + colbase + c[u]));
+                w[u][jl] = tw[q];
+                if (INV) w[u][jl].y = -w[u][jl].y;  // the inverse recurrence yields exactly the conjugates
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int jl = 0; jl < (1 << st); jl++)
+#pragma unroll
+                for (int jh = 0; jh < (NP >> (st + 1)); jh++) {
+                    const int j0 = (jh << (st + 1)) | jl;
+                    fftx_bfly(v[u][j0], v[u][j0 | (1 << st)], w[u][jl]);
+                }
     }
 #pragma unroll
-    for (int j = 0; j < NP; j++) t[(base + ((unsigned)j << a)) * Cp + c] = v[j];
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int j = 0; j < NP; j++) t[(base[u] + ((unsigned)j << a)) * Cp + c[u]] = v[u][j];
 }
 
-// all groups of one chunk of K stages starting at local stage a: 4096 >> K groups over 256 threads
-template <int K, int L, bool FIRST>
-__device__ __forceinline__ void fftx_chunk(float2 *__restrict__ t, int a, int s0, unsigned colbase, const double2 *__restrict__ tw, int inverse)
+// all groups of one chunk of K stages starting at local stage a: 4096 >> K groups over 256 threads, U at a time
+template <int K, int L, bool FIRST, int U, bool INV>
+__device__ __forceinline__ void fftx_chunk(float2 *__restrict__ t, int a, int s0, unsigned colbase, const double2 *__restrict__ tw)
 {
     constexpr unsigned C = 4096u >> L, Cp = C + 1u;
     constexpr unsigned NG = 4096u >> K;
+    static_assert(NG % (256u * U) == 0, "groups per pass");
 #pragma unroll 1
-    for (unsigned gid = threadIdx.x; gid < NG; gid += 256u) {
-        const unsigned c = gid & (C - 1u), gb = gid / C;
-        const unsigned base = ((gb >> a) << (a + K)) | (gb & ((1u << a) - 1u));
-        fftx_group<K, FIRST>(t, Cp, base, c, a, s0, colbase + c, tw, inverse);
+    for (unsigned g0 = threadIdx.x; g0 < NG; g0 += 256u * U) {
+        unsigned base[U], c[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned gid = g0 + 256u * (unsigned)u;
+            c[u] = gid & (C - 1u);
+            const unsigned gb = gid / C;
+            base[u] = ((gb >> a) << (a + K)) | (gb & ((1u << a) - 1u));
+        }
+        fftx_groups<K, FIRST, U, INV>(t, Cp, base, c, a, s0, colbase, tw);
     }
     __syncthreads();
 }
 
-template <int L, bool FIRST>
+template <int L, bool FIRST, int U, bool INV>
 __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src, int src_mode, long long src_stride, float2 *__restrict__ z,
                                                    float *__restrict__ mag, unsigned n, int m, int s0, int batch,
-                                                   const double2 *__restrict__ tw, int inverse, int epilogue, float nf, FftxKeep keep)
+                                                   const double2 *__restrict__ tw, int epilogue, float inv_nf, FftxKeep keep)
 {
     constexpr unsigned R = 1u << L, C = 4096u >> L, Cp = C + 1u;
     constexpr int LOGC = 12 - L;
@@ -254,11 +274,11 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
     }
     __syncthreads();
     // L stages as chunks of 3, 3, rest
-    if (L >= 3) fftx_chunk<3, L, FIRST>(t, 0, s0, colbase, tw, inverse);
-    if (L >= 6) fftx_chunk<3, L, FIRST>(t, 3, s0, colbase, tw, inverse);
-    if (L == 5) fftx_chunk<2, L, FIRST>(t, 3, s0, colbase, tw, inverse);
-    if (L == 7) fftx_chunk<1, L, FIRST>(t, 6, s0, colbase, tw, inverse);
-    if (L == 8) fftx_chunk<2, L, FIRST>(t, 6, s0, colbase, tw, inverse);
+    if (L >= 3) fftx_chunk<3, L, FIRST, U, INV>(t, 0, s0, colbase, tw);
+    if (L >= 6) fftx_chunk<3, L, FIRST, U, INV>(t, 3, s0, colbase, tw);
+    if (L == 5) fftx_chunk<2, L, FIRST, U, INV>(t, 3, s0, colbase, tw);
+    if (L == 7) fftx_chunk<1, L, FIRST, 2 * U, INV>(t, 6, s0, colbase, tw);
+    if (L == 8) fftx_chunk<2, L, FIRST, U, INV>(t, 6, s0, colbase, tw);
     const bool filter = keep.on && (int)w != keep.full_w;
     if (FIRST) {
         // column c is block B = rev_{m-L}(r0 + c): R contiguous results per block
@@ -268,9 +288,9 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
             const unsigned long long B = fftx_rev(r0 + c, m - L);
             float2 v = t[row * Cp + c];
             const unsigned long long at = B * R + row;
-            if (epilogue == 1 || epilogue == 2) {
-                v.x = v.x / nf;
-                v.y = v.y / nf;
+            if (epilogue == 1 || epilogue == 2) {  // fft.c:167-175 divides by (float)n, a power of two: the same bits as
+                v.x = v.x * inv_nf;                // this multiplication by its exact reciprocal (also where the quotient
+                v.y = v.y * inv_nf;                // is subnormal: both round the same exact value)
             }
             if (epilogue == 1) mag[(long long)w * n + at] = sqrtf(v.x * v.x + v.y * v.y);
             else if (!filter || at == 0ull || (at >= keep.lo0 && at < keep.hi0) || (at >= keep.lo1 && at < keep.hi1)) zb[at] = v;
@@ -282,8 +302,8 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
             float2 v = t[row * Cp + c];
             const unsigned long long at = gbase + ((unsigned long long)row << s0) + c;
             if (epilogue == 1 || epilogue == 2) {
-                v.x = v.x / nf;
-                v.y = v.y / nf;
+                v.x = v.x * inv_nf;
+                v.y = v.y * inv_nf;
             }
             if (epilogue == 1) mag[(long long)w * n + at] = sqrtf(v.x * v.x + v.y * v.y);
             else if (!filter || at == 0ull || (at >= keep.lo0 && at < keep.hi0) || (at >= keep.lo1 && at < keep.hi1)) zb[at] = v;
@@ -402,17 +422,29 @@ static int fftx_plan(int m, FftxTrip *trips)
 
 static const FftxKeep FFTX_KEEP_ALL = {0, -1, 0u, 0u, 0u, 0u};
 
-template <bool FIRST>
+template <bool FIRST, int U, bool INV>
 static bool fftx_launch_fast(tsdrgpu_t *g, hipStream_t st, int L, unsigned blocks, const float *src, int src_mode, long long src_stride, float2 *z,
-                             float *mag, uint32_t n, int m, int s0, int batch, const double2 *d_tw, int inverse, int epi, const FftxKeep &keep)
+                             float *mag, uint32_t n, int m, int s0, int batch, const double2 *d_tw, int epi, const FftxKeep &keep)
 {
+    const float inv_nf = 1.0f / (float)n;  // exact: n is a power of two
     switch (L) {
-        case 5: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<5, FIRST>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, (float)n, keep); return true;
-        case 6: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<6, FIRST>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, (float)n, keep); return true;
-        case 7: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<7, FIRST>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, (float)n, keep); return true;
-        case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<8, FIRST>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, (float)n, keep); return true;
+        case 5: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<5, FIRST, U, INV>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, epi, inv_nf, keep); return true;
+        case 6: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<6, FIRST, U, INV>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, epi, inv_nf, keep); return true;
+        case 7: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<7, FIRST, U, INV>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, epi, inv_nf, keep); return true;
+        case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_fast<8, FIRST, U, INV>), blocks, 256, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, epi, inv_nf, keep); return true;
         default: return false;
     }
+}
+
+template <int U>
+static bool fftx_launch_fast_u(tsdrgpu_t *g, hipStream_t st, int L, unsigned blocks, const float *src, int src_mode, long long src_stride, float2 *z,
+                               float *mag, uint32_t n, int m, int s0, int batch, const double2 *d_tw, int inverse, int epi, const FftxKeep &keep)
+{
+    if (s0 == 0)
+        return inverse ? fftx_launch_fast<true, U, true>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, epi, keep)
+                       : fftx_launch_fast<true, U, false>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, epi, keep);
+    return inverse ? fftx_launch_fast<false, U, true>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, epi, keep)
+                   : fftx_launch_fast<false, U, false>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, epi, keep);
 }
 
 // One transform (forward: from `src`; inverse: from the real array `mag`) of `batch` windows into z.  `keep` filters what
@@ -436,8 +468,9 @@ static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int sr
         if (fast_ok) {
             const unsigned blocks = (n / 4096u) * (unsigned)batch;
             const FftxKeep &kp = last ? keep : FFTX_KEEP_ALL;
-            done = s0 == 0 ? fftx_launch_fast<true>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, kp)
-                           : fftx_launch_fast<false>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, kp);
+            static const int two = (getenv("TSDRGPU_FFTX_U") && getenv("TSDRGPU_FFTX_U")[0] == '2') ? 1 : 0;  // groups per thread and pass (A/B)
+            done = two ? fftx_launch_fast_u<2>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, kp)
+                       : fftx_launch_fast_u<1>(g, st, L, blocks, src, src_mode, src_stride, z, mag, n, m, s0, batch, d_tw, inverse, epi, kp);
         }
         if (!done) {
             if (C > width) C = width;
