@@ -18,6 +18,11 @@ FS = 300_000
 NWIN = 5
 
 
+def windows_for_rank(total_windows, rank, world):
+    """the partition bench.py / tests/dist_worker.py use: window k belongs to rank k mod world"""
+    return list(range(rank, total_windows, world))
+
+
 def make_windows(orc):
     rng = np.random.default_rng(77)
     cap = orc.capture_size(FS)
@@ -33,22 +38,26 @@ def make_windows(orc):
 def worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     from oracle import oracle as orc
-    from tempestsdr_amd import shard
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     xs = make_windows(orc)
     flo, flen, llo, llen = orc.lag_windows(FS)
     sums = np.zeros(flen + llen)
-    mine = shard.windows_for_rank(NWIN, rank, world)
+    mine = windows_for_rank(NWIN, rank, world)
     for w in mine:  # mode 1 of tsdrgpu_autocorr_run: plain sums of |R| per lag
         corr = orc.fft_autocorrelation(xs[w]).astype(np.float64)
         mag = np.sqrt(corr[0::2] ** 2 + corr[1::2] ** 2)
         sums[:flen] += mag[flo:flo + flen]
         sums[flen:] += mag[llo:llo + llen]
-    plots, total = shard.allreduce_plots(torch.from_numpy(sums), len(mine), dist)
+    # tsdrgpu_autocorr_allreduce: one sum all-reduce of the per-lag sums, then the division by the global window count
+    t = torch.from_numpy(sums)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    cnt = torch.tensor([float(len(mine))], dtype=torch.float64)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    total = int(round(float(cnt.item())))
     if rank == 0:
-        np.save(out_path, np.concatenate([[total], plots.numpy()]))
+        np.save(out_path, np.concatenate([[total], (t / total).numpy()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,17 +76,16 @@ def test_sharded_autocorrelation_equals_running_mean(orc, tmp_path):
         ac.run(x)
     want = np.concatenate([ac.frame, ac.line])
     assert np.allclose(got[1:], want, rtol=1e-12, atol=0)
-    from tempestsdr_amd import shard
-    d = shard.detect_mode(got[1:1 + ac.flen], got[1 + ac.flen:], ac.flo, ac.llo, FS)
-    assert d["frame_lag"] == ac.flo + int(np.argmax(ac.frame))
-    assert abs(d["framerate"] - 60.0) < 0.5
+    # lag -> frame rate as the GUI derives it (PlotVisualizer.java:233-236 first maximum, Main.java:1301-1303)
+    frame_lag = ac.flo + int(np.argmax(got[1:1 + ac.flen]))
+    assert frame_lag == ac.flo + int(np.argmax(ac.frame))
+    assert abs(FS / frame_lag - 60.0) < 0.5
 
 
 def test_window_partition_covers_everything():
-    from tempestsdr_amd import shard
     for world in (1, 2, 3, 8):
         for total in (0, 1, 7, 17, 64):
-            seen = sorted(w for r in range(world) for w in shard.windows_for_rank(total, r, world))
+            seen = sorted(w for r in range(world) for w in windows_for_rank(total, r, world))
             assert seen == list(range(total))
-            sizes = [len(shard.windows_for_rank(total, r, world)) for r in range(world)]
+            sizes = [len(windows_for_rank(total, r, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
