@@ -210,6 +210,9 @@ def fuzz_autocorr_multi(g, rng):
         if ac.argmax() != (int(np.argmax(ac_o.frame)), int(np.argmax(ac_o.line))):
             return f"autocorr exact argmax fs={fs}"
         return None
+    # certified mode (the engine's default): float32 transform + argmax certificate, exact replay when it fails;
+    # the answer must be the oracle's argmax, the float32 plots within the bound the certificate rests on
+    ac.set_certify(int(rng.integers(1, 3)))
     first = int(rng.integers(1, nwin))
     ac.run(d, from_iq, ac.capture, first)
     ac.run(d, from_iq, ac.capture, nwin - first, in_offset=first * ac.capture * (2 if from_iq else 1))
@@ -221,8 +224,18 @@ def fuzz_autocorr_multi(g, rng):
     fi, li = ac.argmax()
     if (fi, li) != (int(np.argmax(f)), int(np.argmax(l))):
         return f"autocorr argmax rule fs={fs}"
-    if ac_o.frame[fi] < np.max(ac_o.frame) * (1 - 2e-4) or ac_o.line[li] < np.max(ac_o.line) * (1 - 2e-4):
-        return f"autocorr argmax fs={fs} nwin={nwin}"
+    c = ac.certificate()
+    if max(np.max(np.abs(f - ac_o.frame)), np.max(np.abs(l - ac_o.line))) > 0.5 * 8e-6 * c.r0:
+        return f"autocorr certificate premise fs={fs} nwin={nwin}: plots further from the oracle's than KAPPA/2 * R0"
+    if (c.frame_certified and fi != int(np.argmax(ac_o.frame))) or (c.line_certified and li != int(np.argmax(ac_o.line))):
+        return f"autocorr CERTIFIED argmax differs fs={fs} nwin={nwin}"
+    fi, li, promoted = ac.argmax_certified()
+    if (fi, li) != (int(np.argmax(ac_o.frame)), int(np.argmax(ac_o.line))):
+        return f"autocorr certified-mode argmax fs={fs} nwin={nwin} promoted={promoted}"
+    if promoted:
+        f, l, _ = ac.plots()
+        if not (np.array_equal(f, ac_o.frame) and np.array_equal(l, ac_o.line)):
+            return f"autocorr promoted plots fs={fs} nwin={nwin}"
     return None
 
 

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o pmc -- \
-      python $R/bench.py --steps 1 --warmup 1 --passes 4 --no-cpu-baseline --no-e2e --no-profile --pmc-calibrate > $OUT/$C.log 2>&1
+      python $R/bench.py --steps 1 --warmup 1 --passes 4 --no-cpu-baseline --no-e2e --no-legs --serial --no-profile --pmc-calibrate > $OUT/$C.log 2>&1
 done
 cd $R
 PMC_SOURCE="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of 'bench.py --steps 1 --warmup 1 --passes 4 --pmc-calibrate' at commit $(cat $R/.commit_id 2>/dev/null || echo unknown), scripts/pmc_collect.sh (not collected live)" \
