@@ -23,7 +23,13 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 # bit-exact stages: no FMA contraction (the reference is built without it)
 STRICT = ["-ffp-contract=off"]
 
-HIP_SOURCES = [("tsdrgpu_core.hip", STRICT), ("tsdrgpu_frame.hip", STRICT), ("tsdrgpu_fft.hip", []), ("tsdrgpu_fftx.hip", STRICT),
+# The FFT kernels are complex float32 arithmetic on register arrays.  hipcc's SLP vectoriser turns it into v_pk_*_f32
+# pairs — which on gfx950 issue at half the rate of the plain instructions, so nothing is gained per flop — and pays for
+# the pairing with register moves: k_ac_rows had 725 v_mov_b32 among 2481 VALU instructions (29 %), without the pass 59
+# among 2321, all of them full-rate.  TSDRGPU_SLP=1 builds the old way (A/B).
+NOSLP = [] if os.environ.get("TSDRGPU_SLP") == "1" else ["-fno-slp-vectorize"]
+
+HIP_SOURCES = [("tsdrgpu_core.hip", STRICT), ("tsdrgpu_frame.hip", STRICT), ("tsdrgpu_fft.hip", NOSLP), ("tsdrgpu_fftx.hip", STRICT),
                ("tsdrgpu_extras.hip", STRICT), ("tsdrgpu_rccl.hip", [])]
 LIB = os.path.join(HERE, "libtsdrgpu.so")
 
