@@ -389,6 +389,8 @@ int tsdrgpu_comm_create(tsdrgpu_t *g, tsdrgpu_comm_t **out, int world, int rank,
 void tsdrgpu_comm_destroy(tsdrgpu_comm_t *c);
 int tsdrgpu_comm_allreduce_f64(tsdrgpu_comm_t *c, double *d_buf, int64_t count, int lane); /* in place, ncclSum */
 int tsdrgpu_comm_allreduce_f32max(tsdrgpu_comm_t *c, float *d_buf, int64_t count, int lane); /* in place, ncclMax */
+int tsdrgpu_comm_broadcast_f32(tsdrgpu_comm_t *c, float *d_buf, int64_t count, int root, int lane);      /* in place */
+int tsdrgpu_comm_allgather_f32(tsdrgpu_comm_t *c, float *d_buf, int64_t count_per_rank, int lane);       /* in place: rank r's part at r*count */
 int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t *c, uint64_t total_windows);
 
 /* ---- a13/a14: super-bandwidth stitch --------------------------------------------- */
@@ -400,6 +402,24 @@ int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t *c, uint64
 int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered,
                           int samples_in_frame, float *d_out, int32_t *h_offsets,
                           uint32_t *h_total);
+/* SURVEY 8(e) row 3 — the stitch with ONE HOP PER GPU (rank r holds hop r; superbandwidth.c:121-152).  Everything but
+ * two steps is per hop; the two steps are exchanges the caller makes between the phases:
+ *   _reference   hop 0's rank transforms its abs-diff signal; *d_ref (n floats) is broadcast from that rank
+ *                (tsdrgpu_comm_broadcast_f32, root = the rank of hop 0)
+ *   _spectrum    this rank's offset against hop 0 (cross-correlation peak), rotation and transform; its spectrum lands in
+ *                slot my_hop of *d_spectra, which is all-gathered in place (tsdrgpu_comm_allgather_f32, n floats per hop);
+ *                the hop buffer is left holding the spectrum like the reference's
+ *   _finish      the inverse transform of the concatenated spectra (on every rank that calls it) -> d_out
+ * The kernels and their order are tsdrgpu_superb_stitch's, so offsets and the stitched signal are bit-identical to the
+ * single-GPU call.  Measured worth: the exchanges (32 + 256 MB at 4 x 2^23 samples) cost more than
+ * the 1.5 ms the whole stitch takes on one GPU — the form exists for hosts whose hops already live on different GPUs. */
+typedef struct tsdrgpu_superb_shard tsdrgpu_superb_shard_t;
+int tsdrgpu_superb_shard_create(tsdrgpu_t *g, tsdrgpu_superb_shard_t **out, int nhops, int my_hop, int gathered, int samples_in_frame);
+void tsdrgpu_superb_shard_destroy(tsdrgpu_superb_shard_t *sh);
+int tsdrgpu_superb_shard_reference(tsdrgpu_superb_shard_t *sh, const float *d_my_hop, float **d_ref, int64_t *n_floats);
+int tsdrgpu_superb_shard_spectrum(tsdrgpu_superb_shard_t *sh, float *d_my_hop, float **d_spectra, int64_t *n_floats_per_hop,
+                                  int32_t *h_my_offset);
+int tsdrgpu_superb_shard_finish(tsdrgpu_superb_shard_t *sh, float *d_out, uint32_t *h_total);
 /* The same stitch with every transform in the reference's own arithmetic (see tsdrgpu_autocorr_set_exact): hop
  * offsets and the stitched signal bit-identical to superb_ondataready. */
 int tsdrgpu_superb_stitch_exact(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered, int samples_in_frame,

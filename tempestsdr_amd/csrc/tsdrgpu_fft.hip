@@ -1565,3 +1565,152 @@ extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nho
     if (h_total) *h_total = total;
     return TSDRGPU_OK;
 }
+
+// ---------------------------------------------------------------------------
+// the stitch with ONE HOP PER GPU.  superb_ondataready (superbandwidth.c:121-152) aligns hops 1..3
+// to hop 0 (abs-diff, cross-correlation, peak), rotates them, transforms every hop and inverse-transforms the
+// concatenated spectra.  All of it but two things is per hop: the reference spectrum of hop 0 (needed by everybody:
+// one broadcast of bn complex values) and the final transform (needs everybody's spectrum: one all-gather of
+// nhops * per complex values).  The phases below run the single-GPU call's kernels on this rank's hop, so offsets and
+// the stitched signal are bit-identical to tsdrgpu_superb_stitch; the exchanges are the caller's (tsdrgpu_comm_broadcast_f32
+// / _allgather_f32 over RCCL), which is how the two-process tests run them through gloo on one device.
+// ---------------------------------------------------------------------------
+struct tsdrgpu_superb_shard {
+    tsdrgpu_t *g;
+    int nhops, my_hop, gathered, samples_in_frame;
+    uint32_t per, total, nfl, bn, nfft;
+    float2 *ws;      // [A bn][FA 2 bn][B bn][FB 2 bn][R per][S 2 per][ALL total (+ work total)][BIG 2 nfft]
+    float2 *A, *FA, *B, *FB, *R, *S, *ALL, *BIG;
+    float2 *fa;      // where the reference spectrum sits (FA or FA + bn)
+    int *d_off;
+    float *pval;
+    int *pidx;
+    int phase;       // 0 created, 1 reference queued, 2 spectrum queued
+};
+
+extern "C" int tsdrgpu_superb_shard_create(tsdrgpu_t *g, tsdrgpu_superb_shard_t **out, int nhops, int my_hop, int gathered, int samples_in_frame)
+{
+    if (!g || !out || nhops < 1 || nhops > 64 || my_hop < 0 || my_hop >= nhops || gathered < 2 || samples_in_frame < 1)
+        return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_superb_shard_create", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_superb_shard_t *sh = (tsdrgpu_superb_shard_t *)calloc(1, sizeof(*sh));
+    if (!sh) return TSDRGPU_ENOMEM;
+    sh->g = g;
+    sh->nhops = nhops;
+    sh->my_hop = my_hop;
+    sh->gathered = gathered;
+    sh->samples_in_frame = samples_in_frame;
+    sh->per = pow2_floor((uint32_t)gathered);  // superbandwidth.c:124
+    sh->total = (uint32_t)nhops * sh->per;
+    sh->nfl = sh->per * 2;
+    const int bsize = ((int)sh->nfl / samples_in_frame) * samples_in_frame;  // superb_bestfit sizes, superbandwidth.c:84-86
+    if (bsize < 2) {
+        free(sh);
+        return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_superb_shard_create", "hop shorter than one frame");
+    }
+    sh->bn = pow2_floor((uint32_t)bsize) / 2;
+    sh->nfft = pow2_floor(sh->total);
+    const size_t bn = sh->bn, per = sh->per, total = sh->total, nfft = sh->nfft;
+    const size_t f2 = bn * 6 + per * 3 + total + 2 * nfft;
+    const size_t bytes = f2 * sizeof(float2) + sizeof(int) * 4 + (sizeof(float) + sizeof(int)) * (size_t)SB_ARG_BLOCKS + 64;
+    if (hipMalloc((void **)&sh->ws, bytes) != hipSuccess) {
+        free(sh);
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_superb_shard_create", "work buffers");
+    }
+    sh->A = sh->ws;
+    sh->FA = sh->A + bn;
+    sh->B = sh->FA + 2 * bn;
+    sh->FB = sh->B + bn;
+    sh->R = sh->FB + 2 * bn;
+    sh->S = sh->R + per;
+    sh->ALL = sh->S + 2 * per;
+    sh->BIG = sh->ALL + total;
+    sh->d_off = (int *)(sh->BIG + 2 * nfft);
+    sh->pval = (float *)(sh->d_off + 4);
+    sh->pidx = (int *)(sh->pval + SB_ARG_BLOCKS);
+    *out = sh;
+    return TSDRGPU_OK;
+}
+
+extern "C" void tsdrgpu_superb_shard_destroy(tsdrgpu_superb_shard_t *sh)
+{
+    if (!sh) return;
+    (void)hipStreamSynchronize(sh->g->stream);
+    (void)hipFree(sh->ws);
+    free(sh);
+}
+
+// phase 1.  The rank of hop 0 transforms its abs-diff signal; every rank gets the buffer the caller broadcasts it into.
+extern "C" int tsdrgpu_superb_shard_reference(tsdrgpu_superb_shard_t *sh, const float *d_my_hop, float **d_ref, int64_t *n_floats)
+{
+    if (!sh || !d_my_hop) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = sh->g;
+    hipStream_t st = g->stream;
+    // the reference spectrum always ends up in the first half of FA (hop 0's rank copies it there if the transform's
+    // ping-pong ended in the second), so that every rank exchanges the same buffer
+    if (sh->my_hop == 0) {
+        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_abs_diff, (sh->bn + 255) / 256, 256, (const float2 *)d_my_hop, sh->A, sh->bn);
+        KERNEL_CHECK(g, "k_abs_diff");
+        float2 *fa = run_fft(g, sh->A, 0, sh->bn, sh->FA, sh->FA + sh->bn, sh->bn, 1, 0, false, 1.0f / (float)sh->bn);
+        if (fa != sh->FA) HIP_TRY(g, hipMemcpyAsync(sh->FA, fa, sizeof(float2) * sh->bn, hipMemcpyDeviceToDevice, st));
+    }
+    sh->fa = sh->FA;
+    sh->phase = 1;
+    if (d_ref) *d_ref = (float *)sh->FA;
+    if (n_floats) *n_floats = 2 * (int64_t)sh->bn;
+    return TSDRGPU_OK;
+}
+
+// phase 2 (after the broadcast).  This rank's offset against hop 0, its rotation, its spectrum — written into slot
+// my_hop of the gather buffer, which the caller all-gathers in place.
+extern "C" int tsdrgpu_superb_shard_spectrum(tsdrgpu_superb_shard_t *sh, float *d_my_hop, float **d_spectra, int64_t *n_floats_per_hop,
+                                             int32_t *h_my_offset)
+{
+    if (!sh || !d_my_hop) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = sh->g;
+    if (sh->phase != 1) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_superb_shard_spectrum", "call tsdrgpu_superb_shard_reference first");
+    hipStream_t st = g->stream;
+    const uint32_t bn = sh->bn, per = sh->per;
+    HIP_TRY(g, hipMemsetAsync(sh->d_off, 0, sizeof(int) * 4, st));
+    if (sh->my_hop != 0) {
+        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_my_hop, sh->B, bn);
+        float2 *fb = run_fft(g, sh->B, 0, bn, sh->FB, sh->FB + bn, bn, 1, 0, false, 1.0f / (float)bn);
+        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_mul_conj_batch, dim3((bn + 255) / 256, 1), 256, sh->fa, fb, bn);
+        float2 *other = (fb == sh->FB) ? sh->FB + bn : sh->FB;
+        float2 *xc = run_fft(g, fb, 0, bn, fb, other, bn, 1, 1, false, 1.0f);
+        TSDR_LAUNCH(g, PROF_ARGMAX, st, k_argmax_abs_partial, dim3(SB_ARG_BLOCKS, 1), 256, xc, (long long)bn, bn, sh->pval, sh->pidx);
+        TSDR_LAUNCH(g, PROF_ARGMAX, st, k_argmax_abs_final, 1, 64, sh->pval, sh->pidx, sh->d_off);
+        KERNEL_CHECK(g, "hop alignment");
+    }
+    TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_rotate, (sh->nfl + 255) / 256, 256, d_my_hop, (float *)sh->R, sh->nfl, sh->d_off);
+    float2 *sp = run_fft(g, sh->R, 0, per, sh->S, sh->S + per, per, 1, 0, false, 1.0f / (float)per);
+    KERNEL_CHECK(g, "hop transform");
+    HIP_TRY(g, hipMemcpyAsync(sh->ALL + (size_t)sh->my_hop * per, sp, sizeof(float2) * per, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(g, hipMemcpyAsync(d_my_hop, sp, sizeof(float2) * per, hipMemcpyDeviceToDevice, st));  // the reference leaves the spectrum in the hop buffer
+    if (h_my_offset) {
+        HIP_TRY(g, hipMemcpyAsync(h_my_offset, sh->d_off, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(g, hipStreamSynchronize(st));
+    }
+    sh->phase = 2;
+    if (d_spectra) *d_spectra = (float *)sh->ALL;
+    if (n_floats_per_hop) *n_floats_per_hop = 2 * (int64_t)per;
+    return TSDRGPU_OK;
+}
+
+// phase 3 (after the all-gather): the inverse transform of the concatenated spectra -> d_out (nhops * 2 * per floats)
+extern "C" int tsdrgpu_superb_shard_finish(tsdrgpu_superb_shard_t *sh, float *d_out, uint32_t *h_total)
+{
+    if (!sh || !d_out) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = sh->g;
+    if (sh->phase != 2) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_superb_shard_finish", "call tsdrgpu_superb_shard_spectrum first");
+    hipStream_t st = g->stream;
+    const uint32_t total = sh->total, nfft = sh->nfft;
+    if (total > nfft)  // what lies beyond the largest power of two keeps the spectra (fft_perform truncates, fft.c:101-105)
+        HIP_TRY(g, hipMemcpyAsync(d_out + 2 * (size_t)nfft, sh->ALL + nfft, sizeof(float2) * (size_t)(total - nfft), hipMemcpyDeviceToDevice, st));
+    float2 *res = run_fft(g, sh->ALL, 0, nfft, sh->BIG, sh->BIG + nfft, nfft, 1, 1, false, 1.0f);
+    KERNEL_CHECK(g, "stitch transform");
+    HIP_TRY(g, hipMemcpyAsync(d_out, res, sizeof(float2) * (size_t)nfft, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(g, hipStreamSynchronize(st));
+    sh->phase = 0;
+    if (h_total) *h_total = total;
+    return TSDRGPU_OK;
+}

@@ -24,6 +24,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*CommDestroy)(ncclComm_t);
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t);
     const char *(*GetErrorString)(ncclResult_t);
 };
 static RcclApi g_rccl;
@@ -43,6 +45,9 @@ static const RcclApi *rccl()
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(dl, "ncclCommDestroy");
     a.AllReduce = (decltype(a.AllReduce))dlsym(dl, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(dl, "ncclGetErrorString");
+    a.Broadcast = (decltype(a.Broadcast))dlsym(dl, "ncclBroadcast");
+    a.AllGather = (decltype(a.AllGather))dlsym(dl, "ncclAllGather");
+    if (!a.Broadcast || !a.AllGather) { dlclose(dl); return nullptr; }
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
         dlclose(dl);
         return nullptr;
@@ -123,6 +128,35 @@ extern "C" int tsdrgpu_comm_allreduce_f32max(tsdrgpu_comm_t *c, float *d_buf, in
     if (!st) return tsdr_fail(g, TSDRGPU_EINVAL, "allreduce", "bad lane");
     const ncclResult_t rc = r->AllReduce(d_buf, d_buf, (size_t)count, 7 /* ncclFloat32 */, 2 /* ncclMax */, c->comm, st);
     if (rc != ncclSuccess_) return tsdr_fail(g, TSDRGPU_EHIP, "ncclAllReduce", r->GetErrorString(rc));
+    return TSDRGPU_OK;
+}
+
+// The two exchanges of the super-bandwidth stitch with one hop per GPU (tsdrgpu_superb_shard_*): hop 0's reference
+// spectrum goes from its rank to everybody, every rank's hop spectrum to everybody (in place: rank r's part sits at
+// r * count_per_rank of the buffer).
+extern "C" int tsdrgpu_comm_broadcast_f32(tsdrgpu_comm_t *c, float *d_buf, int64_t count, int root, int lane)
+{
+    if (!c || !d_buf || count < 0 || root < 0 || root >= c->world) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = c->g;
+    const RcclApi *r = rccl();
+    if (!r) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_comm_broadcast_f32", "librccl.so.1 not found");
+    hipStream_t st = tsdr_lane_stream(g, lane);
+    if (!st) return tsdr_fail(g, TSDRGPU_EINVAL, "broadcast", "bad lane");
+    const ncclResult_t rc = r->Broadcast(d_buf, d_buf, (size_t)count, 7 /* ncclFloat32 */, root, c->comm, st);
+    if (rc != ncclSuccess_) return tsdr_fail(g, TSDRGPU_EHIP, "ncclBroadcast", r->GetErrorString(rc));
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_comm_allgather_f32(tsdrgpu_comm_t *c, float *d_buf, int64_t count_per_rank, int lane)
+{
+    if (!c || !d_buf || count_per_rank < 0) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = c->g;
+    const RcclApi *r = rccl();
+    if (!r) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_comm_allgather_f32", "librccl.so.1 not found");
+    hipStream_t st = tsdr_lane_stream(g, lane);
+    if (!st) return tsdr_fail(g, TSDRGPU_EINVAL, "allgather", "bad lane");
+    const ncclResult_t rc = r->AllGather(d_buf + (size_t)c->rank * (size_t)count_per_rank, d_buf, (size_t)count_per_rank, 7 /* ncclFloat32 */, c->comm, st);
+    if (rc != ncclSuccess_) return tsdr_fail(g, TSDRGPU_EHIP, "ncclAllGather", r->GetErrorString(rc));
     return TSDRGPU_OK;
 }
 

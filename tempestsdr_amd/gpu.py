@@ -102,6 +102,13 @@ _SIGS = {
     "tsdrgpu_comm_destroy": (None, [vp]),
     "tsdrgpu_comm_allreduce_f64": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
     "tsdrgpu_autocorr_allreduce": (C.c_int, [vp, vp, C.c_uint64]),
+    "tsdrgpu_comm_broadcast_f32": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int]),
+    "tsdrgpu_comm_allgather_f32": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
+    "tsdrgpu_superb_shard_create": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tsdrgpu_superb_shard_destroy": (None, [vp]),
+    "tsdrgpu_superb_shard_reference": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
+    "tsdrgpu_superb_shard_spectrum": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "tsdrgpu_superb_shard_finish": (C.c_int, [vp, vp, C.POINTER(C.c_uint32)]),
     "tsdrgpu_zero": (C.c_int, [vp, vp, C.c_size_t]),
     "tsdrgpu_timer_start": (C.c_int, [vp]),
     "tsdrgpu_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
@@ -540,12 +547,49 @@ class Comm:
     def allreduce_f32max(self, d_ptr, count, lane=0):
         self.ctx._ck(self.ctx.lib.tsdrgpu_comm_allreduce_f32max(self.h, d_ptr, int(count), int(lane)))
 
+    def broadcast_f32(self, d_ptr, count, root, lane=0):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_comm_broadcast_f32(self.h, d_ptr, int(count), int(root), int(lane)))
+
+    def allgather_f32(self, d_ptr, count_per_rank, lane=0):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_comm_allgather_f32(self.h, d_ptr, int(count_per_rank), int(lane)))
+
     def allreduce_f64(self, d_ptr, count, lane=0):
         self.ctx._ck(self.ctx.lib.tsdrgpu_comm_allreduce_f64(self.h, d_ptr, int(count), int(lane)))
 
     def destroy(self):
         if getattr(self, "h", None):
             self.ctx.lib.tsdrgpu_comm_destroy(self.h)
+        self.h = None
+
+
+class SuperbShard:
+    """One hop of the super-bandwidth stitch on this GPU (tsdrgpu_superb_shard_*): reference() -> broadcast ->
+    spectrum() -> all-gather -> finish()."""
+
+    def __init__(self, ctx, nhops, my_hop, gathered, samples_in_frame):
+        self.ctx = ctx
+        h = vp()
+        ctx._ck(ctx.lib.tsdrgpu_superb_shard_create(ctx.h, C.byref(h), nhops, my_hop, gathered, samples_in_frame))
+        self.h = h
+
+    def reference(self, d_hop):
+        p, n = vp(), C.c_int64()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_superb_shard_reference(self.h, d_hop.at(0), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def spectrum(self, d_hop):
+        p, n, off = vp(), C.c_int64(), C.c_int32()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_superb_shard_spectrum(self.h, d_hop.at(0), C.byref(p), C.byref(n), C.byref(off)))
+        return p.value, n.value, off.value
+
+    def finish(self, d_out):
+        t = C.c_uint32()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_superb_shard_finish(self.h, d_out.at(0), C.byref(t)))
+        return t.value
+
+    def destroy(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.tsdrgpu_superb_shard_destroy(self.h)
         self.h = None
 
 

@@ -73,3 +73,83 @@ def test_rccl_from_c_one_rank(orc):
         assert calls == nwin
         assert np.allclose(f, rf, rtol=1e-12, atol=0) and np.allclose(l, rl, rtol=1e-12, atol=0)
     comm.destroy()
+
+
+# ---------------------------------------------------------------------------
+# the super-bandwidth stitch with one hop per GPU (tsdrgpu_superb_shard_*)
+# ---------------------------------------------------------------------------
+def _copy_dev(g, dst, src, nfloats):
+    g._ck(g.lib.tsdrgpu_copy(g.h, dst, src, nfloats * 4))
+
+
+def test_sharded_stitch_equals_the_single_gpu_stitch_and_the_oracle(orc):
+    """Four hop objects in one process (one per 'rank'), the two exchanges done by device copies: hop offsets identical to
+    the oracle's, the stitched signal bit-identical to tsdrgpu_superb_stitch and within 1e-4*max of the oracle's."""
+    from gpu_util import golden
+    import cases
+    g = ctx()
+    gold = golden()
+    fs, fv = cases.SUPERB["fs"], cases.SUPERB["fv"]
+    sif = int(fs / fv)
+    hops = [h.copy() for h in gold["superb_hops"]]
+    nh, gathered = len(hops), hops[0].size // 2
+    want, offs = orc.superb_stitch([h.copy() for h in hops], sif)
+    d_single = [g.to_device(h) for h in hops]
+    d_ref_out = g.empty(want.size)
+    single_offs, total = g.superb_stitch(d_single, gathered, sif, d_ref_out)
+    shards = [gpu.SuperbShard(g, nh, k, gathered, sif) for k in range(nh)]
+    d_hops = [g.to_device(h) for h in hops]
+    refs = [sh.reference(d) for sh, d in zip(shards, d_hops)]
+    for k in range(1, nh):  # broadcast from the rank of hop 0
+        _copy_dev(g, refs[k][0], refs[0][0], refs[0][1])
+    specs = [sh.spectrum(d) for sh, d in zip(shards, d_hops)]
+    per2 = specs[0][1]
+    for k in range(nh):  # all-gather: everybody's slot to everybody
+        for j in range(nh):
+            if j != k:
+                _copy_dev(g, specs[j][0] + 4 * k * per2, specs[k][0] + 4 * k * per2, per2)
+    assert [s[2] for s in specs] == [int(o) for o in offs] == [int(o) for o in single_offs]
+    for k, sh in enumerate(shards):
+        d_out = g.empty(want.size)
+        assert sh.finish(d_out) == total
+        got = d_out.download()
+        assert np.array_equal(got, d_ref_out.download()), k
+        assert np.max(np.abs(got - want)) <= 1e-4 * np.max(np.abs(want))
+        sh.destroy()
+    # every hop buffer is left holding its spectrum, like the single-GPU call's (and the reference's)
+    for a, b in zip(d_hops, d_single):
+        assert np.array_equal(a.download(), b.download())
+
+
+def test_sharded_stitch_collectives_over_rccl_one_rank(orc):
+    """ncclBroadcast / ncclAllGather from C (tsdrgpu_comm_broadcast_f32 / _allgather_f32) on a one-rank communicator
+    between the phases of a one-hop stitch."""
+    g = ctx()
+    rng = np.random.default_rng(4)
+    gathered, sif = 70_000, 5_000
+    hop = rng.standard_normal(2 * gathered).astype(np.float32)
+    d_a, d_b = g.to_device(hop), g.to_device(hop)
+    per = 1 << (gathered.bit_length() - 1)
+    d_want, d_got = g.empty(2 * per), g.empty(2 * per)
+    g.superb_stitch([d_a], gathered, sif, d_want)
+    comm = gpu.Comm(g, 1, 0, gpu.Comm.unique_id(g))
+    sh = gpu.SuperbShard(g, 1, 0, gathered, sif)
+    p, n = sh.reference(d_b)
+    comm.broadcast_f32(p, n, 0)
+    p, n, off = sh.spectrum(d_b)
+    comm.allgather_f32(p, n)
+    assert off == 0 and sh.finish(d_got) == per
+    assert np.array_equal(d_got.download(), d_want.download())
+    sh.destroy()
+    comm.destroy()
+
+
+def test_sharded_stitch_in_four_processes_equals_the_oracle():
+    """one process per hop, exchanges through gloo (tests/stitch_worker.py)"""
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "stitch_worker.py"), str(r), "4", str(port)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(4)]
+    outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "sharded stitch equals the oracle: True" in outs[0]
