@@ -574,7 +574,7 @@ def main():
         except Exception as e:
             redo_stats = {"error": repr(e)}
 
-    # side metric: the detector in the reference's own FFT arithmetic (what tsdr_readasync uses by default)
+    # side metric: the detector in the reference's own FFT arithmetic (what a certified epoch is replayed through)
     exact_ac = None
     if rank == 0 and not args.no_profile and not sharded and not args.leg:
         acx = gpu.Autocorr(g, fs)

@@ -94,7 +94,7 @@ def main():
         flat["_note"] = (f"HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units), "
                          f"FETCH_SIZE x{ff:.3f} and WRITE_SIZE x{wf:.3f} calibrated on k_demod_vec4 (known 8 B read + 4 B "
                          "written per sample); bench workload: 1 s of 100 MS/s IQ per pass (60 frames; 17 windows transformed "
-                         "6+6+5 per launch); k_ac_cols = launch-weighted mean of its two trips; scripts/pmc_collect.sh")
+                         "9+8 per launch); k_ac_cols = launch-weighted mean of its two trips; scripts/pmc_collect.sh")
         json.dump(flat, open(sys.argv[3], "w"), indent=1)
     return res
 
