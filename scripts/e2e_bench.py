@@ -75,7 +75,10 @@ def main():
     if os.path.exists(rawfile):
         leg("mi355x_rawfile_plugin", tsdrlib.LIB, rawfile, f"{path} {args.fs} float")
         if args.reference and os.path.exists(reflib):
-            leg("reference_cpu_rawfile_plugin", reflib, rawfile, f"{path} {args.fs} float", free=False)
+            try:  # the reference's own teardown is not safe (use-after-free, TSDRLibrary.c:523-527): a crash there is its, not ours
+                leg("reference_cpu_rawfile_plugin", reflib, rawfile, f"{path} {args.fs} float", free=False)
+            except RuntimeError as ex:
+                out["reference_cpu_rawfile_plugin"] = {"error": str(ex)[:300]}
     print(json.dumps(out))
 
 
