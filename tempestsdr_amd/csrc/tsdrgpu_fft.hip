@@ -12,7 +12,17 @@
 #include "tsdrgpu_internal.h"
 #include "fft4step.h"
 
-#define AC_SUBBATCH 9
+// windows per launch of the float32 plan (TSDRGPU_AC_SUBBATCH overrides for experiments: 1..32)
+static int ac_subbatch()
+{
+    static const int v = [] {
+        const char *e = getenv("TSDRGPU_AC_SUBBATCH");
+        const int n = e ? atoi(e) : 9;
+        return n < 1 ? 1 : (n > 32 ? 32 : n);
+    }();
+    return v;
+}
+#define AC_SUBBATCH (ac_subbatch())
 
 // one tsdrgpu_autocorr_run call of the current epoch, as the certified mode remembers it for an exact replay
 struct AcLogRec {
