@@ -484,13 +484,15 @@ static void *plot_thread(void *arg)
         /* the snapshot is complete once plot_ready has fired; its way home is queued here, on the DOWNLOAD lane, so
          * that the detector's lane never waits for a copy engine */
         int deliver = plots && tsdrgpu_event_sync(e->g, e->plot_ready) == 0;
-        if (deliver && e->plot.certify) {
+        if (plots && e->plot.certify) {
             /* certified mode: the argmax kernels ran in front of the snapshot.  A plot whose argmax is not provably the
-             * reference's does not leave: the device thread replays the epoch exactly and publishes that plot instead */
+             * reference's does not leave: the device thread replays the epoch exactly and publishes that plot instead.
+             * (The result is collected in any case, so that the next update can queue its own.) */
             int32_t fi, li;
             tsdrgpu_ac_certificate_t c;
-            if (tsdrgpu_autocorr_argmax_result(e->plot.ac, &fi, &li) == 0 && tsdrgpu_autocorr_certificate(e->plot.ac, &c) == 0 &&
-                !(c.frame_certified && c.line_certified)) {
+            const int got = tsdrgpu_autocorr_argmax_result(e->plot.ac, &fi, &li) == 0 && tsdrgpu_autocorr_certificate(e->plot.ac, &c) == 0;
+            if (!got) deliver = 0; /* no certificate, no delivery */
+            else if (deliver && !(c.frame_certified && c.line_certified)) {
                 deliver = 0;
                 e->n_plots_held++;
                 e->det_promote = 1;

@@ -173,3 +173,54 @@ def test_resampler_tiny_and_huge_chunks(orc):
         n = rs.process(g.to_device(mag), 0, chunk, nch, r, 1.0, 0, d_out)
         assert n == want.size and np.array_equal(d_out.download(n), want), (chunk, nch, r)
         assert rs.state() == (ref_rs.st.contrib, ref_rs.st.offset)
+
+
+def test_round3_entry_points_reject_misuse_and_take_empty_input(orc):
+    """The certified detector, the band resampler, the band chain and the sharded stitch: empty calls are no-ops, calls out
+    of order or out of range fail with TSDRGPU_E* (never a crash, never a silent wrong answer)."""
+    g = ctx()
+    d = g.empty(1 << 16)
+    # certified autocorrelation
+    ac = gpu.Autocorr(g, 300_000)
+    ac.set_certify(1, retain_bytes=1)  # rounded up to one window
+    ac.run(d, 0, ac.capture, 0)        # no window: nothing retained, nothing run
+    fi, li, promoted = ac.argmax_certified()  # an all-zero plot: every lag ties -> replayed (nothing to replay) -> index 0
+    assert (fi, li, promoted) == (0, 0, 1) and ac.certificate().exact_epoch
+    ac.reset()
+    assert not ac.certificate().exact_epoch or ac.certificate().promotions == 1
+    with pytest.raises(gpu.TsdrGpuError):
+        ac.set_certify(3)
+    ac.set_certify(0)
+    with pytest.raises(gpu.TsdrGpuError):
+        ac.promote()  # certified mode is off
+    # band resampler
+    rs = gpu.Resampler(g)
+    assert rs.process_band(d, 0, 100, 0, 2.0, 1.0, 16, 16, 0, 16, 0, d, 4) == (0, 0)
+    for bad in (dict(y0=8, rows=16), dict(y0=0, rows=0), dict(phase=16 * 16), dict(cap=0)):
+        kw = dict(y0=0, rows=16, phase=0, cap=4)
+        kw.update(bad)
+        with pytest.raises(gpu.TsdrGpuError):
+            rs.process_band(d, 0, 100, 2, 2.0, 1.0, 16, 16, kw["y0"], kw["rows"], kw["phase"], d, kw["cap"])
+    assert rs.state() == (0.0, 0.0)  # a refused call leaves the carried state alone
+    rs.track_frames(4096)
+    with pytest.raises(gpu.TsdrGpuError):
+        rs.process_band(d, 0, 100, 2, 2.0, 1.0, 16, 16, 0, 16, 0, d, 4)  # frame tracking is a full-frame feature
+    # band chain
+    pp = gpu.PostProcess(g)
+    with pytest.raises(gpu.TsdrGpuError):
+        pp._nframes = 1
+        pp.band_advance(d, 0, 1)  # no band run is open
+    with pytest.raises(gpu.TsdrGpuError):
+        pp.band_begin(d, 1, 64, 64, 32, 64)  # rows beyond the frame
+    pp.band_begin(d, 1, 64, 64, 32, 32)
+    with pytest.raises(gpu.TsdrGpuError):
+        pp.band_advance(d, 2, 2)  # band index out of range
+    # sharded stitch
+    with pytest.raises(gpu.TsdrGpuError):
+        gpu.SuperbShard(g, 4, 4, 20_000, 2_000)  # my_hop out of range
+    sh = gpu.SuperbShard(g, 2, 1, 20_000, 2_000)
+    with pytest.raises(gpu.TsdrGpuError):
+        sh.spectrum(d)  # before the reference
+    with pytest.raises(gpu.TsdrGpuError):
+        sh.finish(d)
+    sh.destroy()
