@@ -26,10 +26,61 @@
 // (threads = pthreads, __shared__ = static, __syncthreads = barrier) against numpy before a GPU sees them.
 #pragma once
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AC4_SCALAR_COMPLEX)
+// Complex arithmetic on register PAIRS with the packed float32 instructions of gfx950 (VOP3P, full rate: two flops per
+// lane and issue).  A sum or difference is one v_pk_add_f32; multiplying by -i is not an operation at all but a pair
+// of operand modifiers on the addition that consumes it (op_sel swaps the halves, neg_hi / neg_lo flips one sign); a
+// complex product is v_pk_mul_f32 + v_pk_fma_f32 with the broadcast, the swap and the sign as modifiers.  The compiler
+// does not find these forms by itself: from scalar code its SLP vectoriser reaches v_pk_* but pays for gathering the
+// pairs with register moves (725 v_mov_b32 among k_ac_rows' 2 481 VALU instructions), and from <2 x float> code it
+// materialises every swap and negation (a v_pk_add with 0 plus two moves per multiplication by -i) — hence the few
+// lines of inline assembly.  Operand modifiers: op_sel[i] / op_sel_hi[i] = which half of source i feeds the low / high
+// result lane (0 low, 1 high; defaults 0 / 1); neg_lo[i] / neg_hi[i] negate source i for that lane.
+typedef float ac4_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ac4_v2 ac4_v(float2 a) { return __builtin_bit_cast(ac4_v2, a); }
+__device__ __forceinline__ float2 ac4_f(ac4_v2 a) { return __builtin_bit_cast(float2, a); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return ac4_f(ac4_v(a) + ac4_v(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return ac4_f(ac4_v(a) - ac4_v(b)); }
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b)
+{
+    ac4_v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(ac4_v(a)), "v"(ac4_v(b)));
+    return ac4_f(r);
+}
+// a - (-i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ float2 csub_mi(float2 a, float2 b)
+{
+    ac4_v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(ac4_v(a)), "v"(ac4_v(b)));
+    return ac4_f(r);
+}
+// a * (-i) = (a.y, -a.x), where no addition follows that could absorb it: one multiplication by the pair (1, -1)
+__device__ __forceinline__ float2 mul_mi(float2 a)
+{
+    ac4_v2 r;
+    const ac4_v2 c = {1.0f, -1.0f};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(ac4_v(a)), "v"(c));
+    return ac4_f(r);
+}
+// (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    ac4_v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(ac4_v(a)), "v"(ac4_v(b)));  // (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"          // + (a.y (-b.y), a.y b.x)
+        : "=v"(r)
+        : "v"(ac4_v(a)), "v"(ac4_v(b)), "v"(t));
+    return ac4_f(r);
+}
+#else
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) { return make_float2(a.x + b.y, a.y - b.x); }  // a + (-i) b
+__device__ __forceinline__ float2 csub_mi(float2 a, float2 b) { return make_float2(a.x - b.y, a.y + b.x); }  // a - (-i) b
+#endif
 
 // ---------------------------------------------------------------------------
 // small DFTs in registers (forward, e^{-2 pi i/R}), outputs in natural order
@@ -44,11 +95,11 @@ __device__ __forceinline__ void dft2(float2 &a, float2 &b)
 __device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
 {
     const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
-    const float2 s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+    const float2 s13 = cadd(a1, a3), d13 = csub(a1, a3);
     a0 = cadd(s02, s13);
-    a1 = cadd(d02, d13);
+    a1 = cadd_mi(d02, d13);  // d02 + (-i) d13
     a2 = csub(s02, s13);
-    a3 = csub(d02, d13);
+    a3 = csub_mi(d02, d13);
 }
 
 template <int R>
