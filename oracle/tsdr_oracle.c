@@ -20,11 +20,15 @@
  * orc_frame_to_rgb is pinned against the reference's JNI shim itself, compiled from
  * JavaGUI/jni/TSDRLibraryNDK.c behind a stub jni.h (oracle/jni_stub, oracle/ref_shim_jni.c;
  * tests/test_oracle_vs_ref.py::test_frame_to_rgb_*).
- * PARITY UNPINNED for the restatements of JAVA code, which cannot be run here (no JVM):
- * orc_plot_populate (PlotVisualizer.populateData) and the mode-detection logic
- * (Main.java / VideoMode.java); they are integer / max-only / f64-division logic, checked
- * against line-by-line transliterations in tests/test_extras_cpu.py and against committed
- * fixtures (tests/golden/java_fixtures.json) derived from those.
+ * The restatements of JAVA code — orc_plot_populate / orc_plotscale_default
+ * (PlotVisualizer.populateData, ZoomableXScale) — and the library's mode-detection logic
+ * (Main.java / VideoMode.java) are pinned against the reference's own compiled classes: the image
+ * has no JVM, so the released jar (Release/JavaGUI/JTempestSDR.jar) is executed by a bytecode
+ * interpreter of ours (tests/golden/minijvm.py, driven by tests/golden/make_java_fixtures_jvm.py);
+ * what the classes computed is committed as tests/golden/java_fixtures_jvm.json and checked
+ * exactly by tests/test_extras_cpu.py (which also re-runs the interpreter on fresh cases where the
+ * jar is present).  A JDK library call made by those methods (Math, boxing, HashMap) is the
+ * interpreter's native, not the JDK's: that much of the pin is ours.
  *
  * Build: gcc -O3 -fPIC -shared -ffp-contract=off (no fast-math; the reference
  * is built -O3 without fast-math, TempestSDR/makefile:21).
@@ -857,8 +861,8 @@ ORC_API void orc_frame_to_rgb(const float *frame, int32_t *rgb, int64_t n, int i
    to repeat the previous column's value), before the y scaling of PlotVisualizer.java:245-246.
    lowest/highest are what scale_y.setLowestHighestValue receives (:243); max_index is the
    argmax the GUI reads back through getMaxIndex() (:226-229).
-   PARITY UNPINNED: the reference for this function is Java and no JDK exists in the build image,
-   so this restatement could not be run against it.
+   Pinned against the reference's compiled PlotVisualizer / ZoomableXScale classes executed by
+   tests/golden/minijvm.py (tests/golden/java_fixtures_jvm.json, tests/test_extras_cpu.py).
    --------------------------------------------------------------------------- */
 typedef struct {
     double one_val_in_pixels, one_px_in_values, offset_val, min_value;

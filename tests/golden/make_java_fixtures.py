@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Golden fixtures for the two pieces of the reference that are JAVA (no JVM in this image, so they cannot be
-executed: parity for them stays "unpinned" until one is available).  Each function below is a LITERAL, line-by-line
+"""Golden fixtures for the two pieces of the reference that are JAVA, by hand transliteration (round 2; the pin proper
+is make_java_fixtures_jvm.py, which executes the reference's compiled classes with a bytecode interpreter and whose
+results this file's must equal — tests/test_extras_cpu.py).  Each function below is a LITERAL, line-by-line
 transliteration of the cited Java source — same statements, same order, same integer/double conversions — written
 independently of oracle/tsdr_oracle.c; the Java lines are quoted beside every statement.  The fixtures it writes
 (tests/golden/java_fixtures.json) are what tests/test_extras_cpu.py checks the oracle's C restatements and the

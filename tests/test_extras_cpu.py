@@ -4,6 +4,7 @@ restatement of the Java GUI's logic."""
 import ctypes as C
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -192,8 +193,8 @@ def test_oracle_frame_to_rgb_vs_vectorised_formulation(orc, inverted):
 
 # --------------------------------------------------------------------------
 # Fixtures from the literal Java transliterations (tests/golden/make_java_fixtures.py -> java_fixtures.json).
-# The reference for these rows is Java and the image has no JVM, so parity stays UNPINNED; what is checked is
-# that the oracle's C restatement and the library's host logic reproduce the transliteration exactly.
+# The image has no JVM; the pin for these rows is further down: the reference's released jar executed by the
+# bytecode interpreter of tests/golden/minijvm.py (java_fixtures_jvm.json), which the transliteration must equal.
 # --------------------------------------------------------------------------
 def _java_fixtures():
     import json
@@ -237,3 +238,111 @@ def test_modedetect_equals_java_transliteration():
             assert (d.framerate, d.height, d.linerate) == (want["fps"], want["height"], want["linerate"])
             assert (d.accepted, d.seen) == (want["accepted"], want["seen"])
             assert d.mode_id == want["mode"] and d.mode_name.decode() == want["mode_name"]
+
+
+# --------------------------------------------------------------------------
+# The pin of the Java rows (f2 mode detection, f4 plot decimation): tests/golden/java_fixtures_jvm.json is what the
+# reference's OWN compiled classes (Release/JavaGUI/JTempestSDR.jar: ZoomableXScale, PlotVisualizer.populateData,
+# Main.onIncommingPlot and its transformers, VideoMode) computed when executed by tests/golden/minijvm.py.
+# --------------------------------------------------------------------------
+def _jvm_fixtures():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "java_fixtures_jvm.json")))
+
+
+def test_transliteration_equals_the_reference_bytecode():
+    a, b = _java_fixtures(), _jvm_fixtures()
+    assert a["n_modes"] == b["n_modes"] == 80
+    assert a["populate"] == b["populate"]
+    assert a["closest_mode"] == b["closest_mode"]
+    assert len(a["modedetect"]) == len(b["modedetect"])
+    for ra, rb in zip(a["modedetect"], b["modedetect"]):
+        assert ra["samplerate"] == rb["samplerate"] and len(ra["steps"]) == len(rb["steps"])
+        for sa, sb in zip(ra["steps"], rb["steps"]):
+            want = dict(sa["out"])
+            want.pop("linerate")  # the GUI never computes it
+            assert sa["in"] == sb["in"] and want == sb["out"]
+
+
+def test_oracle_plot_populate_equals_the_reference_bytecode(orc):
+    import hashlib
+    from oracle.oracle import PlotScale
+    fx = _jvm_fixtures()
+    assert len(fx["populate"]) == 10 and len(fx["populate_zoomed"]) == 32
+    for case in fx["populate"] + fx["populate_zoomed"]:
+        data = _fixture_plot(case)
+        s = PlotScale()
+        for k, v in case["scale"].items():
+            setattr(s, k, v)
+        vis, lo, hi, mi = orc.plot_populate(data, case["nwidth"], s)
+        assert (lo, hi, mi) == (case["lowest"], case["highest"], case["max_index"]), (case["size"], case.get("actions"))
+        assert hashlib.sha256(np.asarray(vis, np.float64).tobytes()).hexdigest() == case["visdata_sha"], (case["size"], case.get("actions"))
+
+
+def test_plotscale_default_equals_the_reference_bytecode(orc):
+    lib = gpu.load_library()
+    for case in _jvm_fixtures()["plotscale_default"]:
+        a, b = gpu.PlotScale(), orc.PlotScale()
+        lib.tsdrgpu_plotscale_default(case["size"], case["nwidth"], C.byref(a))
+        orc.lib.orc_plotscale_default(case["size"], case["nwidth"], C.byref(b))
+        for k, v in case["scale"].items():
+            assert getattr(a, k) == v and getattr(b, k) == v, (case["size"], case["nwidth"], k)
+
+
+def test_modedetect_equals_the_reference_bytecode():
+    build.build(verbose=False)
+    fx = _jvm_fixtures()
+    table = fx["mode_table"]
+    accepted = 0
+    for run in fx["modedetect"] + fx["modedetect_random"]:
+        md = gpu.ModeDetect()
+        for step in run["steps"]:
+            fo, fi, lo, li = step["in"]
+            d = md.feed(fo, fi, lo, li, run["samplerate"])
+            want = step["out"]
+            assert (d.framerate, d.height) == (want["fps"], want["height"])
+            assert (d.accepted, d.seen) == (want["accepted"], want["seen"])
+            assert d.mode_id == want["mode"] and d.mode_name.decode() == want["mode_name"]
+            assert [d.mode_name.decode(), d.mode_width, d.mode_height, d.mode_refresh] == table[d.mode_id]
+            accepted += d.accepted
+    assert accepted > 50
+    md = gpu.ModeDetect()
+    for (fo, fi, lo, li, fs, fps, height, mode) in fx["closest_random"]:
+        md.reset()
+        d = md.feed(fo, fi, lo, li, fs)
+        assert (d.framerate, d.height, d.mode_id) == (fps, height, mode)
+    assert len(set(c[7] for c in fx["closest_random"])) > 60  # most of the table is some query's answer
+
+
+def test_reference_bytecode_live(orc):
+    """Where the reference tree is present (the build container), run the jar's classes through the interpreter on
+    cases that are NOT in the committed fixtures and hold the oracle and the library to them."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_java_fixtures_jvm as J
+    if not J.jar_available():
+        pytest.skip("reference jar not present")
+    import hashlib
+    from oracle.oracle import PlotScale
+    assert hashlib.sha256(open(J.JAR, "rb").read()).hexdigest() == _jvm_fixtures()["jar_sha256"]
+    build.build(verbose=False)
+    vm = J.VM(J.JAR)
+    r = np.random.default_rng(int.from_bytes(os.urandom(4), "little"))
+    for _ in range(4):
+        size, nwidth = int(r.integers(50, 4000)), int(r.integers(100, 1500))
+        sx, actions = J.user_zoomed_scale(vm, size, nwidth, r)
+        case = J.plot_case(vm, size, nwidth, None, None, int(r.integers(1, 2**31)), sx=sx)
+        s = PlotScale()
+        for k, v in case["scale"].items():
+            setattr(s, k, v)
+        vis, lo, hi, mi = orc.plot_populate(_fixture_plot(case), nwidth, s)
+        assert (lo, hi, mi) == (case["lowest"], case["highest"], case["max_index"]), (size, nwidth, actions, case["seed"])
+        assert hashlib.sha256(np.asarray(vis, np.float64).tobytes()).hexdigest() == case["visdata_sha"], (size, nwidth, actions, case["seed"])
+    modes = J.video_modes(vm)
+    det, md = J.MainDetector(vm), gpu.ModeDetect()
+    fs = 50_000_000
+    for _ in range(12):
+        fo, fi, lo_, li = 400_000, 433_333 + int(r.integers(-1, 2)), 300, 441 + int(r.integers(-1, 2)) * int(r.random() < 0.2)
+        want = det.on_plots(fo, fi, lo_, li, fs)
+        d = md.feed(fo, fi, lo_, li, fs)
+        assert (d.framerate, d.height, d.accepted, d.seen) == (want["fps"], want["height"], want["accepted"], want["seen"])
+        assert d.mode_id == J.closest(vm, modes, want["fps"], want["height"])

@@ -110,6 +110,34 @@ def test_plot_columns_bit_exact(orc, size, nwidth, zoom, offpx):
     assert got[1:] == want[1:]
 
 
+def test_plot_columns_equal_the_reference_bytecode():
+    """f4 pinned: the device's columns == what the reference's own PlotVisualizer.populateData / ZoomableXScale classes
+    computed (tests/golden/java_fixtures_jvm.json: the released jar executed by tests/golden/minijvm.py), for default
+    scales and for zoom states reached through the scale's public zoom / drag methods."""
+    import hashlib
+    import json
+    import os
+    from tempestsdr_amd import gpu as G
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "java_fixtures_jvm.json")))
+    g = ctx()
+    cases = fx["populate"] + fx["populate_zoomed"]
+    assert len(cases) == 42
+    for case in cases:
+        r = np.random.default_rng(case["seed"])
+        size, nwidth = case["size"], case["nwidth"]
+        data = r.random(size) + 0.2 * np.sin(np.arange(size) / 37.0)
+        data[r.integers(0, size, 3)] = 1.5
+        d = g.empty(2 * size, np.float32)
+        g._ck(g.lib.tsdrgpu_upload(g.h, d.ptr, data.ctypes.data, data.nbytes))
+        g.sync()
+        s = G.PlotScale()
+        for k, v in case["scale"].items():
+            setattr(s, k, v)
+        vis, lo, hi, mi = g.plot_columns(d.ptr, size, nwidth, s)
+        assert (lo, hi, mi) == (case["lowest"], case["highest"], case["max_index"]), (size, nwidth, case.get("actions"))
+        assert hashlib.sha256(np.asarray(vis, np.float64).tobytes()).hexdigest() == case["visdata_sha"], (size, nwidth, case.get("actions"))
+
+
 def test_plot_columns_on_autocorr_plot(orc):
     """The frame-lag plot of an autocorrelation run, decimated on the device, vs the oracle on the downloaded plot."""
     from tempestsdr_amd import gpu as G
