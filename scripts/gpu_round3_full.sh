@@ -18,5 +18,6 @@ timeout 600 python scripts/e2e_bench.py --reference > $O/e2e.json 2> $O/e2e.txt;
 grep -E "^(mi355x|reference)" $O/e2e.txt | cut -c1-200
 bash scripts/gpu_exact_prof.sh > $O/exact_prof.txt 2>&1; grep "us/window" $O/exact_prof.txt
 (cd scripts/micro && hipcc --offload-arch=gfx950 -O2 -o mall_bench mall_bench.hip 2>/dev/null && ./mall_bench) > $O/mall_bench.txt 2>&1
+(cd scripts/micro && hipcc --offload-arch=gfx950 -O2 -w -o tile_read_bench tile_read_bench.hip 2>/dev/null && ./tile_read_bench) > $O/tile_read_bench.txt 2>&1
 timeout 400 python scripts/fuzz_parity.py 400 > $O/fuzz_parity.txt 2>&1; tail -3 $O/fuzz_parity.txt
 timeout 400 python scripts/fuzz_engine.py 40 > $O/fuzz_engine.txt 2>&1; tail -3 $O/fuzz_engine.txt

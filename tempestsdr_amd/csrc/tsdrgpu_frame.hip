@@ -112,24 +112,7 @@ struct tsdrgpu_postproc {
 typedef float float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef float float4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_min(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
-    return v;
-}
+#include "wave_reduce.h"  // wave_sum / wave_min / wave_max: the shuffle tree's additions, result in lane 0
 
 __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ frames, long long fstride, int W, int H,
                                                      int tiles_x, int tiles_y, float *__restrict__ bmin,

@@ -237,3 +237,20 @@ def test_frame_snr_matches_dsp_autogain_run(orc, n, sentinels):
         assert np.isnan(got.value) == np.isnan(want) and np.isinf(got.value) == np.isinf(want)
     else:
         assert abs(got.value - want) <= 1e-9 * abs(want) + np.spacing(want)
+
+
+def test_wave_reductions_equal_the_shuffle_tree(tmp_path):
+    """tempestsdr_amd/csrc/wave_reduce.h (permlane swaps + DPP row shifts) must give lane 0 the shuffle tree's result bit
+    for bit — the partial sums of the frame statistics, and with them the strips, depend on the order of additions."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "wave_reduce_check")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-w", "-o", exe, os.path.join(root, "scripts", "micro", "wave_reduce_check.hip")],
+                   check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr
