@@ -218,10 +218,13 @@ def main():
                          "exercise the RCCL path on a 1-GPU box")
     ap.add_argument("--torch-collective", action="store_true",
                     help="skip the library's own RCCL communicator and take the torch.distributed safety net (testing)")
-    ap.add_argument("--fuse", action="store_true",
-                    help="fused run: min/max from the resampler (frame tracking) and the sync detector's sums from the "
-                         "normalise/IIR pass instead of a separate statistics pass (k_frame_stats).  Moves 12P instead of "
-                         "16P bytes per frame but measured slower on MI355X (DESIGN.md section 4), so it is opt-in")
+    ap.add_argument("--fuse", dest="fuse", action="store_true", default=None,
+                    help="fused run (tsdrgpu_postproc_begin_minmax): per-frame min/max from the resampler (frame tracking), so ONE trip "
+                         "over the raw frames gathers the sync detector's sums and writes the normalised frames (12P instead of 16P "
+                         "bytes per frame); the pass's sync detector and autocorrelation then run beside the NEXT pass's resampler. "
+                         "Default at motion blur 0 (a flat kernel, +4 %%); with blur > 0 the trip walks the frames tile by tile and "
+                         "is slower than the separate kernels (DESIGN.md section 4), so it is off unless asked for")
+    ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="separate statistics kernel and normalise/IIR pass (16P bytes per frame)")
     ap.add_argument("--no-split", action="store_true",
                     help="one tsdrgpu_postproc_run per batch instead of _begin / autocorrelation / _finish "
                          "(the split hides the ~0.1 ms frame-to-frame chain behind the FFT passes)")
@@ -263,6 +266,10 @@ def main():
     if args.blur is not None:
         blur = args.blur
         wl_name += f", motion blur {blur:g}"
+    if args.fuse is None:
+        args.fuse = blur == 0.0
+    if args.bands or args.frames_per_launch > 0 or args.no_split:
+        args.fuse = False
     if args.leg:
         args.no_e2e = args.no_cpu_baseline = args.no_legs = True
     W = geometry(fs, h, fv)
@@ -300,6 +307,14 @@ def main():
     frames_cap = max_pix // P + 1
     out = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
     d_pix, d_out = DevPtr(pix), DevPtr(out)
+    # fused run: pixel and frame buffers alternate, so that a pass's sync detector (side lane) and its autocorrelation
+    # (background lane) run beside the NEXT pass's resampler; its _finish is called behind that resampler
+    fuse_bufs = None
+    if args.fuse and not args.bands:
+        pix2 = torch.empty(max_pix, dtype=torch.float32, device=dev)
+        out2 = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
+        fuse_bufs = [(d_pix, d_out), (DevPtr(pix2), DevPtr(out2))]
+    fuse_open = [None]  # the frame buffer of the fused run that is still open
     band = None
     if args.bands:
         # bands start on multiples of 32 rows (the statistics tiles); the last one takes the remainder
@@ -446,6 +461,27 @@ def main():
         # Cache when the statistics and the normalise/IIR pass read them back.
         cps = nchunks if args.frames_per_launch <= 0 else max(1, args.frames_per_launch * 10)
         done_chunks = 0
+        if fuse and fuse_bufs is not None:
+            cur_pix, cur_out = fuse_bufs[pass_no[0] % 2]
+            nxt_pix = fuse_bufs[(pass_no[0] + 1) % 2][0]
+            n = rs.process(d_iq, 1, chunk, nchunks, up, down, 0, cur_pix, out_offset=carry)
+            avail = carry + n
+            F = avail // P
+            if fuse_open[0] is not None:  # the previous pass: its chain ran beside the resampler above
+                pp.finish(fuse_open[0], want_info=False)
+            mn_ptr, mx_ptr, _ = rs.frame_minmax(download=False)
+            pp.begin_minmax(cur_pix, F, W, h, mn_ptr, mx_ptr, cur_out, motionblur=blur)
+            fuse_open[0] = cur_out
+            if last:  # a step's last pass (and every instrumented pass) is closed at once, the autocorrelation behind it:
+                pp.finish(fuse_open[0], want_info=False)  # with one lane for the autocorrelation nothing runs beside anything
+                fuse_open[0] = None
+            run_autocorr()
+            rem = avail - F * P
+            if rem:  # the incomplete frame goes on at the head of the other pixel buffer
+                g._ck(g.lib.tsdrgpu_copy(g.h, nxt_pix.at(0), cur_pix.at(F * P), rem * 4))
+            carry = rem
+            frames_done += F
+            return finish_pass(last)
         while done_chunks < nchunks:
             k = min(cps, nchunks - done_chunks)
             n = rs.process(d_iq, 1, chunk, k, up, down, 0, d_pix, in_offset=2 * done_chunks * chunk, out_offset=carry)
@@ -464,8 +500,11 @@ def main():
                 # frame statistics, then the latency-bound frame-to-frame chain on the side stream while
                 # the autocorrelation passes keep the main stream busy, then the normalise/IIR pass
                 pp.begin(d_pix, F, W, h, motionblur=blur)
+                if last:  # (see the fused run above)
+                    pp.finish(d_out, want_info=False)
                 run_autocorr()
-                pp.finish(d_out, want_info=False)
+                if not last:
+                    pp.finish(d_out, want_info=False)
             elif F:
                 pp.run(d_pix, F, W, h, d_out, motionblur=blur, want_info=False)
             rem = avail - F * P
@@ -674,6 +713,9 @@ def main():
             "frame_path_blur": leg(["--config", "2", "--blur", "0.5", "--steps", "4", "--passes", "40"],
                                    "the headline configuration with motion blur 0.5: the IIR is live, every batch takes the frame-by-frame "
                                    "k_frame_pass (state in registers across the batch's frames: 8P bytes moved per frame = 8P credited)"),
+            "frame_path_unfused": leg(["--config", "2", "--no-fuse", "--steps", "4", "--passes", "40"],
+                                      "the headline configuration with the split run instead of the fused one: k_frame_stats, then the "
+                                      "normalise/IIR pass (16P bytes per frame moved); the autocorrelation beside the pass of its own batch"),
         }
 
     if dist is not None:
@@ -706,9 +748,10 @@ def main():
         # The autocorrelation has ONE figure, 28N+16L per window, for all of its kernels together, so it gets one
         # group entry: bytes per window x windows / (sum of its kernels' durations).
         bfrac = (band["rows"] / h) if band is not None else 1.0  # a band touches its share of samples and pixels
+        fused_flat = bool(args.fuse) and blur == 0.0  # statistics + normalise/IIR in one flat kernel (profiler stage k_frame_pass)
         own = {"k_rs_area": (8.0 * S + 4.0 * P) * (nsamples / S) * bfrac,
                "k_frame_stats": 4.0 * P * frames_pass * bfrac,
-               "k_frame_pass": 8.0 * P * frames_pass * bfrac}
+               "k_frame_pass": (12.0 if args.fuse else 8.0) * P * frames_pass * bfrac}
         kernels = {}
         for k, bytes_pass in own.items():
             ms, n = per_pass(k)
@@ -717,7 +760,12 @@ def main():
                               "alg_bytes_per_launch": int(bytes_pass / n),
                               "achieved_GBs": round(bytes_pass / (ms * 1e-3) / 1e9, 1),
                               "frac": round(bytes_pass / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                if k == "k_frame_pass" and n > 1.5:
+                if k == "k_frame_pass" and args.fuse:
+                    kernels[k]["note"] = ("fused run: k_frame_stats<store> does the work of k_frame_stats (4P) and of the normalise/IIR pass "
+                                          "(8P) in ONE trip that moves 8P — credited with the 12P of the two stages it replaces; + the "
+                                          "literal pass gated on the device's redo flag (returns at once)" if fused_flat else
+                                          "fused run, tile-walking form (motion blur > 0): credited with the 12P of the two stages it replaces")
+                elif k == "k_frame_pass" and n > 1.5:
                     kernels[k]["note"] = ("stage of three launches: k_frame_pass_par (the frame-parallel pass, motion blur 0) + "
                                           "k_pass_state (new IIR state) + k_frame_pass gated on the device's redo flag (returns at once)")
         ac_group = [k for k in ("k_ac_cols", "k_ac_rows", "k_fft_lds", "k_ac_mid", "k_accumulate") if k in prof]
@@ -800,8 +848,13 @@ def main():
                        "samples_per_step_per_gpu": nsamples * args.passes, "passes_per_step": args.passes,
                        "stage_order": "library default (autogain, sync, IIR)",
                        "lanes": "one (--serial)" if args.serial else
+                                ("frame path on the COMPUTE lane; a pass's sync chain (SIDE lane) and autocorrelation (BACKGROUND lane) run "
+                                 "beside the next pass's resampler (pixel and frame buffers alternate)") if args.fuse else
                                 "frame path on the COMPUTE lane, sync chain on the SIDE lane, autocorrelation on the BACKGROUND lane (beside the "
                                 "normalise/IIR pass of its batch)",
+                       "frame_path": ("fused run (tsdrgpu_postproc_begin_minmax / _finish): per-frame min/max from the resampler's frame "
+                                      "tracking, one trip over the raw frames for statistics + normalise/IIR (12P bytes per frame moved)")
+                                     if args.fuse else "split run (tsdrgpu_postproc_begin / _finish): statistics kernel, then the normalise/IIR pass",
                        "sync_detector": "fast (toss-ups not redone)" if args.fast_sync else
                                         "contract-exact: toss-up decisions redone with the reference's own strip sums (library default)",
                        "autocorrelation": (f"float32 transform, {trips.split(' ')[0]}-trip plan, uncertified (--uncertified)" if args.uncertified else
@@ -833,8 +886,8 @@ def main():
                            "frac": round(frame_bytes_pass / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_ms else None,
                            "alg_bytes_per_frame": int(8 * S + 16 * P), "frames_per_pass": round(frames_pass, 3),
                            "chain": "on the side stream, overlapped with the autocorrelation" if chain_hidden else "in line",
-                           "statistics": "min/max in k_rs_area, row/column sums in the normalise/IIR pass (12P bytes per frame "
-                                         "instead of 16P)" if fused else "k_frame_stats"},
+                           "statistics": "min/max in k_rs_area (frame tracking), row/column sums in the one trip that also writes the "
+                                         "normalised frames (12P bytes per frame moved, 16P credited)" if fused else "k_frame_stats"},
             "autocorrelation": autocorr,
             "whole_pass": {"alg_bytes": int(frame_bytes_pass + ac_bytes_pass),
                            "achieved_GBs": round((frame_bytes_pass + ac_bytes_pass) / (ms_pass * 1e-3) / 1e9, 1),

@@ -230,10 +230,15 @@ int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsdrgpu_pp_fra
  * green lines of syncdetector.c:209-223 patched in afterwards) on the side stream — the separate
  * statistics read of every frame (4 bytes/pixel of 16) disappears.  Results are bit-identical to
  * tsdrgpu_postproc_run.  Everything is queued here, so d_out is given now; _finish(pp, d_out, h_info) joins
- * the streams.  Any other parameter combination silently takes the _begin path (min/max ignored).
- * Measured on MI355X (1080p, 60-frame batches) this form is NOT faster than _begin/_finish although it
- * moves a quarter less data: the tile-shaped pass and the min/max reduction inside the instruction-bound
- * resampler cost what the saved read gains — an alternative, not the default. */
+ * the streams (the same d_out; the raw frames must stay untouched until then: _finish may redo the batch from
+ * them).  Any other parameter combination silently takes the _begin path (min/max ignored).
+ * With motion blur 0 and nframes >= 8 the trip is one FLAT kernel over (tile, frame) — the statistics kernel that
+ * also stores the normalised pixels; a -0.0 or non-finite pixel or state raises a device flag and the literal pass,
+ * queued by _finish and gated on that flag, redoes the batch.  On MI355X (1080p, 60-frame batches) that is the fast
+ * form: 12P instead of 16P bytes per frame, +5 % on the whole pass when the caller lets a batch's sync detector run
+ * beside the next batch's resampler (call _finish for batch k behind tsdrgpu_resample of batch k+1, with two pixel
+ * buffers; bench.py does).  With motion blur > 0 the trip has to walk the frames tile by tile and is slower than
+ * _begin/_finish. */
 int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width, int height,
                                   const tsdrgpu_pp_params_t *params, const float *d_fmin, const float *d_fmax,
                                   float *d_out);

@@ -36,6 +36,8 @@ def short(name):
     k = m.group(1)
     if k == "k_rs_area_up":  # the sample-parallel form of the same stage (bench.py's stage name is k_rs_area)
         k = "k_rs_area"
+    if k == "k_frame_stats" and re.search(r"k_frame_stats<\s*true\s*>", name):  # the fused run's statistics + store trip
+        k = "k_frame_stats_store"
     if k == "k_ac_cols":  # one kernel template, two trips: <log2 N1, input mode, LAST>
         k += "_trip3" if re.search(r"k_ac_cols<[^>]*true>", name) else "_trip1"
     return k

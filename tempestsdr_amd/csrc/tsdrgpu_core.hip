@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) void k_rs_area_band(const RsChunk *__restrict_
 // DPP wave shift: lane l of a wave holds sample base + l - 2, lanes 0 and 1 are ghosts that only feed lane 2.
 // A workgroup (4 waves x `rounds` x 62 samples) writes its pixels [pix_in(sA), pix_in(sB)) into an LDS tile laid
 // out with the output's 16-byte phase, then stores the tile with dwordx4.  Used when 1 <= r <= 8 (the
-// reference's geometry always upsamples by ~2) and frame tracking is off; anything else runs k_rs_area.
+// reference's geometry always upsamples by ~2); anything else runs k_rs_area.
 // ---------------------------------------------------------------------------
 #define RSU_LANES 62     // samples per wave and round
 #define RSU_BATCH 4     // rounds whose loads are in flight together
@@ -1020,7 +1020,8 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
 // the workgroups whose span overlaps it (chunk range from the host), joins frame 0 with the
 // incomplete frame carried from the previous call and leaves the call's last, incomplete frame
 // in the other carry slot.  min/max are order independent, so this is exact.
-__global__ __launch_bounds__(256) void k_rs_minmax(const RsBlockMM *__restrict__ slots, int gx, const RsFrameRange *__restrict__ ranges,
+#define RSMM_T 1024  // a frame's ~7000 records are read by one workgroup: 7 dependent loads per lane instead of 29
+__global__ __launch_bounds__(RSMM_T) void k_rs_minmax(const RsBlockMM *__restrict__ slots, int gx, const RsFrameRange *__restrict__ ranges,
                                                    int ntouched, int ncomplete, const float *__restrict__ carry_in,
                                                    float *__restrict__ carry_out, float *__restrict__ fmin_, float *__restrict__ fmax_)
 {
@@ -1033,14 +1034,15 @@ __global__ __launch_bounds__(256) void k_rs_minmax(const RsBlockMM *__restrict__
         if (b.f0 == j) { lo = fminf(lo, b.mn0); hi = fmaxf(hi, b.mx0); }
         else if (b.f0 >= 0 && b.f0 + 1 == j) { lo = fminf(lo, b.mn1); hi = fmaxf(hi, b.mx1); }
     }
-    __shared__ float red[4][2];
+    __shared__ float red[RSMM_T / 64][2];
     lo = rs_wave_min(lo);
     hi = rs_wave_max(hi);
     if ((threadIdx.x & 63) == 63) { red[threadIdx.x >> 6][0] = lo; red[threadIdx.x >> 6][1] = hi; }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    lo = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
-    hi = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+    lo = red[0][0];
+    hi = red[0][1];
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) { lo = fminf(lo, red[w][0]); hi = fmaxf(hi, red[w][1]); }
     if (j == 0) { lo = fminf(lo, carry_in[0]); hi = fmaxf(hi, carry_in[1]); }
     fmin_[j] = lo;
     fmax_[j] = hi;
@@ -1320,7 +1322,7 @@ extern "C" int tsdrgpu_resample(tsdrgpu_resampler_t *rs, const float *d_in, int 
         }
         KERNEL_CHECK(g, "k_rs_area");
         if (track && ntouched > 0) {
-            TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, k_rs_minmax, (unsigned)ntouched, 256, rs->d_slots, mm_gx, d_rg, ntouched, ncomplete,
+            TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, k_rs_minmax, (unsigned)ntouched, RSMM_T, rs->d_slots, mm_gx, d_rg, ntouched, ncomplete,
                         rs->d_carry + 2 * rs->parity, rs->d_carry + 2 * (1 - rs->parity), rs->d_fmin, rs->d_fmax);
             KERNEL_CHECK(g, "k_rs_minmax");
             rs->parity = 1 - rs->parity;

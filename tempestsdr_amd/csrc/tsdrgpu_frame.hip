@@ -114,10 +114,61 @@ typedef float float4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 #include "wave_reduce.h"  // wave_sum / wave_min / wave_max: the shuffle tree's additions, result in lane 0
 
+// STORE (the fused run at motion blur 0, tsdrgpu_postproc_begin_minmax): the autogain's range is already known (min/max from
+// the resampler), so the same trip also writes the normalised frame — what k_frame_pass_par would read the frame a
+// second time for.  The checks that guard the frame-parallel form of the IIR (see k_frame_pass_par) are made here.
+struct StatsStore {
+    float *dst;
+    long long dstride;
+    const struct ChainOut *chain;
+    const float *screen;
+    int *odd;
+};
+__device__ __forceinline__ void stats_store_tile(const float (&val)[TILE_H / 4][4], const StatsStore &st, int f, int W, int H, int x0, int y0,
+                                                 int lane, int wave)
+{
+    const float lastmin = st.chain[f].lastmin, span = st.chain[f].span;
+    float *outp = st.dst + (long long)f * st.dstride;
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < TILE_H / 4; r++) {
+        const int y = y0 + wave + 4 * r;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float v = val[r][j];
+            o[j] = (v > 250.0f || v < -250.0f) ? v : ((v - lastmin) / span);  // dsp.c:80-86, as pass_one(PASS_NORMALISE)
+        }
+        const int xl = x0 + 4 * lane;
+        if (y < H && xl + 4 <= W) {
+            float4_a4 t;
+#pragma unroll
+            for (int j = 0; j < 4; j++) t[j] = o[j];
+            *reinterpret_cast<float4_a4 *>(outp + (long long)y * W + xl) = t;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = xl + j;
+            if (y < H && x < W) {
+                if (xl + 4 > W) outp[(long long)y * W + x] = o[j];
+                // what the frame-parallel IIR at coefficient 0 cannot reproduce: a non-finite value (it sticks to its pixel
+                // in the reference) and -0.0 (the reference's sum with the old state's +0 gives +0)
+                bad |= !(fabsf(o[j]) <= 3.4028234664e38f) || __float_as_uint(o[j]) == 0x80000000u;
+                if (f == 0) bad |= !(fabsf(st.screen[(long long)y * W + x]) <= 3.4028234664e38f);  // the incoming state has to be finite
+            }
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(st.odd, 1);
+}
+
+// column of a lane's j-th value inside the tile: lanes stride the 64-column quarters (every load covers 256 contiguous
+// bytes), or — in the storing form — own four neighbouring columns (dwordx4 loads and stores)
+#define STATS_CX(j_) (STORE ? 4 * lane + (j_) : lane + 64 * (j_))
+template <bool STORE>
 __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ frames, long long fstride, int W, int H,
                                                      int tiles_x, int tiles_y, float *__restrict__ bmin,
                                                      float *__restrict__ bmax, float *__restrict__ colp,
-                                                     float *__restrict__ rowp, int *__restrict__ tflag, int want_strips)
+                                                     float *__restrict__ rowp, int *__restrict__ tflag, int want_strips, StatsStore st)
 {
     // 1-D grid, XCD-aware: a tile row is 1 KB that rarely starts on a 128-byte line (W*4 is no multiple
     // of 128), so horizontally adjacent tiles share a cache line; workgroups go round-robin to the 8
@@ -141,12 +192,19 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
     for (int r = 0; r < ROWS; r++) {
         const int y = y0 + wave + 4 * r;
         const float *row = src + (long long)(y < H ? y : 0) * W;
+        if (STORE && y < H && x0 + 4 * lane + 4 <= W) {  // the storing form: a lane's four columns are neighbours, one dwordx4
+            const float4_a4 t = *reinterpret_cast<const float4_a4 *>(row + x0 + 4 * lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) val[r][j] = t[j];
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int x = x0 + lane + 64 * j;
+            const int x = x0 + STATS_CX(j);
             val[r][j] = (y < H && x < W) ? row[x] : NAN;  // NaN = outside the frame (neither branch below takes it)
         }
     }
+    if (STORE) stats_store_tile(val, st, f, W, H, x0, y0, lane, wave);
     // phase 2.  Sentinel pixels (|v| > 250) are rare — raw resampler output has none — so their partial
     // sums are only reduced and written when the tile holds any (tflag), which saves two thirds of the
     // partial-sum traffic; k_frame_reduce reads them under the same flag.
@@ -194,7 +252,7 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
         for (int j = 0; j < 4; j++) {
             const float v = val[r][j];
             const bool sent = (v > 250.0f) || (v < -250.0f);  // dsp.c:57
-            const bool inside = (y < H) && (x0 + lane + 64 * j < W);
+            const bool inside = (y < H) && (x0 + STATS_CX(j) < W);
             if (inside) {
                 if (sent) {
                     cs[j] += v; cc[j] += 1.f; rs += v; rc += 1.f;
@@ -234,10 +292,10 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
     if (want_strips) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            sh[0][wave][lane + 64 * j] = cns[j];
+            sh[0][wave][STATS_CX(j)] = cns[j];
             if (tile_sent) {
-                sh[1][wave][lane + 64 * j] = cs[j];
-                sh[2][wave][lane + 64 * j] = cc[j];
+                sh[1][wave][STATS_CX(j)] = cs[j];
+                sh[2][wave][STATS_CX(j)] = cc[j];
             }
         }
     }
@@ -261,6 +319,8 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
         tflag[b] = tile_sent;
     }
 }
+
+#undef STATS_CX
 
 // ---------------------------------------------------------------------------
 // k_frame_reduce: grid (blocks over the strip, 3, F): y=0 min/max of the frame
@@ -1516,8 +1576,8 @@ static int launch_stats_tiles(tsdrgpu_postproc_t *pp, const float *frames, long 
     tsdrgpu_t *g = pp->g;
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
     const unsigned grid = (unsigned)tiles_x * tiles_y * F;
-    TSDR_LAUNCH(g, PROF_FRAME_STATS, g->stream, k_frame_stats, grid, 256, frames, fstride, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp,
-                pp->d_rowp, pp->d_tflag, want_strips);
+    TSDR_LAUNCH(g, PROF_FRAME_STATS, g->stream, k_frame_stats<false>, grid, 256, frames, fstride, W, H, tiles_x, tiles_y, pp->d_bmin, pp->d_bmax, pp->d_colp,
+                pp->d_rowp, pp->d_tflag, want_strips, StatsStore{});
     KERNEL_CHECK(g, "k_frame_stats");
     return TSDRGPU_OK;
 }
@@ -1597,6 +1657,25 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
     return TSDRGPU_OK;
 }
 
+// the frame-by-frame (literal) pass; with `gate` it only runs if *gate was raised by the frame-parallel form before it
+static int launch_pass_literal(tsdrgpu_postproc_t *pp, int flags, const float *src, long long sstride, float *dst, long long dstride,
+                               int F, int W, int H, float a, const int *gate)
+{
+    tsdrgpu_t *g = pp->g;
+    // four pixels per lane (one dwordx4 per frame; the vector types only claim float alignment)
+    const int vw = 4;
+    pass_fn fn = pick_pass(flags, vw);
+    if (!fn) return tsdr_fail(g, TSDRGPU_EINVAL, "k_frame_pass", "unsupported flag combination");
+    const long long P = (long long)W * H;
+    long long blocks = (P / vw + 255) / 256;
+    const long long cap = (long long)g->prop.multiProcessorCount * 16;
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) & ~7LL;  // a multiple of the 8 XCDs (the kernel's span order relies on it)
+    TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, fn, (unsigned)blocks, 256, src, sstride, dst, dstride, F, W, H, pp->d_chain, pp->d_screen, a, gate);
+    KERNEL_CHECK(g, "k_frame_pass");
+    return TSDRGPU_OK;
+}
+
 static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long long sstride, float *dst, long long dstride,
                        int F, int W, int H, float a)
 {
@@ -1630,19 +1709,7 @@ static int launch_pass(tsdrgpu_postproc_t *pp, int flags, const float *src, long
         KERNEL_CHECK(g, "k_pass_state");
         gate = pp->d_odd;  // ... and the literal form below only runs if the flag was raised
     }
-    // four pixels per lane (one dwordx4 per frame; the vector types only claim float alignment)
-    const int vw = 4;
-    (void)sstride;
-    pass_fn fn = pick_pass(flags, vw);
-    if (!fn) return tsdr_fail(g, TSDRGPU_EINVAL, "k_frame_pass", "unsupported flag combination");
-    const long long P = (long long)W * H;
-    long long blocks = (P / vw + 255) / 256;
-    const long long cap = (long long)g->prop.multiProcessorCount * 16;
-    if (blocks > cap) blocks = cap;
-    blocks = (blocks + 7) & ~7LL;  // a multiple of the 8 XCDs (the kernel's span order relies on it)
-    TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, fn, (unsigned)blocks, 256, src, sstride, dst, dstride, F, W, H, pp->d_chain, pp->d_screen, a, gate);
-    KERNEL_CHECK(g, "k_frame_pass");
-    return TSDRGPU_OK;
+    return launch_pass_literal(pp, flags, src, sstride, dst, dstride, F, W, H, a, gate);
 }
 
 // buffers and per-run state for F frames of W x H (everything before the first launch of a run)
@@ -1847,6 +1914,46 @@ extern "C" int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float
     rc = launch_chain(pp, d_frames, Ps, F, W, H, 1, 0, 1, prm);
     pp->ext_fmin = pp->ext_fmax = nullptr;
     if (rc) return rc;
+    // Motion blur 0: a frame's output does not depend on the previous one's, so the trip is a FLAT kernel over (tile, frame)
+    // — k_frame_stats<true>: the statistics kernel that also stores the normalised pixels — instead of tiles that walk
+    // the frames.  Same guard as launch_pass: the exceptions (non-finite values, -0.0) raise *d_odd and the literal
+    // pass, queued by _finish behind the sync detector and gated on the flag, redoes the batch from the raw frames.
+    static const int tiles_only = getenv("TSDRGPU_FUSE_TILES") ? 1 : 0;
+    const bool overlap = (const float *)d_out < d_frames + (long long)F * Ps && d_frames < (const float *)d_out + (long long)F * Ps;
+    if (a == 0.0f && F >= 8 && !overlap && !tiles_only) {
+        const int ftiles_y = (H + TILE_H - 1) / TILE_H;
+        if (!pp->d_odd && hipMalloc(&pp->d_odd, sizeof(int)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "flag");
+        HIP_TRY(g, hipMemsetAsync(pp->d_odd, 0, sizeof(int), g->stream));
+        StatsStore st;
+        st.dst = d_out; st.dstride = Ps; st.chain = pp->d_chain; st.screen = pp->d_screen; st.odd = pp->d_odd;
+        TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, k_frame_stats<true>, (unsigned)(tiles_x * ftiles_y * F), 256, d_frames, Ps, W, H, tiles_x, ftiles_y,
+                    pp->d_bmin, pp->d_bmax, pp->d_colp, pp->d_rowp, pp->d_tflag, 1, st);
+        KERNEL_CHECK(g, "k_frame_stats<store>");
+        TSDR_LAUNCH(g, PROF_FRAME_REDUCE, g->stream, k_frame_reduce, dim3(((W > H ? W : H) + 255) / 256, 3, F), 256, W, H, tiles_x, ftiles_y, pp->d_bmin,
+                    pp->d_bmax, pp->d_colp, pp->d_rowp, pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_tflag, 1, 0, TILE_H);
+        KERNEL_CHECK(g, "k_frame_reduce");
+        HIP_TRY(g, hipEventRecord(pp->ev_stats, g->stream));
+        HIP_TRY(g, hipStreamWaitEvent(g->stream2, pp->ev_stats, 0));
+        pp->chain_st = g->stream2;
+        pp->ext_fmin = d_fmin;
+        pp->ext_fmax = d_fmax;
+        rc = launch_chain(pp, d_frames, Ps, F, W, H, 0, 1, 1, prm);
+        pp->ext_fmin = pp->ext_fmax = nullptr;
+        pp->chain_st = nullptr;
+        if (rc) return rc;
+        if (lines) {  // the painted lines, by the literal per-pixel recurrence from the pre-batch state (d_screen2: scratch)
+            TSDR_LAUNCH(g, PROF_CHAIN, g->stream2, k_fix_lines, dim3(((W > H ? W : H) + 255) / 256, 2, F), 256, d_frames, Ps, d_out, Ps, F, W, H,
+                        pp->d_chain, pp->d_screen, pp->d_screen2, a);
+            KERNEL_CHECK(g, "k_fix_lines");
+        }
+        // the new state: the last frame as it now stands, unless the batch is about to be redone
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream2, k_pass_state, (unsigned)(g->prop.multiProcessorCount * 4), 256,
+                    (const float *)(d_out + (long long)(F - 1) * Ps), pp->d_screen, (int)P, (const int *)pp->d_odd);
+        KERNEL_CHECK(g, "k_pass_state");
+        HIP_TRY(g, hipEventRecord(pp->ev_chain, g->stream2));
+        pp->pending = 4;
+        return TSDRGPU_OK;
+    }
     TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, k_frame_tile_pass, (unsigned)(tiles_x * tiles_y), 512, d_frames, Ps, d_out, Ps, F, W, H, tiles_x,
                 tiles_y, pp->d_chain, pp->d_screen, pp->d_screen2, a, pp->d_colp, pp->d_rowp, pp->d_tflag, pp->d_dump);
     KERNEL_CHECK(g, "k_frame_tile_pass");
@@ -1896,6 +2003,15 @@ extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsd
     if (mode == 2) return tsdrgpu_postproc_run(pp, pp->p_frames, F, W, H, prm, d_out, h_info);
     HIP_TRY(g, hipStreamWaitEvent(g->stream, pp->ev_chain, 0));
     if (mode == 3) {  // fused run: the frames are already in the d_out given to begin_minmax
+        if (h_info) return pp_copy_info(pp, F, h_info);
+        return TSDRGPU_OK;
+    }
+    if (mode == 4) {  // flat fused run: ... unless a frame held one of the exceptions; then the literal pass redoes the batch
+        const float a0 = prm->motionblur;
+        const int lines0 = (a0 == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+        const long long Pl = (long long)W * H;
+        int rc0;
+        if ((rc0 = launch_pass_literal(pp, PASS_NORMALISE | lines0 | PASS_IIR, pp->p_frames, Pl, d_out, Pl, F, W, H, a0, pp->d_odd))) return rc0;
         if (h_info) return pp_copy_info(pp, F, h_info);
         return TSDRGPU_OK;
     }

@@ -401,6 +401,85 @@ def test_exact_ties_resolve_a_toss_up(orc):
             assert np.array_equal(d_out.download(), want, equal_nan=True), (trial, k)
 
 
+@pytest.mark.parametrize("negzero", [0, 1])
+@pytest.mark.parametrize("odd", [0, 1])
+@pytest.mark.parametrize("h", [131, 64])
+def test_flat_fused_run_equals_oracle(orc, negzero, odd, h):
+    """tsdrgpu_postproc_begin_minmax at motion blur 0 with batches of >= 8 frames: ONE flat trip over the raw frames
+    (k_frame_stats<true>: tile statistics + normalised store), the painted lines patched in behind the sync detector,
+    the literal pass queued behind it and gated on the flag that a -0.0 (or non-finite) pixel raises.  The oracle's
+    frames bit for bit (sign of zero included) and its per-frame state, over batches of 4 (tile form), 12 and 8 (flat
+    form) frames, with sentinels, a frame of zero range, and frames at odd float offsets."""
+    g = ctx()
+    fs, fv = (2_010_000 if odd else 2_000_000), 60.0
+    geo = orc.geometry(fs, h, fv)
+    w = geo.width
+    n = w * h
+    rng = np.random.default_rng(70 + h)
+    frames = [cases.frame_pattern(w, h, 3 * k, rng) for k in range(24)]
+    frames[9][rng.integers(0, n, 30)] = np.float32(512.0)
+    frames[13][:] = np.float32(0.25)
+    frames[21][rng.integers(0, n, 3)] = np.float32(-1024.0)
+    if negzero:
+        frames[6][17] = np.float32(-0.0)
+        frames[19][n - 1] = np.float32(-0.0)
+    cfg = (0, 0, 0, 0, 0.0)
+    want, states, _ = run_orc(orc, frames, fs, h, fv, cfg)
+    pp = gpu.PostProcess(g)
+    d_in = g.to_device(np.concatenate([np.zeros(odd, np.float32)] + frames))
+    d_out = g.empty(len(frames) * n + odd)
+    mn, mx = _minmax(frames)
+    d_mn, d_mx = g.to_device(mn), g.to_device(mx)
+    infos = []
+    for s, k in ((0, 4), (4, 12), (16, 8)):
+        pp.begin_minmax(d_in, k, w, h, d_mn.at(s), d_mx.at(s), d_out, 0.0, 0.1, 0, 0, 0, 0, 0, frames_offset=s * n + odd, out_offset=s * n + odd)
+        infos += pp.finish(d_out, out_offset=s * n + odd)
+    got = d_out.download()[odd:].reshape(len(frames), n)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for k, (info, (si, sd)) in enumerate(zip(infos, states)):
+        assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) == tuple(si[:7]), f"frame {k}"
+    # the state a following plain run starts from
+    extra = [cases.frame_pattern(w, h, 100 + k, rng) for k in range(3)]
+    d_e = g.to_device(np.concatenate(extra))
+    d_o = g.empty(3 * n)
+    pp.run(d_e, 3, w, h, d_o, 0.5, 0.1, 0, 0, 0, 0, 0)
+    ref = gpu.PostProcess(g)
+    d_all = g.to_device(np.concatenate(frames))
+    ref.run(d_all, len(frames), w, h, g.empty(len(frames) * n), 0.0, 0.1, 0, 0, 0, 0, 0)
+    d_o2 = g.empty(3 * n)
+    ref.run(d_e, 3, w, h, d_o2, 0.5, 0.1, 0, 0, 0, 0, 0)
+    assert np.array_equal(d_o.download().view(np.uint32), d_o2.download().view(np.uint32))
+
+
+def test_flat_fused_run_full_size_equals_plain_run():
+    """... and at the headline frame size (2962 x 1125, 16 frames, partial tiles on both edges) against the plain run."""
+    g = ctx()
+    w, h, F = 2962, 1125, 16
+    n = w * h
+    rng = np.random.default_rng(3)
+    base = (rng.random(n, dtype=np.float32) * 0.2)
+    frames = []
+    for k in range(F):
+        fr = base + np.float32(0.01 * k)
+        fr.reshape(h, w)[(37 * k) % h:((37 * k) % h) + 40, :] += np.float32(0.6)
+        fr.reshape(h, w)[:, (91 * k) % w:((91 * k) % w) + 150] += np.float32(0.5)
+        frames.append(fr.astype(np.float32))
+    frames[5][rng.integers(0, n, 50)] = np.float32(256.0)
+    d_in = g.to_device(np.concatenate(frames))
+    mn, mx = _minmax(frames)
+    a, b = gpu.PostProcess(g), gpu.PostProcess(g)
+    d_a, d_b = g.empty(F * n), g.empty(F * n)
+    ia = a.run(d_in, F, w, h, d_a)
+    d_mn, d_mx = g.to_device(mn), g.to_device(mx)
+    b.begin_minmax(d_in, F, w, h, d_mn.at(0), d_mx.at(0), d_b)
+    ib = b.finish(d_b)
+    ga, gb = d_a.download().view(np.uint32), d_b.download().view(np.uint32)
+    bad = np.flatnonzero(ga != gb)
+    assert bad.size == 0, (bad.size, [(int(i) // n, (int(i) % n) // w, int(i) % w) for i in bad[:8]])
+    key = lambda i: (i.lastmin, i.lastmax, i.dx, i.vx, i.stripx, i.dy, i.vy, i.stripy, i.locked)
+    assert [key(i) for i in ia] == [key(i) for i in ib]
+
+
 @pytest.mark.parametrize("cfg", [(0, 0, 0, 0, 0.0), (1, 0, 0, 0, 0.0), (1, 1, 0, 0, 0.0), (0, 1, 1, 0, 0.0)])
 @pytest.mark.parametrize("negzero", [0, 1])
 @pytest.mark.parametrize("odd", [0, 1])
