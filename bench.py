@@ -472,8 +472,8 @@ def main():
             mn_ptr, mx_ptr, _ = rs.frame_minmax(download=False)
             pp.begin_minmax(cur_pix, F, W, h, mn_ptr, mx_ptr, cur_out, motionblur=blur)
             fuse_open[0] = cur_out
-            if last:  # a step's last pass (and every instrumented pass) is closed at once, the autocorrelation behind it:
-                pp.finish(fuse_open[0], want_info=False)  # with one lane for the autocorrelation nothing runs beside anything
+            if last or args.serial:  # a step's last pass (and every instrumented pass) is closed at once, the autocorrelation
+                pp.finish(fuse_open[0], want_info=False)  # behind it: with one lane for the autocorrelation nothing runs beside anything
                 fuse_open[0] = None
             run_autocorr()
             rem = avail - F * P
@@ -500,10 +500,10 @@ def main():
                 # frame statistics, then the latency-bound frame-to-frame chain on the side stream while
                 # the autocorrelation passes keep the main stream busy, then the normalise/IIR pass
                 pp.begin(d_pix, F, W, h, motionblur=blur)
-                if last:  # (see the fused run above)
+                if last or args.serial:  # (see the fused run above)
                     pp.finish(d_out, want_info=False)
                 run_autocorr()
-                if not last:
+                if not (last or args.serial):
                     pp.finish(d_out, want_info=False)
             elif F:
                 pp.run(d_pix, F, W, h, d_out, motionblur=blur, want_info=False)
