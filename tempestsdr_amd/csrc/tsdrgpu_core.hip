@@ -569,32 +569,43 @@ struct RsFrameRange {
     int c_lo, c_hi;  // chunks that overlap the frame
 };
 
-// wave64 min/max with DPP row shifts + row broadcasts (6 VALU instructions, result in lane 63);
-// min/max are exact, so the order does not matter
-template <int CTRL>
-__device__ __forceinline__ float rs_dpp(float v)
+// wave64 min/max with DPP row shifts + row broadcasts, result in lane 63.  The values travel as order-preserving
+// integer keys (sign-magnitude -> two's complement: the floats' order, -0 below +0, no NaN among pixels): an integer
+// min/max takes the DPP operand itself — six instructions per reduction — where the float form cost a v_mov_dpp, a
+// canonicalising v_max and the min per step (27 instructions; the frame tracking's two reductions were half of what it
+// added to the resampler's instruction count).
+__device__ __forceinline__ int rs_fkey(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    const int b = __builtin_bit_cast(int, v);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float rs_funkey(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
+template <int CTRL>
+__device__ __forceinline__ int rs_dpp(int v, int identity)  // lanes without a source lane read the operation's identity
+{
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
 }
 __device__ __forceinline__ float rs_wave_min(float v)
 {
-    v = fminf(v, rs_dpp<0x111>(v));  // row_shr:1
-    v = fminf(v, rs_dpp<0x112>(v));  // row_shr:2
-    v = fminf(v, rs_dpp<0x114>(v));  // row_shr:4
-    v = fminf(v, rs_dpp<0x118>(v));  // row_shr:8   -> lane 15 of each row holds the row's min
-    v = fminf(v, rs_dpp<0x142>(v));  // row_bcast:15
-    v = fminf(v, rs_dpp<0x143>(v));  // row_bcast:31 -> lane 63 holds the wave's min
-    return v;
+    int k = rs_fkey(v);
+    k = min(k, rs_dpp<0x111>(k, 0x7fffffff));  // row_shr:1
+    k = min(k, rs_dpp<0x112>(k, 0x7fffffff));  // row_shr:2
+    k = min(k, rs_dpp<0x114>(k, 0x7fffffff));  // row_shr:4
+    k = min(k, rs_dpp<0x118>(k, 0x7fffffff));  // row_shr:8   -> lane 15 of each row holds the row's min
+    k = min(k, rs_dpp<0x142>(k, 0x7fffffff));  // row_bcast:15
+    k = min(k, rs_dpp<0x143>(k, 0x7fffffff));  // row_bcast:31 -> lane 63 holds the wave's min
+    return rs_funkey(k);
 }
 __device__ __forceinline__ float rs_wave_max(float v)
 {
-    v = fmaxf(v, rs_dpp<0x111>(v));
-    v = fmaxf(v, rs_dpp<0x112>(v));
-    v = fmaxf(v, rs_dpp<0x114>(v));
-    v = fmaxf(v, rs_dpp<0x118>(v));
-    v = fmaxf(v, rs_dpp<0x142>(v));
-    v = fmaxf(v, rs_dpp<0x143>(v));
-    return v;
+    int k = rs_fkey(v);
+    k = max(k, rs_dpp<0x111>(k, (int)0x80000000));
+    k = max(k, rs_dpp<0x112>(k, (int)0x80000000));
+    k = max(k, rs_dpp<0x114>(k, (int)0x80000000));
+    k = max(k, rs_dpp<0x118>(k, (int)0x80000000));
+    k = max(k, rs_dpp<0x142>(k, (int)0x80000000));
+    k = max(k, rs_dpp<0x143>(k, (int)0x80000000));
+    return rs_funkey(k);
 }
 // frame index / offset of the pixel `add` pixels after (f, rem)
 __device__ __forceinline__ void rs_frame_of(long long P, int f, long long rem, long long add, int *fo, long long *ro)

@@ -36,30 +36,53 @@ __device__ __forceinline__ float wave_sum(float v)
     v += WR_ROW_SHL(v, 0.f, 1);
     return v;
 }
+// min / max: the values travel as order-preserving integer keys (the floats' order, -0 below +0; callers hold no NaN),
+// so that every step is ONE integer min / max with the DPP operand folded in — the float form pays a v_mov_dpp and a
+// canonicalising v_max per step
+__device__ __forceinline__ int wr_key(float v)
+{
+    const int b = __builtin_bit_cast(int, v);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float wr_unkey(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
+#define WR_SWAP32I(v_, lo_, hi_)                                                                       \
+    {                                                                                                  \
+        const auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)(v_), (unsigned)(v_), false, false); \
+        lo_ = (int)r_[0];                                                                              \
+        hi_ = (int)r_[1];                                                                              \
+    }
+#define WR_SWAP16I(v_, lo_, hi_)                                                                       \
+    {                                                                                                  \
+        const auto r_ = __builtin_amdgcn_permlane16_swap((unsigned)(v_), (unsigned)(v_), false, false); \
+        lo_ = (int)r_[0];                                                                              \
+        hi_ = (int)r_[1];                                                                              \
+    }
+#define WR_ROW_SHLI(v_, old_, N_) __builtin_amdgcn_update_dpp((int)(old_), (v_), 0x100 + (N_), 0xf, 0xf, false)
+
 __device__ __forceinline__ float wave_min(float v)
 {
-    float a, b;
-    WR_SWAP32(v, a, b);
-    v = fminf(a, b);
-    WR_SWAP16(v, a, b);
-    v = fminf(a, b);
-    v = fminf(v, WR_ROW_SHL(v, v, 8));
-    v = fminf(v, WR_ROW_SHL(v, v, 4));
-    v = fminf(v, WR_ROW_SHL(v, v, 2));
-    v = fminf(v, WR_ROW_SHL(v, v, 1));
-    return v;
+    int k = wr_key(v), a, b;
+    WR_SWAP32I(k, a, b);
+    k = min(a, b);
+    WR_SWAP16I(k, a, b);
+    k = min(a, b);
+    k = min(k, WR_ROW_SHLI(k, 0x7fffffff, 8));
+    k = min(k, WR_ROW_SHLI(k, 0x7fffffff, 4));
+    k = min(k, WR_ROW_SHLI(k, 0x7fffffff, 2));
+    k = min(k, WR_ROW_SHLI(k, 0x7fffffff, 1));
+    return wr_unkey(k);
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-    float a, b;
-    WR_SWAP32(v, a, b);
-    v = fmaxf(a, b);
-    WR_SWAP16(v, a, b);
-    v = fmaxf(a, b);
-    v = fmaxf(v, WR_ROW_SHL(v, v, 8));
-    v = fmaxf(v, WR_ROW_SHL(v, v, 4));
-    v = fmaxf(v, WR_ROW_SHL(v, v, 2));
-    v = fmaxf(v, WR_ROW_SHL(v, v, 1));
-    return v;
+    int k = wr_key(v), a, b;
+    WR_SWAP32I(k, a, b);
+    k = max(a, b);
+    WR_SWAP16I(k, a, b);
+    k = max(a, b);
+    k = max(k, WR_ROW_SHLI(k, 0x80000000, 8));
+    k = max(k, WR_ROW_SHLI(k, 0x80000000, 4));
+    k = max(k, WR_ROW_SHLI(k, 0x80000000, 2));
+    k = max(k, WR_ROW_SHLI(k, 0x80000000, 1));
+    return wr_unkey(k);
 }
 #endif
