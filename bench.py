@@ -266,14 +266,14 @@ def main():
     if args.blur is not None:
         blur = args.blur
         wl_name += f", motion blur {blur:g}"
-    if args.fuse is None:
-        args.fuse = blur == 0.0
-    if args.bands or args.frames_per_launch > 0 or args.no_split:
-        args.fuse = False
     if args.leg:
         args.no_e2e = args.no_cpu_baseline = args.no_legs = True
     W = geometry(fs, h, fv)
     P = W * h
+    if args.fuse is None:
+        args.fuse = blur == 0.0  # the flat fused run; with motion blur the tile-walking form loses to the separate kernels
+    if args.bands or args.frames_per_launch > 0 or args.no_split:
+        args.fuse = False
     chunk = int(0.1 * fs / fv)  # TSDRLibrary.c:335
     nchunks = int(args.seconds * fs) // chunk
     nsamples = nchunks * chunk

@@ -1443,6 +1443,20 @@ __global__ __launch_bounds__(256) void k_fix_lines(const float *__restrict__ src
     screen_out[pix] = s;
 }
 
+// The flat fused run (motion blur 0): a frame's painted column / row is PIX_G whatever lay underneath and whatever the
+// old state was, as long as that state is finite ((float)((double)(s * 0) + 512.0) = 512) — and a non-finite state has
+// raised the redo flag, which replaces the whole batch.  grid (ceil(max(W,H)/256), 2, F): axis 0 the column dx, axis 1
+// the row dy of frame blockIdx.z.
+__global__ __launch_bounds__(256) void k_paint_lines(float *__restrict__ dst, long long dstride, int W, int H, const ChainOut *__restrict__ chain)
+{
+    const int axis = blockIdx.y, f = blockIdx.z;
+    const int at = axis == 0 ? chain[f].dx : chain[f].dy;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = axis == 0 ? at : i, y = axis == 0 ? i : at;
+    if (x < 0 || x >= W || y < 0 || y >= H) return;
+    dst[(long long)f * dstride + (long long)y * W + x] = PIX_G;
+}
+
 typedef void (*pass_fn)(const float *, long long, float *, long long, int, int, int, const ChainOut *, float *, float, const int *);
 typedef void (*pass_par_fn)(const float *, long long, float *, long long, int, int, const ChainOut *, const float *, int *);
 static pass_par_fn pick_pass_par(int flags)
@@ -1941,10 +1955,9 @@ extern "C" int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float
         pp->ext_fmin = pp->ext_fmax = nullptr;
         pp->chain_st = nullptr;
         if (rc) return rc;
-        if (lines) {  // the painted lines, by the literal per-pixel recurrence from the pre-batch state (d_screen2: scratch)
-            TSDR_LAUNCH(g, PROF_CHAIN, g->stream2, k_fix_lines, dim3(((W > H ? W : H) + 255) / 256, 2, F), 256, d_frames, Ps, d_out, Ps, F, W, H,
-                        pp->d_chain, pp->d_screen, pp->d_screen2, a);
-            KERNEL_CHECK(g, "k_fix_lines");
+        if (lines) {  // the painted lines
+            TSDR_LAUNCH(g, PROF_CHAIN, g->stream2, k_paint_lines, dim3(((W > H ? W : H) + 255) / 256, 2, F), 256, d_out, Ps, W, H, pp->d_chain);
+            KERNEL_CHECK(g, "k_paint_lines");
         }
         // the new state: the last frame as it now stands, unless the batch is about to be redone
         TSDR_LAUNCH(g, PROF_CHAIN, g->stream2, k_pass_state, (unsigned)(g->prop.multiProcessorCount * 4), 256,
