@@ -8,7 +8,9 @@ passes back to back, so that 20 steps time more than a second of GPU work.
 A pass is:
 
     a1+a2  fused AM demod + area resample      IQ -> pixel stream   (600 chunks)
-    a3..a8 dsp_post_process, library-default stage order, every frame delivered
+    a3..a8 dsp_post_process, library-default stage order, every frame delivered — at motion blur 0 through the fused run
+           (tsdrgpu_postproc_begin_minmax: min/max from the resampler, statistics + normalise/IIR in one trip; --no-fuse
+           for the separate kernels), a batch's sync detector beside the next batch's resampler
     a9..a12 FFT autocorrelation of EVERY 3.1/55 s capture window + lag accumulation
             (+ RCCL all-reduce of the per-lag sums when N > 1) + argmax
 
@@ -852,9 +854,12 @@ def main():
                                  "beside the next pass's resampler (pixel and frame buffers alternate)") if args.fuse else
                                 "frame path on the COMPUTE lane, sync chain on the SIDE lane, autocorrelation on the BACKGROUND lane (beside the "
                                 "normalise/IIR pass of its batch)",
-                       "frame_path": ("fused run (tsdrgpu_postproc_begin_minmax / _finish): per-frame min/max from the resampler's frame "
-                                      "tracking, one trip over the raw frames for statistics + normalise/IIR (12P bytes per frame moved)")
-                                     if args.fuse else "split run (tsdrgpu_postproc_begin / _finish): statistics kernel, then the normalise/IIR pass",
+                       "frame_path": (("fused run (tsdrgpu_postproc_begin_minmax / _finish): per-frame min/max from the resampler's frame "
+                                       "tracking, one trip over the raw frames for statistics + normalise/IIR (12P bytes per frame moved)")
+                                      if args.fuse else "split run (tsdrgpu_postproc_begin / _finish): statistics kernel, then the normalise/IIR pass")
+                                     + "; batches of one second (60 frames).  Every form of the run gives the same frames and state bit "
+                                       "for bit (tests/test_gpu_postproc.py); the streaming engine behind tsdr_readasync takes frames as "
+                                       "they arrive (batches of 1-2) through tsdrgpu_postproc_run",
                        "sync_detector": "fast (toss-ups not redone)" if args.fast_sync else
                                         "contract-exact: toss-up decisions redone with the reference's own strip sums (library default)",
                        "autocorrelation": (f"float32 transform, {trips.split(' ')[0]}-trip plan, uncertified (--uncertified)" if args.uncertified else
