@@ -79,7 +79,8 @@ def fuzz_postproc(g, rng):
     cfg = (int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), 0,
            float(rng.choice([0.0, 0.0, 0.25, 0.5, 0.9375])))
     lbs, aap, ash, pll, mb = cfg
-    F = int(rng.integers(1, 9))
+    # batches of >= 8 frames take the frame-parallel pass and, in the fused run at motion blur 0, the flat fused trip
+    F = int(rng.integers(1, 9)) if rng.random() < 0.6 else int(rng.integers(8, 21))
     frames = [cases.frame_pattern(w, h, int(rng.integers(0, 50)), rng) for _ in range(F)]
     for fr in frames:
         r = rng.random()
@@ -93,7 +94,9 @@ def fuzz_postproc(g, rng):
             fr *= np.float32(rng.choice([200.0, 1e-4, -1.0]))     # large / tiny / negative ranges
         elif r < 0.33:
             fr[rng.integers(0, w * h, max(1, w * h // 3))] = np.float32(1024.0)  # a third of the frame sentinel
-        elif r < 0.40:  # periodic structure: checkerboard / stripes with random pitch
+        elif r < 0.36:
+            fr[rng.integers(0, w * h, 3)] = np.float32(-0.0)      # -0.0: the frame-parallel forms must hand the batch to the literal pass
+        elif r < 0.43:  # periodic structure: checkerboard / stripes with random pitch
             yy, xx = np.mgrid[0:h, 0:w]
             px, py = int(rng.integers(1, 20)), int(rng.integers(1, 20))
             pat = ((xx // px + (yy // py) * int(rng.integers(0, 2))) % 2) * np.float32(0.55) + np.float32(0.2)
@@ -109,7 +112,7 @@ def fuzz_postproc(g, rng):
     d_out = g.empty(F * w * h)
     infos, s = [], 0
     while s < F:
-        k = int(rng.integers(1, F - s + 1))
+        k = int(rng.integers(1, F - s + 1)) if rng.random() < 0.5 else F - s
         mode = int(rng.integers(0, 3))
         if mode == 0:
             infos += pp.run(d_in, k, w, h, d_out, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * w * h, out_offset=s * w * h)
@@ -136,6 +139,8 @@ def fuzz_postproc(g, rng):
                     f"{(i.dx, i.vx, i.stripx, i.dy, i.vy, i.stripy, i.locked)} oracle={tuple(int(v) for v in si[:7])}")
         if not np.array_equal(got[k], want[k], equal_nan=True):
             return f"postproc frame fs={fs} h={h} w={w} cfg={cfg} F={F} frame={k} maxdiff={np.nanmax(np.abs(got[k] - want[k]))}"
+        if not np.array_equal(np.signbit(got[k]), np.signbit(want[k])):
+            return f"postproc frame fs={fs} h={h} w={w} cfg={cfg} F={F} frame={k}: sign of a zero differs"
     return None
 
 
