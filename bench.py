@@ -224,8 +224,8 @@ def main():
                     help="fused run (tsdrgpu_postproc_begin_minmax): per-frame min/max from the resampler (frame tracking), so ONE trip "
                          "over the raw frames gathers the sync detector's sums and writes the normalised frames (12P instead of 16P "
                          "bytes per frame); the pass's sync detector and autocorrelation then run beside the NEXT pass's resampler. "
-                         "Default at motion blur 0 (a flat kernel, +4 %%); with blur > 0 the trip walks the frames tile by tile and "
-                         "is slower than the separate kernels (DESIGN.md section 4), so it is off unless asked for")
+                         "The default: at motion blur 0 the trip is a flat kernel (+6 %%); with blur > 0 it walks the frames tile by "
+                         "tile with the IIR state in registers (+3 %%)")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="separate statistics kernel and normalise/IIR pass (16P bytes per frame)")
     ap.add_argument("--no-split", action="store_true",
                     help="one tsdrgpu_postproc_run per batch instead of _begin / autocorrelation / _finish "
@@ -273,7 +273,7 @@ def main():
     W = geometry(fs, h, fv)
     P = W * h
     if args.fuse is None:
-        args.fuse = blur == 0.0  # the flat fused run; with motion blur the tile-walking form loses to the separate kernels
+        args.fuse = True  # flat trip at motion blur 0 (+6 %); with motion blur the trip walks the frames tile by tile (+3 %)
     if args.bands or args.frames_per_launch > 0 or args.no_split:
         args.fuse = False
     chunk = int(0.1 * fs / fv)  # TSDRLibrary.c:335
@@ -712,9 +712,13 @@ def main():
         legs = {
             "configs[1]": leg(["--config", "1", "--steps", "4", "--passes", "100"], "25 MS/s, 1024x768@60 (1033x806 frames), 1 s batches"),
             "configs[4]": leg(["--config", "4", "--steps", "4", "--passes", "25"], "200 MS/s, 3840x2160@60 (2962x2250 frames), motion blur 15/16, 1 s batches"),
-            "frame_path_blur": leg(["--config", "2", "--blur", "0.5", "--steps", "4", "--passes", "40"],
-                                   "the headline configuration with motion blur 0.5: the IIR is live, every batch takes the frame-by-frame "
-                                   "k_frame_pass (state in registers across the batch's frames: 8P bytes moved per frame = 8P credited)"),
+            "frame_path_blur": leg(["--config", "2", "--blur", "0.5", "--no-fuse", "--steps", "4", "--passes", "40"],
+                                   "the headline configuration with motion blur 0.5 through the split run: the IIR is live, every batch takes "
+                                   "the frame-by-frame k_frame_pass (state in registers across the batch's frames: 8P bytes moved per frame = "
+                                   "8P credited)"),
+            "frame_path_blur_fused": leg(["--config", "2", "--blur", "0.5", "--steps", "4", "--passes", "40"],
+                                         "... and through the fused run, the default: one trip walks the batch's frames tile by tile "
+                                         "(k_frame_tile_pass: statistics + normalise + IIR, 8P moved, 12P credited)"),
             "frame_path_unfused": leg(["--config", "2", "--no-fuse", "--steps", "4", "--passes", "40"],
                                       "the headline configuration with the split run instead of the fused one: k_frame_stats, then the "
                                       "normalise/IIR pass (16P bytes per frame moved); the autocorrelation beside the pass of its own batch"),
