@@ -237,8 +237,8 @@ int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsdrgpu_pp_fra
  * queued by _finish and gated on that flag, redoes the batch.  On MI355X (1080p, 60-frame batches) that is the fast
  * form: 12P instead of 16P bytes per frame, +5 % on the whole pass when the caller lets a batch's sync detector run
  * beside the next batch's resampler (call _finish for batch k behind tsdrgpu_resample of batch k+1, with two pixel
- * buffers; bench.py does).  With motion blur > 0 the trip has to walk the frames tile by tile and is slower than
- * _begin/_finish. */
+ * buffers; bench.py does).  With motion blur > 0 the trip has to walk the frames tile by tile with the IIR state in
+ * registers: a slower kernel, but in the same call order still 1-4 % ahead of _begin/_finish. */
 int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width, int height,
                                   const tsdrgpu_pp_params_t *params, const float *d_fmin, const float *d_fmax,
                                   float *d_out);
