@@ -98,6 +98,7 @@ struct tsdrgpu_postproc {
     double *d_relay;            // [items][nmax]: sums so far (f32 values carried as f64 through the sum all-reduce)
     size_t cap_items, cap_hflags, cap_relay;
     const float *ext_fmin, *ext_fmax;  // per-frame min/max supplied by the caller (fused run), else null
+    float *p_out;                      // the fused run's frame buffer (given to _begin_minmax; _finish must name the same)
     int p_F, p_W, p_H;
     tsdrgpu_pp_params_t p_prm;
 };
@@ -1908,6 +1909,7 @@ extern "C" int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float
         return rc;
     }
     pp->p_frames = d_frames;
+    pp->p_out = d_out;
     pp->p_F = F; pp->p_W = W; pp->p_H = H;
     pp->p_prm = *prm;
     int rc;
@@ -2010,6 +2012,8 @@ extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsd
     if (!pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_finish", "no split run is open");
     tsdrgpu_t *g = pp->g;
     const int mode = pp->pending;
+    if ((mode == 3 || mode == 4) && d_out != pp->p_out)  // the run stays open: the caller can still finish it properly
+        return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_finish", "the fused run's frames are in the buffer given to _begin_minmax: name the same one");
     pp->pending = 0;
     const int F = pp->p_F, W = pp->p_W, H = pp->p_H;
     const tsdrgpu_pp_params_t *prm = &pp->p_prm;

@@ -224,3 +224,28 @@ def test_round3_entry_points_reject_misuse_and_take_empty_input(orc):
     with pytest.raises(gpu.TsdrGpuError):
         sh.finish(d)
     sh.destroy()
+
+
+def test_fused_run_must_be_finished_into_its_own_buffer():
+    """tsdrgpu_postproc_begin_minmax queues the frames into the d_out it is given; _finish with another buffer is refused
+    (the gated literal redo would otherwise land elsewhere than the frames), the run stays open and can still be closed."""
+    g = ctx()
+    w, h, F = 300, 64, 8
+    n = w * h
+    rng = np.random.default_rng(2)
+    frames = rng.random(F * n, dtype=np.float32)
+    d_in, d_out, d_other = g.to_device(frames), g.empty(F * n), g.empty(F * n)
+    fr = frames.reshape(F, n)
+    d_mn, d_mx = g.to_device(fr.min(axis=1)), g.to_device(fr.max(axis=1))
+    pp = gpu.PostProcess(g)
+    pp.begin_minmax(d_in, F, w, h, d_mn.at(0), d_mx.at(0), d_out)
+    with pytest.raises(gpu.TsdrGpuError):
+        pp.finish(d_other)
+    with pytest.raises(gpu.TsdrGpuError):
+        pp.run(d_in, F, w, h, d_other)  # still open
+    info = pp.finish(d_out)
+    ref = gpu.PostProcess(g)
+    want = g.empty(F * n)
+    info_r = ref.run(d_in, F, w, h, want)
+    assert np.array_equal(d_out.download().view(np.uint32), want.download().view(np.uint32))
+    assert [(i.dx, i.dy, i.lastmin, i.lastmax) for i in info] == [(i.dx, i.dy, i.lastmin, i.lastmax) for i in info_r]
