@@ -346,3 +346,55 @@ def test_reference_bytecode_live(orc):
         d = md.feed(fo, fi, lo_, li, fs)
         assert (d.framerate, d.height, d.accepted, d.seen) == (want["fps"], want["height"], want["accepted"], want["seen"])
         assert d.mode_id == J.closest(vm, modes, want["fps"], want["height"])
+
+
+def test_minijvm_arithmetic_follows_the_jvm_specification():
+    """The bytecode interpreter behind the Java pins (tests/golden/minijvm.py) on hand-assembled method bodies: Java's
+    integer division and remainder (truncating, sign of the dividend), 32/64-bit wrap-around, shifts that mask their
+    count, saturating d2i / d2l with NaN -> 0, the NaN bias of dcmpl / dcmpg, iinc, a backward branch (JVMS 6.5)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import minijvm
+
+    vm = minijvm.VM.__new__(minijvm.VM)  # no jar: the snippets touch no class
+    vm.names, vm.classes, vm.statics, vm.initialised, vm.hooks, vm.trace = set(), {}, {}, set(), {}, []
+
+    def run(code, desc, *args):
+        return vm.run(None, (8, bytes(code)), list(args), desc, static=True)
+
+    ILOAD0, ILOAD1, IRET = 0x1a, 0x1b, 0xac
+    assert run([ILOAD0, ILOAD1, 0x6c, IRET], "(II)I", -7, 2) == -3           # idiv truncates toward zero
+    assert run([ILOAD0, ILOAD1, 0x70, IRET], "(II)I", -7, 2) == -1           # irem: sign of the dividend
+    assert run([ILOAD0, ILOAD1, 0x70, IRET], "(II)I", 7, -2) == 1
+    assert run([ILOAD0, ILOAD1, 0x60, IRET], "(II)I", 2**31 - 1, 1) == -2**31  # iadd wraps
+    assert run([ILOAD0, ILOAD1, 0x68, IRET], "(II)I", 65536, 65536) == 0       # imul wraps
+    assert run([ILOAD0, ILOAD1, 0x6c, IRET], "(II)I", -2**31, -1) == -2**31    # the one overflowing division
+    assert run([ILOAD0, ILOAD1, 0x78, IRET], "(II)I", 1, 33) == 2              # ishl masks the count to 5 bits
+    assert run([ILOAD0, ILOAD1, 0x7a, IRET], "(II)I", -16, 2) == -4            # ishr is arithmetic
+    assert run([ILOAD0, ILOAD1, 0x7c, IRET], "(II)I", -16, 28) == 15           # iushr is logical
+    with pytest.raises(ZeroDivisionError):
+        run([ILOAD0, ILOAD1, 0x6c, IRET], "(II)I", 1, 0)
+    DLOAD0, D2I, D2L, LRET = 0x26, 0x8e, 0x8f, 0xad
+    for x, want in [(1e20, 2**31 - 1), (-1e20, -2**31), (float("nan"), 0), (-2.9, -2), (2.9, 2), (float("inf"), 2**31 - 1)]:
+        assert run([DLOAD0, D2I, IRET], "(D)I", x) == want
+    assert run([DLOAD0, D2L, LRET], "(D)J", 1e30) == 2**63 - 1 and run([DLOAD0, D2L, LRET], "(D)J", -1e30) == -2**63
+    DLOAD2 = 0x28
+    nan = float("nan")
+    assert run([DLOAD0, DLOAD2, 0x97, IRET], "(DD)I", nan, 1.0) == -1 and run([DLOAD0, DLOAD2, 0x98, IRET], "(DD)I", nan, 1.0) == 1
+    assert run([DLOAD0, DLOAD2, 0x97, IRET], "(DD)I", 2.0, 1.0) == 1 and run([DLOAD0, DLOAD2, 0x98, IRET], "(DD)I", 1.0, 1.0) == 0
+    LLOAD0, LLOAD2 = 0x1e, 0x20
+    assert run([LLOAD0, LLOAD2, 0x69, LRET], "(JJ)J", 2**62, 4) == 0                 # lmul wraps at 64 bits
+    assert run([LLOAD0, LLOAD2, 0x94, IRET], "(JJ)I", -5, 3) == -1                   # lcmp
+    # int s = 0; for (int i = 0; i < n; i++) s += i; return s;   (javac's shape: iinc + backward goto)
+    loop = [0x03, 0x3c,              # iconst_0, istore_1        s
+            0x03, 0x3d,              # iconst_0, istore_2        i
+            0x1c, 0x1a, 0xa2, 0, 13,  # 4: iload_2, iload_0, if_icmpge +13 -> 19
+            0x1b, 0x1c, 0x60, 0x3c,  # 9: iload_1, iload_2, iadd, istore_1
+            0x84, 2, 1,              # 13: iinc 2, 1
+            0xa7, 0xff, 0xf4,        # 16: goto -12 -> 4
+            0x1b, IRET]              # 19: iload_1, ireturn
+    assert run(loop, "(I)I", 10) == 45 and run(loop, "(I)I", 0) == 0
+    # (int) Math.round(x) and (long) (x * y) as Main.roundData / hashHeightAndFPS compile them
+    ok, v = vm.native("java/lang/Math", "round", "(D)J", [2.5])
+    assert ok and v == 3
+    ok, v = vm.native("java/lang/Math", "round", "(D)J", [-2.5])
+    assert ok and v == -2  # floor(x + 0.5)
