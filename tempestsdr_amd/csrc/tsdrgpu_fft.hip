@@ -90,8 +90,19 @@ static int ac_xbatch()
 #define AC_XBATCH (ac_xbatch())
 
 // (register DFTs, twiddle helpers and the three-trip autocorrelation kernels: fft4step.h)
+// |z|^2 and |z| exactly as complex_to_abs_diff forms them (superbandwidth.c:67-81): one definition for the stand-alone kernel
+// and for the transform's fused load, so that both give the same bits
+__device__ __forceinline__ float sb_mag2(float2 c) { return c.x * c.x + c.y * c.y; }
+__device__ __forceinline__ float sb_absdiff(const float2 *__restrict__ z, long long i)
+{
+    const float2 c = z[i];
+    const float cur = sqrtf(sb_mag2(c));
+    const float prev = (i == 0) ? sb_mag2(c) : sqrtf(sb_mag2(z[i - 1]));
+    return cur - prev;
+}
+
 template <int IN_MODE>
-__device__ __forceinline__ float2 fft_load(const void *__restrict__ xin, long long base, long long at)
+__device__ __forceinline__ float2 fft_load(const void *__restrict__ xin, long long base, long long at, unsigned n, const int *__restrict__ aux)
 {
     if (IN_MODE == 0) return ((const float2 *)xin + base)[at];
     if (IN_MODE == 1) return make_float2(((const float *)xin + base)[at], 0.f);
@@ -102,6 +113,16 @@ __device__ __forceinline__ float2 fft_load(const void *__restrict__ xin, long lo
     if (IN_MODE == 3) {
         const float *x = (const float *)xin + base;
         return make_float2(x[2 * at], x[2 * at + 1]);
+    }
+    if (IN_MODE == 5) return make_float2(sb_absdiff((const float2 *)xin + base, at), 0.f);  // complex_to_abs_diff of the input
+    if (IN_MODE == 6) {  // the input rotated left by *aux floats (superbandwidth.c:135-137)
+        const float *x = (const float *)((const float2 *)xin + base);
+        const unsigned nfl = 2u * n, off = (unsigned)*aux;
+        unsigned s0 = 2u * (unsigned)at + off;
+        if (s0 >= nfl) s0 -= nfl;
+        unsigned s1 = 2u * (unsigned)at + 1u + off;
+        if (s1 >= nfl) s1 -= nfl;
+        return make_float2(x[s0], x[s1]);
     }
     const float2 *x = (const float2 *)xin + base;
     const float2 a = x[2 * at], b = x[2 * at + 1];
@@ -120,7 +141,7 @@ __device__ __forceinline__ float2 fft_load(const void *__restrict__ xin, long lo
 // ---------------------------------------------------------------------------
 template <int R, int IN_MODE, bool OUT_MAG>
 __global__ __launch_bounds__(256) void k_fft_pass(const void *__restrict__ xin, long long in_stride, float2 *__restrict__ y,
-                                                  unsigned n, unsigned Ns, int conj_in, int conj_out, float scale)
+                                                  unsigned n, unsigned Ns, int conj_in, int conj_out, float scale, const int *__restrict__ aux)
 {
     const unsigned T = n / R;
     const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,7 +149,7 @@ __global__ __launch_bounds__(256) void k_fft_pass(const void *__restrict__ xin, 
     const unsigned b = blockIdx.y;
     float2 v[R];
 #pragma unroll
-    for (int t = 0; t < R; t++) v[t] = fft_load<IN_MODE>(xin, (long long)b * in_stride, (long long)j + (long long)t * T);
+    for (int t = 0; t < R; t++) v[t] = fft_load<IN_MODE>(xin, (long long)b * in_stride, (long long)j + (long long)t * T, n, aux);
     if (conj_in) {
 #pragma unroll
         for (int t = 0; t < R; t++) v[t].y = -v[t].y;
@@ -199,7 +220,8 @@ static const FftKeep KEEP_ALL = {0, -1, 0u, 0u, 0u, 0u};
 
 template <int R1, int IN_MODE, bool OUT_MAG>
 __global__ __launch_bounds__(256) void k_fft_lds(const void *__restrict__ xin, long long in_stride, float2 *__restrict__ y,
-                                                 unsigned n, unsigned Ns, int conj_in, int conj_out, float scale, FftKeep keep)
+                                                 unsigned n, unsigned Ns, int conj_in, int conj_out, float scale, FftKeep keep,
+                                                 const int *__restrict__ aux)
 {
     constexpr int R = 16 * R1;
     constexpr int C = 256 / R1;
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(256) void k_fft_lds(const void *__restrict__ xin, l
         for (int i = 0; i < R1; i++) {
             const unsigned nidx = q * G + a + 16 * i;
             const long long at = (long long)j + (long long)nidx * T;
-            float2 val = fft_load<IN_MODE>(xin, (long long)b * in_stride, at);
+            float2 val = fft_load<IN_MODE>(xin, (long long)b * in_stride, at, n, aux);
             if (conj_in) val.y = -val.y;
             v[a * R1 + i] = val;
         }
@@ -320,27 +342,27 @@ static PassPlan plan_passes(uint32_t n)
 
 template <int IN_MODE, bool OUT_MAG>
 static void launch_pass(tsdrgpu_t *g, hipStream_t st, int R, const void *x, long long in_stride, float2 *y, unsigned n, unsigned Ns, int batch,
-                        int conj_in, int conj_out, float scale, const FftKeep &keep = KEEP_ALL)
+                        int conj_in, int conj_out, float scale, const FftKeep &keep = KEEP_ALL, const int *aux = nullptr)
 {
     if (n >= 4096) {
         const int R1 = R / 16;
         dim3 grid(n / 4096, batch);  // (n/R)/C tiles, R*C = 4096
         switch (R1) {
-            case 1: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<1, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
-            case 2: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<2, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
-            case 4: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<4, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
-            case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<8, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
-            default: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<16, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep); break;
+            case 1: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<1, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep, aux); break;
+            case 2: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<2, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep, aux); break;
+            case 4: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<4, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep, aux); break;
+            case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<8, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep, aux); break;
+            default: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_lds<16, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, keep, aux); break;
         }
         return;
     }
     const unsigned T = n / R;
     dim3 grid((T + 255) / 256, batch);
     switch (R) {
-        case 2: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<2, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-        case 4: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<4, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-        case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<8, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
-        default: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<16, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale); break;
+        case 2: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<2, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, aux); break;
+        case 4: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<4, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, aux); break;
+        case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<8, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, aux); break;
+        default: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fft_pass<16, IN_MODE, OUT_MAG>), grid, 256, x, in_stride, y, n, Ns, conj_in, conj_out, scale, aux); break;
     }
 }
 
@@ -352,7 +374,8 @@ static void launch_pass(tsdrgpu_t *g, hipStream_t st, int R, const void *x, long
 // inverse transform as conj(FFT(conj(x)))); scale / mag_out apply to pass count-1.
 static float2 *run_fft_range(tsdrgpu_t *g, const void *in, int in_mode, long long in_stride, float2 *a, float2 *b, uint32_t n,
                              int batch, const int *radix, int count, int pbegin, int pend, unsigned Ns0, int conj_first,
-                             int conj_last, bool mag_out, float scale, hipStream_t st, const FftKeep &keep = KEEP_ALL)
+                             int conj_last, bool mag_out, float scale, hipStream_t st, const FftKeep &keep = KEEP_ALL,
+                             const int *aux = nullptr)
 {
     unsigned Ns = Ns0;
     const void *src = in;
@@ -376,6 +399,8 @@ static float2 *run_fft_range(tsdrgpu_t *g, const void *in, int in_mode, long lon
                 case 1: launch_pass<1, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
                 case 2: launch_pass<2, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
                 case 3: launch_pass<3, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
+                case 5: launch_pass<5, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc, last ? keep : KEEP_ALL); break;
+                case 6: launch_pass<6, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc, last ? keep : KEEP_ALL, aux); break;
                 default: launch_pass<4, false>(g, st, R, src, sstride, dst, n, Ns, batch, cin, cout, sc); break;
             }
         }
@@ -1403,15 +1428,7 @@ __global__ __launch_bounds__(256) void k_abs_diff(const float2 *__restrict__ z, 
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float2 c = z[i];
-    const float cur = sqrtf(c.x * c.x + c.y * c.y);
-    float prev;
-    if (i == 0) prev = c.x * c.x + c.y * c.y;
-    else {
-        const float2 p = z[i - 1];
-        prev = sqrtf(p.x * p.x + p.y * p.y);
-    }
-    out[i] = make_float2(cur - prev, 0.f);
+    out[i] = make_float2(sb_absdiff(z, i), 0.f);
 }
 
 // superb_bestfit's peak search (superbandwidth.c:100-116): first maximum of |.| over n points of each of
@@ -1538,15 +1555,26 @@ extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nho
     hipStream_t st = g->stream;
     HIP_TRY(g, hipMemsetAsync(d_off, 0, sizeof(int) * nhops, st));
 
+    // A transform's first pass reads its input through a mode of its own, so complex_to_abs_diff (superbandwidth.c:67-81)
+    // and the rotation (:135-137) are loads of the first pass instead of kernels with a round trip over HBM each; the hop
+    // buffers are separate allocations, so that pass runs hop by hop and the remaining passes batched.
+    const PassPlan pb = plan_passes(bn), pp_ = plan_passes(per), pf = plan_passes(nfft);
     if (nb > 0) {
-        // complex_to_abs_diff of every hop (superbandwidth.c:67-81), then ONE forward transform of hop 0's and one
-        // batched transform of the others', the products, one batched inverse transform, the peaks
-        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_hops[0], A, bn);
-        for (int i = 1; i < nhops; i++)
-            TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_abs_diff, (bn + 255) / 256, 256, (const float2 *)d_hops[i], B + (size_t)(i - 1) * bn, bn);
-        KERNEL_CHECK(g, "k_abs_diff");
-        float2 *fa = run_fft(g, A, 0, bn, FA, FA + bn, bn, 1, 0, false, 1.0f / (float)bn);
-        float2 *fb = run_fft(g, B, 0, bn, FB, FB + (size_t)bn * nb, bn, nb, 0, false, 1.0f / (float)bn);
+        // ONE forward transform of hop 0's abs-diff signal and one batched transform of the others', the products, one
+        // batched inverse transform, the peaks
+        float2 *fa = run_fft_range(g, d_hops[0], 5, 0, FA, FA + bn, bn, 1, pb.radix, pb.count, 0, pb.count, 1, 0, 0, false, 1.0f / (float)bn, st);
+        float2 *fb;
+        if (pb.count == 1) {
+            for (int i = 1; i < nhops; i++)
+                (void)run_fft_range(g, d_hops[i], 5, 0, FB + (size_t)(i - 1) * bn, nullptr, bn, 1, pb.radix, 1, 0, 1, 1, 0, 0, false, 1.0f / (float)bn, st);
+            fb = FB;
+        } else {
+            for (int i = 1; i < nhops; i++)
+                (void)run_fft_range(g, d_hops[i], 5, 0, FB + (size_t)(i - 1) * bn, nullptr, bn, 1, pb.radix, pb.count, 0, 1, 1, 0, 0, false, 1.0f, st);
+            fb = run_fft_range(g, FB, 0, bn, FB, FB + (size_t)bn * nb, bn, nb, pb.radix, pb.count, 1, pb.count, (unsigned)pb.radix[0], 0, 0, false,
+                               1.0f / (float)bn, st);
+        }
+        KERNEL_CHECK(g, "abs-diff transforms");
         TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_mul_conj_batch, dim3((bn + 255) / 256, nb), 256, fa, fb, bn);
         KERNEL_CHECK(g, "k_mul_conj_batch");
         float2 *other = (fb == FB) ? FB + (size_t)bn * nb : FB;
@@ -1555,23 +1583,41 @@ extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nho
         TSDR_LAUNCH(g, PROF_ARGMAX, st, k_argmax_abs_final, nb, 64, pval, pidx, d_off + 1);
         KERNEL_CHECK(g, "k_argmax_abs");
     }
-    // rotate every hop by its offset (hop 0: none) into one contiguous buffer, one batched forward transform:
-    // the result IS the concatenation of the spectra in hop order, no fftshift (superbandwidth.c:135-144)
-    for (int i = 0; i < nhops; i++)
-        TSDR_LAUNCH(g, PROF_SUPERB_MISC, st, k_rotate, (nfl + 255) / 256, 256, d_hops[i], (float *)(R + (size_t)i * per), nfl, d_off + i);
-    KERNEL_CHECK(g, "k_rotate");
-    float2 *sp = run_fft(g, R, 0, per, S, S + total, per, nhops, 0, false, 1.0f / (float)per);
+    // every hop rotated by its offset (hop 0: none) and transformed: the result IS the concatenation of the spectra in hop
+    // order, no fftshift (superbandwidth.c:135-144)
+    float2 *sp;
+    if (pp_.count == 1) {
+        for (int i = 0; i < nhops; i++)
+            (void)run_fft_range(g, d_hops[i], 6, 0, S + (size_t)i * per, nullptr, per, 1, pp_.radix, 1, 0, 1, 1, 0, 0, false, 1.0f / (float)per, st,
+                                KEEP_ALL, d_off + i);
+        sp = S;
+    } else {
+        for (int i = 0; i < nhops; i++)
+            (void)run_fft_range(g, d_hops[i], 6, 0, S + (size_t)i * per, nullptr, per, 1, pp_.radix, pp_.count, 0, 1, 1, 0, 0, false, 1.0f, st,
+                                KEEP_ALL, d_off + i);
+        sp = run_fft_range(g, S, 0, per, S, S + total, per, nhops, pp_.radix, pp_.count, 1, pp_.count, (unsigned)pp_.radix[0], 0, 0, false,
+                           1.0f / (float)per, st);
+    }
     KERNEL_CHECK(g, "hop transforms");
-    for (int i = 0; i < nhops; i++)  // the reference leaves every hop buffer holding its spectrum
-        HIP_TRY(g, hipMemcpyAsync(d_hops[i], sp + (size_t)i * per, sizeof(float2) * per, hipMemcpyDeviceToDevice, st));
-    // inverse transform over the largest power of two <= total; what lies beyond keeps the spectra
+    // the reference leaves every hop buffer holding its spectrum, and what lies beyond the largest power of two <= total
+    // keeps the spectra: copies that nothing below reads, so they go beside the stitch transform on the side stream
+    HIP_TRY(g, hipEventRecord(g->fork, st));
+    HIP_TRY(g, hipStreamWaitEvent(g->stream2, g->fork, 0));
+    for (int i = 0; i < nhops; i++)
+        HIP_TRY(g, hipMemcpyAsync(d_hops[i], sp + (size_t)i * per, sizeof(float2) * per, hipMemcpyDeviceToDevice, g->stream2));
     if (total > nfft)
-        HIP_TRY(g, hipMemcpyAsync(d_out + 2 * (size_t)nfft, sp + nfft, sizeof(float2) * (size_t)(total - nfft), hipMemcpyDeviceToDevice, st));
-    float2 *res = run_fft(g, sp, 0, nfft, BIG, BIG + nfft, nfft, 1, 1, false, 1.0f);
-    KERNEL_CHECK(g, "stitch transform");
-    HIP_TRY(g, hipMemcpyAsync(d_out, res, sizeof(float2) * (size_t)nfft, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(g, hipMemcpyAsync(d_out + 2 * (size_t)nfft, sp + nfft, sizeof(float2) * (size_t)(total - nfft), hipMemcpyDeviceToDevice, g->stream2));
+    // the passes ping-pong between two buffers: the caller's d_out takes the place of the one the last pass writes
+    {
+        float2 *out2 = (float2 *)d_out;
+        float2 *a = (pf.count & 1) ? out2 : BIG, *b = (pf.count & 1) ? BIG : out2;
+        float2 *res = run_fft_range(g, sp, 0, nfft, a, b, nfft, 1, pf.radix, pf.count, 0, pf.count, 1, 1, 1, false, 1.0f, st);
+        KERNEL_CHECK(g, "stitch transform");
+        if (res != out2) HIP_TRY(g, hipMemcpyAsync(d_out, res, sizeof(float2) * (size_t)nfft, hipMemcpyDeviceToDevice, st));
+    }
     if (h_offsets) HIP_TRY(g, hipMemcpyAsync(h_offsets, d_off, sizeof(int) * nhops, hipMemcpyDeviceToHost, st));
     HIP_TRY(g, hipStreamSynchronize(st));
+    HIP_TRY(g, hipStreamSynchronize(g->stream2));
     if (h_total) *h_total = total;
     return TSDRGPU_OK;
 }
