@@ -365,12 +365,27 @@ __global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x,
         const int *fl = tflag + (long long)f * tiles_x * tiles_y + (cols ? i / TILE_W : (i / tile_h) * tiles_x);
         const int fstep = cols ? tiles_x : 1;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int p = 0; p < parts; p++) {
-            const float *s3 = src + (long long)p * 3 * n + i;
-            a0 += (double)s3[0];
-            if (fl[p * fstep]) {
-                a1 += (double)s3[n];
-                a2 += (double)s3[2 * n];
+        // the partials of twelve tiles are requested together (the loop used to pay a load's latency per tile: a strip
+        // element has up to ~70 of them and the kernel too few threads to hide that), then added in the same order
+        constexpr int RB = 12;
+        for (int p0 = 0; p0 < parts; p0 += RB) {
+            float v0[RB];
+            int sf[RB];
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                const int p = p0 + k < parts ? p0 + k : parts - 1;
+                v0[k] = src[(long long)p * 3 * n + i];
+                sf[k] = fl[p * fstep];
+            }
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                if (p0 + k >= parts) break;
+                a0 += (double)v0[k];
+                if (sf[k]) {
+                    const float *s3 = src + (long long)(p0 + k) * 3 * n + i;
+                    a1 += (double)s3[n];
+                    a2 += (double)s3[2 * n];
+                }
             }
         }
         dst[i] = a0;
