@@ -99,6 +99,7 @@ struct tsdrgpu_postproc {
     size_t cap_items, cap_hflags, cap_relay;
     const float *ext_fmin, *ext_fmax;  // per-frame min/max supplied by the caller (fused run), else null
     float *p_out;                      // the fused run's frame buffer (given to _begin_minmax; _finish must name the same)
+    int *clear_with_autogain;          // a device flag the next autogain chain launch zeroes (null: none)
     int p_F, p_W, p_H;
     tsdrgpu_pp_params_t p_prm;
 };
@@ -443,8 +444,9 @@ __device__ __forceinline__ FitBest better(FitBest a, FitBest b)
 __global__ __launch_bounds__(64) void k_autogain_chain(int F, const float *__restrict__ frames, long long fstride,
                                                        const float *__restrict__ fmin_, const float *__restrict__ fmax_,
                                                        PpState *__restrict__ state, ChainOut *__restrict__ out,
-                                                       int do_autogain, float norm)
+                                                       int do_autogain, float norm, int *__restrict__ clear)
 {
+    if (clear && threadIdx.x == 0) *clear = 0;  // the redo flag of the pass queued behind this kernel (saves a memset's launch)
     // stage the per-frame inputs in LDS in parallel, then one lane walks the recurrence
     __shared__ float sv0[256], slo[256], shi[256];
     float lastmax = state->lastmax, lastmin = state->lastmin;
@@ -1639,7 +1641,7 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
     if (do_autogain || !pp->chain_has_autogain) {
         TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, frames, fstride, pp->ext_fmin ? pp->ext_fmin : pp->d_fmin,
                     pp->ext_fmax ? pp->ext_fmax : pp->d_fmax, pp->d_state, pp->d_chain,
-                                                  do_autogain, prm->lowpasscoeff);
+                                                  do_autogain, prm->lowpasscoeff, pp->clear_with_autogain);
         KERNEL_CHECK(g, "k_autogain_chain");
         pp->chain_has_autogain = 1;
     }
@@ -1940,21 +1942,23 @@ extern "C" int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float
     if ((rc = ensure(g, &pp->d_colp, &pp->cap_colp, (size_t)F * tiles_y * 3 * W))) return rc;
 
     // autogain IIR from the supplied min/max, then normalise + IIR + partial sums in one trip
+    static const int tiles_only = getenv("TSDRGPU_FUSE_TILES") ? 1 : 0;
+    const bool overlap = (const float *)d_out < d_frames + (long long)F * Ps && d_frames < (const float *)d_out + (long long)F * Ps;
+    const bool flat = a == 0.0f && F >= 8 && !overlap && !tiles_only;
+    if (flat && !pp->d_odd && hipMalloc(&pp->d_odd, sizeof(int)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "flag");
     pp->ext_fmin = d_fmin;
     pp->ext_fmax = d_fmax;
+    pp->clear_with_autogain = flat ? pp->d_odd : nullptr;  // the flat trip's redo flag is zeroed by the chain kernel in front of it
     rc = launch_chain(pp, d_frames, Ps, F, W, H, 1, 0, 1, prm);
+    pp->clear_with_autogain = nullptr;
     pp->ext_fmin = pp->ext_fmax = nullptr;
     if (rc) return rc;
     // Motion blur 0: a frame's output does not depend on the previous one's, so the trip is a FLAT kernel over (tile, frame)
     // — k_frame_stats<true>: the statistics kernel that also stores the normalised pixels — instead of tiles that walk
     // the frames.  Same guard as launch_pass: the exceptions (non-finite values, -0.0) raise *d_odd and the literal
     // pass, queued by _finish behind the sync detector and gated on the flag, redoes the batch from the raw frames.
-    static const int tiles_only = getenv("TSDRGPU_FUSE_TILES") ? 1 : 0;
-    const bool overlap = (const float *)d_out < d_frames + (long long)F * Ps && d_frames < (const float *)d_out + (long long)F * Ps;
-    if (a == 0.0f && F >= 8 && !overlap && !tiles_only) {
+    if (flat) {
         const int ftiles_y = (H + TILE_H - 1) / TILE_H;
-        if (!pp->d_odd && hipMalloc(&pp->d_odd, sizeof(int)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "flag");
-        HIP_TRY(g, hipMemsetAsync(pp->d_odd, 0, sizeof(int), g->stream));
         StatsStore st;
         st.dst = d_out; st.dstride = Ps; st.chain = pp->d_chain; st.screen = pp->d_screen; st.odd = pp->d_odd;
         TSDR_LAUNCH(g, PROF_FRAME_PASS, g->stream, k_frame_stats<true>, (unsigned)(tiles_x * ftiles_y * F), 256, d_frames, Ps, W, H, tiles_x, ftiles_y,
@@ -2334,7 +2338,7 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
             TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_xmax,
                         pp->d_strip_x, pp->d_strip_y, pp->d_fmin, pp->d_fmax, pp->d_v0);
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 1,
-                        prm->lowpasscoeff);
+                        prm->lowpasscoeff, (int *)nullptr);
             KERNEL_CHECK(g, "k_autogain_chain");
             pp->relay_items = 0;
             if (exact) {
