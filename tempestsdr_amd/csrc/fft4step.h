@@ -230,10 +230,18 @@ __device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, un
 // ---------------------------------------------------------------------------
 #define AC4_ROW 4096u  // N2: the row length of the plan
 
+// Columns per tile: 16 (runs of 128 bytes of complex points) up to column length 512, where the tile is 64 KiB and two
+// workgroups share a CU; at 1024 sixteen columns are 128 KiB — one workgroup of 1024 threads per CU, every barrier a
+// stall of the whole CU — so there the tile is 8 columns wide: 64 KiB and 512 threads again (trip 1's points are 16
+// bytes of IQ, so its runs stay 128 bytes; trip 3 reads 64-byte runs).  Measured at N = 2^23: 0.642 -> 0.587 ms per 17
+// windows; at column length 512 eight columns change nothing (0.2489 vs 0.2486 ms).
+#ifndef AC4_C8_FROM
+#define AC4_C8_FROM 1024u
+#endif
 template <int LOGN1>
 struct ColGeom {
     static constexpr unsigned N1 = 1u << LOGN1;
-    static constexpr unsigned C = (N1 >= 256u) ? 16u : 4096u / N1;
+    static constexpr unsigned C = (N1 >= AC4_C8_FROM) ? 8u : (N1 >= 256u) ? 16u : 4096u / N1;
     static constexpr unsigned NT = N1 * C / 16u;  // threads per workgroup
     static constexpr unsigned Q = N1 / 16u;
     static constexpr int R0 = (LOGN1 % 4) ? (1 << (LOGN1 % 4)) : 16;  // radix of the first pass
