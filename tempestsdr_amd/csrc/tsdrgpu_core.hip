@@ -1040,10 +1040,20 @@ __global__ __launch_bounds__(RSMM_T) void k_rs_minmax(const RsBlockMM *__restric
     const RsFrameRange rg = ranges[j];
     float lo = INFINITY, hi = -INFINITY;
     const long long first = (long long)rg.c_lo * gx * 4, last = (long long)rg.c_hi * gx * 4;  // 4 wave records per workgroup
-    for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
-        const RsBlockMM b = slots[i];
-        if (b.f0 == j) { lo = fminf(lo, b.mn0); hi = fmaxf(hi, b.mx0); }
-        else if (b.f0 >= 0 && b.f0 + 1 == j) { lo = fminf(lo, b.mn1); hi = fmaxf(hi, b.mx1); }
+    // four records per lane requested together (the loop is a chain of load latencies otherwise)
+    for (long long i0 = first + threadIdx.x; i0 < last; i0 += 4LL * blockDim.x) {
+        RsBlockMM b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long i = i0 + (long long)k * blockDim.x;
+            b[k] = slots[i < last ? i : last - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + (long long)k * blockDim.x >= last) break;
+            if (b[k].f0 == j) { lo = fminf(lo, b[k].mn0); hi = fmaxf(hi, b[k].mx0); }
+            else if (b[k].f0 >= 0 && b[k].f0 + 1 == j) { lo = fminf(lo, b[k].mn1); hi = fmaxf(hi, b[k].mx1); }
+        }
     }
     __shared__ float red[RSMM_T / 64][2];
     lo = rs_wave_min(lo);
