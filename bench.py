@@ -233,7 +233,7 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="keep the autocorrelation on the COMPUTE lane, one kernel after the other.  Default: it runs on the "
                          "BACKGROUND (lowest priority) lane beside the normalise/IIR pass of the same batch — its VALU-heavy FFT "
-                         "trips and the bandwidth-bound frame kernels fill each other's gaps (+3.7 % measured).  The per-kernel "
+                         "trips and the bandwidth-bound frame kernels fill each other's gaps (+3.7 %% measured).  The per-kernel "
                          "durations behind `roofline` / `kernels` are always taken in the serial mode, where a kernel's time is its own")
     ap.add_argument("--overlap", action="store_true", help="(default now; kept so that old command lines still parse)")
     args = ap.parse_args()
