@@ -355,9 +355,9 @@ def main():
                 comm.destroy()
                 comm = None
             print(f"[bench rank {rank}] tsdrgpu_comm_create unavailable ({comm_err}); using torch.distributed", file=sys.stderr)
-            for a_ in acs:  # (+ 1: the accumulated lag-0 value behind the plots sums like the lags)
-                pp_, pn_ = a_.device_plots()
-                plots_ts[id(a_)] = torch.as_tensor(_DevArray(pp_, pn_ + 1), device=dev)
+            for a_ in acs:  # (the lags and the accumulated lag-0 value behind them, which sums like the lags)
+                pp_, pn_ = a_.device_sums()
+                plots_ts[id(a_)] = torch.as_tensor(_DevArray(pp_, pn_), device=dev)
     my_windows = len(range(rank, nwin, world)) if strong else nwin
     total_windows = nwin if strong else nwin * world
 

@@ -362,8 +362,15 @@ int tsdrgpu_autocorr_plots_async(tsdrgpu_autocorr_t *ac, double *h_frame, double
 /* a device-side copy (frame plot first, then the line plot) taken on the object's lane by a kernel; copy it home on
  * another lane once an event recorded behind this call has fired (the streaming engine's plot thread does) */
 int tsdrgpu_autocorr_plots_snapshot(tsdrgpu_autocorr_t *ac, const double **d_snapshot, uint64_t *h_calls);
-/* device plots: frame_len + line_len doubles, contiguous (frame first) */
+/* device plots: frame_len + line_len doubles, contiguous (frame first).  One more double sits behind them: the
+ * accumulated lag-0 value R0, the scale of the argmax certificate; *count does not include it. */
 int tsdrgpu_autocorr_device_plots(tsdrgpu_autocorr_t *ac, double **d_plots, int64_t *count);
+/* The buffer a caller that runs its OWN collective (instead of tsdrgpu_autocorr_allreduce) must sum over the ranks after
+ * tsdrgpu_autocorr_run(mode 1): the same pointer, *count = frame_len + line_len + 1 — the lags and R0.  Reducing only
+ * the lags would leave R0 rank-local while tsdrgpu_autocorr_finalize_sums divides it by the global window count: the
+ * certificate's margin KAPPA * R0 would come out `world` times too small. */
+int tsdrgpu_autocorr_device_sums(tsdrgpu_autocorr_t *ac, double **d_sums, int64_t *count);
+/* after the sum over the ranks: divides lags and R0 by the global window count; calls := total_windows */
 int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t total_windows);
 /* argmax (lowest index wins ties, PlotVisualizer.java:233-236); syncs */
 int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *frame_idx, int32_t *line_idx);

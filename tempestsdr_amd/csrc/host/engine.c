@@ -202,7 +202,7 @@ static int gpu_ok(struct engine *e, int rc, const char *what)
         snprintf(e->fail_msg, sizeof(e->fail_msg), "GPU stage '%s' failed (%d): %s", what, rc, tsdrgpu_last_error(e->g));
         fprintf(stderr, "tsdr: %s\n", e->fail_msg);
         e->t->running = 0;
-        if (e->t->plugin.loaded && e->t->plugin.stop) e->t->plugin.stop();
+        (void)tsdr_plugin_stop_once(e->t); /* (tsdr_stop on the host's thread may be doing the same right now) */
     }
     return 0;
 }
@@ -332,18 +332,18 @@ static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, i
     int ok = 1;
     if (items) {
         const size_t bytes = (size_t)items * sample_bytes(type);
-        if (s->consumed_valid) { tsdrgpu_event_sync(e->g, s->consumed); s->consumed_valid = 0; } /* long done in practice */
-        if (s->dcap < items) {
+        if (s->consumed_valid) { ok = gpu_ok(e, tsdrgpu_event_sync(e->g, s->consumed), "slot wait"); s->consumed_valid = 0; } /* long done in practice */
+        if (ok && s->dcap < items) {
             tsdrgpu_free(e->g, s->d);
             s->d = NULL; s->dcap = 0;
-            if (tsdrgpu_alloc(e->g, (void **)&s->d, (size_t)items * sizeof(float)) == 0) s->dcap = items; else ok = 0;
+            if (gpu_ok(e, tsdrgpu_alloc(e->g, (void **)&s->d, (size_t)items * sizeof(float)), "block buffer")) s->dcap = items; else ok = 0;
         }
         void *dst = s->d;
         if (type != TSDRX_SAMPLE_FLOAT32) { /* narrow samples cross PCIe as they are; the device thread decodes them */
             if (ok && s->raw_cap < bytes) {
                 tsdrgpu_free(e->g, s->d_raw);
                 s->d_raw = NULL; s->raw_cap = 0;
-                if (tsdrgpu_alloc(e->g, &s->d_raw, bytes) == 0) s->raw_cap = bytes; else ok = 0;
+                if (gpu_ok(e, tsdrgpu_alloc(e->g, &s->d_raw, bytes), "raw block buffer")) s->raw_cap = bytes; else ok = 0;
             }
             dst = s->d_raw;
         }
@@ -352,13 +352,14 @@ static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, i
             if (s->hcap < items) { /* sized for float32, the widest format */
                 tsdrgpu_free_host(e->g, s->h);
                 s->h = NULL; s->hcap = 0;
-                if (tsdrgpu_alloc_host(e->g, (void **)&s->h, (size_t)items * sizeof(float)) == 0) s->hcap = items; else ok = 0;
+                if (gpu_ok(e, tsdrgpu_alloc_host(e->g, (void **)&s->h, (size_t)items * sizeof(float)), "pinned bounce buffer")) s->hcap = items; else ok = 0;
             }
             if (ok) { memcpy(s->h, buf, bytes); src = s->h; }
         }
         /* the plugin's buffer is ours only until we return: wait for the DMA (about 40 us for RawFile's 2 MB) */
         const double t1 = e->stats ? now_s() : 0.0;
-        if (ok) ok = tsdrgpu_upload_lane(e->g, dst, src, bytes) == 0 && tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD) == 0;
+        /* a failing device call ends the session here as well (gpu_ok; the error text is this thread's own) */
+        if (ok) ok = gpu_ok(e, tsdrgpu_upload_lane(e->g, dst, src, bytes), "upload") && gpu_ok(e, tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD), "upload wait");
         if (e->stats) e->s_plugin_dma += now_s() - t1;
     }
     s->raw_type = type;

@@ -235,12 +235,25 @@ int tsdr_setparameter_double(tsdr_lib_t *t, int parameter, double value) /* TSDR
     return ok(t);
 }
 
+/* tsdr_stop (host thread) and an engine worker that saw a device call fail may decide to stop the plugin at the same
+ * moment: whoever comes first makes the call, the other one takes its result. */
+int tsdr_plugin_stop_once(tsdr_lib_t *t)
+{
+    if (!t->plugin.loaded || !t->plugin.stop) return TSDR_OK;
+    pthread_mutex_lock(&t->lock);
+    const int first = !t->stop_sent;
+    t->stop_sent = 1;
+    pthread_mutex_unlock(&t->lock);
+    if (first) t->stop_status = t->plugin.stop();
+    return t->stop_status;
+}
+
 int tsdr_stop(tsdr_lib_t *t) /* TSDRLibrary.c:213-224 */
 {
     pthread_mutex_lock(&t->lock);
     const int was_running = t->running;
     pthread_mutex_unlock(&t->lock);
-    const int status = (was_running && t->plugin.loaded) ? t->plugin.stop() : TSDR_OK;
+    const int status = (was_running && t->plugin.loaded) ? tsdr_plugin_stop_once(t) : TSDR_OK;
     /* Wait until tsdr_readasync has torn the pipeline down — also when the plugin's readasync returned on its
      * own and the teardown is merely still in progress (running already 0, nativerunning still 1): nobody may
      * unload the plugin or free the library under it. */
@@ -268,6 +281,8 @@ static int readasync_common(tsdr_lib_t *t, tsdr_readasync_function cb, tsdrx_rea
     t->rgb_inverted = inverted;
     t->nativerunning = 1;
     t->running = 1;
+    t->stop_sent = 0;
+    t->stop_status = TSDR_OK;
     pthread_mutex_unlock(&t->lock);
 
     int status = tsdr_getsamplerate(t);

@@ -52,6 +52,9 @@ struct tsdr_lib {
     double pixelrate, refreshrate, pixeltimeoversampletime;
 
     volatile int running;       /* workers should keep going */
+    volatile int stop_sent;     /* tsdrplugin_stop was called for this run (tsdr_plugin_stop_once): tsdr_stop and a failing
+                                   engine worker may both want to, the plugin hears it once */
+    int stop_status;            /* what that call returned */
     volatile int nativerunning; /* tsdr_readasync is on some thread's stack */
     uint32_t centfreq;
     float gain, motionblur;
@@ -82,6 +85,7 @@ struct tsdr_lib {
 void tsdr_geometry_update(tsdr_lib_t *t, uint32_t samplerate); /* set_internal_samplerate */
 void tsdr_announce_value(tsdr_lib_t *t, int id, double a0, double a1);
 int tsdr_set_error(tsdr_lib_t *t, int status, const char *msg);
+int tsdr_plugin_stop_once(tsdr_lib_t *t); /* tsdrplugin_stop for the current run, at most once, from any thread */
 
 /* engine.c — the streaming pipeline behind tsdr_readasync */
 int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx); /* blocks inside the plugin's readasync */

@@ -1381,7 +1381,10 @@ extern "C" int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in,
     if (touched > band_capacity_frames) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resample_band", "band buffer too small");
     const size_t tab_bytes = sizeof(RsChunk) * (size_t)nchunks;
     const size_t ent_off = (tab_bytes + 15) & ~(size_t)15;
-    const size_t bytes = ent_off + sizeof(RsBandEntry) * (size_t)(2 * nchunks + 2);
+    // a chunk's output touches n_out / P + 2 frames at most (usually 1 or 2: the library polls 0.1 frame at a time, but
+    // nothing forbids small frames with large chunks), each at most one band entry
+    const size_t max_ent = (size_t)(2 * (long long)nchunks + total / P + 2);
+    const size_t bytes = ent_off + sizeof(RsBandEntry) * max_ent;
     const int slot = staging_acquire(g, &rs->ring, bytes);
     if (slot < 0) return slot;
     RsChunk *tab = (RsChunk *)rs->ring.h[slot];
@@ -1404,6 +1407,10 @@ extern "C" int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in,
             e.p_hi = (int)(hi - g0);
             e.pad = 0;
             e.dst_off = j * Pb + (lo - j * P - b_lo);
+            if ((size_t)nent >= max_ent || nent >= 65535) {
+                staging_release(g, &rs->ring, slot);
+                return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resample_band", "too many band entries in one call (<= 65535)");
+            }
             ent[nent++] = e;
             if (e.p_hi - e.p_lo > max_span) max_span = e.p_hi - e.p_lo;
         }

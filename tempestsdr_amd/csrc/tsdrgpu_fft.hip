@@ -1227,6 +1227,17 @@ extern "C" int tsdrgpu_autocorr_device_plots(tsdrgpu_autocorr_t *ac, double **d_
     return TSDRGPU_OK;
 }
 
+// What a caller that runs its own collective has to sum over the ranks: the lags AND the accumulated lag-0 value behind
+// them (the scale R0 of the argmax certificate) — finalize_sums divides all of it by the global window count, so an R0
+// left rank-local would make the certificate's margin too small by a factor `world`.
+extern "C" int tsdrgpu_autocorr_device_sums(tsdrgpu_autocorr_t *ac, double **d_sums, int64_t *count)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    if (d_sums) *d_sums = ac->d_plots;
+    if (count) *count = (int64_t)ac->frame_len + ac->line_len + 1;
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t total_windows)
 {
     if (!ac || total_windows == 0) return TSDRGPU_EINVAL;

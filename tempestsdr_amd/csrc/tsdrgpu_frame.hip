@@ -80,7 +80,10 @@ struct tsdrgpu_postproc {
     hipStream_t chain_st;       // where launch_chain queues (the context's main stream unless split)
     hipEvent_t ev_stats, ev_chain;
     int pending;                // 1: begin() done, chain queued on the side stream; 2: begin() deferred everything;
-                                // 3: fused run (begin_minmax) queued completely, finish() only joins the streams
+                                // 3: fused run (begin_minmax) queued completely, finish() only joins the streams;
+                                // 4: the flat fused run (finish() also queues the gated literal pass);
+                                // PEND_BAND: a row-band run — only band_finish / band_advance close it
+#define PEND_BAND 5
     const float *p_frames;
     // row-band sharding (tsdrgpu_postproc_band_begin / _finish)
     int band_y0, band_rows;     // this rank's rows [y0, y0 + rows) of every frame
@@ -1558,7 +1561,8 @@ extern "C" int tsdrgpu_postproc_reset(tsdrgpu_postproc_t *pp)
 {
     if (!pp) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
-    if (pp->pending == 1) HIP_TRY(g, hipStreamWaitEvent(g->stream, pp->ev_chain, 0));  // an abandoned split run
+    if (pp->pending == 1 || pp->pending == 3 || pp->pending == 4)
+        HIP_TRY(g, hipStreamWaitEvent(g->stream, pp->ev_chain, 0));  // an abandoned split / fused run: its side-lane work first
     pp->pending = 0;
     // dsp_post_process_init (dsp.c:112-132): autogain 0/0, sync detector zeroed, sizes forgotten
     HIP_TRY(g, hipMemsetAsync(pp->d_state, 0, sizeof(PpState), g->stream));
@@ -2029,6 +2033,8 @@ extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsd
 {
     if (!pp || !d_out) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_finish", "bad argument") : TSDRGPU_EINVAL;
     if (!pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_finish", "no split run is open");
+    if (pp->pending == PEND_BAND)
+        return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_finish", "a band run is open: tsdrgpu_postproc_band_finish / _band_advance close it");
     tsdrgpu_t *g = pp->g;
     const int mode = pp->pending;
     if ((mode == 3 || mode == 4) && d_out != pp->p_out)  // the run stays open: the caller can still finish it properly
@@ -2153,7 +2159,7 @@ extern "C" int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *
     pp->band_y0 = y0;
     pp->band_rows = rows;
     pp->band_stage = 0;
-    pp->pending = 4;
+    pp->pending = PEND_BAND;
     if (d_xsum) *d_xsum = pp->d_xsum;
     if (n_xsum) *n_xsum = (int64_t)F * 3 * (W + Htot);
     if (d_xmax) *d_xmax = pp->d_xmax;
@@ -2165,7 +2171,7 @@ extern "C" int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out
 {
     if (!pp || !d_out_band) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_finish", "bad argument") : TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
-    if (pp->pending != 4) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_finish", "no band run is open");
+    if (pp->pending != PEND_BAND) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_finish", "no band run is open");
     pp->pending = 0;
     const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H, y0 = pp->band_y0, rows = pp->band_rows;
     const tsdrgpu_pp_params_t *prm = &pp->p_prm;
@@ -2315,7 +2321,7 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
     if (!pp || !d_out_band || !h_more || nbands < 1 || band_index < 0 || band_index >= nbands)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_advance", "bad argument") : TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
-    if (pp->pending != 4) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_advance", "no band run is open");
+    if (pp->pending != PEND_BAND) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_advance", "no band run is open");
     const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H, y0 = pp->band_y0, rows = pp->band_rows;
     const tsdrgpu_pp_params_t *prm = &pp->p_prm;
     const int nmax = W > Htot ? W : Htot;

@@ -165,10 +165,9 @@ extern "C" int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t
     if (!ac || !c || total_windows == 0) return TSDRGPU_EINVAL;
     double *d_plots = nullptr;
     int64_t count = 0;
-    int rc = tsdrgpu_autocorr_device_plots(ac, &d_plots, &count);
+    int rc = tsdrgpu_autocorr_device_sums(ac, &d_plots, &count);  // the lags + the lag-0 scale of the certificate
     if (rc) return rc;
-    // + 1: the accumulated lag-0 value behind the plots (the scale of the argmax certificate) sums like the lags
-    rc = tsdrgpu_comm_allreduce_f64(c, d_plots, count + 1, tsdrgpu_autocorr_lane(ac));
+    rc = tsdrgpu_comm_allreduce_f64(c, d_plots, count, tsdrgpu_autocorr_lane(ac));
     if (rc) return rc;
     return tsdrgpu_autocorr_finalize_sums(ac, total_windows);
 }

@@ -147,6 +147,7 @@ _SIGS = {
     "tsdrgpu_autocorr_set_async": (C.c_int, [vp, C.c_int]),
     "tsdrgpu_autocorr_plots": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
+    "tsdrgpu_autocorr_device_sums": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
     "tsdrgpu_autocorr_set_exact": (C.c_int, [vp, C.c_int]),
     "tsdrgpu_autocorr_set_plan": (C.c_int, [vp, C.c_int]),
@@ -639,6 +640,12 @@ class Autocorr:
     def device_plots(self):
         p, n = vp(), C.c_int64()
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_device_plots(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def device_sums(self):
+        """what a caller's own collective must sum over the ranks: the lags + the lag-0 scale of the certificate"""
+        p, n = vp(), C.c_int64()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_device_sums(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
     def allreduce(self, comm, total_windows):

@@ -37,6 +37,23 @@ def test_static_archive_has_the_api(libs):
     out = subprocess.run(["nm", a], capture_output=True, text=True, check=True).stdout
     for s in hu.TSDR_SYMBOLS:
         assert f" T {s}" in out
+    # ... and nothing else: the internals (engine_run, plugin_host_load, tsdr_set_error, drop_shift_with ...) are local to
+    # the archive's one object, so a host that links it statically (JavaGUI/jni/makefile:122) cannot collide with them
+    glob = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "TDBRW")
+    assert glob == sorted(list(hu.TSDR_SYMBOLS) + ["tsdrx_get_stats", "tsdrx_readasync_rgb"])
+
+
+def test_static_archive_links_into_a_host(libs, tmp_path):
+    """the JNI shim's way of using the library: link libTSDRLibrary.a (+ -ltsdrgpu) into the host's own object"""
+    src = tmp_path / "host.c"
+    src.write_text('#include "TSDRLibrary.h"\n'
+                   'int engine_run(void) { return 7; }  /* a host symbol with the name of one of our internals */\n'
+                   'int main(void) { tsdr_lib_t *t = 0; tsdr_init(&t, 0, 0, 0); if (!t) return 1; tsdr_free(&t); return engine_run() - 7; }\n')
+    d = os.path.dirname(hu.LIB)
+    exe = tmp_path / "host"
+    subprocess.run(["gcc", "-I" + os.path.join(hu.ROOT, "include"), str(src), os.path.join(d, "libTSDRLibrary.a"), "-L" + d, "-ltsdrgpu",
+                    "-Wl,-rpath," + d, "-lpthread", "-ldl", "-lm", "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
 
 
 def test_error_paths_match_reference(libs):
