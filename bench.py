@@ -220,6 +220,13 @@ def main():
                          "exercise the RCCL path on a 1-GPU box")
     ap.add_argument("--torch-collective", action="store_true",
                     help="skip the library's own RCCL communicator and take the torch.distributed safety net (testing)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend.  gloo = DRY RUN of the N-rank code paths on a box with fewer GPUs than ranks: "
+                         "RCCL refuses two ranks on one device, so every exchange goes device -> host -> gloo -> device (implies "
+                         "--torch-collective).  The numbers of such a run mean nothing; its argument handling, band edges, window "
+                         "shares, exchanges and JSON line are what an 8-GPU node will execute (tests/test_gpu_dryrun.py)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="every rank uses GPU 0 instead of GPU LOCAL_RANK (with --dist-backend gloo: N ranks on a 1-GPU box)")
     ap.add_argument("--fuse", dest="fuse", action="store_true", default=None,
                     help="fused run (tsdrgpu_postproc_begin_minmax): per-frame min/max from the resampler (frame tracking), so ONE trip "
                          "over the raw frames gathers the sync detector's sums and writes the normalised frames (12P instead of 16P "
@@ -240,16 +247,21 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    gloo = args.dist_backend == "gloo"
+    if gloo:
+        args.torch_collective = True
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        kw = {} if gloo else {"device_id": torch.device("cuda", local)}
+        if world == 1:
+            dist.init_process_group(args.dist_backend, rank=0, world_size=1, **kw)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group(args.dist_backend, **kw)
     sharded = dist is not None  # autocorrelation as per-lag sums + all-reduce
     if args.bands:
         if not sharded:
@@ -257,6 +269,18 @@ def main():
         args.scaling = "strong"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if gloo else dev  # where the scalars of the timing contract are reduced
+
+    def reduce_dev(ptr, n, f64, op=None):
+        """all-reduce of a raw device buffer through torch.distributed, in place (the caller synchronises around it)"""
+        t = torch.as_tensor((_DevArray if f64 else _DevArrayF)(ptr, n), device=dev)
+        kw = {} if op is None else {"op": op}
+        if gloo:  # dry run: through the host
+            hcopy = t.cpu()
+            dist.all_reduce(hcopy, **kw)
+            t.copy_(hcopy)
+        else:
+            dist.all_reduce(t, **kw)
 
     # BASELINE.json configs (0-based).  [2] is the one the headline metric is quoted on and the default; the
     # others reuse the harness for the numbers DESIGN.md lists beside it (their `metric` string says which).
@@ -348,16 +372,16 @@ def main():
         # safety net: if the library's own communicator cannot be set up on this node, the same all-reduce goes
         # through torch.distributed (also RCCL) on the plot buffer, with a host synchronisation either side, and
         # the JSON line says so ("collective")
-        agreed = torch.tensor([1 if comm is not None else 0], device=dev)
+        agreed = torch.tensor([1 if comm is not None else 0], device=cdev)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         if not int(agreed.item()):
             if comm is not None:
                 comm.destroy()
                 comm = None
-            print(f"[bench rank {rank}] tsdrgpu_comm_create unavailable ({comm_err}); using torch.distributed", file=sys.stderr)
+            if not args.torch_collective:
+                print(f"[bench rank {rank}] tsdrgpu_comm_create unavailable ({comm_err}); using torch.distributed", file=sys.stderr)
             for a_ in acs:  # (the lags and the accumulated lag-0 value behind them, which sums like the lags)
-                pp_, pn_ = a_.device_sums()
-                plots_ts[id(a_)] = torch.as_tensor(_DevArray(pp_, pn_), device=dev)
+                plots_ts[id(a_)] = a_.device_sums()
     my_windows = len(range(rank, nwin, world)) if strong else nwin
     total_windows = nwin if strong else nwin * world
 
@@ -389,7 +413,7 @@ def main():
             a.allreduce(comm, total_windows)
         else:
             g.sync()
-            dist.all_reduce(plots_ts[id(a)])
+            reduce_dev(*plots_ts[id(a)], True)
             torch.cuda.synchronize()
             a.finalize_sums(total_windows)
 
@@ -428,9 +452,8 @@ def main():
             comm.allreduce_f32max(pm, nm)  # {-min, max, pixel 0}
         else:
             g.sync()
-            dist.all_reduce(torch.as_tensor(_DevArray(ps, ns), device=dev))
-            mx = torch.as_tensor(_DevArrayF(pm, nm), device=dev)
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            reduce_dev(ps, ns, True)
+            reduce_dev(pm, nm, False, dist.ReduceOp.MAX)
             torch.cuda.synchronize()
         run_autocorr()  # behind the exchange: the tiny replicated chain then finds the device busy with the FFT trips
         while True:
@@ -442,7 +465,7 @@ def main():
                 comm.allreduce_f64(buf, nb)
             else:
                 g.sync()
-                dist.all_reduce(torch.as_tensor(_DevArray(buf, nb), device=dev))
+                reduce_dev(buf, nb, True)
                 torch.cuda.synchronize()
         band["phase"] = (band["phase"] + n) % P
         if band["phase"]:  # the incomplete frame goes on in slot 0 of the next pass
@@ -724,11 +747,18 @@ def main():
                                       "normalise/IIR pass (16P bytes per frame moved); the autocorrelation beside the pass of its own batch"),
         }
 
+    shares = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        # what every rank did, for the record (and for the dry run's checks): its share of the capture windows, its rows
+        mine = {"rank": rank, "windows_per_pass": my_windows, "of": total_windows,
+                "rows": None if band is None else [band["y0"], band["y0"] + band["rows"]],
+                "argmax": [int(fi), int(li)], "epochs_replayed_exact": promoted_passes[0]}
+        shares = [None] * world
+        dist.all_gather_object(shares, mine)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        fr = torch.tensor([frames_done], dtype=torch.float64, device=dev)
+        fr = torch.tensor([frames_done], dtype=torch.float64, device=cdev)
         dist.all_reduce(fr)
         frames_total = float(fr.item())
     else:
@@ -888,7 +918,10 @@ def main():
             "roofline": roofline,
             "collective": (None if not sharded else
                            "ncclAllReduce(f64 sum) queued by the library (tsdrgpu_autocorr_allreduce) on the autocorrelation lane"
-                           if comm is not None else "torch.distributed all_reduce (library communicator unavailable on this node)"),
+                           if comm is not None else
+                           ("DRY RUN: device -> host -> gloo -> device (--dist-backend gloo)" if gloo else
+                            "torch.distributed all_reduce (library communicator unavailable on this node)")),
+            "ranks": shares,
             "kernels": kernels,
             "frame_path": {"kernels_ms_per_pass": round(frame_ms, 4),
                            "achieved_GBs": round(frame_bytes_pass / (frame_ms * 1e-3) / 1e9, 1) if frame_ms else None,

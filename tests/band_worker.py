@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_distributed.py::test_row_bands_in_two_processes_equal_the_oracle: one rank of the frame path
 sharded by ROW BANDS, one process per rank, the HIP kernels in every rank.
-usage: band_worker.py <rank> <world> <port>
+usage: band_worker.py <rank> <world> <port> [config]      config: "small" (8 MS/s, 507x525, default) or "config4" (BASELINE
+configs[4]: 200 MS/s, 2962x2250 frames, motion blur 15/16 — 0.15 s of signal, what 8 GPUs would each be fed)
 
 Every rank receives the whole (seeded) IQ stream — in production every GPU is fed the same blocks — and owns rows
 [y0, y0 + rows) of every frame: tsdrgpu_resample_band produces only those rows, tsdrgpu_postproc_band_begin their
@@ -19,18 +20,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     rank, world, port = (int(a) for a in sys.argv[1:4])
+    config = sys.argv[4] if len(sys.argv) > 4 else "small"
     import torch
     import torch.distributed as dist
     from tempestsdr_amd import gpu, synth
     from oracle import oracle as orc
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     g = gpu.TsdrGpu(0)
-    fs, h, fv, blur = 8_000_000, 525, 60.0, 0.5
+    if config == "config4":
+        fs, h, fv, blur, mode, calls = 200_000_000, 2250, 60.0, 0.9375, "3840x2160", (37, 54)  # 91 chunks = 0.152 s = 9 whole frames
+    else:
+        fs, h, fv, blur, mode, calls = 8_000_000, 525, 60.0, 0.5, "640x480", (27, 38)  # chunks per batch: frames straddle the batches
     geo = orc.geometry(fs, h, fv)
     W, P = geo.width, geo.width * h
     chunk = orc.chunk_size(fs, fv)
-    calls = (27, 38)  # chunks per batch: frames straddle the batches
-    iq = synth.synth_iq(fs, "640x480", fv, sum(calls) * chunk, seed=0x5EED0007)
+    ntot = sum(calls) * chunk
+    iq = np.empty(2 * ntot, np.float32)
+    for s0 in range(0, ntot, 1 << 22):  # in slices: the generator works in float64 temporaries
+        n0 = min(1 << 22, ntot - s0)
+        iq[2 * s0:2 * (s0 + n0)] = synth.synth_iq(fs, mode, fv, n0, start=s0, seed=0x5EED0007)
     # one frame's worth of silence in the middle of the stream: blank frames, i.e. strips full of exact ties, whose
     # literal collapse has to be relayed band by band
     iq[2 * 30 * chunk:2 * 42 * chunk] = 0.0

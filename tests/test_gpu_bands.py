@@ -165,13 +165,21 @@ def _geo(orc, W, H):
     return geo
 
 
-@pytest.mark.parametrize("W,H,cuts,blur", [(507, 525, (160, 352), 0.0), (1033, 806, (416,), 0.5), (640, 420, (96, 224, 320), 0.9375)])
+def _bench_cuts(H, world):
+    """bench.py --bands' edge rule: bands start on multiples of 32 rows, the last one takes the remainder"""
+    return tuple(32 * ((H * k // world) // 32) for k in range(1, world))
+
+
+@pytest.mark.parametrize("W,H,cuts,blur", [(507, 525, (160, 352), 0.0), (1033, 806, (416,), 0.5), (640, 420, (96, 224, 320), 0.9375),
+                                           # BASELINE configs[4] in its named shape: 2962x2250 frames, motion blur 15/16, EIGHT bands
+                                           (2962, 2250, _bench_cuts(2250, 8), 0.9375)])
 def test_exact_row_bands_equal_the_oracle(orc, W, H, cuts, blur):
-    """2, 3 and 4 bands in the default, contract-exact mode against the ORACLE (dsp_post_process restated, pinned to the
+    """2, 3, 4 and 8 bands in the default, contract-exact mode against the ORACLE (dsp_post_process restated, pinned to the
     compiled reference): frames bit for bit and the sync / autogain records, over batches that hold every kind of
     strip — noisy rasters (toss-ups at most), a blank frame and a noiseless pattern (exact ties: the literal collapse
     is relayed band by band), a sentinel.  State is carried from batch to batch."""
     g = ctx()
+    assert all(c % 32 == 0 for c in cuts) and list(cuts) == sorted(set(cuts))
     rng = np.random.default_rng(3 * W + H)
     edges = (0,) + tuple(cuts) + (H,)
     rows = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]

@@ -38,6 +38,26 @@ def test_two_ranks_on_one_device_match_the_running_mean(fs, nwin):
     assert "merged plots equal the single-rank running mean: True" in outs[0]
 
 
+@pytest.mark.parametrize("kind", ["certified", "flat"])
+def test_eight_rank_sweep_config3_certified_and_replayed(kind):
+    """BASELINE configs[3] in its named shape: the 100 MS/s lag sweep (17 windows of 2^22 samples) sharded over EIGHT ranks
+    (eight processes on the one device; rank 0 owns windows 0, 8, 16, the others two each), the detector in its certified
+    mode.  `certified`: every rank finds the certificate on the global plots, nothing is replayed, the argmax is the
+    single-rank run's.  `flat`: the certificate fails on every rank alike -> every rank replays its own windows in the
+    reference's arithmetic -> SECOND exchange -> the merged plots equal the single-rank exact running mean to 1e-12
+    (tests/dist_worker.py; frameratedetector.c:34-62)."""
+    world, fs, nwin = 8, 100_000_000, 17
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), str(fs), str(nwin), kind],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "window shares [3, 2, 2, 2, 2, 2, 2, 2]" in outs[0]
+    assert f"kind {kind}: promoted {1 if kind == 'flat' else 0}" in outs[0]
+    assert "merged plots equal the single-rank running mean: True" in outs[0]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_bands_in_two_processes_equal_the_oracle(world):
     """SURVEY 8(e) row 2 end to end, one process per rank: band resampler -> band statistics -> exchanges -> relayed literal
@@ -48,6 +68,23 @@ def test_row_bands_in_two_processes_equal_the_oracle(world):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
     outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "bands equal the oracle: True" in outs[0]
+
+
+def test_row_bands_config4_in_eight_processes_equal_the_oracle():
+    """BASELINE configs[4] in its named shape — 200 MS/s, 2962x2250 frames, motion blur 15/16, EIGHT ranks (here eight
+    processes on the one device, exchanges through gloo) — from IQ to frames: every rank resamples only its rows, the
+    strip partials and extrema are all-reduced, the literal collapse of the blank frames' strips is relayed through all
+    eight bands, the replicated chain decides, every rank passes its rows; the reassembled frames and the final sync
+    state are the ORACLE's bit for bit (dsp.c:41-110, syncdetector.c:26-153,171-225)."""
+    world = 8
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "band_worker.py"), str(r), str(world), str(port), "config4"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "frames 9 of 2962x2250 in 8 bands" in outs[0]
     assert "bands equal the oracle: True" in outs[0]
 
 
