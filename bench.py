@@ -657,6 +657,51 @@ def main():
                             "through when its argmax certificate fails"}
         acx.destroy()
 
+    # side metric: the detector's STEADY STATE as the engine runs it — certified mode 1 (the library retains the windows in a
+    # ring sized from free HBM), ONE epoch of >= 1000 windows with a plot update (argmax + certificate, every 16th with the
+    # runtime premise check) after every 17: which transform does a long epoch actually run through, and how fast
+    steady = None
+    if rank == 0 and not args.no_profile and not sharded and not args.leg:
+        try:
+            acs_ = gpu.Autocorr(g, fs)
+            acs_.set_plan(args.plan)
+            acs_.set_certify(1)
+            ring, _, _ = acs_.retention()
+            acs_.run(d_iq, 1, acs_.capture, nwin, mode=0)
+            acs_.argmax()
+            acs_.reset()
+            g.sync()
+            reps = max(1, -(-1000 // nwin))
+            updates_held = 0
+            tx = time.perf_counter()
+            for r_ in range(reps):
+                acs_.run(d_iq, 1, acs_.capture, nwin, mode=0)
+                if r_:
+                    acs_.argmax_result()
+                    c_ = acs_.certificate()
+                    updates_held += 0 if (c_.frame_certified and c_.line_certified) else 1
+                acs_.argmax_async()
+            acs_.argmax_result()
+            g.sync()
+            tx = time.perf_counter() - tx
+            c_ = acs_.certificate()
+            _, kept, is_exact = acs_.retention()
+            steady = {"epoch_windows": reps * nwin, "ms_per_window": round(tx / (reps * nwin) * 1e3, 4),
+                      "windows_per_s": round(reps * nwin / tx, 1), "realtime_factor": round(reps * nwin * acs_.capture / tx / fs, 1),
+                      "transform_at_the_end": "exact (reference arithmetic): the epoch was promoted" if is_exact else
+                                              "float32 three-trip, certified (tsdrgpu_autocorr_set_certify mode 1)",
+                      "ring_windows": ring, "ring_GiB": round(ring * 4.0 * acs_.n / 2 ** 30, 2), "windows_retained": kept,
+                      "plot_updates": reps, "plot_updates_uncertified": updates_held, "epochs_replayed_exact": int(c_.promotions),
+                      "premise_checks": int(c_.premise_checks), "premise_failures": int(c_.premise_failures),
+                      "premise_err_over_r0": (float(c_.premise_err) / float(c_.premise_r0)) if c_.premise_r0 else None,
+                      "alg_bytes_per_window": int(28 * acs_.n + 16 * (acs_.flen + acs_.llen)),
+                      "frac": round((28 * acs_.n + 16 * (acs_.flen + acs_.llen)) / (tx / (reps * nwin)) / 1e9 / HBM_PEAK_GBS, 4),
+                      "note": "incl. the copy of every window into the retention ring (8N read + 4N written on top of the transform's "
+                              "traffic) and the premise checks (one exact transform per 16 plot updates)"}
+            acs_.destroy()
+        except Exception as ex:  # noqa: BLE001
+            steady = {"error": repr(ex)}
+
     # side metric: the product path end to end — libTSDRLibrary.so behind the tsdr_* API, fed by the in-memory source
     # plugin, every block DMA'd in, every frame DMA'd out to the frame callback (PCIe-inclusive; never `value`)
     e2e, cpu_pipeline = None, None
@@ -903,6 +948,8 @@ def main():
                                            "reference's own FFT arithmetic (bit-identical plots).  One epoch = one pass; windows retained by the "
                                            "caller (mode 2: the stream is HBM-resident; the engine retains copies, mode 1)"),
                        "autocorr_epochs_replayed_exact": promoted_passes[0],
+                       "autocorr_premise_checks": [int(a_.certificate().premise_checks) for a_ in acs],
+                       "autocorr_premise_failures": [int(a_.certificate().premise_failures) for a_ in acs],
                        "row_bands": None if band is None else
                                     {"bands": world, "this_rank_rows": [band["y0"], band["y0"] + band["rows"]], "of": h,
                                      "exchange": "per batch: sum all-reduce of the strip partials (3 x (W+H) doubles per frame) + max all-reduce "
@@ -945,6 +992,7 @@ def main():
             "configs": legs,
             "superbandwidth": superb,
             "exact_autocorr": exact_ac,
+            "steady_state": steady,
             "sync_redo_last_batch": redo_stats,
             "device": g.device_name(),
         }

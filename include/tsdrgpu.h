@@ -322,16 +322,30 @@ int tsdrgpu_autocorr_set_exact(tsdrgpu_autocorr_t *ac, int on);
  * tsdrgpu_autocorr_reset) are replayed through the exact form (tsdrgpu_autocorr_promote): plots, argmax and
  * last correlation are then bit-identical to the reference's, and the rest of the epoch runs exact.
  *   mode 1: the library retains the windows — the first fft_n samples of each, demodulated, in a ring of
- *           retain_bytes (0 = 1 GiB) in HBM; the float32 transform reads the ring.  An epoch that outgrows the ring is
- *           promoted (one exact replay) and continues exact: long epochs cost what the exact form costs, short ones
- *           (a sweep over a recording, a GUI that resets on every parameter change) what the fast form costs.
+ *           retain_bytes in HBM (0 = a quarter of the device's free memory at the time of the call, at most 32 GiB: 2048
+ *           windows of 2^22 samples, 116 s of real-time signal at 100 MS/s); the float32 transform reads the ring.  An
+ *           epoch that outgrows the ring is promoted (one exact replay) and continues exact: such epochs cost what the
+ *           exact form costs from then on, shorter ones (a sweep over a recording, a GUI that resets on every parameter
+ *           change, two minutes of live signal) what the fast form costs.
  *   mode 2: the caller retains them: every buffer passed to tsdrgpu_autocorr_run since the last reset must stay valid
  *           and unchanged until the next reset (a recording resident in HBM).  No copy is made.
  *   mode 0: off (plain float32 form; the certificate is still computed and reported).
  * Switching modes mid-epoch resets the object.  tsdrgpu_autocorr_last_corr returns the reference's bits in either
- * certified mode (the last window is transformed once more in the exact form when the epoch is still fast). */
+ * certified mode (the last window is transformed once more in the exact form when the epoch is still fast).
+ * THE PREMISE IS AN ERROR MODEL, NOT A THEOREM, AND IT IS CHECKED AT RUN TIME.  KAPPA / 2 = 4e-6 is ~40x the rounding
+ * error c * eps * sqrt(log2 N) * R0 that the error model of DESIGN.md section 2 predicts and every measurement shows
+ * (2e-8 .. 3.6e-7 * R0); a worst-case bound of the same form (eps * log2 N * R0 for the inverse transform alone) is
+ * already larger than that, so no choice of KAPPA makes the certificate a proof.  Therefore every check_every-th plot
+ * update (TSDRGPU_AC_CHECK_EVERY, default 16, and always the first one after this call) also runs the newest retained
+ * window through the reference's arithmetic and compares the two on the device: max |float32 - exact| over the lag windows
+ * must be <= (KAPPA / 2) * (the window's lag-0 value), otherwise that update's certificate FAILS like any other and the
+ * epoch is replayed exactly.  tsdrgpu_ac_certificate_t reports the check; TSDR_GPU_AUTOCORR=exact (the engine) or
+ * tsdrgpu_autocorr_set_exact remain for hosts that want the reference's bits unconditionally. */
 #define TSDRGPU_AC_CERT_KAPPA 8e-6
 int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, size_t retain_bytes);
+/* mode 1's retention ring: its capacity in windows, how many of the current epoch it holds, and whether the epoch has
+ * been promoted (or the object is in exact mode) — i.e. which transform the next window will go through */
+int tsdrgpu_autocorr_retention(tsdrgpu_autocorr_t *ac, int *ring_windows, int *retained_windows, int *epoch_is_exact);
 /* Replays the current epoch in the reference's arithmetic (no-op when it already is exact).  In a sharded run
  * (mode 1 sums + tsdrgpu_autocorr_allreduce) it leaves this rank's exact sums: repeat the all-reduce afterwards. */
 int tsdrgpu_autocorr_promote(tsdrgpu_autocorr_t *ac);
@@ -342,6 +356,10 @@ typedef struct tsdrgpu_ac_certificate {
     double frame_best, frame_runner_up, line_best, line_runner_up; /* plot values */
     double r0;                            /* accumulated lag-0 value */
     double margin;                        /* TSDRGPU_AC_CERT_KAPPA * r0: what best - runner_up must exceed */
+    /* the runtime check of the premise (see above): did this update carry one, did it hold, what it measured */
+    int premise_checked, premise_ok;
+    double premise_err, premise_r0;       /* max |float32 - exact| over the lags of the checked window; that window's lag-0 value */
+    long premise_checks, premise_failures; /* of this object so far */
 } tsdrgpu_ac_certificate_t;
 /* the certificate that came with the last argmax collected (tsdrgpu_autocorr_argmax / _argmax_result) */
 int tsdrgpu_autocorr_certificate(tsdrgpu_autocorr_t *ac, tsdrgpu_ac_certificate_t *out);

@@ -39,6 +39,9 @@ struct AcArgHost {
     int certified[2];
     double best[2], second[2];
     double r0, margin;
+    int premise_checked;   // this update carried a runtime check of the certificate's premise (ac_premise_check)
+    int premise_ok;        // ... and the float32 window lay within (KAPPA / 2) * R0 of the reference's arithmetic
+    double premise_err, premise_r0;  // max |fast - exact| over the lag windows of the checked window, its lag-0 value
 };
 
 struct tsdrgpu_autocorr {
@@ -76,6 +79,11 @@ struct tsdrgpu_autocorr {
     int log_count, log_cap;
     float *d_ring;     // certify == 1: ring_cap windows of n magnitudes
     int ring_cap, ring_count;
+    // runtime check of the certificate's premise (ac_premise_check)
+    int check_every;       // every n-th plot update of a float32 epoch (0: never); the first update after set_certify always
+    int since_check;       // plot updates since the last check (-1: none yet)
+    unsigned long long *d_check;  // [0] max |fast - exact| as the bits of a non-negative double, [1] the checked window's lag-0 value
+    long premise_checks, premise_failures;
 };
 // windows per launch of the exact form (TSDRGPU_XBATCH overrides: 1..16)
 static int ac_xbatch()
@@ -831,7 +839,7 @@ __global__ __launch_bounds__(256) void k_argmax_partial(const double *__restrict
 __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ pval, const double *__restrict__ psec,
                                                      const int *__restrict__ pidx, const double *__restrict__ plots, int frame_len,
                                                      int line_len, double kappa, int exact_epoch, AcArgHost *__restrict__ out,
-                                                     AcArgHost *__restrict__ h_out)
+                                                     AcArgHost *__restrict__ h_out, const unsigned long long *__restrict__ check)
 {
     const int plot = blockIdx.x;
     ArgTop a = {-1.0, -1.0, 0x7fffffff};
@@ -844,7 +852,20 @@ __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ 
         const double r0 = plots[frame_len + line_len];
         const double margin = kappa * r0;
         // a plot of one lag has no runner-up (second stays -1); NaNs compare false and leave the plot uncertified
-        const int ok = exact_epoch || len <= 1 || (a.best - a.second > margin);
+        // the premise, when this update carries a check of it: one retained window went through the reference's arithmetic
+        // as well, and its float32 lags must lie within (kappa / 2) * (its own lag-0 value) of those (NaNs compare false)
+        int p_ok = 1;
+        double p_err = 0.0, p_r0 = 0.0;
+        if (check) {
+            p_err = __longlong_as_double((long long)check[0]);
+            p_r0 = __longlong_as_double((long long)check[1]);
+            p_ok = (p_err <= 0.5 * kappa * p_r0) ? 1 : 0;
+        }
+        const int ok = exact_epoch || (p_ok && (len <= 1 || (a.best - a.second > margin)));
+        if (plot == 0) {
+            out->premise_checked = check ? 1 : 0; out->premise_ok = p_ok; out->premise_err = p_err; out->premise_r0 = p_r0;
+            if (h_out) { h_out->premise_checked = check ? 1 : 0; h_out->premise_ok = p_ok; h_out->premise_err = p_err; h_out->premise_r0 = p_r0; }
+        }
         out->idx[plot] = r;
         out->certified[plot] = ok;
         out->best[plot] = a.best;
@@ -960,6 +981,7 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
     (void)hipFree(ac->d_xz);
     (void)hipFree(ac->d_xmag);
     (void)hipFree(ac->d_ring);
+    (void)hipFree(ac->d_check);
     free(ac->log);
     free(ac);
 }
@@ -1249,16 +1271,77 @@ extern "C" int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t t
     return TSDRGPU_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The certificate's premise, checked while the detector runs.  The certificate (best - runner_up > KAPPA * R0) proves the
+// float32 argmax to be the reference's IF every float32 plot value lies within (KAPPA / 2) * R0 of the reference's.  That
+// holds with a wide margin on everything measured (DESIGN.md section 2 has the error model), but it is a statement about
+// rounding errors, not a theorem — so it is also CHECKED: on the first plot update after tsdrgpu_autocorr_set_certify and
+// on every check_every-th one after that (TSDRGPU_AC_CHECK_EVERY, default 16; 0 = never) the newest retained window goes through
+// the reference's arithmetic as well (one exact transform, ~0.13 ms at 2^22) and its lags are compared on the device
+// with the float32 transform's: max |fast - exact| <= (KAPPA / 2) * (that window's exact lag-0 value), or the certificate
+// of this update fails — the caller promotes the epoch like for any other uncertified plot.  A plot is a mean over
+// windows of per-window values and R0 the same mean of the per-window lag-0 values, so the per-window bound carries over.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_premise_diff(const float *__restrict__ fast, const float2 *__restrict__ exact, int frame_lo, int frame_len,
+                                                      int line_lo, int line_len, unsigned long long *__restrict__ check)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double d = 0.0;
+    if (i <= frame_len + line_len) {
+        const int lag = (i < frame_len) ? (frame_lo + i) : (i < frame_len + line_len ? line_lo + (i - frame_len) : 0);
+        const float2 v = exact[lag];
+        const double re = v.x, im = v.y;
+        const double want = sqrt(re * re + im * im);       // what k_fftx_accumulate folds into the plots
+        const double got = fabs((double)fast[lag]);        // what k_accumulate folds
+        d = fabs(got - want);
+        if (!(d == d)) d = __longlong_as_double(0x7ff8000000000000LL);  // NaN: larger than everything below, fails the bound
+        if (lag == 0) check[1] = (unsigned long long)__double_as_longlong(want);
+    }
+    // non-negative doubles order like their bit patterns (NaN above infinity)
+    unsigned long long bits = (unsigned long long)__double_as_longlong(d);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_down(bits, o, 64);
+        bits = ob > bits ? ob : bits;
+    }
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(check, bits);
+}
+
+// queues the check behind the last run; 0 = not due / not possible, 1 = queued (d_check is valid behind it), < 0 error
+static int ac_premise_check(tsdrgpu_autocorr_t *ac)
+{
+    tsdrgpu_t *g = ac->g;
+    if (!ac->certify || ac->exact || ac->epoch_exact || ac->check_every <= 0 || ac->log_count <= 0 || !ac->d_last || ac->last_exact) return 0;
+    if (ac->since_check >= 0 && ac->since_check + 1 < ac->check_every) { ac->since_check++; return 0; }
+    int rc = ac_ensure_exact(ac);
+    if (rc) return rc;
+    if (!ac->d_check && hipMalloc(&ac->d_check, 2 * sizeof(unsigned long long)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr", "premise check");
+    const AcLogRec &r = ac->log[ac->log_count - 1];  // its final window is the one d_last holds whole
+    const float *src = r.src + (size_t)(r.nwindows - 1) * (size_t)r.stride * (r.is_iq ? 2 : 1);
+    if ((rc = fftx_correlate(g, ac->st, src, r.is_iq, r.stride, 1, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag))) return rc;
+    if (hipMemsetAsync(ac->d_check, 0, 2 * sizeof(unsigned long long), ac->st) != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_autocorr", "premise check");
+    const int L = ac->frame_len + ac->line_len + 1;
+    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_premise_diff, (L + 255) / 256, 256, (const float *)ac->d_last, (const float2 *)ac->d_xz, ac->frame_lo, ac->frame_len,
+                ac->line_lo, ac->line_len, ac->d_check);
+    if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_autocorr", "k_premise_diff");
+    ac->since_check = 0;
+    ac->premise_checks++;
+    return 1;
+}
+
 // queue the two-stage argmax of the current plots; its last kernel writes the result and the certificate to pinned memory
 extern "C" int tsdrgpu_autocorr_argmax_async(tsdrgpu_autocorr_t *ac)
 {
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     if (ac->arg_pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_argmax_async", "the previous result was not collected");
+    const int checked = ac_premise_check(ac);
+    if (checked < 0) return checked;
     TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_partial, dim3(ARGMAX_BLOCKS, 2), 256, ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_psec,
                 ac->d_pidx);
     TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_final, 2, 64, ac->d_pval, ac->d_psec, ac->d_pidx, ac->d_plots, ac->frame_len, ac->line_len,
-                (double)TSDRGPU_AC_CERT_KAPPA, (ac->exact || ac->epoch_exact) ? 1 : 0, ac->d_arg, ac->h_arg);
+                (double)TSDRGPU_AC_CERT_KAPPA, (ac->exact || ac->epoch_exact) ? 1 : 0, ac->d_arg, ac->h_arg,
+                (const unsigned long long *)(checked ? ac->d_check : nullptr));
     KERNEL_CHECK(g, "k_argmax");
     HIP_TRY(g, hipEventRecord(ac->ev_arg, ac->st));
     ac->arg_pending = 1;
@@ -1273,6 +1356,7 @@ extern "C" int tsdrgpu_autocorr_argmax_result(tsdrgpu_autocorr_t *ac, int32_t *f
     HIP_TRY(g, hipEventSynchronize(ac->ev_arg));
     ac->arg_pending = 0;
     ac->res = *ac->h_arg;
+    if (ac->res.premise_checked && !ac->res.premise_ok) ac->premise_failures++;
     if (frame_idx) *frame_idx = ac->res.idx[0];
     if (line_idx) *line_idx = ac->res.idx[1];
     return TSDRGPU_OK;
@@ -1299,6 +1383,12 @@ extern "C" int tsdrgpu_autocorr_certificate(tsdrgpu_autocorr_t *ac, tsdrgpu_ac_c
     out->margin = ac->res.margin;
     out->exact_epoch = (ac->exact || ac->epoch_exact) ? 1 : 0;
     out->promotions = ac->promotions;
+    out->premise_checked = ac->res.premise_checked;
+    out->premise_ok = ac->res.premise_ok;
+    out->premise_err = ac->res.premise_err;
+    out->premise_r0 = ac->res.premise_r0;
+    out->premise_checks = ac->premise_checks;
+    out->premise_failures = ac->premise_failures;
     return TSDRGPU_OK;
 }
 
@@ -1389,9 +1479,23 @@ extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, si
     if (!mode) return TSDRGPU_OK;
     int rc = ac_ensure_exact(ac);  // the table is built on the host (tens of ms at 2^22): now, not at the first promotion
     if (rc) return rc;
+    {
+        const char *e = getenv("TSDRGPU_AC_CHECK_EVERY");
+        ac->check_every = e ? atoi(e) : 16;
+        ac->since_check = -1;  // the first plot update of the object is checked
+    }
     int cap = 1024;
     if (mode == 1) {
-        if (retain_bytes == 0) retain_bytes = (size_t)1 << 30;
+        if (retain_bytes == 0) {
+            // default: a quarter of what is free on the device right now, at most 32 GiB (2048 windows of 2^22 samples =
+            // 116 s of real-time signal at 100 MS/s), at least 256 MiB — HBM is not the scarce resource on a 288 GB part,
+            // and an epoch that outgrows the ring costs one exact replay and runs in the (4x slower) exact form from then on
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
+            retain_bytes = free_b / 4;
+            if (retain_bytes > ((size_t)32 << 30)) retain_bytes = (size_t)32 << 30;
+            if (retain_bytes < ((size_t)256 << 20)) retain_bytes = (size_t)256 << 20;
+        }
         size_t w = retain_bytes / (sizeof(float) * (size_t)ac->n);
         if (w < 1) w = 1;
         if (w > 65535) w = 65535;
@@ -1409,6 +1513,15 @@ extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, si
     }
     ac->log_cap = cap;
     ac->certify = mode;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_autocorr_retention(tsdrgpu_autocorr_t *ac, int *ring_windows, int *retained_windows, int *epoch_is_exact)
+{
+    if (!ac) return TSDRGPU_EINVAL;
+    if (ring_windows) *ring_windows = ac->certify == 1 ? ac->ring_cap : 0;
+    if (retained_windows) *retained_windows = ac->certify == 1 ? ac->ring_count : 0;
+    if (epoch_is_exact) *epoch_is_exact = (ac->exact || ac->epoch_exact) ? 1 : 0;
     return TSDRGPU_OK;
 }
 

@@ -46,7 +46,9 @@ class AcCertificate(C.Structure):
     """tsdrgpu_ac_certificate_t: the argmax certificate of the certified autocorrelation mode."""
     _fields_ = [("frame_certified", C.c_int), ("line_certified", C.c_int), ("exact_epoch", C.c_int), ("promotions", C.c_int),
                 ("frame_best", C.c_double), ("frame_runner_up", C.c_double), ("line_best", C.c_double),
-                ("line_runner_up", C.c_double), ("r0", C.c_double), ("margin", C.c_double)]
+                ("line_runner_up", C.c_double), ("r0", C.c_double), ("margin", C.c_double),
+                ("premise_checked", C.c_int), ("premise_ok", C.c_int), ("premise_err", C.c_double), ("premise_r0", C.c_double),
+                ("premise_checks", C.c_long), ("premise_failures", C.c_long)]
 
 
 class PPFrameInfo(C.Structure):
@@ -147,6 +149,7 @@ _SIGS = {
     "tsdrgpu_autocorr_set_async": (C.c_int, [vp, C.c_int]),
     "tsdrgpu_autocorr_plots": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
+    "tsdrgpu_autocorr_retention": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tsdrgpu_autocorr_device_sums": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
     "tsdrgpu_autocorr_set_exact": (C.c_int, [vp, C.c_int]),
@@ -670,6 +673,12 @@ class Autocorr:
 
     def promote(self):
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_promote(self.h))
+
+    def retention(self):
+        """(ring capacity in windows, windows of the epoch retained, epoch runs in the exact form)"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_retention(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, bool(c.value)
 
     def certificate(self):
         c = AcCertificate()

@@ -10,7 +10,7 @@ kind (default "plain"):
   certified  the detector's CERTIFIED mode as bench.py / the engine run it: after the exchange every rank takes the argmax
              and its certificate on the (identical) global plots; the raster-like stream must be certified on every rank
              and no epoch replayed
-  flat       a nearly flat stream: the certificate MUST fail on every rank alike, every rank replays ITS windows in the
+  flat       a constant stream (every lag of every plot ties): the certificate MUST fail on every rank alike, every rank replays ITS windows in the
              reference's arithmetic (tsdrgpu_autocorr_promote), the exact sums are exchanged a SECOND time and the merged
              plots equal the single-rank exact running mean (frameratedetector.c:34-62, fft.c:49-64,96-176)"""
 import os
@@ -36,7 +36,7 @@ def main():
     period = int(fs / 60.0)
     tot = nwin * ac.capture
     if kind == "flat":
-        x = (1.0 + 0.05 * rng.random(tot)).astype(np.float32)
+        x = np.full(tot, 0.25, np.float32)  # every lag ties (best == runner-up): the certificate cannot hold
     else:
         x = rng.random(tot).astype(np.float32) * np.float32(0.3) + (np.arange(tot) % period < period // 10).astype(np.float32)
     d_in = g.to_device(x)

@@ -122,6 +122,102 @@ def test_hard_windows_identical_argmax(orc, fs, kind):
         assert promoted == 1
 
 
+# ---------------------------------------------------------------------------
+# the premise of the certificate, checked at run time (ac_premise_check in tsdrgpu_fft.hip), on inputs chosen to stress it
+# ---------------------------------------------------------------------------
+def _adversarial(kind, fs, capture, seed):
+    rng = np.random.default_rng(seed)
+    n = capture
+    t = np.arange(n)
+    period = int(fs / 60.0)
+    pattern = ((t % period) < period // 7).astype(np.float64) + 0.3 * ((t % (period // 525)) < 40)
+    if kind == "dc1e6":      # DC 1e6 + 1e-3 signal: the signal is far below half an ulp of the carrier, the window is flat in float32
+        return (1e6 + 1e-3 * pattern).astype(np.float32)
+    if kind == "dc1e3":      # DC 1e3 + 1e-3 signal: the signal survives as ~16 quantisation levels on a huge pedestal
+        return (1e3 + 1e-3 * pattern + 1e-4 * rng.random(n)).astype(np.float32)
+    if kind == "tiny":       # 1e-30 amplitudes: the squares inside the magnitude underflow in float32 (fft.c:34-45)
+        return (1e-30 * (pattern + 0.1 * rng.random(n))).astype(np.float32)
+    if kind == "small":      # 1e-18: squares ~1e-36 .. 1e-43 straddle the subnormal range
+        return (1e-18 * (pattern + 0.1 * rng.random(n))).astype(np.float32)
+    if kind == "impulse":    # one sample: a flat spectrum, every lag but 0 is rounding noise around zero
+        x = np.zeros(n, np.float32)
+        x[n // 3] = 1.0
+        return x
+    if kind == "heavy":      # heavy-tailed noise: a few samples carry most of the energy
+        return np.minimum(np.abs(rng.standard_cauchy(n)), 1e6).astype(np.float32)
+    if kind == "lognormal":
+        return rng.lognormal(0.0, 3.0, n).astype(np.float32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("fs,kind", [(25_000_000, "dc1e6"), (25_000_000, "dc1e3"), (25_000_000, "tiny"), (25_000_000, "small"),
+                                     (25_000_000, "impulse"), (25_000_000, "heavy"), (25_000_000, "lognormal"),
+                                     (100_000_000, "dc1e3"), (100_000_000, "heavy"),
+                                     (200_000_000, "heavy"), (200_000_000, "lognormal")])  # 200 MS/s: windows of 2^23 points
+def test_adversarial_windows_premise_checked_at_runtime(orc, fs, kind):
+    """Inputs outside the classes the KAPPA bound was measured on.  What must hold regardless of whether the bound does:
+    the first plot update of the object carries the runtime check (one window through the reference's arithmetic as well);
+    if the float32 plots are further than (KAPPA/2)*R0 from the oracle's, the check has noticed and the certificate failed;
+    and the argmax pair the certified mode returns is the oracle's, identically."""
+    g = ctx()
+    ac = gpu.Autocorr(g, fs)
+    ac.set_certify(1)
+    x = _adversarial(kind, fs, ac.capture, 11 + fs % 7)
+    o = orc.Autocorr(fs)
+    o.run(x)
+    ac.run(g.to_device(x), 0, ac.capture, 1)
+    f, l, _ = ac.plots()
+    fi0, li0 = ac.argmax()
+    c = ac.certificate()
+    assert c.premise_checked == 1 and c.premise_checks == 1, "the first update after set_certify is always checked"
+    dist = max(np.max(np.abs(f - o.frame)), np.max(np.abs(l - o.line)))
+    # one window: the plots ARE that window's lags, so the device's measurement is the distance to the oracle
+    assert c.premise_err == pytest.approx(dist, rel=1e-12, abs=0)
+    assert c.premise_r0 == pytest.approx(c.r0, rel=1e-5, abs=0)  # (exact vs float32 lag 0)
+    violated = not (dist <= 0.5 * KAPPA * c.premise_r0)
+    assert c.premise_ok == (0 if violated else 1)
+    if violated:
+        assert not (c.frame_certified or c.line_certified), "a violated premise must fail the certificate"
+        assert c.premise_failures == 1
+    if c.frame_certified and c.line_certified:
+        assert (fi0, li0) == (int(np.argmax(o.frame)), int(np.argmax(o.line)))
+    fi, li, promoted = ac.argmax_certified()
+    assert (fi, li) == (int(np.argmax(o.frame)), int(np.argmax(o.line)))
+    if promoted:
+        f2, l2, _ = ac.plots()
+        assert np.array_equal(f2, o.frame) and np.array_equal(l2, o.line)
+    ac.destroy()
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/certify_dist.txt", "a") as fh:
+            r0 = c.premise_r0 if c.premise_r0 else float("nan")
+            fh.write(f"{fs} adversarial:{kind} dist/R0={dist / r0:.3e} margin/R0={KAPPA:.1e} premise_ok={c.premise_ok} "
+                     f"certified={int(bool(c.frame_certified and c.line_certified))} promoted={promoted}\n")
+
+
+def test_premise_check_cadence(orc):
+    """The check runs on the first plot update of the object and then on every 16th (TSDRGPU_AC_CHECK_EVERY), whatever the
+    epochs in between; on a raster it measures a distance well inside the bound and leaves the certificate alone."""
+    g = ctx()
+    fs = 25_000_000
+    ac = gpu.Autocorr(g, fs)
+    ac.set_certify(2)
+    data, is_iq = _windows("raster", fs, 1, ac.capture, 21)
+    d_in = g.to_device(data)
+    seen = []
+    for k in range(34):
+        ac.reset()
+        ac.run(d_in, is_iq, ac.capture, 1)
+        ac.argmax()
+        c = ac.certificate()
+        seen.append(c.premise_checked)
+        assert c.frame_certified and c.line_certified and c.premise_ok == 1
+        if c.premise_checked:
+            assert 0 < c.premise_err <= 0.5 * KAPPA * c.premise_r0
+    assert seen == [1] + ([0] * 15 + [1]) * 2 + [0]
+    assert ac.certificate().premise_checks == 3 and ac.certificate().premise_failures == 0
+    ac.destroy()
+
+
 def test_epoch_of_several_calls_and_sums(orc):
     """An epoch of three run() calls replayed in call order, in both accumulation modes; reset opens a fast epoch."""
     g = ctx()
