@@ -63,7 +63,16 @@ typedef void (*tsdrplugin_readasync_raw_function)(const void *buf, uint64_t item
  * tsdrplugin_readasync has returned, before anything can call cleanup/init).  Without the promise every block is
  * copied through the library's own pinned buffers, which is what the plugin ABI guarantees to be safe: the
  * reference's plugins (RawFile, Mirics, SDRplay) free their buffer INSIDE tsdrplugin_readasync, before it returns.
- * TSDR_GPU_ZEROCOPY=0 disables the direct path, =1 forces it for a plugin the user knows to be stable. */
+ * TSDR_GPU_ZEROCOPY=0 disables the direct path, =1 forces it for a plugin the user knows to be stable.
+ * The return value is a set of bits: TSDRX_MEMORY_MAPPED is the promise above (any non-zero value of older plugins is
+ * read as this bit alone... so they keep returning 1).  TSDRX_MEMORY_IMMUTABLE adds that the CONTENTS of a block
+ * handed to the tsdrplugin_readasync callback do not change for as long as tsdrplugin_readasync runs (a recording, not a
+ * ring that hardware refills), TSDRX_MEMORY_IMMUTABLE_RAW the same for tsdrplugin_readasync_raw: only then may the library
+ * return from the callback while its DMA out of the block is still in flight, so that consecutive blocks' transfers
+ * overlap (TSDR_GPU_ASYNC_UPLOAD=0 makes it wait regardless). */
+#define TSDRX_MEMORY_MAPPED 1
+#define TSDRX_MEMORY_IMMUTABLE 2
+#define TSDRX_MEMORY_IMMUTABLE_RAW 4
 
 #ifdef __cplusplus
 }

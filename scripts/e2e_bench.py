@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--file-seconds", type=float, default=0.3)
     ap.add_argument("--reference", action="store_true", help="also run the reference's CPU library on the same file")
+    ap.add_argument("--only", default="", help="comma-separated leg names (default: all)")
+    ap.add_argument("--variants", action="store_true", help="A/B legs of the engine's switches (round 4)")
     args = ap.parse_args()
     rawfile = os.path.join(ROOT, "oracle", "_ref", "libTSDRPlugin_RawFile_bench.so")
     reflib = os.path.join(ROOT, "oracle", "_ref", "libtsdr_ref.so")
@@ -46,11 +48,13 @@ def main():
     out = {"config": f"{args.fs/1e6:g} MS/s float32 IQ recording of {n/args.fs:.3f} s replayed free-running, h={args.height}, fv={args.fv}",
            "host_cores": os.cpu_count()}
 
-    def leg(name, lib, plugin, params, env=None, free=True, set_int=()):
+    def leg(name, lib, plugin, params, env=None, free=True, set_int=(), rgb=False):
         # every leg in a process of its own, like a host application (and so that no leg inherits another's runtime state)
         e = {"TSDR_GPU_STATS": "1"}
         e.update(env or {})
-        r = tsdrlib.throughput_subprocess(lib, plugin, params, args.height, args.fv, args.seconds, env=e, set_int=set_int, free=free)
+        if args.only and name not in args.only.split(","):
+            return
+        r = tsdrlib.throughput_subprocess(lib, plugin, params, args.height, args.fv, args.seconds, env=e, set_int=set_int, free=free, rgb=rgb)
         print(r.pop("stderr_tail", ""), file=sys.stderr)
         r["effective_Msps"] = r["frames_per_s"] * S / 1e6
         out[name] = r
@@ -72,6 +76,26 @@ def main():
                 break
             np.clip(np.round(a * 20000.0), -32768, 32767).astype(np.int16).tofile(fout)
     leg("mi355x_mem_plugin_int16_raw", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path16} {args.fs} {block} 0 0 int16")
+    path8 = "/tmp/e2e_iq.s8"
+    with open(path, "rb") as fin, open(path8, "wb") as fout:
+        while True:
+            a = np.fromfile(fin, np.float32, 1 << 22)
+            if a.size == 0:
+                break
+            np.clip(np.round(a * 100.0), -128, 127).astype(np.int8).tofile(fout)
+    # the narrowest way in and the viewer's format out: int8 IQ (2 bytes per sample in), packed RGB frames (8 bytes per sample out)
+    leg("mi355x_mem_plugin_int8_raw_rgb_out", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path8} {args.fs} {block} 0 0 int8", rgb=True)
+    leg("mi355x_mem_plugin_rgb_out", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0", rgb=True)
+    if args.variants:
+        base = (tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0")
+        leg("variant_uploads_waited_for", *base, {"TSDR_GPU_ASYNC_UPLOAD": "0"})
+        leg("variant_ring_1GiB", *base, {"TSDR_GPU_AUTOCORR_RETAIN_MB": "1024"})
+        leg("variant_no_premise_check", *base, {"TSDRGPU_AC_CHECK_EVERY": "0"})
+        leg("variant_plots_off", *base, set_int=[(3, 1)])
+        leg("variant_block_8MiB", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {4 * block} 0 0")
+        leg("variant_exact_detector", *base, {"TSDR_GPU_AUTOCORR": "exact"})
+        if os.path.exists(rawfile):
+            leg("variant_rawfile_no_copy_thread", tsdrlib.LIB, rawfile, f"{path} {args.fs} float", {"TSDR_GPU_COPY_THREAD": "0"})
     if os.path.exists(rawfile):
         leg("mi355x_rawfile_plugin", tsdrlib.LIB, rawfile, f"{path} {args.fs} float")
         if args.reference and os.path.exists(reflib):

@@ -34,10 +34,13 @@
 
 #include "tsdr_host.h"
 
-#define NSLOT 32           /* input blocks in flight: when the host is slow the backlog turns into bigger batches */
-#define NFRAMEQ 16         /* frames on their way to / waiting for the video callback */
+#define NSLOT 64           /* input blocks in flight: when the host is slow the backlog turns into bigger batches */
+#define NFRAMEQ 48         /* frames on their way to / waiting for the video callback */
 #define NOUT 6             /* post-processed batches whose frames may still be downloading */
-#define MAX_FRAME_BATCH 16
+#define MAX_FRAME_BATCH 32
+#define FUSE_MIN_FRAMES 8  /* a backlog of at least this many frames takes the fused run (tsdrgpu_postproc_begin_minmax) */
+#define MAX_CHUNKS_PER_CALL 120 /* resampler chunks per call (0.1 frame each): a backlog of 12 frames in one launch group */
+#define MM_CAP 4096        /* per-frame min/max values kept for frames that wait in the pixel stream */
 #define MAX_HOSTREG 512    /* page-locked ranges of plugin memory */
 #define MAX_HOSTREJ 16     /* ranges that could not be page-locked, remembered so that the call is not repeated */
 #define NORMALISATION_LOWPASS_COEFF (0.1f) /* TSDRLibrary.c:37 */
@@ -88,6 +91,8 @@ typedef struct {
     int64_t dropped;
     tsdrgpu_event_t *consumed; /* COMPUTE lane is done reading d */
     int consumed_valid;
+    tsdrgpu_event_t *uploaded; /* UPLOAD lane has written d (or d_raw): the device thread waits for it ON THE HOST */
+    int uploaded_valid;
 } in_slot_t;
 
 typedef struct {
@@ -125,6 +130,24 @@ struct engine {
     pthread_cond_t q_nonempty;
     int plugin_thread_bound;
     int zero_copy;
+    int immutable;   /* the plugin promises that a block's CONTENTS stay as they are while tsdrplugin_readasync runs: its DMA may
+                        still be in flight when the callback returns (tsdrplugin_memory_stable, bits 1 / 2) */
+    /* the second half of a bounce-buffer copy runs on a helper thread while the plugin's thread copies the first */
+    pthread_t th_copy;
+    int copy_thread_on;
+    pthread_mutex_t cm;
+    pthread_cond_t c_wake;
+    volatile int copy_state; /* 0 idle, 1 job posted, 2 done */
+    volatile int copy_quit, copy_sleeping;
+    void *copy_dst; const void *copy_src; size_t copy_n;
+    /* per-frame min/max out of the resampler (frame tracking) for the frames that wait in the pixel stream: what the
+     * fused run needs instead of a statistics read of its own */
+    float *d_mm_min, *d_mm_max;
+    int mm_off, mm_n;        /* valid entries [mm_off, mm_off + mm_n): one per whole frame behind the `mm_nohead` first ones */
+    int mm_nohead;           /* whole frames at the head of the pixel stream that have no min/max (tracking started later) */
+    int mm_drop_first;       /* the tracker's next completed frame began before tracking did: its min/max is partial */
+    int64_t track_P;         /* frame size the resampler is tracking (0: off) */
+    long n_fused_batches, n_fused_frames;
     struct { char *p; size_t n; } reg[MAX_HOSTREG];
     int nreg;
     struct { char *p; size_t n; } rej[MAX_HOSTREJ]; /* ranges hipHostRegister refused */
@@ -314,6 +337,56 @@ static size_t sample_bytes(int type)
     return (type == TSDRX_SAMPLE_INT8 || type == TSDRX_SAMPLE_UINT8) ? 1 : ((type == TSDRX_SAMPLE_INT16 || type == TSDRX_SAMPLE_UINT16) ? 2 : 4);
 }
 
+/* ---- bounce-buffer copy in two halves ------------------------------------------------ */
+/* A plugin that made no promise about its memory (every reference plugin) is served through pinned buffers of ours, and
+ * the copy into them has to be complete when the callback returns.  2 MiB at memcpy speed is ~60-200 us on the plugin's
+ * own thread — more than the DMA that follows it — so a helper takes the second half.  The helper spins for a short while
+ * after a job (blocks of a free-running source follow each other within ~100 us) and sleeps on a condition variable
+ * otherwise (a live source's blocks are milliseconds apart: the wake-up latency does not matter there). */
+static void *copy_thread(void *arg)
+{
+    struct engine *e = (struct engine *)arg;
+    double last = now_s();
+    for (;;) {
+        if (e->copy_state == 1) {
+            __sync_synchronize();
+            memcpy(e->copy_dst, e->copy_src, e->copy_n);
+            __sync_synchronize();
+            e->copy_state = 2;
+            last = now_s();
+            continue;
+        }
+        if (e->copy_quit) break;
+        if (now_s() - last < 300e-6) { __builtin_ia32_pause(); continue; }
+        pthread_mutex_lock(&e->cm);
+        e->copy_sleeping = 1;
+        while (e->copy_state != 1 && !e->copy_quit) pthread_cond_wait(&e->c_wake, &e->cm);
+        e->copy_sleeping = 0;
+        pthread_mutex_unlock(&e->cm);
+    }
+    return NULL;
+}
+
+static void bounce_copy(struct engine *e, void *dst, const void *src, size_t n)
+{
+    if (!e->copy_thread_on || n < ((size_t)256 << 10)) { memcpy(dst, src, n); return; }
+    const size_t half = (n / 2) & ~(size_t)63;
+    e->copy_dst = (char *)dst + half;
+    e->copy_src = (const char *)src + half;
+    e->copy_n = n - half;
+    __sync_synchronize();
+    e->copy_state = 1;
+    if (e->copy_sleeping) {
+        pthread_mutex_lock(&e->cm);
+        pthread_cond_signal(&e->c_wake);
+        pthread_mutex_unlock(&e->cm);
+    }
+    memcpy(dst, src, half);
+    while (e->copy_state != 2) __builtin_ia32_pause();
+    __sync_synchronize();
+    e->copy_state = 0;
+}
+
 static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, int64_t dropped)
 {
     struct engine *e = (struct engine *)ctx;
@@ -348,18 +421,27 @@ static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, i
             dst = s->d_raw;
         }
         const void *src = buf;
+        /* the previous DMA into this slot's device buffer / out of its bounce buffer (NSLOT blocks ago) is long complete */
+        if (ok && s->uploaded_valid) { ok = gpu_ok(e, tsdrgpu_event_sync(e->g, s->uploaded), "slot upload wait"); s->uploaded_valid = 0; }
+        int wait_dma = 0; /* must the DMA be complete when we return? */
         if (ok && !plugin_memory_pinned(e, (void *)buf, bytes)) {
             if (s->hcap < items) { /* sized for float32, the widest format */
                 tsdrgpu_free_host(e->g, s->h);
                 s->h = NULL; s->hcap = 0;
                 if (gpu_ok(e, tsdrgpu_alloc_host(e->g, (void **)&s->h, (size_t)items * sizeof(float)), "pinned bounce buffer")) s->hcap = items; else ok = 0;
             }
-            if (ok) { memcpy(s->h, buf, bytes); src = s->h; }
+            /* the copy is what has to be complete on return; the DMA out of OUR buffer then runs behind the callback's back */
+            if (ok) { bounce_copy(e, s->h, buf, bytes); src = s->h; }
+        } else if (ok) {
+            /* straight out of the plugin's memory: the block is the plugin's again when we return — unless it promised that
+             * its contents do not change while it streams (a recording): then this DMA and the next ones overlap */
+            wait_dma = !e->immutable;
         }
-        /* the plugin's buffer is ours only until we return: wait for the DMA (about 40 us for RawFile's 2 MB) */
         const double t1 = e->stats ? now_s() : 0.0;
         /* a failing device call ends the session here as well (gpu_ok; the error text is this thread's own) */
-        if (ok) ok = gpu_ok(e, tsdrgpu_upload_lane(e->g, dst, src, bytes), "upload") && gpu_ok(e, tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD), "upload wait");
+        if (ok) ok = gpu_ok(e, tsdrgpu_upload_lane(e->g, dst, src, bytes), "upload");
+        if (ok && wait_dma) ok = gpu_ok(e, tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD), "upload wait");
+        else if (ok) { ok = gpu_ok(e, tsdrgpu_event_record(e->g, s->uploaded, TSDRGPU_LANE_UPLOAD), "upload event"); s->uploaded_valid = ok; }
         if (e->stats) e->s_plugin_dma += now_s() - t1;
     }
     s->raw_type = type;
@@ -748,6 +830,12 @@ static void deliver_frames(struct engine *e, out_buf_t *ob, int F, int W, int H)
     }
 }
 
+/* parameter sets the fused run handles itself (the others silently take its split path: nothing gained) */
+static int fused_wanted(const tsdrgpu_pp_params_t *p)
+{
+    return !p->lowpass_before_sync && !p->autogain_after_proc && !p->autoshift && !p->pll;
+}
+
 static void run_frames(struct engine *e)
 {
     tsdr_lib_t *t = e->t;
@@ -770,6 +858,7 @@ static void run_frames(struct engine *e)
         prm.motionblur = t->motionblur;
         prm.lowpasscoeff = NORMALISATION_LOWPASS_COEFF;
         if (prm.pll) F = 1; /* the PLL's nudge feeds back into the geometry between frames */
+        if (e->mm_nohead > 0 && F > e->mm_nohead) F = e->mm_nohead; /* frames from before the tracking started go on their own */
         out_buf_t *ob = &e->out[e->out_next];
         e->out_next = (e->out_next + 1) % NOUT;
         if (ob->busy) { /* its frames have left the device? */
@@ -795,7 +884,24 @@ static void run_frames(struct engine *e)
             ob->info_cap = MAX_FRAME_BATCH;
         }
         tsdrgpu_pp_frameinfo_t info;
-        if (!gpu_ok(e, tsdrgpu_postproc_run(e->pp, e->pix.d + e->pix.rd, F, W, H, &prm, ob->d, prm.pll ? &info : NULL), "postproc")) return;
+        /* A backlog (the source runs ahead of us) goes through the FUSED run — the path bench.py times: the resampler has
+         * left every frame's min / max (frame tracking, run_resampler), so one trip over the raw frames gathers the sync
+         * detector's sums and writes the normalised frames (12 instead of 16 bytes per pixel moved).  Frames and state are
+         * bit-identical to tsdrgpu_postproc_run's (tests/test_gpu_postproc.py).  Frames that arrive one or two at a time
+         * — a live source — take the plain run: there the launches, not the bytes, are what costs. */
+        const int fuse = e->mm_nohead == 0 && F >= FUSE_MIN_FRAMES && e->mm_n >= F && fused_wanted(&prm);
+        if (fuse) {
+            if (!gpu_ok(e, tsdrgpu_postproc_begin_minmax(e->pp, e->pix.d + e->pix.rd, F, W, H, &prm, e->d_mm_min + e->mm_off, e->d_mm_max + e->mm_off, ob->d),
+                        "postproc (fused)") ||
+                !gpu_ok(e, tsdrgpu_postproc_finish(e->pp, ob->d, NULL), "postproc (fused)"))
+                return;
+            e->n_fused_batches++;
+            e->n_fused_frames += F;
+        } else if (!gpu_ok(e, tsdrgpu_postproc_run(e->pp, e->pix.d + e->pix.rd, F, W, H, &prm, ob->d, prm.pll ? &info : NULL), "postproc")) return;
+        /* the frames' min/max entries go with them */
+        if (e->mm_nohead > 0) e->mm_nohead -= F; /* (F was capped to the head frames above) */
+        else if (e->mm_n >= F) { e->mm_off += F; e->mm_n -= F; if (!e->mm_n) e->mm_off = 0; }
+        else { e->mm_off = e->mm_n = 0; }
         if (t->rgb_cb) {
             /* the JNI shim's pixel loop (TSDRLibraryNDK.c:222-276) on the device: frame after frame into the viewer's
              * persistent pixel buffer (transparent pixels keep their colour), a copy of which goes home */
@@ -834,6 +940,16 @@ static void run_frames(struct engine *e)
     }
 }
 
+/* stops the resampler's frame tracking; frames still waiting in the pixel stream lose their min/max (plain run) */
+static void track_off(struct engine *e)
+{
+    if (e->track_P) (void)tsdrgpu_resampler_track_frames(e->rs, 0, 0);
+    e->track_P = 0;
+    e->mm_off = e->mm_n = 0;
+    e->mm_nohead = 1 << 30; /* every frame now in the stream, and every later one until tracking restarts */
+    e->mm_drop_first = 0;
+}
+
 static void run_resampler(struct engine *e)
 {
     tsdr_lib_t *t = e->t;
@@ -856,7 +972,7 @@ static void run_resampler(struct engine *e)
         if (nchunks <= 0) break;
         /* while pixels are being skipped or a manual shift is pending go chunk by chunk like the reference */
         if (e->pix_difference != 0 || t->syncoffset != 0) nchunks = 1;
-        else if (nchunks > 40) nchunks = 40;
+        else if (nchunks > MAX_CHUNKS_PER_CALL) nchunks = MAX_CHUNKS_PER_CALL;
         if (nchunks > 1 && t->params_int[PARAM_INT_FRAMERATE_PLL]) {
             /* PLL on: a frame completed by a chunk may nudge the refresh rate, which the NEXT chunk's ratio must already
              * see (TSDRLibrary.c:335-340 re-reads the geometry per chunk) — so one call takes the chunks up to and
@@ -878,12 +994,45 @@ static void run_resampler(struct engine *e)
         if (e->pix_difference == 0) {
             /* the usual case: straight into the pixel stream */
             if (!stream_reserve(e, &e->pix, (size_t)count)) return;
+            /* frame tracking for the fused run: on while whole batches can use it (area mode, default stage order, frames
+             * of >= 4096 pixels), restarted whenever the frame grid of the pixel stream moved */
+            const int want_track = !nearest && totalpixels >= 4096 && !t->params_int[PARAM_LOW_PASS_BEFORE_SYNC] &&
+                                   !t->params_int[PARAM_AUTOGAIN_AFTER_PROCESSING] && !t->params_int[PARAM_INT_AUTOSHIFT] &&
+                                   !t->params_int[PARAM_INT_FRAMERATE_PLL] && e->d_mm_min != NULL;
+            if (!want_track) track_off(e);
+            else if (e->track_P != (int64_t)totalpixels) {
+                const size_t live = e->pix.wr - e->pix.rd;
+                const int64_t phase = (int64_t)(live % (size_t)totalpixels);
+                if (tsdrgpu_resampler_track_frames(e->rs, (int64_t)totalpixels, phase) == 0) {
+                    e->track_P = totalpixels;
+                    e->mm_off = e->mm_n = 0;
+                    e->mm_nohead = (int)(live / (size_t)totalpixels) + (phase ? 1 : 0); /* their pixels (or part of them) predate the tracking */
+                    e->mm_drop_first = phase ? 1 : 0;
+                } else track_off(e);
+            }
             if (!gpu_ok(e, tsdrgpu_resample(e->rs, e->iq.d + e->iq.rd, !e->iq_is_mag, (uint32_t)chunk, nchunks, up, down, nearest,
                                             e->pix.d + e->pix.wr, (int64_t)(e->pix.cap - e->pix.wr), &n),
                         "resample"))
                 return;
             e->pix.wr += (size_t)n;
+            if (e->track_P) {
+                const float *mn = NULL, *mx = NULL;
+                int k = 0;
+                if (tsdrgpu_resampler_frame_minmax(e->rs, &mn, &mx, &k) == 0 && k > 0) {
+                    const int skip = e->mm_drop_first ? 1 : 0;
+                    e->mm_drop_first = 0;
+                    const int take = k - skip;
+                    if (take > 0) {
+                        if (e->mm_off + e->mm_n + take > MM_CAP) track_off(e); /* (thousands of frames waiting: cannot happen with the queues' sizes) */
+                        else if (gpu_ok(e, tsdrgpu_copy(e->g, e->d_mm_min + e->mm_off + e->mm_n, mn + skip, (size_t)take * sizeof(float)), "min/max") &&
+                                 gpu_ok(e, tsdrgpu_copy(e->g, e->d_mm_max + e->mm_off + e->mm_n, mx + skip, (size_t)take * sizeof(float)), "min/max"))
+                            e->mm_n += take;
+                        else return;
+                    }
+                } else if (k < 0) track_off(e);
+            }
         } else {
+            track_off(e); /* pixels are about to be skipped: the frame grid moves */
             /* dsp_dropped_compensation_add with a ring that always accepts (dsp.c:326-346) */
             if (!ensure_dev(e, &e->d_rs, &e->rs_cap, (size_t)count + 16)) return;
             if (!gpu_ok(e, tsdrgpu_resample(e->rs, e->iq.d + e->iq.rd, !e->iq_is_mag, (uint32_t)chunk, nchunks, up, down, nearest,
@@ -1075,6 +1224,14 @@ static void *device_thread(void *arg)
         const int head = e->q_head, n = e->q_count;
         pthread_mutex_unlock(&e->qm);
         const double t0 = e->stats ? now_s() : 0.0;
+        /* blocks whose DMA may still be in flight (the plugin thread did not wait for it): the UPLOAD lane is in order,
+         * so the newest of them stands for all — waited for here, on the host, never on the device (see download_thread) */
+        for (int i = n - 1; i >= 0; i--) {
+            in_slot_t *sl = &e->slot[(head + i) % NSLOT];
+            if (!sl->uploaded_valid || !sl->nfloats) continue;
+            gpu_ok(e, tsdrgpu_event_sync(e->g, sl->uploaded), "upload wait");
+            break;
+        }
         for (int i = 0; i < n; i++) process_block(e, &e->slot[(head + i) % NSLOT]);
         gather_flush(e);
         /* the plugin thread may refill these slots once the COMPUTE lane has read them */
@@ -1128,13 +1285,16 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     int ok = tsdrgpu_create(&e->g, dev) == 0 && tsdrgpu_resampler_create(e->g, &e->rs) == 0 && tsdrgpu_postproc_create(e->g, &e->pp) == 0 &&
              tsdrgpu_event_create(e->g, &e->plot_ready) == 0 && tsdrgpu_event_create(e->g, &e->plot_home) == 0 &&
              tsdrgpu_event_create(e->g, &e->det_read) == 0;
-    for (int i = 0; ok && i < NSLOT; i++) ok = tsdrgpu_event_create(e->g, &e->slot[i].consumed) == 0;
+    for (int i = 0; ok && i < NSLOT; i++) ok = tsdrgpu_event_create(e->g, &e->slot[i].consumed) == 0 && tsdrgpu_event_create(e->g, &e->slot[i].uploaded) == 0;
+    if (ok) ok = tsdrgpu_alloc(e->g, (void **)&e->d_mm_min, MM_CAP * sizeof(float)) == 0 && tsdrgpu_alloc(e->g, (void **)&e->d_mm_max, MM_CAP * sizeof(float)) == 0;
+    e->mm_nohead = 1 << 30; /* no tracking yet */
     for (int i = 0; ok && i < NFRAMEQ; i++)
         ok = tsdrgpu_event_create(e->g, &e->fq[i].ready) == 0 && tsdrgpu_alloc_host(e->g, (void **)&e->fq[i].h_info, sizeof(tsdrgpu_pp_frameinfo_t)) == 0;
     for (int i = 0; ok && i < NOUT; i++) ok = tsdrgpu_event_create(e->g, &e->out[i].done) == 0 && tsdrgpu_event_create(e->g, &e->out[i].last_dl) == 0;
     if (!ok) {
         if (e->g) {
-            for (int i = 0; i < NSLOT; i++) tsdrgpu_event_destroy(e->g, e->slot[i].consumed);
+            for (int i = 0; i < NSLOT; i++) { tsdrgpu_event_destroy(e->g, e->slot[i].consumed); tsdrgpu_event_destroy(e->g, e->slot[i].uploaded); }
+            tsdrgpu_free(e->g, e->d_mm_min); tsdrgpu_free(e->g, e->d_mm_max);
             for (int i = 0; i < NFRAMEQ; i++) { tsdrgpu_event_destroy(e->g, e->fq[i].ready); tsdrgpu_free_host(e->g, e->fq[i].h_info); }
             for (int i = 0; i < NOUT; i++) { tsdrgpu_event_destroy(e->g, e->out[i].done); tsdrgpu_event_destroy(e->g, e->out[i].last_dl); }
             tsdrgpu_event_destroy(e->g, e->plot_ready); tsdrgpu_event_destroy(e->g, e->plot_home);
@@ -1158,8 +1318,18 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     {   /* DMA straight out of the plugin's memory only when the plugin promises that it is stable
          * (tsdrplugin_memory_stable, include/TSDRLibraryExt.h); TSDR_GPU_ZEROCOPY=0 / =1 override */
         const char *z = getenv("TSDR_GPU_ZEROCOPY");
+        const int promise = t->plugin.memory_stable ? t->plugin.memory_stable() : 0;
         if (z && (z[0] == '0' || z[0] == '1')) e->zero_copy = z[0] == '1';
-        else e->zero_copy = t->plugin.memory_stable && t->plugin.memory_stable() != 0;
+        else e->zero_copy = (promise & TSDRX_MEMORY_MAPPED) != 0;
+        /* ... and its DMAs overlap the plugin's next blocks only when the plugin also promises that a block's contents stay
+         * untouched while it streams (decided below, once it is known which of its two entry points is used);
+         * TSDR_GPU_ASYNC_UPLOAD=0 waits for every DMA like round 3 did */
+        e->immutable = promise;
+    }
+    {   /* the helper for bounce-buffer copies (only plugins without the promise need it); TSDR_GPU_COPY_THREAD=0: off */
+        const char *c = getenv("TSDR_GPU_COPY_THREAD");
+        pthread_mutex_init(&e->cm, NULL); pthread_cond_init(&e->c_wake, NULL);
+        if (!(c && c[0] == '0') && !e->zero_copy) e->copy_thread_on = pthread_create(&e->th_copy, NULL, copy_thread, e) == 0;
     }
     pthread_mutex_init(&e->qm, NULL); pthread_cond_init(&e->q_nonempty, NULL);
     pthread_mutex_init(&e->fm, NULL); pthread_cond_init(&e->f_nonempty, NULL); pthread_cond_init(&e->f_queued, NULL);
@@ -1180,6 +1350,10 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
      * (TSDRLibraryExt.h) is taken up on it unless TSDR_GPU_RAW=0 */
     const char *rawenv = getenv("TSDR_GPU_RAW");
     const int use_raw = t->plugin.readasync_raw && !(rawenv && rawenv[0] == '0');
+    {
+        const char *a = getenv("TSDR_GPU_ASYNC_UPLOAD");
+        e->immutable = e->zero_copy && !(a && a[0] == '0') && (e->immutable & (use_raw ? TSDRX_MEMORY_IMMUTABLE_RAW : TSDRX_MEMORY_IMMUTABLE)) != 0;
+    }
     const int status = use_raw ? t->plugin.readasync_raw(on_block_raw, e) : t->plugin.readasync(on_block, e);
 
     t->running = 0;
@@ -1190,6 +1364,14 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     pthread_join(th_down, NULL);
     pthread_join(th_video, NULL);
     pthread_join(th_plot, NULL);
+    if (e->copy_thread_on) {
+        pthread_mutex_lock(&e->cm);
+        e->copy_quit = 1;
+        pthread_cond_signal(&e->c_wake);
+        pthread_mutex_unlock(&e->cm);
+        pthread_join(e->th_copy, NULL);
+    }
+    pthread_mutex_destroy(&e->cm); pthread_cond_destroy(&e->c_wake);
 
     if (e->stats) {
         const double T = now_s() - e->t_start;
@@ -1199,11 +1381,15 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
                 "tsdr stats: plugin thread busy %.0f%% (DMA wait %.0f%%) | device thread busy %.0f%% (waiting for output buffers %.0f%%) | "
                 "video thread: waiting for frames %.0f%%, in the callback %.0f%%\n"
                 "tsdr stats: device thread: appending blocks %.0f%% | resampler %.0f%% | frame path %.0f%% | detector %.0f%%\n"
+                "tsdr stats: frames through the fused run %ld in %ld batches | uploads %s\n"
                 "tsdr stats: detector %s | plots held back for an exact replay %ld | epochs replayed %ld\n",
                 T, e->n_blocks, e->n_blocks_lost, e->n_frames_made, e->n_frames_lost, e->n_batches, e->n_resample_calls, e->n_windows, e->nreg,
                 100 * e->s_plugin_busy / T, 100 * e->s_plugin_dma / T, 100 * e->s_dev_busy / T, 100 * e->s_dev_wait_out / T,
                 100 * e->s_video_wait / T, 100 * e->s_video_cb / T,
                 100 * e->s_dev_blocks / T, 100 * (e->s_dev_rs - e->s_dev_frames) / T, 100 * e->s_dev_frames / T, 100 * e->s_dev_det / T,
+                e->n_fused_frames, e->n_fused_batches,
+                e->zero_copy ? (e->immutable ? "straight out of the plugin's memory, DMAs in flight behind the callback" : "straight out of the plugin's memory, each waited for")
+                             : (e->copy_thread_on ? "through pinned bounce buffers (copy in two halves), DMAs in flight behind the callback" : "through pinned bounce buffers"),
                 e->ac_certified ? "certified (float32 + argmax certificate)" : "exact or plain (TSDR_GPU_AUTOCORR)", e->n_plots_held, e->n_promotions);
     }
     tsdrgpu_bind_thread(e->g);
@@ -1220,7 +1406,10 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
         tsdrgpu_free(e->g, e->slot[i].d);
         tsdrgpu_free(e->g, e->slot[i].d_raw);
         tsdrgpu_event_destroy(e->g, e->slot[i].consumed);
+        tsdrgpu_event_destroy(e->g, e->slot[i].uploaded);
     }
+    tsdrgpu_free(e->g, e->d_mm_min);
+    tsdrgpu_free(e->g, e->d_mm_max);
     for (int i = 0; i < NFRAMEQ; i++) {
         tsdrgpu_free_host(e->g, e->fq[i].h);
         tsdrgpu_free_host(e->g, e->fq[i].h_info);

@@ -94,7 +94,12 @@ int tsdrplugin_init(const char *params)
 
 /* include/TSDRLibraryExt.h: the recording (and the conversion block) stay where they are from tsdrplugin_init to
  * tsdrplugin_cleanup, so the library may page-lock them and DMA straight out of them */
-TSDRPLUGIN_API int tsdrplugin_memory_stable(void) { return 1; }
+/* ... and the recording's contents never change: blocks handed over in their native format always point into it, blocks of
+ * the plain callback do when the recording is float32 (narrow formats are converted into one reused block) */
+TSDRPLUGIN_API int tsdrplugin_memory_stable(void)
+{
+    return TSDRX_MEMORY_MAPPED | TSDRX_MEMORY_IMMUTABLE_RAW | (g_type == TSDRX_SAMPLE_FLOAT32 ? TSDRX_MEMORY_IMMUTABLE : 0);
+}
 
 uint32_t tsdrplugin_setsamplerate(uint32_t rate) { (void)rate; return g_rate; }
 uint32_t tsdrplugin_getsamplerate(void) { return g_rate; }

@@ -49,7 +49,10 @@ def load(path=LIB):
     return lib
 
 
-def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, setup=None, free=True):
+RGB_CB = C.CFUNCTYPE(None, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p)
+
+
+def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, setup=None, free=True, rgb=False):
     """Loads `plugin` into the library at `libpath`, lets it stream for `seconds` and counts what reaches the
     callbacks.  Both the reference's pipeline and ours are lossy by design (whole blocks / frames are dropped when a
     stage cannot keep up), so frames delivered per wall second x samples per frame is the effective rate."""
@@ -78,7 +81,12 @@ def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, set
     if setup:
         setup(lib, h)
     status = {}
-    th = threading.Thread(target=lambda: status.setdefault("rc", lib.tsdr_readasync(h, cbs[0], None)))
+    if rgb:  # frames as packed RGB converted on the device (include/TSDRLibraryExt.h)
+        rgb_cb = RGB_CB(lambda buf, w, hh, ctx: on_frame(buf, w, hh, ctx))
+        lib.tsdrx_readasync_rgb.argtypes = [vp, RGB_CB, vp, C.c_int]
+        th = threading.Thread(target=lambda: status.setdefault("rc", lib.tsdrx_readasync_rgb(h, rgb_cb, None, 0)))
+    else:
+        th = threading.Thread(target=lambda: status.setdefault("rc", lib.tsdr_readasync(h, cbs[0], None)))
     th.start()
     time.sleep(warmup)  # device context, buffers, page-locking of the source's memory
     f0, p0, t0 = cnt["frames"], cnt["plots"], time.time()
@@ -92,7 +100,7 @@ def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, set
             "status": status.get("rc")}
 
 
-def throughput_subprocess(libpath, plugin, params, height, fv, seconds, env=None, timeout=120, set_int=(), free=True):
+def throughput_subprocess(libpath, plugin, params, height, fv, seconds, env=None, timeout=120, set_int=(), free=True, rgb=False):
     """throughput_run in a process of its own — what a host application is — started with GPU_MAX_HW_QUEUES=2 like a
     launcher script would (tsdrgpu_core.hip says why) instead of inheriting the caller's runtime state."""
     import json
@@ -103,7 +111,7 @@ def throughput_subprocess(libpath, plugin, params, height, fv, seconds, env=None
     # optimum on MI355X (tsdrgpu_core.hip); a caller's env overrides
     e["GPU_MAX_HW_QUEUES"] = "2"
     e.update(env or {})
-    extra = ["free" if free else "nofree"] + [str(v) for pair in set_int for v in pair]  # tsdr_setparameter_int(id, value) pairs
+    extra = [("free" if free else "nofree") + ("+rgb" if rgb else "")] + [str(v) for pair in set_int for v in pair]  # tsdr_setparameter_int(id, value) pairs
     out = subprocess.run([sys.executable, "-m", "tempestsdr_amd.tsdrlib", libpath, plugin, params, str(height), str(fv), str(seconds)] + extra,
                          env=e, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -119,5 +127,6 @@ if __name__ == "__main__":
     import sys
     a = sys.argv[1:]
     pairs = [(int(a[i]), int(a[i + 1])) for i in range(7, len(a) - 1, 2)]
-    print(json.dumps(throughput_run(a[0], a[1], a[2], int(a[3]), float(a[4]), float(a[5]), free=(len(a) < 7 or a[6] == "free"),
+    print(json.dumps(throughput_run(a[0], a[1], a[2], int(a[3]), float(a[4]), float(a[5]), free=(len(a) < 7 or a[6].startswith("free")),
+                                    rgb=(len(a) >= 7 and a[6].endswith("+rgb")),
                                     setup=(lambda lib, h: [lib.tsdr_setparameter_int(h, i, v) for i, v in pairs]) if pairs else None)))
