@@ -30,9 +30,15 @@ struct RcclApi {
 };
 static RcclApi g_rccl;
 
+static const RcclApi *rccl_load();
+// resolved once, also when several host threads (one per device, host/tsdr_sweep.c) come here at the same time
 static const RcclApi *rccl()
 {
-    if (g_rccl.dl) return &g_rccl;
+    static const RcclApi *const api = rccl_load();
+    return api;
+}
+static const RcclApi *rccl_load()
+{
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *dl = nullptr;
     for (const char *n : names)

@@ -131,3 +131,17 @@ def test_reference_rawfile_plugin_loads(libs):
     assert s.lib.tsdr_loadplugin(s.h, raw.encode(), b"/tmp/x.bin 8000000 float") == 0
     assert s.lib.tsdr_getsamplerate(s.h) == 0
     s.close()
+
+
+def test_sweep_tool_is_built_and_has_no_cpu_path(libs, tmp_path):
+    """tempestsdr_amd/tsdr_sweep (csrc/host/tsdr_sweep.c): the multi-GPU lag sweep's C host; without a HIP device it says so"""
+    tool = os.path.join(os.path.dirname(hu.LIB), "tsdr_sweep")
+    assert os.access(tool, os.X_OK)
+    out = subprocess.run([tool], capture_output=True, text=True)
+    assert out.returncode == 2 and "usage:" in out.stderr
+    import torch
+    if not torch.cuda.is_available():
+        f = tmp_path / "rec.f32"
+        np.zeros(2 * 450909 + 16, np.float32).tofile(f)
+        out = subprocess.run([tool, str(f), "8000000"], capture_output=True, text=True)
+        assert out.returncode == 1 and "no usable HIP device" in out.stderr
