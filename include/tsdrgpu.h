@@ -349,6 +349,12 @@ int tsdrgpu_autocorr_retention(tsdrgpu_autocorr_t *ac, int *ring_windows, int *r
 /* Replays the current epoch in the reference's arithmetic (no-op when it already is exact).  In a sharded run
  * (mode 1 sums + tsdrgpu_autocorr_allreduce) it leaves this rank's exact sums: repeat the all-reduce afterwards. */
 int tsdrgpu_autocorr_promote(tsdrgpu_autocorr_t *ac);
+/* The same replay in bounded steps, for a streaming host that must not stall its queue behind a long epoch's replay (2048
+ * retained windows of 2^22 samples = 0.28 s of transforms): the first call opens it, every call replays up to max_windows
+ * windows, *h_remaining = windows still to go.  While it is > 0 the plots are partial — tsdrgpu_autocorr_run and the
+ * argmax calls return TSDRGPU_ESTATE — and the host skips its capture windows, as the reference's detector thread
+ * does whenever it is busy (frameratedetector.c:128-187 takes a window only when it is idle). */
+int tsdrgpu_autocorr_promote_step(tsdrgpu_autocorr_t *ac, int max_windows, int *h_remaining);
 typedef struct tsdrgpu_ac_certificate {
     int frame_certified, line_certified; /* 1: this plot's argmax is provably the reference's */
     int exact_epoch;                      /* 1: the plots are in the reference's own arithmetic (bit-identical) */

@@ -40,6 +40,7 @@
 #define MAX_FRAME_BATCH 32
 #define FUSE_MIN_FRAMES 8  /* a backlog of at least this many frames takes the fused run (tsdrgpu_postproc_begin_minmax) */
 #define MAX_CHUNKS_PER_CALL 120 /* resampler chunks per call (0.1 frame each): a backlog of 12 frames in one launch group */
+#define DET_REPLAY_STEP 16 /* windows of an exact replay per device-thread turn (2 ms at 2^22 samples): the frame path keeps flowing */
 #define MM_CAP 4096        /* per-frame min/max values kept for frames that wait in the pixel stream */
 #define MAX_HOSTREG 512    /* page-locked ranges of plugin memory */
 #define MAX_HOSTREJ 16     /* ranges that could not be page-locked, remembered so that the call is not repeated */
@@ -120,6 +121,7 @@ struct engine {
     int det_read_valid;
     int ac_certified;          /* the detector runs in its certified mode (default): plots leave only with a certificate */
     volatile int det_promote;  /* plot thread -> device thread: the last plot's argmax was not certified, replay the epoch exactly */
+    int det_replaying;         /* an epoch is being replayed in the reference's arithmetic, DET_REPLAY_STEP windows per turn */
     long n_promotions, n_plots_held;
 
     /* input queue */
@@ -393,13 +395,16 @@ static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, i
     if (!e->t->running || (items & 1)) return;
     if (!e->plugin_thread_bound) { tsdrgpu_bind_thread(e->g); e->plugin_thread_bound = 1; }
     const double t0 = e->stats ? now_s() : 0.0;
-    pthread_mutex_lock(&e->qm);
-    if (e->q_count == NSLOT) { /* device thread is behind: lose the whole block */
+    /* device thread is behind: lose the whole block.  Decided without the queue's mutex — a free-running source whose DMAs we
+     * no longer wait for comes here tens of millions of times per second, and a plugin thread spinning on the mutex starved
+     * the device thread of it (measured: 95 % of the device thread's time went into getting it).  Only this thread raises
+     * q_count, so a queue seen full here can only have become emptier; pending_drop and n_blocks_lost are this thread's own. */
+    if (*(volatile int *)&e->q_count == NSLOT) {
         e->pending_drop += (int64_t)(items / 2) + dropped;
         e->n_blocks_lost++;
-        pthread_mutex_unlock(&e->qm);
         return;
     }
+    pthread_mutex_lock(&e->qm);
     in_slot_t *s = &e->slot[(e->q_head + e->q_count) % NSLOT]; /* only this thread produces: the slot stays ours */
     pthread_mutex_unlock(&e->qm);
     int ok = 1;
@@ -445,12 +450,11 @@ static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, i
         if (e->stats) e->s_plugin_dma += now_s() - t1;
     }
     s->raw_type = type;
-    pthread_mutex_lock(&e->qm);
     if (!ok) { /* could not stage the block: count it as lost, like a full queue */
         e->pending_drop += (int64_t)(items / 2) + dropped;
-        pthread_mutex_unlock(&e->qm);
         return;
     }
+    pthread_mutex_lock(&e->qm);
     s->nfloats = items;
     s->dropped = dropped + e->pending_drop;
     e->pending_drop = 0;
@@ -666,6 +670,7 @@ static void detector_rebuild(struct engine *e, uint32_t fs)
         }
     }
     e->det_promote = 0;
+    e->det_replaying = 0;
     /* The detector's transforms run in line on the COMPUTE lane.  On its own (BACKGROUND) lane they would overlap the
      * frame path, but every window then needs two device-side waits between the lanes, and a barrier packet parked in
      * one hardware queue slows the other queues of the process down (see download_thread): measured 1.8-2.4 GS/s
@@ -742,29 +747,40 @@ static void run_detector(struct engine *e, uint32_t fs)
         if (!e->ac) { e->det.rd = e->det.wr = 0; return; }
     }
     const uint32_t capture = e->ac_capture;
-    if (e->det_promote) { /* the plot thread held a plot back: its epoch once more, in the reference's arithmetic */
+    if (e->det_promote && !e->det_replaying) { /* the plot thread held a plot back: its epoch once more, in the reference's arithmetic */
         pthread_mutex_lock(&e->pm);
         const int busy = e->plot_pending; /* (the plot thread clears it right after raising the request) */
         pthread_mutex_unlock(&e->pm);
         if (!busy) {
             e->det_promote = 0;
-            if (gpu_ok(e, tsdrgpu_autocorr_promote(e->ac), "autocorr promote")) {
-                e->n_promotions++;
-                publish_plot(e);
-            }
+            e->det_replaying = 1;
         }
+    }
+    if (e->det_replaying && !t->detector_purge && !t->params_int[PARAM_AUTOCORR_PLOTS_RESET]) {
+        /* DET_REPLAY_STEP windows per device-thread turn, the frame path's launches in between; the capture windows that
+         * arrive meanwhile are skipped, like the reference's detector thread skips what arrives while it is busy
+         * (frameratedetector.c:128-187).  (A pending reset cancels the replay: the loop below sees to it.) */
+        int remaining = 0;
+        if (!gpu_ok(e, tsdrgpu_autocorr_promote_step(e->ac, DET_REPLAY_STEP, &remaining), "autocorr promote")) return;
+        e->det.rd += ((e->det.wr - e->det.rd) / 2 / capture) * (size_t)capture * 2;
+        if (remaining > 0) return;
+        e->det_replaying = 0;
+        e->n_promotions++;
+        publish_plot(e);
     }
     while ((e->det.wr - e->det.rd) / 2 >= capture && t->running) {
         if (t->detector_purge) { /* frameratedetector.c:171-176 */
             t->detector_purge = 0;
             tsdrgpu_autocorr_reset(e->ac);
             e->det_promote = 0;
+            e->det_replaying = 0;
         }
         if (t->params_int[PARAM_AUTOCORR_PLOTS_RESET]) { /* frameratedetector.c:97-104 */
             const uint32_t orig = t->params_int[PARAM_AUTOCORR_PLOTS_RESET];
             t->params_int[PARAM_AUTOCORR_PLOTS_RESET] = 0;
             tsdrgpu_autocorr_reset(e->ac);
             e->det_promote = 0;
+            e->det_replaying = 0;
             if (orig == 1) {
                 pthread_mutex_lock(&e->pm);
                 e->plot_reset_announce = 1;
@@ -772,6 +788,13 @@ static void run_detector(struct engine *e, uint32_t fs)
                 pthread_mutex_unlock(&e->pm);
             }
         }
+        if (e->ac_certified && !e->det_replaying) {
+            /* a certified epoch that is about to outgrow the retention ring continues in the reference's arithmetic: replayed
+             * here in steps, not by the library in one go (0.28 s of transforms for 2048 windows of 2^22 samples) */
+            int ring = 0, kept = 0, exact = 0;
+            if (tsdrgpu_autocorr_retention(e->ac, &ring, &kept, &exact) == 0 && !exact && ring > 0 && kept + 1 > ring) e->det_replaying = 1;
+        }
+        if (e->det_replaying) return; /* (the next turn starts stepping, above) */
         if (!gpu_ok(e, tsdrgpu_autocorr_run(e->ac, e->det.d + e->det.rd, 1, capture, 1, 0), "autocorr")) return;
         e->det.rd += (size_t)capture * 2;
         e->n_windows++;
@@ -1221,7 +1244,9 @@ static void *device_thread(void *arg)
         }
         /* everything that is queued goes into the sample streams first: when the source runs ahead, the resampler and
          * the frame path below then work on several blocks per launch instead of one */
-        const int head = e->q_head, n = e->q_count;
+        /* ... but at most half of the slots per turn: the plugin thread refills (and the UPLOAD lane fills) the other half
+         * while this one is being worked on */
+        const int head = e->q_head, n = e->q_count > NSLOT / 2 ? NSLOT / 2 : e->q_count;
         pthread_mutex_unlock(&e->qm);
         const double t0 = e->stats ? now_s() : 0.0;
         /* blocks whose DMA may still be in flight (the plugin thread did not wait for it): the UPLOAD lane is in order,

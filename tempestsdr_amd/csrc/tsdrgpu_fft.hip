@@ -84,6 +84,9 @@ struct tsdrgpu_autocorr {
     int since_check;       // plot updates since the last check (-1: none yet)
     unsigned long long *d_check;  // [0] max |fast - exact| as the bits of a non-negative double, [1] the checked window's lag-0 value
     long premise_checks, premise_failures;
+    int premise_broken;    // a check of this epoch failed: no plot of it is certified any more (until it is promoted or reset)
+    // incremental promotion (tsdrgpu_autocorr_promote_step)
+    int replay_rec, replay_win;  // next log record / window inside it to replay; replay_rec < 0: no replay in progress
 };
 // windows per launch of the exact form (TSDRGPU_XBATCH overrides: 1..16)
 static int ac_xbatch()
@@ -861,7 +864,9 @@ __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ 
             p_r0 = __longlong_as_double((long long)check[1]);
             p_ok = (p_err <= 0.5 * kappa * p_r0) ? 1 : 0;
         }
-        const int ok = exact_epoch || (p_ok && (len <= 1 || (a.best - a.second > margin)));
+        // exact_epoch: 1 = the plots are the reference's bits; -1 = an earlier check of this (float32) epoch failed: nothing
+        // of it is certified any more
+        const int ok = exact_epoch > 0 || (exact_epoch == 0 && p_ok && (len <= 1 || (a.best - a.second > margin)));
         if (plot == 0) {
             out->premise_checked = check ? 1 : 0; out->premise_ok = p_ok; out->premise_err = p_err; out->premise_r0 = p_r0;
             if (h_out) { h_out->premise_checked = check ? 1 : 0; h_out->premise_ok = p_ok; h_out->premise_err = p_err; h_out->premise_r0 = p_r0; }
@@ -956,6 +961,7 @@ extern "C" int tsdrgpu_autocorr_create(tsdrgpu_t *g, tsdrgpu_autocorr_t **out, u
     }
     memset(ac->h_arg, 0, sizeof(AcArgHost));
     ac->st = g->stream;
+    ac->replay_rec = -1;
     *out = ac;
     return tsdrgpu_autocorr_reset(ac);
 }
@@ -995,6 +1001,9 @@ extern "C" int tsdrgpu_autocorr_reset(tsdrgpu_autocorr_t *ac)
     ac->epoch_exact = 0;
     ac->log_count = 0;
     ac->ring_count = 0;
+    ac->replay_rec = -1;
+    if (ac->premise_broken) ac->since_check = -1;  // the last epoch broke the premise: the next one is checked at its first update
+    ac->premise_broken = 0;
     HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len + 1), ac->st));
     return TSDRGPU_OK;
 }
@@ -1145,24 +1154,61 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
 
 // Replays the epoch's windows (every run since the last reset) in the reference's own arithmetic: the plots then hold
 // what an exact run of the same calls would have left, and the rest of the epoch runs exact.
+extern "C" int tsdrgpu_autocorr_promote_step(tsdrgpu_autocorr_t *ac, int max_windows, int *h_remaining);
 extern "C" int tsdrgpu_autocorr_promote(tsdrgpu_autocorr_t *ac)
 {
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     if (!ac->certify) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_promote", "certified mode is off (tsdrgpu_autocorr_set_certify)");
-    if (ac->epoch_exact || ac->exact) return TSDRGPU_OK;
-    int rc = ac_ensure_exact(ac);
-    if (rc) return rc;
-    HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len + 1), ac->st));
-    ac->calls = 0;
-    ac->epoch_exact = 1;
-    ac->promotions++;
-    for (int i = 0; i < ac->log_count; i++) {
-        const AcLogRec &r = ac->log[i];
-        if ((rc = ac_run_exact(ac, r.src, r.is_iq, r.stride, r.nwindows, r.mode))) return rc;
+    int remaining = 0;
+    return tsdrgpu_autocorr_promote_step(ac, 0x7fffffff, &remaining);
+}
+
+// The same replay a bounded number of windows at a time, for a host that must not block its queue for the whole of a long
+// epoch (2048 retained windows of 2^22 samples are 0.28 s of transforms): the first call opens the replay (plots zeroed, the
+// epoch marked exact), every call replays up to max_windows windows in order, *h_remaining tells how many are left.  Until
+// it reaches 0 the plots are partial: tsdrgpu_autocorr_run returns TSDRGPU_ESTATE and the host skips (or defers) its windows
+// — the reference's detector thread also correlates only the windows it has time for (frameratedetector.c:128-187).
+extern "C" int tsdrgpu_autocorr_promote_step(tsdrgpu_autocorr_t *ac, int max_windows, int *h_remaining)
+{
+    if (!ac || max_windows < 1) return ac ? tsdr_fail(ac->g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_promote_step", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = ac->g;
+    if (h_remaining) *h_remaining = 0;
+    if (!ac->certify) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_promote", "certified mode is off (tsdrgpu_autocorr_set_certify)");
+    if (ac->exact || (ac->epoch_exact && ac->replay_rec < 0)) return TSDRGPU_OK;
+    int rc;
+    if (ac->replay_rec < 0) {  // open the replay
+        if ((rc = ac_ensure_exact(ac))) return rc;
+        HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len + 1), ac->st));
+        ac->calls = 0;
+        ac->epoch_exact = 1;
+        ac->premise_broken = 0;
+        ac->promotions++;
+        ac->replay_rec = 0;
+        ac->replay_win = 0;
     }
-    ac->log_count = 0;
-    ac->ring_count = 0;  // the ring's windows are read by the replay queued above; later runs of this epoch do not retain
+    int budget = max_windows;
+    while (ac->replay_rec < ac->log_count && budget > 0) {
+        const AcLogRec &r = ac->log[ac->replay_rec];
+        const int left = r.nwindows - ac->replay_win;
+        const int take = left < budget ? left : budget;
+        const float *src = r.src + (size_t)ac->replay_win * (size_t)r.stride * (r.is_iq ? 2 : 1);
+        if ((rc = ac_run_exact(ac, src, r.is_iq, r.stride, take, r.mode))) return rc;
+        budget -= take;
+        ac->replay_win += take;
+        if (ac->replay_win == r.nwindows) { ac->replay_rec++; ac->replay_win = 0; }
+    }
+    if (ac->replay_rec >= ac->log_count) {
+        ac->log_count = 0;
+        ac->ring_count = 0;  // the ring's windows are read by the replay queued above; later runs of this epoch do not retain
+        ac->replay_rec = -1;
+        return TSDRGPU_OK;
+    }
+    if (h_remaining) {
+        long long rem = (long long)ac->log[ac->replay_rec].nwindows - ac->replay_win;
+        for (int i = ac->replay_rec + 1; i < ac->log_count; i++) rem += ac->log[i].nwindows;
+        *h_remaining = rem > 0x7fffffff ? 0x7fffffff : (int)rem;
+    }
     return TSDRGPU_OK;
 }
 
@@ -1177,6 +1223,7 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
         HIP_TRY(g, hipEventRecord(g->fork, g->stream));
         HIP_TRY(g, hipStreamWaitEvent(ac->st, g->fork, 0));
     }
+    if (ac->replay_rec >= 0) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_run", "an incremental promotion is in progress (tsdrgpu_autocorr_promote_step)");
     if (ac->exact || ac->epoch_exact) return ac_run_exact(ac, d_in, in_is_iq, stride, nwindows, mode);
     if (!ac->certify) return ac_run_fast(ac, d_in, in_is_iq, stride, nwindows, mode);
     int rc;
@@ -1338,12 +1385,13 @@ extern "C" int tsdrgpu_autocorr_argmax_async(tsdrgpu_autocorr_t *ac)
     if (!ac) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = ac->g;
     if (ac->arg_pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_argmax_async", "the previous result was not collected");
+    if (ac->replay_rec >= 0) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_argmax", "an incremental promotion is in progress: the plots are partial");
     const int checked = ac_premise_check(ac);
     if (checked < 0) return checked;
     TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_partial, dim3(ARGMAX_BLOCKS, 2), 256, ac->d_plots, ac->frame_len, ac->line_len, ac->d_pval, ac->d_psec,
                 ac->d_pidx);
     TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_argmax_final, 2, 64, ac->d_pval, ac->d_psec, ac->d_pidx, ac->d_plots, ac->frame_len, ac->line_len,
-                (double)TSDRGPU_AC_CERT_KAPPA, (ac->exact || ac->epoch_exact) ? 1 : 0, ac->d_arg, ac->h_arg,
+                (double)TSDRGPU_AC_CERT_KAPPA, (ac->exact || ac->epoch_exact) ? 1 : (ac->premise_broken ? -1 : 0), ac->d_arg, ac->h_arg,
                 (const unsigned long long *)(checked ? ac->d_check : nullptr));
     KERNEL_CHECK(g, "k_argmax");
     HIP_TRY(g, hipEventRecord(ac->ev_arg, ac->st));
@@ -1359,7 +1407,10 @@ extern "C" int tsdrgpu_autocorr_argmax_result(tsdrgpu_autocorr_t *ac, int32_t *f
     HIP_TRY(g, hipEventSynchronize(ac->ev_arg));
     ac->arg_pending = 0;
     ac->res = *ac->h_arg;
-    if (ac->res.premise_checked && !ac->res.premise_ok) ac->premise_failures++;
+    if (ac->res.premise_checked && !ac->res.premise_ok) {
+        ac->premise_failures++;
+        ac->premise_broken = 1;  // sticks until the epoch is promoted or reset
+    }
     if (frame_idx) *frame_idx = ac->res.idx[0];
     if (line_idx) *line_idx = ac->res.idx[1];
     return TSDRGPU_OK;

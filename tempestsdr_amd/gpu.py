@@ -149,6 +149,7 @@ _SIGS = {
     "tsdrgpu_autocorr_set_async": (C.c_int, [vp, C.c_int]),
     "tsdrgpu_autocorr_plots": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
+    "tsdrgpu_autocorr_promote_step": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "tsdrgpu_autocorr_retention": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tsdrgpu_autocorr_device_sums": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
@@ -673,6 +674,12 @@ class Autocorr:
 
     def promote(self):
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_promote(self.h))
+
+    def promote_step(self, max_windows):
+        """incremental promotion: replays up to max_windows windows; returns the windows still to go"""
+        r = C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_promote_step(self.h, int(max_windows), C.byref(r)))
+        return r.value
 
     def retention(self):
         """(ring capacity in windows, windows of the epoch retained, epoch runs in the exact form)"""

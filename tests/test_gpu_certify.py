@@ -260,6 +260,74 @@ def test_epoch_of_several_calls_and_sums(orc):
     ac.destroy()
 
 
+def test_incremental_promotion_equals_the_oracle(orc):
+    """tsdrgpu_autocorr_promote_step: the replay of an epoch in bounded steps (what the streaming engine does so that a long
+    epoch's replay does not stall its queue) leaves the same bits as the one-shot form — the ORACLE's; while it is in
+    progress the object refuses new windows and argmax requests."""
+    g = ctx()
+    fs = 8_000_000
+    ac = gpu.Autocorr(g, fs)
+    ac.set_certify(1)
+    data, is_iq = _windows("raster", fs, 5, ac.capture, 31)
+    d_in = g.to_device(data)
+    o, _ = _oracle_plots(orc, fs, data, is_iq, 5, ac.capture)
+    ac.run(d_in, 1, ac.capture, 2)
+    ac.run(d_in, 1, ac.capture, 3, in_offset=4 * ac.capture)
+    assert ac.promote_step(2) == 3
+    with pytest.raises(gpu.TsdrGpuError):
+        ac.run(d_in, 1, ac.capture, 1)
+    with pytest.raises(gpu.TsdrGpuError):
+        ac.argmax()
+    assert ac.promote_step(2) == 1   # crosses from the first run() call's record into the second
+    assert ac.promote_step(2) == 0
+    f, l, calls = ac.plots()
+    assert calls == 5 and np.array_equal(f, o.frame) and np.array_equal(l, o.line)
+    assert ac.argmax() == (int(np.argmax(o.frame)), int(np.argmax(o.line)))
+    c = ac.certificate()
+    assert c.exact_epoch == 1 and c.promotions == 1
+    assert ac.promote_step(4) == 0  # nothing left to do
+    # the epoch continues exact
+    more, _ = _windows("raster", fs, 1, ac.capture, 32)
+    ac.run(g.to_device(more), 1, ac.capture, 1)
+    o.run(orc.am_demod(more))
+    f, l, calls = ac.plots()
+    assert calls == 6 and np.array_equal(f, o.frame) and np.array_equal(l, o.line)
+    ac.destroy()
+
+
+def test_a_failed_premise_check_sticks_until_the_epoch_is_promoted(orc):
+    """1e-18 amplitudes: the squares inside the reference's float32 magnitude fall into the subnormal range, the float32
+    transform's do not in the same way — the premise is violated (measured 4e-3 * R0).  The first update's check notices;
+    from then on NO plot of the epoch is certified, checked or not, until the epoch has been replayed."""
+    g = ctx()
+    fs = 25_000_000
+    ac = gpu.Autocorr(g, fs)
+    ac.set_certify(2)
+    x = _adversarial("small", fs, ac.capture, 5)
+    d_in = g.to_device(x)
+    o = orc.Autocorr(fs)
+    o.run(x)
+    o.run(x)
+    ac.run(d_in, 0, ac.capture, 1)
+    ac.argmax()
+    c = ac.certificate()
+    assert c.premise_checked == 1 and c.premise_ok == 0 and not (c.frame_certified or c.line_certified)
+    ac.run(d_in, 0, ac.capture, 1)
+    ac.argmax()  # this update carries no check (cadence) ...
+    c = ac.certificate()
+    assert c.premise_checked == 0 and not (c.frame_certified or c.line_certified)  # ... and is uncertified all the same
+    fi, li, promoted = ac.argmax_certified()
+    assert promoted == 1 and (fi, li) == (int(np.argmax(o.frame)), int(np.argmax(o.line)))
+    f, l, _ = ac.plots()
+    assert np.array_equal(f, o.frame) and np.array_equal(l, o.line)
+    # the next epoch starts suspicious: its first update is checked again
+    ac.reset()
+    ac.run(d_in, 0, ac.capture, 1)
+    ac.argmax()
+    assert ac.certificate().premise_checked == 1
+    ac.destroy()
+
+
 def test_ring_overflow_promotes(orc):
     """mode 1 with a ring of two windows: the third window outgrows it, the epoch is replayed and continues exact."""
     g = ctx()
