@@ -131,6 +131,7 @@ struct engine {
     pthread_mutex_t qm;
     pthread_cond_t q_nonempty;
     int plugin_thread_bound;
+    in_slot_t *prev_upload; /* plugin thread: the slot whose DMA was queued by the previous callback */
     int zero_copy;
     int immutable;   /* the plugin promises that a block's CONTENTS stay as they are while tsdrplugin_readasync runs: its DMA may
                         still be in flight when the callback returns (tsdrplugin_memory_stable, bits 1 / 2) */
@@ -446,7 +447,18 @@ static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, i
         /* a failing device call ends the session here as well (gpu_ok; the error text is this thread's own) */
         if (ok) ok = gpu_ok(e, tsdrgpu_upload_lane(e->g, dst, src, bytes), "upload");
         if (ok && wait_dma) ok = gpu_ok(e, tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD), "upload wait");
-        else if (ok) { ok = gpu_ok(e, tsdrgpu_event_record(e->g, s->uploaded, TSDRGPU_LANE_UPLOAD), "upload event"); s->uploaded_valid = ok; }
+        else if (ok) {
+            /* TWO in flight: this block's DMA is queued, then the PREVIOUS block's is waited for — the copy engine always has
+             * the next transfer at hand (one at a time, each waited for, left it idle for ~5-8 us per 45 us block), and the
+             * plugin's thread still advances at the link's pace.  (Queueing without ever waiting was measured and is worse:
+             * 25 GB/s through the lane against 35-41 with waits, and a free-running source then calls in tens of millions of
+             * times per second only to be turned away.) */
+            ok = gpu_ok(e, tsdrgpu_event_record(e->g, s->uploaded, TSDRGPU_LANE_UPLOAD), "upload event");
+            s->uploaded_valid = ok;
+            if (ok && e->prev_upload && e->prev_upload != s && e->prev_upload->uploaded_valid)
+                ok = gpu_ok(e, tsdrgpu_event_sync(e->g, e->prev_upload->uploaded), "upload wait");
+            e->prev_upload = s;
+        }
         if (e->stats) e->s_plugin_dma += now_s() - t1;
     }
     s->raw_type = type;

@@ -85,6 +85,7 @@ struct tsdrgpu_autocorr {
     unsigned long long *d_check;  // [0] max |fast - exact| as the bits of a non-negative double, [1] the checked window's lag-0 value
     long premise_checks, premise_failures;
     int premise_broken;    // a check of this epoch failed: no plot of it is certified any more (until it is promoted or reset)
+    int recheck_next;      // ... and the next float32 epoch is checked at its first update
     // incremental promotion (tsdrgpu_autocorr_promote_step)
     int replay_rec, replay_win;  // next log record / window inside it to replay; replay_rec < 0: no replay in progress
 };
@@ -1002,7 +1003,8 @@ extern "C" int tsdrgpu_autocorr_reset(tsdrgpu_autocorr_t *ac)
     ac->log_count = 0;
     ac->ring_count = 0;
     ac->replay_rec = -1;
-    if (ac->premise_broken) ac->since_check = -1;  // the last epoch broke the premise: the next one is checked at its first update
+    if (ac->recheck_next) ac->since_check = -1;  // the last epoch broke the premise: this one is checked at its first update
+    ac->recheck_next = 0;
     ac->premise_broken = 0;
     HIP_TRY(g, hipMemsetAsync(ac->d_plots, 0, sizeof(double) * ((size_t)ac->frame_len + ac->line_len + 1), ac->st));
     return TSDRGPU_OK;
@@ -1361,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_premise_diff(const float *__restrict__ 
 static int ac_premise_check(tsdrgpu_autocorr_t *ac)
 {
     tsdrgpu_t *g = ac->g;
-    if (!ac->certify || ac->exact || ac->epoch_exact || ac->check_every <= 0 || ac->log_count <= 0 || !ac->d_last || ac->last_exact) return 0;
+    if (!ac->certify || ac->exact || ac->epoch_exact || ac->premise_broken || ac->check_every <= 0 || ac->log_count <= 0 || !ac->d_last || ac->last_exact) return 0;
     if (ac->since_check >= 0 && ac->since_check + 1 < ac->check_every) { ac->since_check++; return 0; }
     int rc = ac_ensure_exact(ac);
     if (rc) return rc;
@@ -1410,6 +1412,7 @@ extern "C" int tsdrgpu_autocorr_argmax_result(tsdrgpu_autocorr_t *ac, int32_t *f
     if (ac->res.premise_checked && !ac->res.premise_ok) {
         ac->premise_failures++;
         ac->premise_broken = 1;  // sticks until the epoch is promoted or reset
+        ac->recheck_next = 1;
     }
     if (frame_idx) *frame_idx = ac->res.idx[0];
     if (line_idx) *line_idx = ac->res.idx[1];
