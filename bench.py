@@ -666,7 +666,7 @@ def main():
             acs_ = gpu.Autocorr(g, fs)
             acs_.set_plan(args.plan)
             acs_.set_certify(1)
-            ring, _, _ = acs_.retention()
+            ring, _, _, _ = acs_.retention()
             acs_.run(d_iq, 1, acs_.capture, nwin, mode=0)
             acs_.argmax()
             acs_.reset()
@@ -685,12 +685,13 @@ def main():
             g.sync()
             tx = time.perf_counter() - tx
             c_ = acs_.certificate()
-            _, kept, is_exact = acs_.retention()
+            _, ring_ready, kept, is_exact = acs_.retention()
             steady = {"epoch_windows": reps * nwin, "ms_per_window": round(tx / (reps * nwin) * 1e3, 4),
                       "windows_per_s": round(reps * nwin / tx, 1), "realtime_factor": round(reps * nwin * acs_.capture / tx / fs, 1),
                       "transform_at_the_end": "exact (reference arithmetic): the epoch was promoted" if is_exact else
                                               "float32 three-trip, certified (tsdrgpu_autocorr_set_certify mode 1)",
-                      "ring_windows": ring, "ring_GiB": round(ring * 4.0 * acs_.n / 2 ** 30, 2), "windows_retained": kept,
+                      "ring_windows": ring, "ring_GiB": round(ring * 4.0 * acs_.n / 2 ** 30, 2), "ring_windows_allocated_at_the_end": ring_ready,
+                      "ring_position": kept,
                       "plot_updates": reps, "plot_updates_uncertified": updates_held, "epochs_replayed_exact": int(c_.promotions),
                       "premise_checks": int(c_.premise_checks), "premise_failures": int(c_.premise_failures),
                       "premise_err_over_r0": (float(c_.premise_err) / float(c_.premise_r0)) if c_.premise_r0 else None,

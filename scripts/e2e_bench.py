@@ -88,9 +88,8 @@ def main():
     leg("mi355x_mem_plugin_rgb_out", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0", rgb=True)
     if args.variants:
         base = (tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {block} 0 0")
-        leg("variant_uploads_waited_for", *base, {"TSDR_GPU_ASYNC_UPLOAD": "0"})
+        leg("variant_two_uploads_in_flight", *base, {"TSDR_GPU_ASYNC_UPLOAD": "1"})
         leg("variant_ring_1GiB", *base, {"TSDR_GPU_AUTOCORR_RETAIN_MB": "1024"})
-        leg("variant_ring_1GiB_uploads_waited_for", *base, {"TSDR_GPU_AUTOCORR_RETAIN_MB": "1024", "TSDR_GPU_ASYNC_UPLOAD": "0"})
         leg("variant_no_premise_check", *base, {"TSDRGPU_AC_CHECK_EVERY": "0"})
         leg("variant_plots_off", *base, set_int=[(3, 1)])
         leg("variant_block_8MiB", tsdrlib.LIB, tsdrlib.MEM_PLUGIN, f"{path} {args.fs} {4 * block} 0 0")

@@ -132,6 +132,7 @@ struct engine {
     pthread_cond_t q_nonempty;
     int plugin_thread_bound;
     in_slot_t *prev_upload; /* plugin thread: the slot whose DMA was queued by the previous callback */
+    int async_upload;       /* TSDR_GPU_ASYNC_UPLOAD=1 */
     int zero_copy;
     int immutable;   /* the plugin promises that a block's CONTENTS stay as they are while tsdrplugin_readasync runs: its DMA may
                         still be in flight when the callback returns (tsdrplugin_memory_stable, bits 1 / 2) */
@@ -141,7 +142,7 @@ struct engine {
     pthread_mutex_t cm;
     pthread_cond_t c_wake;
     volatile int copy_state; /* 0 idle, 1 job posted, 2 done */
-    volatile int copy_quit, copy_sleeping;
+    volatile int copy_quit;
     void *copy_dst; const void *copy_src; size_t copy_n;
     /* per-frame min/max out of the resampler (frame tracking) for the frames that wait in the pixel stream: what the
      * fused run needs instead of a statistics read of its own */
@@ -362,9 +363,7 @@ static void *copy_thread(void *arg)
         if (e->copy_quit) break;
         if (now_s() - last < 300e-6) { __builtin_ia32_pause(); continue; }
         pthread_mutex_lock(&e->cm);
-        e->copy_sleeping = 1;
         while (e->copy_state != 1 && !e->copy_quit) pthread_cond_wait(&e->c_wake, &e->cm);
-        e->copy_sleeping = 0;
         pthread_mutex_unlock(&e->cm);
     }
     return NULL;
@@ -377,13 +376,12 @@ static void bounce_copy(struct engine *e, void *dst, const void *src, size_t n)
     e->copy_dst = (char *)dst + half;
     e->copy_src = (const char *)src + half;
     e->copy_n = n - half;
-    __sync_synchronize();
+    /* posted under the helper's mutex: a flag read outside it ("is the helper asleep?") can miss a helper that is just
+     * going to sleep (store-load reordering on both sides) — that was a deadlock */
+    pthread_mutex_lock(&e->cm);
     e->copy_state = 1;
-    if (e->copy_sleeping) {
-        pthread_mutex_lock(&e->cm);
-        pthread_cond_signal(&e->c_wake);
-        pthread_mutex_unlock(&e->cm);
-    }
+    pthread_cond_signal(&e->c_wake);
+    pthread_mutex_unlock(&e->cm);
     memcpy(dst, src, half);
     while (e->copy_state != 2) __builtin_ia32_pause();
     __sync_synchronize();
@@ -436,8 +434,9 @@ static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, i
                 s->h = NULL; s->hcap = 0;
                 if (gpu_ok(e, tsdrgpu_alloc_host(e->g, (void **)&s->h, (size_t)items * sizeof(float)), "pinned bounce buffer")) s->hcap = items; else ok = 0;
             }
-            /* the copy is what has to be complete on return; the DMA out of OUR buffer then runs behind the callback's back */
-            if (ok) { bounce_copy(e, s->h, buf, bytes); src = s->h; }
+            /* the copy is what has to be complete on return; the DMA out of OUR buffer could run behind the callback's back
+             * (TSDR_GPU_ASYNC_UPLOAD=1) but is waited for by default, see engine_run */
+            if (ok) { bounce_copy(e, s->h, buf, bytes); src = s->h; wait_dma = !e->async_upload; }
         } else if (ok) {
             /* straight out of the plugin's memory: the block is the plugin's again when we return — unless it promised that
              * its contents do not change while it streams (a recording): then this DMA and the next ones overlap */
@@ -803,8 +802,8 @@ static void run_detector(struct engine *e, uint32_t fs)
         if (e->ac_certified && !e->det_replaying) {
             /* a certified epoch that is about to outgrow the retention ring continues in the reference's arithmetic: replayed
              * here in steps, not by the library in one go (0.28 s of transforms for 2048 windows of 2^22 samples) */
-            int ring = 0, kept = 0, exact = 0;
-            if (tsdrgpu_autocorr_retention(e->ac, &ring, &kept, &exact) == 0 && !exact && ring > 0 && kept + 1 > ring) e->det_replaying = 1;
+            int ring = 0, ready = 0, kept = 0, exact = 0; /* (ready: what of the ring is allocated so far, tsdrgpu.h) */
+            if (tsdrgpu_autocorr_retention(e->ac, &ring, &ready, &kept, &exact) == 0 && !exact && ring > 0 && kept + 1 > ready) e->det_replaying = 1;
         }
         if (e->det_replaying) return; /* (the next turn starts stepping, above) */
         if (!gpu_ok(e, tsdrgpu_autocorr_run(e->ac, e->det.d + e->det.rd, 1, capture, 1, 0), "autocorr")) return;
@@ -1387,9 +1386,12 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
      * (TSDRLibraryExt.h) is taken up on it unless TSDR_GPU_RAW=0 */
     const char *rawenv = getenv("TSDR_GPU_RAW");
     const int use_raw = t->plugin.readasync_raw && !(rawenv && rawenv[0] == '0');
-    {
+    {   /* TSDR_GPU_ASYNC_UPLOAD=1 opts in to leaving a block's DMA in flight when the callback returns (two in flight at a
+         * time).  Measured on MI355X it is SLOWER than waiting for every DMA — 20-25 GB/s through the UPLOAD lane against
+         * 35-41 GB/s (profiles/round4_e2e_variants.txt) — so the default waits, as in round 3. */
         const char *a = getenv("TSDR_GPU_ASYNC_UPLOAD");
-        e->immutable = e->zero_copy && !(a && a[0] == '0') && (e->immutable & (use_raw ? TSDRX_MEMORY_IMMUTABLE_RAW : TSDRX_MEMORY_IMMUTABLE)) != 0;
+        e->async_upload = a && a[0] == '1';
+        e->immutable = e->async_upload && e->zero_copy && (e->immutable & (use_raw ? TSDRX_MEMORY_IMMUTABLE_RAW : TSDRX_MEMORY_IMMUTABLE)) != 0;
     }
     const int status = use_raw ? t->plugin.readasync_raw(on_block_raw, e) : t->plugin.readasync(on_block, e);
 
@@ -1426,7 +1428,9 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
                 100 * e->s_dev_blocks / T, 100 * (e->s_dev_rs - e->s_dev_frames) / T, 100 * e->s_dev_frames / T, 100 * e->s_dev_det / T,
                 e->n_fused_frames, e->n_fused_batches,
                 e->zero_copy ? (e->immutable ? "straight out of the plugin's memory, DMAs in flight behind the callback" : "straight out of the plugin's memory, each waited for")
-                             : (e->copy_thread_on ? "through pinned bounce buffers (copy in two halves), DMAs in flight behind the callback" : "through pinned bounce buffers"),
+                             : (e->copy_thread_on ? (e->async_upload ? "through pinned bounce buffers (copy in two halves), DMAs in flight behind the callback"
+                                                                       : "through pinned bounce buffers (copy in two halves), each waited for")
+                                                  : "through pinned bounce buffers"),
                 e->ac_certified ? "certified (float32 + argmax certificate)" : "exact or plain (TSDR_GPU_AUTOCORR)", e->n_plots_held, e->n_promotions);
     }
     tsdrgpu_bind_thread(e->g);

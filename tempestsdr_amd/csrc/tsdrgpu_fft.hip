@@ -12,6 +12,12 @@
 #include "tsdrgpu_internal.h"
 #include "fft4step.h"
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 // windows per launch of the float32 plan (TSDRGPU_AC_SUBBATCH overrides for experiments: 1..32)
 static int ac_subbatch()
 {
@@ -42,6 +48,67 @@ struct AcArgHost {
     int premise_checked;   // this update carried a runtime check of the certificate's premise (ac_premise_check)
     int premise_ok;        // ... and the float32 window lay within (KAPPA / 2) * R0 of the reference's arithmetic
     double premise_err, premise_r0;  // max |fast - exact| over the lag windows of the checked window, its lag-0 value
+};
+
+// The retention ring of the certified mode (tsdrgpu_autocorr_set_certify mode 1) in SEGMENTS that a background thread
+// allocates ahead of need.  Fresh device memory costs 40-80 ms per GiB on MI355X the first time it is used (measured,
+// scripts/micro/malloc_bench.hip: hipMalloc of 32 GiB takes 1.4-2.6 s) — in one piece at detector start that was a
+// multi-second stall of the caller's thread, and as lazy pieces on the detector's own lane a hiccup every 64 windows.  So:
+// segment 0 is there when set_certify returns, segment k + 1 is allocated and touched (on a stream of the thread's own)
+// while the detector fills segment k; a consumer that outruns the allocator finds no room and promotes the epoch, like one
+// that outgrows the whole ring.
+struct AcRing {
+    tsdrgpu_t *g = nullptr;
+    size_t seg_bytes = 0;
+    int seg_windows = 0, nseg_max = 0;
+    std::vector<float *> seg;
+    std::atomic<int> ready{0};
+    int want = 0;
+    bool quit = false, failed = false;
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread th;
+
+    bool alloc_one(hipStream_t st)
+    {
+        float *p = nullptr;
+        if (hipMalloc(&p, seg_bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        // the first use of fresh memory is what costs: paid here
+        if (hipMemsetAsync(p, 0, seg_bytes, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(p); return false; }
+        seg[ready.load(std::memory_order_relaxed)] = p;
+        ready.fetch_add(1, std::memory_order_release);
+        return true;
+    }
+    void run()
+    {
+        (void)hipSetDevice(g->device);
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || (!failed && want > ready.load() && ready.load() < nseg_max); });
+            if (quit) break;
+            lk.unlock();
+            const bool ok = alloc_one(st);
+            lk.lock();
+            if (!ok) failed = true;  // no more room on the device: the ring stays as big as it got
+        }
+        lk.unlock();
+        if (st) (void)hipStreamDestroy(st);
+    }
+    void ask(int nseg)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (nseg > want) { want = nseg; cv.notify_one(); }
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_one(); }
+        if (th.joinable()) th.join();
+        for (int i = 0; i < ready.load(); i++) (void)hipFree(seg[i]);
+        seg.clear();
+        ready.store(0);
+    }
 };
 
 struct tsdrgpu_autocorr {
@@ -77,8 +144,8 @@ struct tsdrgpu_autocorr {
     int promotions;    // epochs promoted so far (diagnostics)
     AcLogRec *log;
     int log_count, log_cap;
-    float *d_ring;     // certify == 1: ring_cap windows of n magnitudes
-    int ring_cap, ring_count;
+    AcRing *ring;      // certify == 1: segments of seg_windows windows of n magnitudes each
+    int ring_cap, ring_count;  // capacity when every segment is there / position of the next window (windows)
     // runtime check of the certificate's premise (ac_premise_check)
     int check_every;       // every n-th plot update of a float32 epoch (0: never); the first update after set_certify always
     int since_check;       // plot updates since the last check (-1: none yet)
@@ -987,7 +1054,7 @@ extern "C" void tsdrgpu_autocorr_destroy(tsdrgpu_autocorr_t *ac)
     (void)hipFree(ac->d_tw);
     (void)hipFree(ac->d_xz);
     (void)hipFree(ac->d_xmag);
-    (void)hipFree(ac->d_ring);
+    if (ac->ring) { ac->ring->stop(); delete ac->ring; }
     (void)hipFree(ac->d_check);
     free(ac->log);
     free(ac);
@@ -1214,6 +1281,22 @@ extern "C" int tsdrgpu_autocorr_promote_step(tsdrgpu_autocorr_t *ac, int max_win
     return TSDRGPU_OK;
 }
 
+// where the next `nwindows` windows of the epoch go in the ring (a call's windows lie in one segment), or nullptr when they
+// do not fit — the ring is full, or the allocator has not got that far yet
+static float *ac_ring_slot(tsdrgpu_autocorr_t *ac, int nwindows, int *pos_out)
+{
+    AcRing *rg = ac->ring;
+    if (!rg || nwindows > rg->seg_windows) return nullptr;
+    const int W = rg->seg_windows;
+    int pos = ac->ring_count;
+    if (pos % W + nwindows > W) pos = (pos / W + 1) * W;  // the rest of this segment stays empty
+    const int si = pos / W;
+    if (si >= rg->nseg_max || si >= rg->ready.load(std::memory_order_acquire)) return nullptr;
+    rg->ask(si + 2);  // the next segment is made while this one fills
+    *pos_out = pos;
+    return rg->seg[si] + (size_t)(pos % W) * ac->n;
+}
+
 extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, int64_t stride, int nwindows, int mode)
 {
     if (!ac || !d_in || nwindows < 0 || stride < 0) return ac ? tsdr_fail(ac->g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "bad argument") : TSDRGPU_EINVAL;
@@ -1241,15 +1324,16 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     }
     // the library keeps them: the first n samples of every window, demodulated, into the ring; the float32 transform
     // then reads the ring.  An epoch that outgrows the ring is replayed exactly once and continues in the exact form.
-    if (ac->ring_count + nwindows > ac->ring_cap || ac->log_count >= ac->log_cap) {
+    int pos = 0;
+    float *slot = ac->log_count >= ac->log_cap ? nullptr : ac_ring_slot(ac, nwindows, &pos);
+    if (!slot) {
         if ((rc = tsdrgpu_autocorr_promote(ac))) return rc;
         return ac_run_exact(ac, d_in, in_is_iq, stride, nwindows, mode);
     }
-    float *slot = ac->d_ring + (size_t)ac->ring_count * ac->n;
     if ((rc = fftx_retain(g, ac->st, d_in, in_is_iq, (long long)stride, nwindows, ac->n, slot))) return rc;
     const AcLogRec r = {slot, 0, (long long)ac->n, nwindows, mode};
     ac->log[ac->log_count++] = r;
-    ac->ring_count += nwindows;
+    ac->ring_count = pos + nwindows;
     return ac_run_fast(ac, slot, 0, (long long)ac->n, nwindows, mode);
 }
 
@@ -1526,8 +1610,7 @@ extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, si
         const int rc = tsdrgpu_autocorr_reset(ac);
         if (rc) return rc;
     }
-    (void)hipFree(ac->d_ring);
-    ac->d_ring = nullptr;
+    if (ac->ring) { ac->ring->stop(); delete ac->ring; ac->ring = nullptr; }
     ac->ring_cap = ac->ring_count = 0;
     free(ac->log);
     ac->log = nullptr;
@@ -1553,18 +1636,37 @@ extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, si
             if (retain_bytes > ((size_t)32 << 30)) retain_bytes = (size_t)32 << 30;
             if (retain_bytes < ((size_t)256 << 20)) retain_bytes = (size_t)256 << 20;
         }
-        size_t w = retain_bytes / (sizeof(float) * (size_t)ac->n);
+        const size_t win_bytes = sizeof(float) * (size_t)ac->n;
+        size_t w = retain_bytes / win_bytes;
         if (w < 1) w = 1;
         if (w > 65535) w = 65535;
-        if (hipMalloc(&ac->d_ring, sizeof(float) * (size_t)ac->n * w) != hipSuccess)
+        // segments of about 1 GiB (TSDRGPU_AC_SEGMENT_MB), at least 32 windows, never more than the whole ring
+        const char *sm = getenv("TSDRGPU_AC_SEGMENT_MB");
+        const size_t seg_target = (sm && atol(sm) > 0) ? (size_t)atol(sm) << 20 : (size_t)1 << 30;
+        size_t sw = seg_target / win_bytes;
+        if (sw < 32) sw = 32;
+        if (sw > w) sw = w;
+        AcRing *rg = new (std::nothrow) AcRing();
+        if (!rg) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_set_certify", "retention ring");
+        rg->g = g;
+        rg->seg_windows = (int)sw;
+        rg->seg_bytes = sw * win_bytes;
+        rg->nseg_max = (int)(w / sw);
+        if (rg->nseg_max < 1) rg->nseg_max = 1;
+        rg->seg.assign((size_t)rg->nseg_max, nullptr);
+        if (!rg->alloc_one(ac->st)) {  // segment 0 is there when this call returns
+            delete rg;
             return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_set_certify", "retention ring");
-        ac->ring_cap = (int)w;
-        if (cap < (int)w) cap = (int)w;
+        }
+        rg->want = rg->nseg_max > 1 ? 2 : 1;
+        if (rg->nseg_max > 1) rg->th = std::thread([rg] { rg->run(); });
+        ac->ring = rg;
+        ac->ring_cap = rg->nseg_max * rg->seg_windows;
+        if (cap < ac->ring_cap) cap = ac->ring_cap;
     }
     ac->log = (AcLogRec *)malloc(sizeof(AcLogRec) * (size_t)cap);
     if (!ac->log) {
-        (void)hipFree(ac->d_ring);
-        ac->d_ring = nullptr;
+        if (ac->ring) { ac->ring->stop(); delete ac->ring; ac->ring = nullptr; }
         ac->ring_cap = 0;
         return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_set_certify", "log");
     }
@@ -1573,11 +1675,13 @@ extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, si
     return TSDRGPU_OK;
 }
 
-extern "C" int tsdrgpu_autocorr_retention(tsdrgpu_autocorr_t *ac, int *ring_windows, int *retained_windows, int *epoch_is_exact)
+extern "C" int tsdrgpu_autocorr_retention(tsdrgpu_autocorr_t *ac, int *ring_windows, int *ring_ready, int *retained_windows, int *epoch_is_exact)
 {
     if (!ac) return TSDRGPU_EINVAL;
-    if (ring_windows) *ring_windows = ac->certify == 1 ? ac->ring_cap : 0;
-    if (retained_windows) *retained_windows = ac->certify == 1 ? ac->ring_count : 0;
+    const int on = ac->certify == 1 && ac->ring;
+    if (ring_windows) *ring_windows = on ? ac->ring_cap : 0;
+    if (ring_ready) *ring_ready = on ? ac->ring->ready.load() * ac->ring->seg_windows : 0;
+    if (retained_windows) *retained_windows = on ? ac->ring_count : 0;
     if (epoch_is_exact) *epoch_is_exact = (ac->exact || ac->epoch_exact) ? 1 : 0;
     return TSDRGPU_OK;
 }

@@ -150,7 +150,7 @@ _SIGS = {
     "tsdrgpu_autocorr_plots": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_promote_step": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
-    "tsdrgpu_autocorr_retention": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tsdrgpu_autocorr_retention": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tsdrgpu_autocorr_device_sums": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
     "tsdrgpu_autocorr_set_exact": (C.c_int, [vp, C.c_int]),
@@ -682,10 +682,10 @@ class Autocorr:
         return r.value
 
     def retention(self):
-        """(ring capacity in windows, windows of the epoch retained, epoch runs in the exact form)"""
-        a, b, c = C.c_int(), C.c_int(), C.c_int()
-        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_retention(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        return a.value, b.value, bool(c.value)
+        """(ring capacity in windows, the part of it allocated so far, position of the epoch's next window, epoch runs in the exact form)"""
+        a, r, b, c = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_retention(self.h, C.byref(a), C.byref(r), C.byref(b), C.byref(c)))
+        return a.value, r.value, b.value, bool(c.value)
 
     def certificate(self):
         c = AcCertificate()
