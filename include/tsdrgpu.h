@@ -267,6 +267,35 @@ int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out_band, tsdr
  * decision was a toss-up.  Synchronises.  With exact ties off it is _band_finish. */
 int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_out_band, int band_index, int nbands, double **d_buf,
                                   int64_t *n_buf, int *h_more, tsdrgpu_pp_frameinfo_t *h_info);
+/* The band run in its GENERAL form: every stage order of dsp_post_process (dsp.c:134-239: PARAM_LOW_PASS_BEFORE_SYNC,
+ * PARAM_AUTOGAIN_AFTER_PROCESSING — the GUI's default order among them), PARAM_INT_AUTOSHIFT (the 2-D roll,
+ * syncdetector.c:187-207) and PARAM_INT_FRAMERATE_PLL (syncdetector.c:133-153; replicated: every rank computes the same
+ * nudge, reported in h_info — pass one frame per run then, as with tsdrgpu_postproc_run).  `edges` = the row edges of all
+ * nbands bands (nbands + 1 values from 0 to height, each band starting on a multiple of 32 rows), band_index = this rank's.
+ *     tsdrgpu_postproc_band_open(pp, d_band, F, W, H, edges, nbands, my_band, &prm);
+ *     do { tsdrgpu_postproc_band_step(pp, d_out_band, &x, h_info);
+ *          switch (x.kind) {                       // every rank is asked for the same collective at the same step
+ *          case TSDRGPU_BAND_SUM_F64:       tsdrgpu_comm_allreduce_f64(comm, x.d_buf, x.count, lane);            break;
+ *          case TSDRGPU_BAND_MAX_F32:       tsdrgpu_comm_allreduce_f32max(comm, x.d_buf, x.count, lane);         break;
+ *          case TSDRGPU_BAND_ALLGATHER_F32: tsdrgpu_comm_allgather_f32(comm, x.d_buf, x.count, lane);            break; }
+ *     } while (x.kind != TSDRGPU_BAND_DONE);
+ * The all-gather (count floats PER RANK, rank r's part at r * count) only occurs with autoshift: the roll moves rows
+ * across bands, so every rank receives the frames once (F * height * width floats per batch over xGMI; 27 MB per frame at
+ * 2962 x 2250).  Frames and per-frame records are bit-identical to tsdrgpu_postproc_run with the same parameters in its
+ * default, contract-exact mode, i.e. to the reference; the library-default order without autoshift gives what
+ * _band_begin / _band_advance give. */
+#define TSDRGPU_BAND_DONE 0
+#define TSDRGPU_BAND_SUM_F64 1
+#define TSDRGPU_BAND_MAX_F32 2
+#define TSDRGPU_BAND_ALLGATHER_F32 3
+typedef struct tsdrgpu_band_exchange {
+    int kind;      /* TSDRGPU_BAND_*: what the caller has to do with d_buf before the next step */
+    void *d_buf;   /* device buffer, reduced / gathered IN PLACE over the ranks */
+    int64_t count; /* elements (doubles or floats; per rank for the all-gather) */
+} tsdrgpu_band_exchange_t;
+int tsdrgpu_postproc_band_open(tsdrgpu_postproc_t *pp, const float *d_band, int nframes, int width, int height, const int *edges, int nbands,
+                               int band_index, const tsdrgpu_pp_params_t *params);
+int tsdrgpu_postproc_band_step(tsdrgpu_postproc_t *pp, float *d_out_band, tsdrgpu_band_exchange_t *x, tsdrgpu_pp_frameinfo_t *h_info);
 /* The per-frame record of the last run, without a host synchronisation: packs nframes tsdrgpu_pp_frameinfo_t
  * into the caller's DEVICE buffer on the COMPUTE lane (download it on any lane behind an event). */
 int tsdrgpu_postproc_info_pack(tsdrgpu_postproc_t *pp, tsdrgpu_pp_frameinfo_t *d_info, int nframes);

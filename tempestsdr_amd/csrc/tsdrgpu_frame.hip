@@ -82,7 +82,8 @@ struct tsdrgpu_postproc {
     int pending;                // 1: begin() done, chain queued on the side stream; 2: begin() deferred everything;
                                 // 3: fused run (begin_minmax) queued completely, finish() only joins the streams;
                                 // 4: the flat fused run (finish() also queues the gated literal pass);
-                                // PEND_BAND: a row-band run — only band_finish / band_advance close it
+                                // PEND_BAND: a row-band run — only band_finish / band_advance close it;
+                                // PEND_BAND + 1: a general band run (band_open) — band_step closes it
 #define PEND_BAND 5
     const float *p_frames;
     // row-band sharding (tsdrgpu_postproc_band_begin / _finish)
@@ -100,6 +101,17 @@ struct tsdrgpu_postproc {
     int *h_flags;               // host copy of a flag array [2F]
     double *d_relay;            // [items][nmax]: sums so far (f32 values carried as f64 through the sum all-reduce)
     size_t cap_items, cap_hflags, cap_relay;
+    // general band runs (tsdrgpu_postproc_band_open / _band_step): every stage order, autoshift, PLL
+    struct BandOp { int op, a, b, c; } bprog[24];
+    int bprog_n, bprog_pc;
+    int bsync_stage, bsync_norm;   // the sync detector's sub-machine (relays)
+    int bnbands, bindex, brows_max;
+    int bedges[65];                // row edges of all bands
+    int *d_bedges;
+    const float *bsrc[4];          // the band buffers a program works on: input, tmp1, tmp2, output
+    const float *brelay_src;       // the buffer whose strips are being collapsed
+    float *d_gather;               // [nbands][F][rows_max][W]: the frames every rank needs rows of for the 2-D roll
+    size_t cap_gather;
     const float *ext_fmin, *ext_fmax;  // per-frame min/max supplied by the caller (fused run), else null
     float *p_out;                      // the fused run's frame buffer (given to _begin_minmax; _finish must name the same)
     int *clear_with_autogain;          // a device flag the next autogain chain launch zeroes (null: none)
@@ -1549,7 +1561,7 @@ extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
     (void)hipEventDestroy(pp->ev_chain);
     void *bufs[] = {pp->d_state, pp->d_odd, pp->d_screen, pp->d_screen2, pp->d_dump, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
                     pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain, pp->d_sflag, pp->d_exact,
-                    pp->d_xsum, pp->d_xmax, pp->d_v0, pp->d_chain_band, pp->d_items, pp->d_relay};
+                    pp->d_xsum, pp->d_xmax, pp->d_v0, pp->d_chain_band, pp->d_items, pp->d_relay, pp->d_gather, pp->d_bedges};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (pp->h_chain) (void)hipHostFree(pp->h_chain);
@@ -2033,8 +2045,8 @@ extern "C" int tsdrgpu_postproc_finish(tsdrgpu_postproc_t *pp, float *d_out, tsd
 {
     if (!pp || !d_out) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_finish", "bad argument") : TSDRGPU_EINVAL;
     if (!pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_finish", "no split run is open");
-    if (pp->pending == PEND_BAND)
-        return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_finish", "a band run is open: tsdrgpu_postproc_band_finish / _band_advance close it");
+    if (pp->pending >= PEND_BAND)
+        return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_finish", "a band run is open: tsdrgpu_postproc_band_finish / _band_advance / _band_step close it");
     tsdrgpu_t *g = pp->g;
     const int mode = pp->pending;
     if ((mode == 3 || mode == 4) && d_out != pp->p_out)  // the run stays open: the caller can still finish it properly
@@ -2159,6 +2171,7 @@ extern "C" int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *
     pp->band_y0 = y0;
     pp->band_rows = rows;
     pp->band_stage = 0;
+    pp->brelay_src = nullptr;
     pp->pending = PEND_BAND;
     if (d_xsum) *d_xsum = pp->d_xsum;
     if (n_xsum) *n_xsum = (int64_t)F * 3 * (W + Htot);
@@ -2308,8 +2321,9 @@ static int band_relay_step(tsdrgpu_postproc_t *pp, int band_index)
     if (pp->relay_step != band_index || pp->relay_step == 0) HIP_TRY(g, hipMemsetAsync(pp->d_relay, 0, bytes, g->stream));
     if (pp->relay_step == band_index) {
         const int longest = W > pp->band_rows ? W : pp->band_rows;
-        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_band_relay, dim3((longest + 255) / 256, pp->relay_items), 256, pp->d_items, nmax, pp->p_frames,
-                    (long long)W * pp->band_rows, W, pp->band_rows, pp->band_y0, pp->d_chain, 1, pp->d_relay);
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_band_relay, dim3((longest + 255) / 256, pp->relay_items), 256, pp->d_items, nmax,
+                    pp->brelay_src ? pp->brelay_src : pp->p_frames, (long long)W * pp->band_rows, W, pp->band_rows, pp->band_y0, pp->d_chain,
+                    pp->brelay_src ? pp->bsync_norm : 1, pp->d_relay);
         KERNEL_CHECK(g, "k_band_relay");
     }
     return TSDRGPU_OK;
@@ -2416,6 +2430,385 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
             if (h_info) return pp_copy_info(pp, F, h_info);
             return TSDRGPU_OK;
         }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// General band runs: every stage order of dsp_post_process (dsp.c:134-239), autoshift (syncdetector.c:187-207) and the
+// frame-rate PLL (syncdetector.c:133-153) with the frame path sharded by rows.  tsdrgpu_postproc_band_open compiles the
+// stage order into a short program of steps; tsdrgpu_postproc_band_step runs it until it needs the other ranks and tells
+// the caller which collective to make (sum / max all-reduce of a small buffer, or an all-gather of the frames when the
+// 2-D roll needs rows of other bands), then goes on.  The replicated parts (autogain recurrence, sync detector, PLL) see
+// identical inputs on every rank, so every rank takes the same path and the same decisions.  Contract-exact like the
+// single-GPU run: strips that hold ties or toss-ups are collapsed literally, relayed band by band.
+// ---------------------------------------------------------------------------
+enum { BOP_STATS = 1, BOP_XSUM, BOP_XMAX, BOP_UNPACK, BOP_AUTOGAIN, BOP_SYNC, BOP_GATHER, BOP_PASS, BOP_END };
+
+__global__ __launch_bounds__(256) void k_band_pack_mm(int F, int y0, const float *__restrict__ fmin_, const float *__restrict__ fmax_,
+                                                      const float *__restrict__ frames, long long fstride, float *__restrict__ xmax)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    xmax[f * 4 + 0] = -fmin_[f];
+    xmax[f * 4 + 1] = fmax_[f];
+    xmax[f * 4 + 2] = (y0 == 0) ? frames[(long long)f * fstride] : -INFINITY;  // dsp.c:50-51: v[0] seeds min and max
+    xmax[f * 4 + 3] = -INFINITY;
+}
+
+__global__ __launch_bounds__(256) void k_band_unpack_mm(int F, const float *__restrict__ xmax, float *__restrict__ fmin_, float *__restrict__ fmax_,
+                                                        float *__restrict__ v0)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    fmin_[f] = -xmax[f * 4 + 0];
+    fmax_[f] = xmax[f * 4 + 1];
+    v0[f] = xmax[f * 4 + 2];
+}
+
+__global__ __launch_bounds__(256) void k_band_unpack_sum(int F, int W, int Htot, const double *__restrict__ xsum, double *__restrict__ strip_x,
+                                                         double *__restrict__ strip_y)
+{
+    const int f = blockIdx.z, q = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W + Htot) return;
+    const double v = xsum[((long long)f * 3 + q) * (W + Htot) + i];
+    if (i < W) strip_x[((long long)f * 3 + q) * W + i] = v;
+    else strip_y[((long long)f * 3 + q) * Htot + (i - W)] = v;
+}
+
+// this band's rows of every frame into its slot of the gather buffer [band][F][rows_max][W]
+__global__ __launch_bounds__(256) void k_band_gather_pack(const float *__restrict__ band, int F, int W, int rows, int rows_max, float *__restrict__ slot)
+{
+    const long long n = (long long)F * rows * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long f = i / ((long long)rows * W), r = i - f * rows * W;
+        slot[f * rows_max * W + r] = band[i];
+    }
+}
+
+// The pass with the 2-D roll (syncdetector.c:187-207) for a band: output pixel (x, y0 + y) of frame f takes the pixel
+// (x + dx, y0 + y + dy) (both wrapped) of the FULL frame, found in the gather buffer through the band edges.
+template <int FLAGS>
+__global__ __launch_bounds__(256) void k_band_roll_pass(const float *__restrict__ gath, const int *__restrict__ edges, int nbands, int rows_max,
+                                                        float *__restrict__ dst, long long dstride, int F, int W, int Htot, int y0, int rows,
+                                                        const ChainOut *__restrict__ chain, float *__restrict__ screen, float a)
+{
+    __shared__ int ed[65];
+    for (int i = threadIdx.x; i <= nbands; i += blockDim.x) ed[i] = edges[i];
+    __syncthreads();
+    const int Pb = W * rows;
+    const double one_minus_a = 1.0 - a;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < Pb; p += gridDim.x * blockDim.x) {
+        const int y = p / W, x = p - y * W;
+        float s = (FLAGS & PASS_IIR) ? screen[p] : 0.f;
+        for (int f = 0; f < F; f++) {
+            const int dx = chain[f].dx, dy = chain[f].dy;
+            float lastmin = 0.f, span = 1.f;
+            if (FLAGS & PASS_NORMALISE) { lastmin = chain[f].lastmin; span = chain[f].span; }
+            int sx = x + dx; if (sx >= W) sx -= W;
+            int sy = y0 + y + dy; if (sy >= Htot) sy -= Htot;
+            int b = 0;
+            while (b + 1 < nbands && sy >= ed[b + 1]) b++;
+            const float v = gath[(((long long)b * F + f) * rows_max + (sy - ed[b])) * W + sx];
+            dst[(long long)f * dstride + p] = pass_one(FLAGS, v, s, a, one_minus_a, lastmin, span, false);
+        }
+        if (FLAGS & PASS_IIR) screen[p] = s;
+    }
+}
+
+extern "C" int tsdrgpu_postproc_band_open(tsdrgpu_postproc_t *pp, const float *d_band, int F, int W, int Htot, const int *edges, int nbands,
+                                          int band_index, const tsdrgpu_pp_params_t *prm)
+{
+    if (!pp || !d_band || !prm || !edges || F <= 0 || W <= 0 || Htot <= 0 || nbands < 1 || nbands > 64 || band_index < 0 || band_index >= nbands)
+        return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_open", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    if (pp->pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_open", "a split run is already open");
+    if (edges[0] != 0 || edges[nbands] != Htot) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_open", "the band edges must run from 0 to the frame height");
+    int rows_max = 0;
+    for (int b = 0; b < nbands; b++) {
+        if (edges[b + 1] <= edges[b] || edges[b] % TILE_H) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_open", "bands must be non-empty and start on multiples of 32 rows");
+        if (edges[b + 1] - edges[b] > rows_max) rows_max = edges[b + 1] - edges[b];
+        pp->bedges[b] = edges[b];
+    }
+    pp->bedges[nbands] = Htot;
+    const int y0 = edges[band_index], rows = edges[band_index + 1] - y0;
+    int rc;
+    if ((rc = pp_prepare(pp, F, W, Htot, prm))) return rc;
+    if ((rc = ensure(g, &pp->d_xsum, &pp->cap_xsum, (size_t)F * 3 * (W + Htot)))) return rc;
+    if ((rc = ensure(g, &pp->d_xmax, &pp->cap_xmax, (size_t)F * 4))) return rc;
+    if ((rc = ensure(g, &pp->d_v0, &pp->cap_v0, (size_t)F))) return rc;
+    if ((rc = ensure(g, &pp->d_chain_band, &pp->cap_chain_band, (size_t)F))) return rc;
+    if (!pp->d_bedges && hipMalloc(&pp->d_bedges, sizeof(int) * 65) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "band edges");
+    HIP_TRY(g, hipMemcpyAsync(pp->d_bedges, pp->bedges, sizeof(int) * (size_t)(nbands + 1), hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));  // (bedges may be rewritten by the next open)
+    if (prm->autoshift && (rc = ensure(g, &pp->d_gather, &pp->cap_gather, (size_t)nbands * F * rows_max * W))) return rc;
+    pp->p_frames = d_band;
+    pp->p_F = F; pp->p_W = W; pp->p_H = Htot;
+    pp->p_prm = *prm;
+    pp->band_y0 = y0;
+    pp->band_rows = rows;
+    pp->bnbands = nbands;
+    pp->bindex = band_index;
+    pp->brows_max = rows_max;
+    pp->bsrc[0] = d_band;
+    pp->bsrc[1] = pp->d_tmp1;
+    pp->bsrc[2] = pp->d_tmp2;
+    pp->bsrc[3] = nullptr;  // the caller's output band, known at the first step
+
+    // the program: dsp.c:134-239's four orders.  BOP_PASS: a = flags, b = source buffer, c = destination buffer
+    const float a = prm->motionblur;
+    const int lbs = prm->lowpass_before_sync, aap = prm->autogain_after_proc, roll = prm->autoshift ? PASS_ROLL : 0;
+    int n = 0;
+    auto emit = [&](int op, int x = 0, int y = 0, int z = 0) { pp->bprog[n].op = op; pp->bprog[n].a = x; pp->bprog[n].b = y; pp->bprog[n].c = z; n++; };
+    // sync on the strips of buffer `src` (normalised strips or not), then the pass with the roll / lines
+    auto sync_steps = [&](int src, int norm) {
+        emit(BOP_STATS, src, 1); emit(BOP_XSUM); emit(BOP_UNPACK, 1);
+        emit(BOP_SYNC, src, norm);
+    };
+    auto autogain_steps = [&](int src) {
+        emit(BOP_STATS, src, 0); emit(BOP_XMAX); emit(BOP_UNPACK, 0);
+        emit(BOP_AUTOGAIN, 1);
+    };
+    if (!lbs && !aap) {
+        const int lines = (!prm->autoshift && a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+        // one statistics read serves both: strips and min / max
+        emit(BOP_STATS, 0, 1); emit(BOP_XSUM); emit(BOP_XMAX); emit(BOP_UNPACK, 2);
+        emit(BOP_AUTOGAIN, 1);
+        emit(BOP_SYNC, 0, 1);
+        if (roll) emit(BOP_GATHER, 0);
+        emit(BOP_PASS, PASS_NORMALISE | roll | lines | PASS_IIR, 0, 3);
+    } else if (!lbs && aap) {
+        const int lines = (!prm->autoshift && a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+        sync_steps(0, 0);
+        if (roll) emit(BOP_GATHER, 0);
+        emit(BOP_PASS, roll | lines | PASS_IIR, 0, 1);
+        autogain_steps(1);
+        emit(BOP_PASS, PASS_NORMALISE, 1, 3);
+    } else if (lbs && !aap) {
+        const int lines = (!prm->autoshift && !prm->superresolution) ? PASS_LINES : 0;
+        autogain_steps(0);
+        emit(BOP_PASS, PASS_NORMALISE | PASS_IIR, 0, 1);
+        sync_steps(1, 0);
+        if (roll) emit(BOP_GATHER, 1);
+        emit(BOP_PASS, roll | lines, 1, 3);
+    } else {
+        const int lines = (!prm->autoshift && !prm->superresolution) ? PASS_LINES : 0;
+        emit(BOP_PASS, PASS_IIR, 0, 1);
+        sync_steps(1, 0);
+        if (roll) emit(BOP_GATHER, 1);
+        emit(BOP_PASS, roll | lines, 1, 2);
+        autogain_steps(2);
+        emit(BOP_PASS, PASS_NORMALISE, 2, 3);
+    }
+    emit(BOP_END);
+    pp->bprog_n = n;
+    pp->bprog_pc = 0;
+    pp->bsync_stage = 0;
+    pp->pending = PEND_BAND + 1;
+    return TSDRGPU_OK;
+}
+
+// the sync detector on the exchanged strips, with the relays of the literal collapse; returns 1 when the caller has to
+// all-reduce pp->d_relay (sum), 0 when the detector is done
+static int band_sync_advance(tsdrgpu_postproc_t *pp, int *need_exchange)
+{
+    tsdrgpu_t *g = pp->g;
+    const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H;
+    const tsdrgpu_pp_params_t *prm = &pp->p_prm;
+    const int nmax = W > Htot ? W : Htot;
+    const int norm = pp->bsync_norm;
+    hipStream_t st = g->stream;
+    StripScratch sc;
+    sc.nmax = nmax;
+    sc.blur = pp->d_work;
+    sc.prefix = (double *)(pp->d_work + (((size_t)F * 2 * nmax + 1) & ~(size_t)1));
+    sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
+    SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
+    int *d_amb = pp->d_sflag + (size_t)F * 2, *d_fresh = d_amb + (size_t)F * 2, *d_redo = d_fresh + (size_t)F * 2;
+    const int *const no_gate = nullptr;
+    const int exact = pp->exact_ties;
+    int rc;
+    *need_exchange = 0;
+    for (;;) {
+        switch (pp->bsync_stage) {
+        case 0: {  // tie flags on the exchanged strips
+            if (!pp->chain_has_autogain) {  // a sync-only step: the chain record repeats the carried autogain state
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 0,
+                            prm->lowpasscoeff, (int *)nullptr);
+                KERNEL_CHECK(g, "k_autogain_chain");
+                pp->chain_has_autogain = 1;
+            }
+            pp->relay_items = 0;
+            if (exact) {
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, norm, pp->d_sflag);
+                KERNEL_CHECK(g, "k_strip_flag");
+                if ((rc = band_collect_items(pp, pp->d_sflag, 2 * F, &pp->relay_items))) return rc;
+            } else {
+                HIP_TRY(g, hipMemsetAsync(pp->d_sflag, 0, sizeof(int) * (size_t)F * 2, st));
+            }
+            pp->relay_step = 0;
+            pp->bsync_stage = pp->relay_items ? 1 : 2;
+            break;
+        }
+        case 1:
+        case 3: {  // relay: one step per call, the caller all-reduces the buffer in between
+            if (pp->relay_step == 0 && (rc = ensure(g, &pp->d_relay, &pp->cap_relay, (size_t)pp->relay_items * nmax))) return rc;
+            if (pp->relay_step < pp->bnbands) {
+                if ((rc = band_relay_step(pp, pp->bindex))) return rc;
+                pp->relay_step++;
+                *need_exchange = 1;
+                return TSDRGPU_OK;
+            }
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_band_relay_take, dim3((nmax + 255) / 256, pp->relay_items), 256, pp->d_items, nmax, W, Htot, pp->d_relay,
+                        pp->d_exact);
+            KERNEL_CHECK(g, "k_band_relay_take");
+            pp->bsync_stage = pp->bsync_stage == 1 ? 2 : 4;
+            if (pp->bsync_stage == 4) {  // run 1 of the chain: only the strips that changed, from the saved state
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, norm, pp->taps[0],
+                            pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, (const int *)d_redo);
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, Htot, sc, pp->d_state + 1, spec, (const int *)d_redo, (const int *)d_fresh);
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, Htot, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1, d_amb,
+                            (const int *)d_redo);
+                KERNEL_CHECK(g, "k_sync_chain");
+            }
+            break;
+        }
+        case 2: {  // run 0 of the chain; with exact ties on, its toss-ups are the second relay's items
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, norm, pp->taps[0],
+                        pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, no_gate);
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, Htot, sc, pp->d_state, spec, no_gate, no_gate);
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, Htot, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1,
+                        exact ? d_amb : (int *)nullptr, no_gate);
+            KERNEL_CHECK(g, "k_sync_chain");
+            pp->relay_items = 0;
+            if (exact) {
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_redo_prepare, 1, 256, 2 * F, d_amb, pp->d_sflag, d_redo, d_fresh);
+                KERNEL_CHECK(g, "k_redo_prepare");
+                if ((rc = band_collect_items(pp, d_fresh, 2 * F, &pp->relay_items))) return rc;
+            }
+            pp->relay_step = 0;
+            pp->bsync_stage = pp->relay_items ? 3 : 4;
+            break;
+        }
+        default:
+            pp->bsync_stage = 0;
+            return TSDRGPU_OK;
+        }
+    }
+}
+
+extern "C" int tsdrgpu_postproc_band_step(tsdrgpu_postproc_t *pp, float *d_out_band, tsdrgpu_band_exchange_t *x, tsdrgpu_pp_frameinfo_t *h_info)
+{
+    if (!pp || !d_out_band || !x) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_step", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    if (pp->pending != PEND_BAND + 1) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_step", "no band run is open (tsdrgpu_postproc_band_open)");
+    const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H, y0 = pp->band_y0, rows = pp->band_rows;
+    const tsdrgpu_pp_params_t *prm = &pp->p_prm;
+    const long long Pb = (long long)W * rows;
+    hipStream_t st = g->stream;
+    pp->bsrc[3] = d_out_band;
+    x->kind = TSDRGPU_BAND_DONE;
+    x->d_buf = nullptr;
+    x->count = 0;
+    int rc;
+    for (;;) {
+        const auto op = pp->bprog[pp->bprog_pc];
+        switch (op.op) {
+        case BOP_STATS: {  // a = source buffer, b = with strips
+            const float *src = pp->bsrc[op.a];
+            if ((rc = launch_stats(pp, src, Pb, F, W, rows, op.b))) return rc;
+            if (op.b) {
+                TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_pack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, y0, rows, pp->d_strip_x, pp->d_strip_y,
+                            pp->d_fmin, pp->d_fmax, src, Pb, pp->d_xsum, pp->d_xmax);
+                KERNEL_CHECK(g, "k_band_pack");
+            } else {
+                TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_pack_mm, (F + 255) / 256, 256, F, y0, pp->d_fmin, pp->d_fmax, src, Pb, pp->d_xmax);
+                KERNEL_CHECK(g, "k_band_pack_mm");
+            }
+            pp->bprog_pc++;
+            break;
+        }
+        case BOP_XSUM:
+            pp->bprog_pc++;
+            x->kind = TSDRGPU_BAND_SUM_F64; x->d_buf = pp->d_xsum; x->count = (int64_t)F * 3 * (W + Htot);
+            return TSDRGPU_OK;
+        case BOP_XMAX:
+            pp->bprog_pc++;
+            x->kind = TSDRGPU_BAND_MAX_F32; x->d_buf = pp->d_xmax; x->count = (int64_t)F * 4;
+            return TSDRGPU_OK;
+        case BOP_UNPACK:  // a: 0 = min/max, 1 = strips, 2 = both
+            if (op.a != 0) {
+                TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack_sum, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_strip_x, pp->d_strip_y);
+                KERNEL_CHECK(g, "k_band_unpack_sum");
+            }
+            if (op.a != 1) {
+                TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack_mm, (F + 255) / 256, 256, F, pp->d_xmax, pp->d_fmin, pp->d_fmax, pp->d_v0);
+                KERNEL_CHECK(g, "k_band_unpack_mm");
+            }
+            pp->bprog_pc++;
+            break;
+        case BOP_AUTOGAIN:
+            TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 1,
+                        prm->lowpasscoeff, (int *)nullptr);
+            KERNEL_CHECK(g, "k_autogain_chain");
+            pp->chain_has_autogain = 1;
+            pp->bprog_pc++;
+            break;
+        case BOP_SYNC: {  // a = the buffer the strips came from, b = strips normalised
+            pp->brelay_src = pp->bsrc[op.a];
+            pp->bsync_norm = op.b;
+            int need = 0;
+            if ((rc = band_sync_advance(pp, &need))) return rc;
+            if (need) {
+                x->kind = TSDRGPU_BAND_SUM_F64; x->d_buf = pp->d_relay; x->count = (int64_t)pp->relay_items * (W > Htot ? W : Htot);
+                return TSDRGPU_OK;
+            }
+            pp->bprog_pc++;
+            break;
+        }
+        case BOP_GATHER: {  // a = the buffer whose frames are rolled
+            float *slot = pp->d_gather + (size_t)pp->bindex * F * pp->brows_max * W;
+            TSDR_LAUNCH(g, PROF_FRAME_PASS, st, k_band_gather_pack, (unsigned)(g->prop.multiProcessorCount * 8), 256, pp->bsrc[op.a], F, W, rows, pp->brows_max, slot);
+            KERNEL_CHECK(g, "k_band_gather_pack");
+            pp->bprog_pc++;
+            x->kind = TSDRGPU_BAND_ALLGATHER_F32; x->d_buf = pp->d_gather; x->count = (int64_t)F * pp->brows_max * W;
+            return TSDRGPU_OK;
+        }
+        case BOP_PASS: {  // a = flags, b = source, c = destination
+            const float a = prm->motionblur;
+            float *dst = const_cast<float *>(pp->bsrc[op.c]);
+            if (op.a & PASS_ROLL) {
+                const unsigned grid = (unsigned)(g->prop.multiProcessorCount * 8);
+                const int fl = op.a & ~PASS_LINES;
+                if (fl == (PASS_NORMALISE | PASS_ROLL | PASS_IIR))
+                    TSDR_LAUNCH(g, PROF_FRAME_PASS, st, (k_band_roll_pass<PASS_NORMALISE | PASS_IIR>), grid, 256, pp->d_gather, pp->d_bedges, pp->bnbands, pp->brows_max, dst, Pb,
+                                F, W, Htot, y0, rows, pp->d_chain, pp->d_screen, a);
+                else if (fl == (PASS_ROLL | PASS_IIR))
+                    TSDR_LAUNCH(g, PROF_FRAME_PASS, st, (k_band_roll_pass<PASS_IIR>), grid, 256, pp->d_gather, pp->d_bedges, pp->bnbands, pp->brows_max, dst, Pb, F, W, Htot,
+                                y0, rows, pp->d_chain, pp->d_screen, a);
+                else
+                    TSDR_LAUNCH(g, PROF_FRAME_PASS, st, (k_band_roll_pass<0>), grid, 256, pp->d_gather, pp->d_bedges, pp->bnbands, pp->brows_max, dst, Pb, F, W, Htot, y0,
+                                rows, pp->d_chain, pp->d_screen, a);
+                KERNEL_CHECK(g, "k_band_roll_pass");
+            } else {
+                // the flat pass on the band as a frame of `rows` rows; the painted lines compare band-local row numbers
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_band_chain, (F + 63) / 64, 64, pp->d_chain, pp->d_chain_band, F, y0);
+                KERNEL_CHECK(g, "k_band_chain");
+                ChainOut *full = pp->d_chain;
+                pp->d_chain = pp->d_chain_band;
+                rc = launch_pass(pp, op.a, pp->bsrc[op.b], Pb, dst, Pb, F, W, rows, a);
+                pp->d_chain = full;
+                if (rc) return rc;
+            }
+            pp->bprog_pc++;
+            break;
+        }
+        default:  // BOP_END
+            pp->pending = 0;
+            pp->brelay_src = nullptr;
+            if (h_info) return pp_copy_info(pp, F, h_info);
+            return TSDRGPU_OK;
         }
     }
 }

@@ -25,6 +25,14 @@ class PPParams(C.Structure):
                 ("motionblur", C.c_float), ("lowpasscoeff", C.c_float)]
 
 
+class BandExchange(C.Structure):
+    """tsdrgpu_band_exchange_t: the collective a general band run asks its caller for"""
+    _fields_ = [("kind", C.c_int), ("d_buf", C.c_void_p), ("count", C.c_int64)]
+
+
+BAND_DONE, BAND_SUM_F64, BAND_MAX_F32, BAND_ALLGATHER_F32 = 0, 1, 2, 3
+
+
 class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int)]
 
@@ -92,6 +100,8 @@ _SIGS = {
     "tsdrgpu_postproc_band_begin": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_int64),
                                               C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_postproc_band_finish": (C.c_int, [vp, vp, vp]),
+    "tsdrgpu_postproc_band_open": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, vp]),
+    "tsdrgpu_postproc_band_step": (C.c_int, [vp, vp, vp, vp]),
     "tsdrgpu_postproc_band_advance": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int), vp]),
     "tsdrgpu_resample_band": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int64, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
@@ -525,6 +535,22 @@ class PostProcess:
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_advance(self.h, d_out_band.at(out_offset), band_index, nbands, C.byref(buf), C.byref(n),
                                                                 C.byref(more), info))
         return more.value, buf.value, n.value, (list(info) if (want_info and not more.value) else None)
+
+    def band_open(self, d_band, nframes, width, height, edges, band_index, motionblur=0.0, lowpasscoeff=0.1, lowpass_before_sync=0,
+                  autogain_after_proc=0, autoshift=0, pll=0, superres=0, frames_offset=0):
+        """General band run (every stage order, autoshift, PLL): tsdrgpu_postproc_band_open; then band_step() until BAND_DONE."""
+        prm = PPParams(lowpass_before_sync, autogain_after_proc, autoshift, pll, superres, motionblur, lowpasscoeff)
+        self._nframes = nframes
+        e = (C.c_int * len(edges))(*[int(v) for v in edges])
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_open(self.h, d_band.at(frames_offset), nframes, width, height, e, len(edges) - 1, band_index,
+                                                             C.byref(prm)))
+
+    def band_step(self, d_out_band, want_info=True, out_offset=0):
+        """one step: returns (kind, buf_ptr, count, infos) — kind says which collective the caller makes on buf (gpu.BAND_*)"""
+        info = (PPFrameInfo * self._nframes)() if want_info else None
+        x = BandExchange()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_step(self.h, d_out_band.at(out_offset), C.byref(x), info))
+        return x.kind, x.d_buf, x.count, (list(info) if (want_info and x.kind == BAND_DONE) else None)
 
     def strips(self, width, height):
         c = np.empty(width, np.float32)

@@ -257,3 +257,154 @@ def test_band_resampler_equals_the_oracle_stream(orc, fs, h, y0, rows):
     for j, fr in frames.items():
         ref = want[j * P:(j + 1) * P].reshape(h, W)[y0:y0 + rows]
         assert np.array_equal(fr, ref), (j, int(np.sum(fr != ref)))
+
+
+# ---------------------------------------------------------------------------
+# the GENERAL band run (tsdrgpu_postproc_band_open / _band_step): every stage order, autoshift, PLL — against the ORACLE
+# ---------------------------------------------------------------------------
+def _host_collective(g, kind, ptrs, count):
+    """the collective a step asked for, done on the host over the ranks' device buffers (production: tsdrgpu_comm_* over RCCL)"""
+    if kind == gpu.BAND_ALLGATHER_F32:
+        world = len(ptrs)
+        full = np.empty(world * count, np.float32)
+        for r, p in enumerate(ptrs):  # rank r's part sits at r * count of ITS buffer
+            part = np.empty(count, np.float32)
+            g._ck(g.lib.tsdrgpu_download(g.h, part.ctypes.data, p + 4 * r * count, part.nbytes))
+            g.sync()
+            full[r * count:(r + 1) * count] = part
+        for p in ptrs:
+            g._ck(g.lib.tsdrgpu_upload(g.h, p, full.ctypes.data, full.nbytes))
+        g.sync()
+        return
+    dt = np.float64 if kind == gpu.BAND_SUM_F64 else np.float32
+    bufs = [np.empty(count, dt) for _ in ptrs]
+    for b, p in zip(bufs, ptrs):
+        g._ck(g.lib.tsdrgpu_download(g.h, b.ctypes.data, p, b.nbytes))
+    g.sync()
+    tot = np.sum(bufs, axis=0) if kind == gpu.BAND_SUM_F64 else np.maximum.reduce(bufs)
+    for p in ptrs:
+        g._ck(g.lib.tsdrgpu_upload(g.h, p, tot.ctypes.data, tot.nbytes))
+    g.sync()
+
+
+def _run_bands_general(g, pps, edges, fr, **prm):
+    F, H, W = fr.shape
+    rows = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
+    d_bands = [g.to_device(np.ascontiguousarray(fr[:, y0:y0 + n, :]).reshape(-1)) for (y0, n) in rows]
+    d_outs = [g.empty(F * W * n) for (_, n) in rows]
+    for k, pp in enumerate(pps):
+        pp.band_open(d_bands[k], F, W, H, edges, k, **prm)
+    kinds = []
+    while True:
+        res = [pp.band_step(d_o) for pp, d_o in zip(pps, d_outs)]
+        assert len({(r[0], r[2]) for r in res}) == 1, "every rank asks for the same collective"
+        kind, _, count, _ = res[0]
+        if kind == gpu.BAND_DONE:
+            infos = [r[3] for r in res]
+            break
+        kinds.append(kind)
+        _host_collective(g, kind, [r[1] for r in res], count)
+    for other in infos[1:]:
+        for a, b in zip(infos[0], other):
+            assert (a.lastmin, a.lastmax, a.dx, a.vx, a.stripx, a.dy, a.vy, a.stripy, a.locked, a.avg_speed, a.pll_fired, a.frameratediff) == \
+                   (b.lastmin, b.lastmax, b.dx, b.vx, b.stripx, b.dy, b.vy, b.stripy, b.locked, b.avg_speed, b.pll_fired, b.frameratediff)
+    outs = [d_o.download().reshape(F, n, W) for d_o, (_, n) in zip(d_outs, rows)]
+    return np.concatenate(outs, axis=1), infos[0], kinds
+
+
+@pytest.mark.parametrize("lbs,aap", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("autoshift", [0, 1])
+def test_general_band_run_every_stage_order_equals_the_oracle(orc, lbs, aap, autoshift):
+    """dsp_post_process's four stage orders (dsp.c:134-239; lbs = PARAM_LOW_PASS_BEFORE_SYNC — the GUI's default —, aap =
+    PARAM_AUTOGAIN_AFTER_PROCESSING) with and without PARAM_INT_AUTOSHIFT (the 2-D roll crosses the bands: all-gather),
+    three bands, batches that hold noisy rasters, a blank frame, a noiseless pattern and a sentinel, state carried over
+    the batches: frames and per-frame records bit-identical to the ORACLE."""
+    g = ctx()
+    W, H, blur = 640, 420, 0.5
+    edges = [0, 128, 288, H]
+    rng = np.random.default_rng(100 * lbs + 10 * aap + autoshift)
+    pps = [gpu.PostProcess(g) for _ in range(3)]
+    opp = orc.PostProcess(_geo(orc, W, H))
+    seen = set()
+    for batch, F in enumerate((3, 9, 2)):
+        fr = _frames(rng, F, W, H, 10 * batch)
+        if batch == 0:
+            fr[1] = 0.25
+            y, x = np.mgrid[0:H, 0:W]
+            fr[2] = (0.3 + 0.5 * ((x // 40) % 2)).astype(np.float32)
+        if batch == 1:
+            fr[3, 5, 7] = 1024.0
+        want = np.stack([opp.run(fr[k].reshape(-1).copy(), blur, 0.1, lbs, aap, autoshift, 0, 0).reshape(H, W) for k in range(F)])
+        got, infos, kinds = _run_bands_general(g, pps, edges, fr, motionblur=blur, lowpass_before_sync=lbs, autogain_after_proc=aap, autoshift=autoshift)
+        seen |= set(kinds)
+        assert np.array_equal(got, want), (batch, int(np.sum(got != want)))
+    assert (gpu.BAND_ALLGATHER_F32 in seen) == bool(autoshift)
+    assert gpu.BAND_SUM_F64 in seen and gpu.BAND_MAX_F32 in seen
+    si, sd = opp.state()
+    last = infos[-1]
+    assert (last.dx, last.vx, last.stripx, last.dy, last.vy, last.stripy, last.locked) == tuple(si[:7])
+
+
+def test_general_band_run_default_order_equals_the_band_advance_form(orc):
+    """library-default order without autoshift: the general machine gives what _band_begin / _band_advance give"""
+    g = ctx()
+    W, H, blur = 507, 525, 0.0
+    edges = [0, 160, 352, H]
+    rows = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
+    rng = np.random.default_rng(5)
+    a_pps, b_pps = [gpu.PostProcess(g) for _ in rows], [gpu.PostProcess(g) for _ in rows]
+    for batch, F in enumerate((4, 6)):
+        fr = _frames(rng, F, W, H, 7 * batch)
+        if batch == 0:
+            fr[2] = 0.5
+        want, winfo, _ = _run_bands(g, a_pps, rows, fr, blur)
+        got, ginfo, _ = _run_bands_general(g, b_pps, edges, fr, motionblur=blur)
+        assert np.array_equal(got, want)
+        assert (want == 512.0).any()  # green lines
+        for a, b in zip(winfo, ginfo):
+            assert (a.lastmin, a.lastmax, a.dx, a.dy, a.stripx, a.stripy, a.locked) == (b.lastmin, b.lastmax, b.dx, b.dy, b.stripx, b.stripy, b.locked)
+
+
+def test_general_band_run_with_the_pll_equals_the_oracle(orc):
+    """PARAM_INT_FRAMERATE_PLL in band mode: the PLL is part of the replicated chain, so every rank reports the same nudge
+    (syncdetector.c:133-153); one frame per run, like tsdrgpu_postproc_run's callers do it."""
+    g = ctx()
+    W, H = 640, 420
+    edges = [0, 224, H]
+    rng = np.random.default_rng(77)
+    pps = [gpu.PostProcess(g) for _ in range(2)]
+    single = gpu.PostProcess(g)
+    geo = _geo(orc, W, H)
+    opp = orc.PostProcess(geo)
+    fired = 0
+    for k in range(14):
+        fr = _frames(rng, 1, W, H, 3 * k)  # the pattern drifts: the sync detector sees a moving blanking interval
+        want = opp.run(fr[0].reshape(-1).copy(), 0.0, 0.1, 0, 0, 0, 1, 0).reshape(H, W)
+        d_full, d_out = g.to_device(fr.reshape(-1)), g.empty(W * H)
+        sinfo = single.run(d_full, 1, W, H, d_out, pll=1)
+        got, infos, _ = _run_bands_general(g, pps, edges, fr, pll=1)
+        assert np.array_equal(got[0], want)
+        a, b = sinfo[0], infos[0]
+        assert (a.dx, a.dy, a.locked, a.pll_fired, a.frameratediff, a.avg_speed) == (b.dx, b.dy, b.locked, b.pll_fired, b.frameratediff, b.avg_speed)
+        fired += b.pll_fired
+    si, sd = opp.state()
+    assert (infos[-1].dx, infos[-1].dy) == (si[0], si[3])
+
+
+def test_general_band_run_config4_eight_bands_gui_order_with_autoshift(orc):
+    """BASELINE configs[4]'s geometry (2962x2250, motion blur 15/16), EIGHT bands with bench.py's edges, the GUI's stage order
+    (low-pass before sync) and autoshift on: the roll moves rows across all eight bands."""
+    g = ctx()
+    W, H, blur = 2962, 2250, 0.9375
+    edges = [0] + list(_bench_cuts(H, 8)) + [H]
+    rng = np.random.default_rng(8)
+    pps = [gpu.PostProcess(g) for _ in range(8)]
+    opp = orc.PostProcess(_geo(orc, W, H))
+    for batch, F in enumerate((3, 2)):
+        fr = _frames(rng, F, W, H, 10 * batch)
+        if batch == 0:
+            fr[1] = 0.25
+        want = np.stack([opp.run(fr[k].reshape(-1).copy(), blur, 0.1, 1, 0, 1, 0, 0).reshape(H, W) for k in range(F)])
+        got, infos, kinds = _run_bands_general(g, pps, edges, fr, motionblur=blur, lowpass_before_sync=1, autoshift=1)
+        assert gpu.BAND_ALLGATHER_F32 in kinds
+        assert np.array_equal(got, want), (batch, int(np.sum(got != want)))
