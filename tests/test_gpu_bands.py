@@ -377,7 +377,10 @@ def test_general_band_run_with_the_pll_equals_the_oracle(orc):
     geo = _geo(orc, W, H)
     opp = orc.PostProcess(geo)
     fired = 0
+    rate = geo.refreshrate
     for k in range(14):
+        if geo.width != W:  # the oracle applies the nudge to its geometry (TSDRLibrary.c:540-550): the frame size changed, stop like
+            break           # tests/test_gpu_postproc.py::test_post_process_pll does
         fr = _frames(rng, 1, W, H, 3 * k)  # the pattern drifts: the sync detector sees a moving blanking interval
         want = opp.run(fr[0].reshape(-1).copy(), 0.0, 0.1, 0, 0, 0, 1, 0).reshape(H, W)
         d_full, d_out = g.to_device(fr.reshape(-1)), g.empty(W * H)
@@ -387,8 +390,10 @@ def test_general_band_run_with_the_pll_equals_the_oracle(orc):
         a, b = sinfo[0], infos[0]
         assert (a.dx, a.dy, a.locked, a.pll_fired, a.frameratediff, a.avg_speed) == (b.dx, b.dy, b.locked, b.pll_fired, b.frameratediff, b.avg_speed)
         fired += b.pll_fired
-    si, sd = opp.state()
-    assert (infos[-1].dx, infos[-1].dy) == (si[0], si[3])
+        rate -= b.frameratediff
+        assert rate == geo.refreshrate, k  # the nudges the bands report are the reference's
+        assert b.pll_fired == opp.state()[0][7]
+    assert k >= 3
 
 
 def test_general_band_run_config4_eight_bands_gui_order_with_autoshift(orc):
