@@ -369,12 +369,12 @@ def test_general_band_run_with_the_pll_equals_the_oracle(orc):
     """PARAM_INT_FRAMERATE_PLL in band mode: the PLL is part of the replicated chain, so every rank reports the same nudge
     (syncdetector.c:133-153); one frame per run, like tsdrgpu_postproc_run's callers do it."""
     g = ctx()
-    W, H = 640, 420
-    edges = [0, 224, H]
+    geo = orc.geometry(2_000_000, 131, 60.0)  # a geometry the library derives itself, so that a nudge keeps it consistent
+    W, H = geo.width, 131
+    edges = [0, 64, H]
     rng = np.random.default_rng(77)
     pps = [gpu.PostProcess(g) for _ in range(2)]
     single = gpu.PostProcess(g)
-    geo = _geo(orc, W, H)
     opp = orc.PostProcess(geo)
     fired = 0
     rate = geo.refreshrate
