@@ -21,6 +21,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     rank, world, port = (int(a) for a in sys.argv[1:4])
     config = sys.argv[4] if len(sys.argv) > 4 else "small"
+    # "gui": the GENERAL band run (tsdrgpu_postproc_band_open / _band_step) with the GUI's stage order (low-pass before sync)
+    # and autoshift — the roll's rows cross the ranks through an all-gather
+    general = len(sys.argv) > 5 and sys.argv[5] == "gui"
     import torch
     import torch.distributed as dist
     from tempestsdr_amd import gpu, synth
@@ -64,15 +67,36 @@ def main():
     for k in calls:
         n, touched = rs.process_band(d_iq, 1, chunk, k, up, down, W, h, y0, rows, phase, d_band, cap, in_offset=2 * done * chunk)
         F = (phase + n) // P
-        ps, ns, pm, nm = pp.band_begin(d_band, F, W, h, y0, rows, motionblur=blur)
-        allreduce(ps, ns, np.float64, dist.ReduceOp.SUM)
-        allreduce(pm, nm, np.float32, dist.ReduceOp.MAX)
-        while True:
-            more, buf, nb, info = pp.band_advance(d_out, rank, world)
-            if not more:
-                break
-            allreduce(buf, nb, np.float64, dist.ReduceOp.SUM)
-            relay_steps += 1
+        if general:
+            pp.band_open(d_band, F, W, h, edges, rank, motionblur=blur, lowpass_before_sync=1, autoshift=1)
+            while True:
+                kind, buf, cnt, info = pp.band_step(d_out)
+                if kind == gpu.BAND_DONE:
+                    break
+                if kind == gpu.BAND_SUM_F64:
+                    allreduce(buf, cnt, np.float64, dist.ReduceOp.SUM)
+                    relay_steps += 1
+                elif kind == gpu.BAND_MAX_F32:
+                    allreduce(buf, cnt, np.float32, dist.ReduceOp.MAX)
+                else:  # all-gather in place: this rank's part sits at rank * cnt
+                    part = np.empty(cnt, np.float32)
+                    g._ck(g.lib.tsdrgpu_download(g.h, part.ctypes.data, buf + 4 * rank * cnt, part.nbytes))
+                    g.sync()
+                    full = torch.empty(world * cnt, dtype=torch.float32)
+                    dist.all_gather_into_tensor(full, torch.from_numpy(part))
+                    fa = full.numpy()
+                    g._ck(g.lib.tsdrgpu_upload(g.h, buf, fa.ctypes.data, fa.nbytes))
+                    g.sync()
+        else:
+            ps, ns, pm, nm = pp.band_begin(d_band, F, W, h, y0, rows, motionblur=blur)
+            allreduce(ps, ns, np.float64, dist.ReduceOp.SUM)
+            allreduce(pm, nm, np.float32, dist.ReduceOp.MAX)
+            while True:
+                more, buf, nb, info = pp.band_advance(d_out, rank, world)
+                if not more:
+                    break
+                allreduce(buf, nb, np.float64, dist.ReduceOp.SUM)
+                relay_steps += 1
         outs.append(d_out.download()[:F * rows * W].reshape(F, rows, W).copy())
         infos += info
         phase = (phase + n) % P
@@ -87,7 +111,8 @@ def main():
         got = np.concatenate(gathered, axis=1)
         pix, _ = orc.demod_resample_stream(iq, geo)
         opp = orc.PostProcess(geo)
-        want = np.stack([opp.run(pix[j * P:(j + 1) * P].copy(), blur).reshape(h, W) for j in range(got.shape[0])])
+        want = np.stack([(opp.run(pix[j * P:(j + 1) * P].copy(), blur, 0.1, 1, 0, 1, 0, 0) if general else opp.run(pix[j * P:(j + 1) * P].copy(), blur)).reshape(h, W)
+                         for j in range(got.shape[0])])
         same = np.array_equal(got, want)
         si, _ = opp.state()
         last = infos[-1]

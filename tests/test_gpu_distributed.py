@@ -88,6 +88,20 @@ def test_row_bands_config4_in_eight_processes_equal_the_oracle():
     assert "bands equal the oracle: True" in outs[0]
 
 
+@pytest.mark.parametrize("world,config", [(3, "small"), (8, "config4")])
+def test_row_bands_gui_order_with_autoshift_in_processes_equal_the_oracle(world, config):
+    """the GENERAL band run end to end from IQ, one process per rank: the GUI's stage order (low-pass before sync) with
+    autoshift on — two statistics rounds, the relayed literal collapse, and the all-gather that carries the rolled rows
+    across the ranks (tests/band_worker.py ... gui); reassembled frames and sync state are the ORACLE's."""
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "band_worker.py"), str(r), str(world), str(port), config, "gui"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "bands equal the oracle: True" in outs[0]
+
+
 def test_rccl_from_c_one_rank(orc):
     """tsdrgpu_rccl_unique_id / tsdrgpu_comm_create / tsdrgpu_autocorr_allreduce with a communicator of one rank:
     the ncclAllReduce is queued by the library on the autocorrelation's lane; sums + all-reduce + finalise equal
