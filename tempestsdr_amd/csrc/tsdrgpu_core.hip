@@ -978,13 +978,16 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
     }
     __syncthreads();
     const int ngroups = (PB - PA + mis + 3) >> 2;
+    const bool zero_tail = PB > PE;  // uniform: only a chunk's last workgroup writes pixels the reference's loop never stores
     for (int grp = threadIdx.x; grp < ngroups; grp += 256) {
         const int p0 = PA - mis + 4 * grp;
         float4 q = tile4[grp];
         float v[4] = {q.x, q.y, q.z, q.w};
+        if (zero_tail) {  // (the kernel's time is its VALU count: twelve instructions per group that all but one workgroup in ~80 can skip)
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (p0 + k >= PE) v[k] = 0.0f;  // pixels the reference's loop never stores
+            for (int k = 0; k < 4; k++)
+                if (p0 + k >= PE) v[k] = 0.0f;
+        }
         const bool whole = p0 >= PA && p0 + 4 <= PB;
         if (whole) {
             *reinterpret_cast<float4 *>(dst + p0) = make_float4(v[0], v[1], v[2], v[3]);
@@ -996,10 +999,30 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
         if (MM) {
             // usual case: a whole group in a span that stays inside one frame, no sentinel among its pixels -> min/max
             // of the four values
-            const float m = fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), M = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            float m, M;
+            if (IQ) {
+                // Demodulated input: every pixel is the result of arithmetic (a square root or a blend), so it cannot be a
+                // SIGNALLING NaN, and then the bare instructions are fminf / fmaxf (a quiet NaN operand is ignored, like the
+                // reference's comparisons ignore it, dsp.c:57-60).  From fminf() the compiler also emits a canonicalising
+                // v_max_f32 x, x per operand (IEEE mode quiets signalling NaNs first): 14 VALU instructions per group instead
+                // of 8, in a kernel whose duration IS its VALU count (SQ counters: 6 waves per SIMD x 16 % each).
+                float t;
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+                asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(t), "v"(v[3]));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(M) : "v"(t), "v"(v[3]));
+            } else {
+                m = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+                M = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            }
             if (whole && !crosses && !(M > 250.0f || m < -250.0f)) {
-                mn0 = fminf(mn0, m);
-                mx0 = fmaxf(mx0, M);
+                if (IQ) {
+                    asm("v_min_f32 %0, %1, %2" : "=v"(mn0) : "v"(mn0), "v"(m));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(mx0) : "v"(mx0), "v"(M));
+                } else {
+                    mn0 = fminf(mn0, m);
+                    mx0 = fmaxf(mx0, M);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
