@@ -666,7 +666,12 @@ def main():
             acs_ = gpu.Autocorr(g, fs)
             acs_.set_plan(args.plan)
             acs_.set_certify(1)
-            ring, _, _, _ = acs_.retention()
+            ring, ready_, _, _ = acs_.retention()
+            t_ring = time.perf_counter()
+            while ready_ < min(ring, 1100 + nwin) and time.perf_counter() - t_ring < 20.0:  # steady state, not start-up: the ring's segments
+                time.sleep(0.05)                                                               # are allocated in the background (tsdrgpu.h)
+                ring, ready_, _, _ = acs_.retention()
+            t_ring = time.perf_counter() - t_ring
             acs_.run(d_iq, 1, acs_.capture, nwin, mode=0)
             acs_.argmax()
             acs_.reset()
@@ -691,6 +696,7 @@ def main():
                       "transform_at_the_end": "exact (reference arithmetic): the epoch was promoted" if is_exact else
                                               "float32 three-trip, certified (tsdrgpu_autocorr_set_certify mode 1)",
                       "ring_windows": ring, "ring_GiB": round(ring * 4.0 * acs_.n / 2 ** 30, 2), "ring_windows_allocated_at_the_end": ring_ready,
+                      "waited_for_the_ring_s": round(t_ring, 2),
                       "ring_position": kept,
                       "plot_updates": reps, "plot_updates_uncertified": updates_held, "epochs_replayed_exact": int(c_.promotions),
                       "premise_checks": int(c_.premise_checks), "premise_failures": int(c_.premise_failures),

@@ -1658,7 +1658,9 @@ extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, si
             delete rg;
             return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_set_certify", "retention ring");
         }
-        rg->want = rg->nseg_max > 1 ? 2 : 1;
+        // the whole ring is asked for at once: the thread works through the segments in the background (a few seconds for
+        // 32 GiB; a real-time stream fills a segment in 3.6 s, a free-running one may catch up with it and promote)
+        rg->want = rg->nseg_max;
         if (rg->nseg_max > 1) rg->th = std::thread([rg] { rg->run(); });
         ac->ring = rg;
         ac->ring_cap = rg->nseg_max * rg->seg_windows;
