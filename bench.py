@@ -905,6 +905,40 @@ def main():
                             "frac": e["frac"], "traffic": traffic_all.get(dom), "avg_launch_ms": e["avg_launch_ms"],
                             "alg_bytes_per_launch": e["alg_bytes_per_launch"]}
             roofline["traffic_source"] = traffic_src
+            # the same fraction from the COMMITTED rocprofv3 --kernel-trace --stats summary of this command (profiles/
+            # kernel_stats.csv; average duration per launch x launches per pass), so that `frac` can be reproduced from profiles/
+            # without running anything: the event-timed figure above is this run's, the rocprof one the committed profile's
+            try:
+                import csv as _csv
+                kpath = os.path.join(ROOT, "profiles", "kernel_stats.csv")
+                avg_ns = {}
+                for row in _csv.DictReader(open(kpath)):
+                    avg_ns[row["Name"]] = float(row["AverageNs"])
+
+                def _avg(pred):
+                    v = [ns for name, ns in avg_ns.items() if pred(name)]
+                    return v[0] if v else None
+
+                if dom == "autocorrelation":
+                    parts = {"k_ac_cols_trip1": _avg(lambda n: "k_ac_cols<" in n and "false>" in n), "k_ac_rows": _avg(lambda n: n.startswith("k_ac_rows") or " k_ac_rows" in n),
+                             "k_ac_cols_trip3": _avg(lambda n: "k_ac_cols<" in n and "true>" in n), "k_accumulate": _avg(lambda n: "k_accumulate" in n)}
+                    if all(v is not None for v in parts.values()):
+                        launches_each = ac_launches / 4.0  # the four kernels of the group are launched equally often
+                        g_ms = sum(parts.values()) * launches_each * 1e-6
+                        roofline["rocprof"] = {"source": "profiles/kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --serial, scripts/gpu_prof.sh)",
+                                               "avg_launch_us": {k: round(v * 1e-3, 2) for k, v in parts.items()}, "launches_per_pass_each": launches_each,
+                                               "group_ms_per_pass": round(g_ms, 4), "achieved_GBs": round(ac_bytes_pass / (g_ms * 1e-3) / 1e9, 1),
+                                               "frac": round(ac_bytes_pass / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                else:
+                    key = {"k_rs_area": "k_rs_area_up<true, true>" if args.fuse else "k_rs_area_up<true, false>", "k_frame_stats": "k_frame_stats<false>",
+                           "k_frame_pass": "k_frame_stats<true>" if fused_flat else "k_frame_pass"}.get(dom, dom)
+                    ns = _avg(lambda n: key in n)
+                    if ns:
+                        b = kernels[dom]["alg_bytes_per_launch"] * kernels[dom]["launches_per_pass"]
+                        roofline["rocprof"] = {"source": "profiles/kernel_stats.csv", "avg_launch_us": round(ns * 1e-3, 2),
+                                               "frac": round(b / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 4)}
+            except Exception as ex:  # noqa: BLE001  (no committed profile: nothing to show)
+                roofline["rocprof"] = {"unavailable": repr(ex)[:120]}
             roofline["measured_over"] = (f"{np_} passes repeated with per-dispatch HIP events right after the timed region, all kernels "
                                          f"on ONE lane ({dt_prof / np_ * 1e3:.3f} ms/pass instrumented and serial vs {ms_pass:.3f} ms/pass timed"
                                          + (")" if args.serial else ", where the autocorrelation runs on the BACKGROUND lane beside the frame path)"))
