@@ -666,12 +666,10 @@ def main():
             acs_ = gpu.Autocorr(g, fs)
             acs_.set_plan(args.plan)
             acs_.set_certify(1)
-            ring, ready_, _, _ = acs_.retention()
             t_ring = time.perf_counter()
-            while ready_ < min(ring, 1100 + nwin) and time.perf_counter() - t_ring < 20.0:  # steady state, not start-up: the ring's segments
-                time.sleep(0.05)                                                               # are allocated in the background (tsdrgpu.h)
-                ring, ready_, _, _ = acs_.retention()
-            t_ring = time.perf_counter() - t_ring
+            acs_.retention_reserve(1100 + nwin, 20000)  # steady state, not start-up: the ring's segments are allocated in the background
+            t_ring = time.perf_counter() - t_ring       # (40-80 ms per fresh GiB); a host that knows its epoch's length says so
+            ring, ready_, _, _ = acs_.retention()
             acs_.run(d_iq, 1, acs_.capture, nwin, mode=0)
             acs_.argmax()
             acs_.reset()

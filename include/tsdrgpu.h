@@ -352,7 +352,7 @@ int tsdrgpu_autocorr_set_exact(tsdrgpu_autocorr_t *ac, int on);
  * last correlation are then bit-identical to the reference's, and the rest of the epoch runs exact.
  *   mode 1: the library retains the windows — the first fft_n samples of each, demodulated, in a ring of
  *           retain_bytes in HBM (0 = a quarter of the device's free memory at the time of the call, at most 32 GiB: 2048
- *           windows of 2^22 samples, 116 s of real-time signal at 100 MS/s), allocated in ~1 GiB segments ahead of need
+ *           windows of 2^22 samples, 116 s of real-time signal at 100 MS/s), allocated in segments of >= 32 windows ahead of need
  *           by a thread of the library's own (tsdrgpu_autocorr_retention); the float32 transform reads the ring.  An
  *           epoch that outgrows the ring is promoted (one exact replay) and continues exact: such epochs cost what the
  *           exact form costs from then on, shorter ones (a sweep over a recording, a GUI that resets on every parameter
@@ -374,11 +374,14 @@ int tsdrgpu_autocorr_set_exact(tsdrgpu_autocorr_t *ac, int on);
 #define TSDRGPU_AC_CERT_KAPPA 8e-6
 int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, size_t retain_bytes);
 /* mode 1's retention ring: its capacity in windows when fully allocated, the part of it that is allocated right now (the ring
- * grows in ~1 GiB segments that a background thread allocates ahead of need: fresh device memory costs 40-80 ms per GiB at
+ * grows in segments of >= 32 windows that a background thread allocates ahead of need: fresh device memory costs 40-80 ms per GiB at
  * first use, which neither the caller's thread nor the detector's lane should wait for), the position of the epoch's next
  * window in it, and whether the epoch has been promoted (or the object is in exact mode) — i.e. which transform the next
  * window will go through.  A window that would not fit into what is allocated promotes the epoch. */
 int tsdrgpu_autocorr_retention(tsdrgpu_autocorr_t *ac, int *ring_windows, int *ring_ready, int *retained_windows, int *epoch_is_exact);
+/* The allocator keeps two segments beyond the one in use ready.  A host that knows its epoch will hold `windows` windows (a
+ * sweep over a recording) asks for that room at once and may wait up to wait_ms for it (0: just ask). */
+int tsdrgpu_autocorr_retention_reserve(tsdrgpu_autocorr_t *ac, int windows, int wait_ms);
 /* Replays the current epoch in the reference's arithmetic (no-op when it already is exact).  In a sharded run
  * (mode 1 sums + tsdrgpu_autocorr_allreduce) it leaves this rank's exact sums: repeat the all-reduce afterwards. */
 int tsdrgpu_autocorr_promote(tsdrgpu_autocorr_t *ac);

@@ -13,6 +13,7 @@
 #include "fft4step.h"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -1292,7 +1293,7 @@ static float *ac_ring_slot(tsdrgpu_autocorr_t *ac, int nwindows, int *pos_out)
     if (pos % W + nwindows > W) pos = (pos / W + 1) * W;  // the rest of this segment stays empty
     const int si = pos / W;
     if (si >= rg->nseg_max || si >= rg->ready.load(std::memory_order_acquire)) return nullptr;
-    rg->ask(si + 2);  // the next segment is made while this one fills
+    rg->ask(si + 3);  // the next two segments are made while this one fills
     *pos_out = pos;
     return rg->seg[si] + (size_t)(pos % W) * ac->n;
 }
@@ -1640,9 +1641,10 @@ extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, si
         size_t w = retain_bytes / win_bytes;
         if (w < 1) w = 1;
         if (w > 65535) w = 65535;
-        // segments of about 1 GiB (TSDRGPU_AC_SEGMENT_MB), at least 32 windows, never more than the whole ring
+        // segments of about 256 MiB (TSDRGPU_AC_SEGMENT_MB), at least 32 windows (a call's windows lie in one segment),
+        // never more than the whole ring: 512 MiB at 100 MS/s, 1 GiB at 200 MS/s
         const char *sm = getenv("TSDRGPU_AC_SEGMENT_MB");
-        const size_t seg_target = (sm && atol(sm) > 0) ? (size_t)atol(sm) << 20 : (size_t)1 << 30;
+        const size_t seg_target = (sm && atol(sm) > 0) ? (size_t)atol(sm) << 20 : (size_t)256 << 20;
         size_t sw = seg_target / win_bytes;
         if (sw < 32) sw = 32;
         if (sw > w) sw = w;
@@ -1658,9 +1660,10 @@ extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, si
             delete rg;
             return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr_set_certify", "retention ring");
         }
-        // the whole ring is asked for at once: the thread works through the segments in the background (a few seconds for
-        // 32 GiB; a real-time stream fills a segment in 3.6 s, a free-running one may catch up with it and promote)
-        rg->want = rg->nseg_max;
+        // two segments beyond the one in use are kept ready (ac_ring_slot): a real-time stream fills a segment in seconds, the
+        // thread makes one in 40-150 ms; a host that knows it will need more says so (tsdrgpu_autocorr_retention_reserve).
+        // (Asking for the whole ring at once made a one-second session allocate — and free — 32 GiB it never used.)
+        rg->want = rg->nseg_max > 1 ? 2 : 1;
         if (rg->nseg_max > 1) rg->th = std::thread([rg] { rg->run(); });
         ac->ring = rg;
         ac->ring_cap = rg->nseg_max * rg->seg_windows;
@@ -1674,6 +1677,22 @@ extern "C" int tsdrgpu_autocorr_set_certify(tsdrgpu_autocorr_t *ac, int mode, si
     }
     ac->log_cap = cap;
     ac->certify = mode;
+    return TSDRGPU_OK;
+}
+
+// asks the allocator for room for `windows` windows of the ring now; waits up to wait_ms for it (0: do not wait)
+extern "C" int tsdrgpu_autocorr_retention_reserve(tsdrgpu_autocorr_t *ac, int windows, int wait_ms)
+{
+    if (!ac || windows < 0 || wait_ms < 0) return TSDRGPU_EINVAL;
+    AcRing *rg = ac->ring;
+    if (ac->certify != 1 || !rg) return tsdr_fail(ac->g, TSDRGPU_ESTATE, "tsdrgpu_autocorr_retention_reserve", "no retention ring (tsdrgpu_autocorr_set_certify mode 1)");
+    int nseg = (windows + rg->seg_windows - 1) / rg->seg_windows;
+    if (nseg > rg->nseg_max) nseg = rg->nseg_max;
+    rg->ask(nseg);
+    for (int waited = 0; waited < wait_ms && rg->ready.load() < nseg; waited += 2) {
+        { std::lock_guard<std::mutex> lk(rg->m); if (rg->failed) break; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
     return TSDRGPU_OK;
 }
 

@@ -160,6 +160,7 @@ _SIGS = {
     "tsdrgpu_autocorr_plots": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint64)]),
     "tsdrgpu_autocorr_device_plots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_promote_step": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
+    "tsdrgpu_autocorr_retention_reserve": (C.c_int, [vp, C.c_int, C.c_int]),
     "tsdrgpu_autocorr_retention": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tsdrgpu_autocorr_device_sums": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_autocorr_finalize_sums": (C.c_int, [vp, C.c_uint64]),
@@ -706,6 +707,9 @@ class Autocorr:
         r = C.c_int()
         self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_promote_step(self.h, int(max_windows), C.byref(r)))
         return r.value
+
+    def retention_reserve(self, windows, wait_ms=0):
+        self.ctx._ck(self.ctx.lib.tsdrgpu_autocorr_retention_reserve(self.h, int(windows), int(wait_ms)))
 
     def retention(self):
         """(ring capacity in windows, the part of it allocated so far, position of the epoch's next window, epoch runs in the exact form)"""
