@@ -38,6 +38,7 @@ typedef struct tsdrx_stats {
     int64_t frames_made, frames_lost_to_viewer;  /* frames post-processed / not delivered because the viewer was slower */
     int64_t windows;                             /* capture windows correlated */
     int64_t plots_held, epochs_replayed;         /* certified detector: plots held back / epochs replayed exactly */
+    int64_t frames_fused;                        /* frames that went through the fused run (backlogs of >= 8 frames) */
 } tsdrx_stats_t;
 int tsdrx_get_stats(tsdr_lib_t *tsdr, tsdrx_stats_t *out);
 

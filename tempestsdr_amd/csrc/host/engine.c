@@ -1306,6 +1306,7 @@ void engine_stats(struct engine *e, tsdrx_stats_t *out)
     out->windows = e->n_windows;
     out->plots_held = e->n_plots_held;
     out->epochs_replayed = e->n_promotions;
+    out->frames_fused = e->n_fused_frames;
 }
 
 int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)

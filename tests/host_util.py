@@ -27,7 +27,7 @@ RGB_CB = C.CFUNCTYPE(None, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p)
 class Stats(C.Structure):
     """tsdrx_stats_t (include/TSDRLibraryExt.h)"""
     _fields_ = [(n, C.c_int64) for n in ("blocks_in", "blocks_lost", "frames_made", "frames_lost_to_viewer", "windows",
-                                          "plots_held", "epochs_replayed")]
+                                          "plots_held", "epochs_replayed", "frames_fused")]
 
 
 def build_test_plugin():

@@ -440,6 +440,27 @@ def test_pipeline_mem_plugin_matches_oracle(orc, iq_file, monkeypatch, zerocopy)
     s.close()
 
 
+def test_pipeline_backlog_takes_the_fused_run(orc, tmp_path):
+    """A source that runs ahead of the engine: the backlog is post-processed in batches of >= 8 frames through the FUSED run
+    (tsdrgpu_postproc_begin_minmax with the resampler's frame tracking — the path bench.py times), and every delivered frame
+    is still the oracle's, in order from the first.  24 blocks of 262 144 samples, free-running, one pass: nothing is lost
+    (the input queue holds 64 blocks, the frame queue 48 frames), so the stream is the deterministic one."""
+    n = 24 * (BLOCK // 2)
+    iq = synth.synth_iq(FS, "640x480", 60.0, n, seed=0x5EED0009)
+    path = tmp_path / "backlog.f32"
+    iq.tofile(path)
+    geo = orc.geometry(FS, H, FV)
+    want = oracle_frames(orc, iq, geo)
+    s, ok, rc = run_session(hu.MEM_PLUGIN, f"{path} {FS} {BLOCK} 1 0", nframes=len(want) - 2, timeout=30)
+    assert ok and rc == 0 and s.status == 0, s.err()
+    st = s.stats()
+    assert st.blocks_lost == 0 and st.frames_lost_to_viewer == 0
+    hits = match_in_order(s.frames, want)
+    assert hits == list(range(len(hits))) and len(hits) >= len(want) - 3
+    assert st.frames_fused >= 8, "the backlog behind the detector's start-up should have gone through the fused run"
+    s.close()
+
+
 @pytest.mark.parametrize("inverted", [0, 1])
 def test_extension_rgb_delivery_matches_the_jni_conversion(orc, iq_file, inverted):
     """tsdrx_readasync_rgb (include/TSDRLibraryExt.h): frames arrive as packed 0x00RRGGBB, converted on the device;
