@@ -1282,19 +1282,19 @@ extern "C" int tsdrgpu_autocorr_promote_step(tsdrgpu_autocorr_t *ac, int max_win
     return TSDRGPU_OK;
 }
 
-// where the next `nwindows` windows of the epoch go in the ring (a call's windows lie in one segment), or nullptr when they
-// do not fit — the ring is full, or the allocator has not got that far yet
-static float *ac_ring_slot(tsdrgpu_autocorr_t *ac, int nwindows, int *pos_out)
+// where the next windows of the epoch go in the ring: as many of `nwindows` as the current segment still holds (*take), or
+// nullptr when there is no room — the ring is full, or the allocator has not got that far yet
+static float *ac_ring_slot(tsdrgpu_autocorr_t *ac, int nwindows, int *pos_out, int *take)
 {
     AcRing *rg = ac->ring;
-    if (!rg || nwindows > rg->seg_windows) return nullptr;
+    if (!rg) return nullptr;
     const int W = rg->seg_windows;
-    int pos = ac->ring_count;
-    if (pos % W + nwindows > W) pos = (pos / W + 1) * W;  // the rest of this segment stays empty
+    const int pos = ac->ring_count;
     const int si = pos / W;
     if (si >= rg->nseg_max || si >= rg->ready.load(std::memory_order_acquire)) return nullptr;
     rg->ask(si + 3);  // the next two segments are made while this one fills
     *pos_out = pos;
+    *take = nwindows < W - pos % W ? nwindows : W - pos % W;
     return rg->seg[si] + (size_t)(pos % W) * ac->n;
 }
 
@@ -1325,17 +1325,23 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     }
     // the library keeps them: the first n samples of every window, demodulated, into the ring; the float32 transform
     // then reads the ring.  An epoch that outgrows the ring is replayed exactly once and continues in the exact form.
-    int pos = 0;
-    float *slot = ac->log_count >= ac->log_cap ? nullptr : ac_ring_slot(ac, nwindows, &pos);
-    if (!slot) {
-        if ((rc = tsdrgpu_autocorr_promote(ac))) return rc;
-        return ac_run_exact(ac, d_in, in_is_iq, stride, nwindows, mode);
+    // (a call's windows go into the ring segment by segment: one piece and one log record per segment touched)
+    for (int done = 0; done < nwindows;) {
+        const float *src = d_in + (size_t)done * (size_t)stride * (in_is_iq ? 2 : 1);
+        int pos = 0, take = 0;
+        float *slot = ac->log_count >= ac->log_cap ? nullptr : ac_ring_slot(ac, nwindows - done, &pos, &take);
+        if (!slot) {  // no room (or not allocated yet): what was run so far is replayed, the rest of the epoch runs exact
+            if ((rc = tsdrgpu_autocorr_promote(ac))) return rc;
+            return ac_run_exact(ac, src, in_is_iq, stride, nwindows - done, mode);
+        }
+        if ((rc = fftx_retain(g, ac->st, src, in_is_iq, (long long)stride, take, ac->n, slot))) return rc;
+        const AcLogRec r = {slot, 0, (long long)ac->n, take, mode};
+        ac->log[ac->log_count++] = r;
+        ac->ring_count = pos + take;
+        if ((rc = ac_run_fast(ac, slot, 0, (long long)ac->n, take, mode))) return rc;
+        done += take;
     }
-    if ((rc = fftx_retain(g, ac->st, d_in, in_is_iq, (long long)stride, nwindows, ac->n, slot))) return rc;
-    const AcLogRec r = {slot, 0, (long long)ac->n, nwindows, mode};
-    ac->log[ac->log_count++] = r;
-    ac->ring_count = pos + nwindows;
-    return ac_run_fast(ac, slot, 0, (long long)ac->n, nwindows, mode);
+    return TSDRGPU_OK;
 }
 
 extern "C" int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *h_frame, double *h_line, uint64_t *h_calls)
