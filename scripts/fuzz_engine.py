@@ -58,9 +58,12 @@ def one(rng, plugin, tmp):
     cfg = (float(rng.choice([0.0, 0.0, 0.25, 0.9375])), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)),
            int(rng.integers(0, 2)))
     mb, lbs, aap, ash, pll = cfg
-    params = f"{path} {fs} {block} 3000"
-    stream = iq
     per = block // 2
+    # half of the sessions whose recording fits the input queue (64 blocks) run the source flat out: the backlog behind the
+    # engine's start-up then goes through batches of >= 8 frames, i.e. the fused run with the resampler's frame tracking
+    free_running = nsamp // per <= 60 and rng.random() < 0.5
+    params = f"{path} {fs} {block} {0 if free_running else 3000}"
+    stream = iq
     if pll == 0 and rng.random() < 0.4 and nsamp // per >= 6:  # (with the PLL the skip unit moves with the geometry)
         # the plugin loses drop_n samples after block drop_at and reports them with the next block; the library
         # then skips whole multiples of one frame's samples (dsp.c:313-368) — same bookkeeping on the oracle side
