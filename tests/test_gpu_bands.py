@@ -7,11 +7,15 @@ tsdrgpu_comm_allreduce_f64 / _f32max over RCCL, which is exercised with a one-ra
 band outputs, the per-frame sync / autogain records and the state carried over several batches must equal the
 single-GPU run bit for bit (its fast mode: a band cannot walk a column through the other bands for the literal
 re-collapse of toss-up strips).  Reference arithmetic: dsp.c:41-110, syncdetector.c:171-225."""
+import os
+
 import numpy as np
 import pytest
 
 from tempestsdr_amd import gpu
 from gpu_util import ctx
+
+HERE_ROOT = os.path.abspath(__file__)
 
 pytestmark = pytest.mark.gpu
 
@@ -413,3 +417,42 @@ def test_general_band_run_config4_eight_bands_gui_order_with_autoshift(orc):
         got, infos, kinds = _run_bands_general(g, pps, edges, fr, motionblur=blur, lowpass_before_sync=1, autoshift=1)
         assert gpu.BAND_ALLGATHER_F32 in kinds
         assert np.array_equal(got, want), (batch, int(np.sum(got != want)))
+
+
+@pytest.mark.parametrize("kernel", ["sample_parallel", "pixel_groups"])
+def test_band_resampler_chunks_longer_than_a_frame(orc, kernel):
+    """A caller may poll more than a frame's worth of samples per dsp_resample_process call (the library polls 0.1 frame, but
+    nothing in the API says so): a chunk's output then touches three or four frames, i.e. more band entries than the two per
+    chunk the table used to be sized for (an advisor finding of round 3: the pinned staging slot was overrun).  Both forms of
+    the band resampler — the sample-parallel kernel and the pixel-group kernel with its entry table (TSDRGPU_RS_GROUPS=1, read
+    once per process: run in a child) — against the ORACLE's stream for the same chunking."""
+    import subprocess
+    import sys
+    if kernel == "pixel_groups" and not os.environ.get("TSDRGPU_RS_GROUPS"):
+        out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x",
+                              os.path.abspath(__file__) + "::test_band_resampler_chunks_longer_than_a_frame[pixel_groups]"],
+                             env=dict(os.environ, TSDRGPU_RS_GROUPS="1"), capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(HERE_ROOT)))
+        assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
+        return
+    from tempestsdr_amd import synth
+    g = ctx()
+    fs, h, fv = 2_000_000, 131, 60.0
+    geo = orc.geometry(fs, h, fv)
+    W, P = geo.width, geo.width * h
+    chunk, nch = 90_000, 7           # 2.7 frames of pixels per chunk
+    y0, rows = 32, 64
+    iq = synth.synth_iq(fs, "640x480", fv, nch * chunk, seed=0x5EED000A)
+    mag = orc.am_demod(iq)
+    up, down = W * h * fv, float(fs)
+    ors = orc.Resampler()
+    want = np.concatenate([ors.process(mag[k * chunk:(k + 1) * chunk], up, down) for k in range(nch)])
+    d_iq = g.to_device(iq)
+    rs_band = gpu.Resampler(g)
+    cap = want.size // P + 3
+    d_band = g.empty(cap * rows * W)
+    n, touched = rs_band.process_band(d_iq, 1, chunk, nch, up, down, W, h, y0, rows, 0, d_band, cap)
+    assert n == want.size and touched == (n + P - 1) // P and touched >= 18
+    got = d_band.download().reshape(cap, rows, W)
+    for j in range(n // P):
+        ref = want[j * P:(j + 1) * P].reshape(h, W)[y0:y0 + rows]
+        assert np.array_equal(got[j], ref), (j, int(np.sum(got[j] != ref)))
