@@ -150,8 +150,11 @@ int tsdrgpu_resampler_frame_minmax(tsdrgpu_resampler_t *rs, const float **d_min,
  * `phase` = pixels of that first frame which earlier calls produced (0 when the call starts on a frame boundary); the
  * caller carries an incomplete last frame (slot *h_frames_touched - 1 when (phase + *h_n_out) % (width*height) != 0) into
  * slot 0 of its next call.  *h_n_out = pixels the full call would have produced.  Area mode; values bit-identical to
- * the corresponding pixels of tsdrgpu_resample's output (dsp.c:256-307 entered at each pixel group through the closed
- * form of resample_math.h). */
+ * the corresponding pixels of tsdrgpu_resample's output.  Ratios 1 <= r <= 8 with frames of >= 4096 pixels (the reference's
+ * geometry) run the sample-parallel kernel in its band form — a band is a contiguous pixel range of every frame, workgroups
+ * outside it return before loading —, anything else the pixel-group kernel over a table of band entries (dsp.c:256-307
+ * entered at each pixel group through the closed form of resample_math.h).  A chunk may be longer than a frame (its output
+ * then touches several frames); at most 65535 band entries per call in the pixel-group form. */
 int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in, int in_is_iq, uint32_t chunk, int nchunks,
                           double upsample_by, double downsample_by, int width, int height, int y0, int rows, int64_t phase,
                           float *d_band, int64_t band_capacity_frames, int64_t *h_n_out, int *h_frames_touched);
