@@ -507,10 +507,17 @@ int tsdrgpu_superb_stitch_exact(tsdrgpu_t *g, float *const *d_hops, int nhops, i
  * (2 per IQ sample).  Bit-exact with the plugin's double division + float store. */
 int tsdrgpu_decode_samples(tsdrgpu_t *g, const void *d_raw, int type, float *d_out, int64_t n);
 
-/* a3, on demand: dsp_autogain_t.snr of a frame as dsp_autogain_run would leave it (TempestSDR/src/dsp.c:69-93: mean over
- * the non-sentinel sum / all pixels, deviations over every pixel).  The reference never reads the field (dsp.c:234 is
- * commented out), so the post-processing run does not produce it; f64 tree sums, ~1e-12 relative to the sequential
- * loop.  Synchronises. */
+/* a3: dsp_autogain_t.snr of a frame as dsp_autogain_run would leave it (TempestSDR/src/dsp.c:69-93: mean over the
+ * non-sentinel sum / all pixels, deviations over every pixel); f64 tree sums, ~1e-12 relative to the sequential loop.
+ * The reference never reads the field (dsp.c:234 is commented out), so a post-processing run produces it only when asked:
+ *   tsdrgpu_postproc_set_snr(pp, 1)  every tsdrgpu_postproc_run / _begin+_finish / _begin_minmax+_finish from now on also
+ *                                    leaves one value per frame — of the frames autogain reads in that stage order (the
+ *                                    input frames, or the low-passed / corrected ones when autogain runs after them):
+ *                                    one more read of those frames, queued beside the sync chain.  Band runs do not.
+ *   tsdrgpu_postproc_snr(pp, h, n)   the first n values of the last run (ESTATE if it produced fewer).  Synchronises.
+ *   tsdrgpu_frame_snr                the same value for any frame on demand (bit-identical to the by-product).  Synchronises. */
+int tsdrgpu_postproc_set_snr(tsdrgpu_postproc_t *pp, int on);
+int tsdrgpu_postproc_snr(tsdrgpu_postproc_t *pp, float *h_snr, int nframes);
 int tsdrgpu_frame_snr(tsdrgpu_t *g, const float *d_frame, int64_t npixels, float *h_snr);
 
 /* f3: frame -> packed 0x00RRGGBB exactly like the JNI shim (JavaGUI/jni/TSDRLibraryNDK.c:222-276):

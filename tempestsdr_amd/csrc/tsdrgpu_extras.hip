@@ -95,20 +95,24 @@ __device__ __forceinline__ double snr_block_sum(double v, double *sh)
     __syncthreads();
     return r;  // the same value in every thread
 }
-__global__ __launch_bounds__(256) void k_snr_sum(const float *__restrict__ x, long long n, double *__restrict__ part)
+// blockIdx.y = frame; part: [F][3][SNR_BLOCKS] (sums, squared deviations, deviations)
+__global__ __launch_bounds__(256) void k_snr_sum(const float *__restrict__ frames, long long stride, long long n, double *__restrict__ parts)
 {
     __shared__ double sh[4];
+    const float *x = frames + (long long)blockIdx.y * stride;
     double s = 0.0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)SNR_BLOCKS * 256) {
         const float v = x[i];
         if (!(v > 250.0 || v < -250)) s += (double)v;
     }
     s = snr_block_sum(s, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (threadIdx.x == 0) parts[(size_t)blockIdx.y * 3 * SNR_BLOCKS + blockIdx.x] = s;
 }
-__global__ __launch_bounds__(256) void k_snr_dev(const float *__restrict__ x, long long n, const double *__restrict__ part, double *__restrict__ part2)
+__global__ __launch_bounds__(256) void k_snr_dev(const float *__restrict__ frames, long long stride, long long n, double *__restrict__ parts)
 {
     __shared__ double sh[4];
+    const float *x = frames + (long long)blockIdx.y * stride;
+    double *part = parts + (size_t)blockIdx.y * 3 * SNR_BLOCKS;
     const double sum = snr_block_sum(part[threadIdx.x], sh);  // SNR_BLOCKS == blockDim.x
     const double mean = sum / (double)n;
     double s2 = 0.0, s1 = 0.0;
@@ -119,19 +123,31 @@ __global__ __launch_bounds__(256) void k_snr_dev(const float *__restrict__ x, lo
     }
     s2 = snr_block_sum(s2, sh);
     s1 = snr_block_sum(s1, sh);
-    if (threadIdx.x == 0) { part2[2 * blockIdx.x] = s2; part2[2 * blockIdx.x + 1] = s1; }
+    if (threadIdx.x == 0) { part[SNR_BLOCKS + blockIdx.x] = s2; part[2 * SNR_BLOCKS + blockIdx.x] = s1; }
 }
-__global__ __launch_bounds__(256) void k_snr_final(long long n, const double *__restrict__ part, const double *__restrict__ part2, float *__restrict__ out)
+__global__ __launch_bounds__(256) void k_snr_final(long long n, const double *__restrict__ parts, float *__restrict__ out)
 {
     __shared__ double sh[4];
+    const double *part = parts + (size_t)blockIdx.x * 3 * SNR_BLOCKS;
     const double sum = snr_block_sum(part[threadIdx.x], sh);
-    const double s2 = snr_block_sum(part2[2 * threadIdx.x], sh);
-    const double s1 = snr_block_sum(part2[2 * threadIdx.x + 1], sh);
+    const double s2 = snr_block_sum(part[SNR_BLOCKS + threadIdx.x], sh);
+    const double s1 = snr_block_sum(part[2 * SNR_BLOCKS + threadIdx.x], sh);
     if (threadIdx.x == 0) {
         const double mean = sum / (double)n;
         const double stdev = sqrt((s2 - s1 * s1 / (double)n) / (double)(n - 1));
-        out[0] = (float)(mean / stdev);
+        out[blockIdx.x] = (float)(mean / stdev);
     }
+}
+// F frames at once on `st` (the post-processing run's by-product, tsdrgpu_postproc_set_snr): d_parts holds
+// tsdr_snr_part_doubles() doubles per frame
+size_t tsdr_snr_part_doubles(void) { return 3 * SNR_BLOCKS; }
+int tsdr_snr_batch(tsdrgpu_t *g, hipStream_t st, const float *d_frames, long long stride, long long npixels, int F, double *d_parts, float *d_snr)
+{
+    TSDR_LAUNCH(g, PROF_EXTRAS, st, k_snr_sum, dim3(SNR_BLOCKS, F), 256, d_frames, stride, npixels, d_parts);
+    TSDR_LAUNCH(g, PROF_EXTRAS, st, k_snr_dev, dim3(SNR_BLOCKS, F), 256, d_frames, stride, npixels, d_parts);
+    TSDR_LAUNCH(g, PROF_EXTRAS, st, k_snr_final, F, 256, npixels, (const double *)d_parts, d_snr);
+    if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "dsp_autogain_t.snr", "launch");
+    return TSDRGPU_OK;
 }
 extern "C" int tsdrgpu_frame_snr(tsdrgpu_t *g, const float *d_frame, int64_t npixels, float *h_snr)
 {
@@ -139,11 +155,7 @@ extern "C" int tsdrgpu_frame_snr(tsdrgpu_t *g, const float *d_frame, int64_t npi
     double *d_part = nullptr;
     if (hipMalloc(&d_part, sizeof(double) * (3 * SNR_BLOCKS + 1)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_frame_snr", "partials");
     float *d_out = reinterpret_cast<float *>(d_part + 3 * SNR_BLOCKS);
-    TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_snr_sum, SNR_BLOCKS, 256, d_frame, (long long)npixels, d_part);
-    TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_snr_dev, SNR_BLOCKS, 256, d_frame, (long long)npixels, (const double *)d_part, d_part + SNR_BLOCKS);
-    TSDR_LAUNCH(g, PROF_EXTRAS, g->stream, k_snr_final, 1, 256, (long long)npixels, (const double *)d_part, (const double *)(d_part + SNR_BLOCKS), d_out);
-    int rc = TSDRGPU_OK;
-    if (hipGetLastError() != hipSuccess) rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_frame_snr", "launch");
+    int rc = tsdr_snr_batch(g, g->stream, d_frame, 0, (long long)npixels, 1, d_part, d_out);
     if (!rc && (hipMemcpyAsync(h_snr, d_out, sizeof(float), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
                 hipStreamSynchronize(g->stream) != hipSuccess))
         rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_frame_snr", "copy");

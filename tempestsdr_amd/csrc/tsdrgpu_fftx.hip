@@ -146,6 +146,9 @@ __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src
 //   * the last trip of the inverse transform stores only what the detector reads (the two lag windows and lag 0),
 //     except for the window kept whole for tsdrgpu_autocorr_last_corr.
 // ---------------------------------------------------------------------------
+#ifndef FFTX_LOAD_UNROLL
+#define FFTX_LOAD_UNROLL 16
+#endif
 struct FftxKeep {
     int on;       // 0: store everything
     int full_w;   // window of the batch stored whole (-1: none)
@@ -249,7 +252,9 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
         const unsigned S = n >> L;
         r0 = tile * C;
         const float *sb = src + (long long)w * src_stride * (src_mode == 0 ? 1 : 2);
-#pragma unroll 4
+        // all 16 gathers of a thread are requested before the first is used: the trip is bound by their latency (SQ counters:
+        // 68 % of a wave's cycles waiting, the VALU 12 % busy)
+#pragma unroll FFTX_LOAD_UNROLL
         for (unsigned e = tid; e < 4096u; e += 256u) {
             const unsigned row = e >> LOGC, c = e & (C - 1u);
             const unsigned long long at = (unsigned long long)fftx_rev(row, L) * S + r0 + c;
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
         const unsigned group = tile / per_group;
         colbase = (tile % per_group) << LOGC;
         gbase = ((unsigned long long)group << (s0 + L)) + colbase;
-#pragma unroll 4
+#pragma unroll FFTX_LOAD_UNROLL
         for (unsigned e = tid; e < 4096u; e += 256u) {
             const unsigned row = e >> LOGC, c = e & (C - 1u);
             t[row * Cp + c] = zb[gbase + ((unsigned long long)row << s0) + c];

@@ -113,6 +113,11 @@ struct tsdrgpu_postproc {
     float *d_gather;               // [nbands][F][rows_max][W]: the frames every rank needs rows of for the 2-D roll
     size_t cap_gather;
     const float *ext_fmin, *ext_fmax;  // per-frame min/max supplied by the caller (fused run), else null
+    // dsp_autogain_t.snr as a by-product (tsdrgpu_postproc_set_snr): one value per frame of the last run
+    int want_snr, snr_frames;
+    double *d_snr_part;
+    float *d_snr;
+    size_t cap_snr_part, cap_snr;
     float *p_out;                      // the fused run's frame buffer (given to _begin_minmax; _finish must name the same)
     int *clear_with_autogain;          // a device flag the next autogain chain launch zeroes (null: none)
     int p_F, p_W, p_H;
@@ -1561,7 +1566,7 @@ extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
     (void)hipEventDestroy(pp->ev_chain);
     void *bufs[] = {pp->d_state, pp->d_odd, pp->d_screen, pp->d_screen2, pp->d_dump, pp->d_tmp1, pp->d_tmp2, pp->d_bmin, pp->d_bmax, pp->d_tflag, pp->d_colp, pp->d_rowp,
                     pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_work, pp->d_chain, pp->d_sflag, pp->d_exact,
-                    pp->d_xsum, pp->d_xmax, pp->d_v0, pp->d_chain_band, pp->d_items, pp->d_relay, pp->d_gather, pp->d_bedges};
+                    pp->d_xsum, pp->d_xmax, pp->d_v0, pp->d_chain_band, pp->d_items, pp->d_relay, pp->d_gather, pp->d_bedges, pp->d_snr_part, pp->d_snr};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (pp->h_chain) (void)hipHostFree(pp->h_chain);
@@ -1660,6 +1665,14 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
                                                   do_autogain, prm->lowpasscoeff, pp->clear_with_autogain);
         KERNEL_CHECK(g, "k_autogain_chain");
         pp->chain_has_autogain = 1;
+    }
+    if (do_autogain && pp->want_snr && !pp->band_mode) {
+        // dsp_autogain_run's other result (dsp.c:69-93): mean / stdev of the frames autogain reads, beside the chain
+        int rc;
+        if ((rc = ensure(g, &pp->d_snr_part, &pp->cap_snr_part, (size_t)F * tsdr_snr_part_doubles()))) return rc;
+        if ((rc = ensure(g, &pp->d_snr, &pp->cap_snr, (size_t)F))) return rc;
+        if ((rc = tsdr_snr_batch(g, st, frames, fstride, (long long)W * H, F, pp->d_snr_part, pp->d_snr))) return rc;
+        pp->snr_frames = F;
     }
     if (do_sync) {
         const int nmax = W > H ? W : H;
@@ -2836,6 +2849,31 @@ extern "C" int tsdrgpu_postproc_info_pack(tsdrgpu_postproc_t *pp, tsdrgpu_pp_fra
     if (nframes == 0) return TSDRGPU_OK;
     TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_info_pack, (nframes + 63) / 64, 64, pp->d_chain, d_info, nframes);
     KERNEL_CHECK(g, "k_info_pack");
+    return TSDRGPU_OK;
+}
+
+// dsp_autogain_t.snr (dsp.c:69-93) as a by-product of every run from now on: one more read of the frames autogain
+// works on, queued beside the chain.  Off by default: the reference computes the field and never reads it (dsp.c:234).
+extern "C" int tsdrgpu_postproc_set_snr(tsdrgpu_postproc_t *pp, int on)
+{
+    if (!pp) return TSDRGPU_EINVAL;
+    if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_set_snr", "a split run is open");
+    pp->want_snr = on ? 1 : 0;
+    pp->snr_frames = 0;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_snr(tsdrgpu_postproc_t *pp, float *h_snr, int nframes)
+{
+    if (!pp || !h_snr || nframes < 0) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_snr", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    if (pp->pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_snr", "a split run is open: call tsdrgpu_postproc_finish first");
+    if (!pp->want_snr || nframes > pp->snr_frames)
+        return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_snr", "the last run did not produce that many values (tsdrgpu_postproc_set_snr, band runs do not)");
+    if (nframes == 0) return TSDRGPU_OK;
+    // the values were queued on the chain's stream, which the main stream has joined by the end of every run
+    HIP_TRY(g, hipMemcpyAsync(h_snr, pp->d_snr, sizeof(float) * nframes, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
     return TSDRGPU_OK;
 }
 

@@ -126,4 +126,7 @@ int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq,
 int fftx_correlate(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
                    const double2 *d_tw, float2 *z, float *mag);
 int fftx_retain(tsdrgpu_t *g, hipStream_t st, const float *src, int is_iq, long long stride, int cnt, uint32_t n, float *dst);
+// tsdrgpu_extras.hip: dsp_autogain_t.snr of F frames (dsp.c:69-93) queued on st; d_parts = tsdr_snr_part_doubles() doubles per frame
+size_t tsdr_snr_part_doubles(void);
+int tsdr_snr_batch(tsdrgpu_t *g, hipStream_t st, const float *d_frames, long long stride, long long npixels, int F, double *d_parts, float *d_snr);
 int fftx_perform(tsdrgpu_t *g, hipStream_t st, const float2 *d_z, float2 *d_work, uint32_t n, const double2 *d_tw, int inverse);

@@ -82,6 +82,8 @@ _SIGS = {
     "tsdrgpu_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "tsdrgpu_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "tsdrgpu_frame_snr": (C.c_int, [vp, vp, C.c_int64, C.POINTER(C.c_float)]),
+    "tsdrgpu_postproc_set_snr": (C.c_int, [vp, C.c_int]),
+    "tsdrgpu_postproc_snr": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int]),
     "tsdrgpu_copy2": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
     "tsdrgpu_gather2": (C.c_int, [vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int]),
     "tsdrgpu_event_create": (C.c_int, [vp, C.POINTER(vp)]),
@@ -476,6 +478,15 @@ class PostProcess:
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_redo_raw(self.h, h.ctypes.data, h.size, C.byref(f)))
         F = f.value
         return tuple(h[k * 2 * F:(k + 1) * 2 * F].reshape(F, 2) for k in range(3))
+
+    def set_snr(self, on=True):
+        """dsp_autogain_t.snr per frame as a by-product of every run from now on (dsp.c:69-93)."""
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_set_snr(self.h, int(on)))
+
+    def snr(self, nframes):
+        out = (C.c_float * max(nframes, 1))()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_snr(self.h, out, nframes))
+        return np.array(out[:nframes], np.float32)
 
     def set_exact_ties(self, on=True):
         """Detect sync-detector decisions that are toss-ups at the precision of the strips and redo them exactly."""

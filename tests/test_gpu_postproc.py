@@ -516,3 +516,57 @@ def test_frame_parallel_pass_and_its_literal_redo(orc, cfg, negzero, odd):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # bit patterns: the sign of zero too
     for k, (info, (si, sd)) in enumerate(zip(infos, states)):
         assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) == tuple(si[:7]), f"frame {k}"
+
+
+@pytest.mark.parametrize("cfg", [(0, 0, 0, 0, 0.0), (1, 0, 1, 0, 0.5), (0, 1, 0, 0, 0.0), (1, 1, 0, 0, 0.25)])
+@pytest.mark.parametrize("form", ["run", "split", "fused"])
+def test_snr_by_product_of_the_run(orc, cfg, form):
+    """dsp_autogain_t.snr (dsp.c:69-93) of every frame as the run's by-product, in the four stage orders (autogain reads the
+    input frames, the low-passed ones or the corrected ones) and the three forms of a run, against the oracle's field after
+    the same frame; 1e-9 relative (f64 tree sums against the reference's sequential f64 loop); the on-demand entry point
+    returns the identical float for the frames the by-product read."""
+    import ctypes as C
+    g = ctx()
+    fs, h, fv = 2_000_000, 131, 60.0
+    w = orc.geometry(fs, h, fv).width
+    rng = np.random.default_rng(7)
+    frames = [cases.frame_pattern(w, h, k, rng) for k in range(8)]
+    _, states, _ = run_orc(orc, frames, fs, h, fv, cfg)
+    want = np.array([sd[2] for _, sd in states], np.float32)
+    lbs, aap, ash, pll, mb = cfg
+    if form == "fused" and (lbs or aap):
+        pytest.skip("the fused run is the default stage order's")
+    pp = gpu.PostProcess(g)
+    with pytest.raises(gpu.TsdrGpuError):
+        pp.snr(1)                      # not asked for
+    pp.set_snr(True)
+    n = w * h
+    F = len(frames)
+    d_in = g.to_device(np.concatenate(frames))
+    d_out = g.empty(F * n)
+    got = []
+    for s in range(0, F, 4):
+        if form == "run":
+            pp.run(d_in, 4, w, h, d_out, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * n, out_offset=s * n)
+        elif form == "split":
+            pp.begin(d_in, 4, w, h, mb, 0.1, lbs, aap, ash, pll, 0, frames_offset=s * n)
+            pp.finish(d_out, out_offset=s * n)
+        else:
+            mn, mx = _minmax(frames[s:s + 4])
+            d_mn, d_mx = g.to_device(mn), g.to_device(mx)
+            pp.begin_minmax(d_in, 4, w, h, d_mn.at(0), d_mx.at(0), d_out, mb, 0.1, lbs, aap, ash, pll, 0,
+                            frames_offset=s * n, out_offset=s * n)
+            pp.finish(d_out, out_offset=s * n)
+        got.append(pp.snr(4))
+        with pytest.raises(gpu.TsdrGpuError):
+            pp.snr(5)
+    got = np.concatenate(got)
+    assert np.all(np.abs(got.astype(np.float64) - want) <= 1e-9 * np.abs(want) + np.spacing(want)), (got, want)
+    if not lbs and not aap:
+        one = C.c_float()
+        g._ck(g.lib.tsdrgpu_frame_snr(g.h, d_in.at(3 * n), n, C.byref(one)))
+        assert np.float32(one.value) == got[3]
+    pp.set_snr(False)
+    pp.run(d_in, 4, w, h, d_out, mb, 0.1, lbs, aap, ash, pll, 0)
+    with pytest.raises(gpu.TsdrGpuError):
+        pp.snr(1)
