@@ -138,7 +138,7 @@ struct tsdrgpu_autocorr {
     int exact;
     double2 *d_tw;   // the reference's twiddle recurrence values, n-1 entries
     float2 *d_xz;    // AC_XBATCH windows of n complex points
-    float *d_xmag;   // and of n magnitudes
+    float *d_xmag;   // and as many of scratch (the forward transform's trips; the magnitudes in the six-trip form)
     // certified mode (tsdrgpu_autocorr_set_certify)
     int certify;       // 0 off, 1 windows retained by the library (ring), 2 retained by the caller
     int epoch_exact;   // this epoch (since the last reset) was promoted: its windows run in the exact form
@@ -1099,7 +1099,7 @@ static int ac_ensure_exact(tsdrgpu_autocorr_t *ac)
     int rc = fftx_build_table(g, ac->n, &ac->d_tw);
     if (rc) return rc;
     if (hipMalloc(&ac->d_xz, sizeof(float2) * (size_t)ac->n * AC_XBATCH) != hipSuccess ||
-        hipMalloc(&ac->d_xmag, sizeof(float) * (size_t)ac->n * AC_XBATCH) != hipSuccess) {
+        hipMalloc(&ac->d_xmag, sizeof(float2) * (size_t)ac->n * AC_XBATCH) != hipSuccess) {
         (void)hipFree(ac->d_xz);
         (void)hipFree(ac->d_tw);
         ac->d_xz = nullptr;

@@ -230,6 +230,26 @@ __device__ __forceinline__ void fftx_chunk(float2 *__restrict__ t, int a, int s0
     __syncthreads();
 }
 
+// the L stages of a tile as chunks: each chunk is one round trip of the tile through LDS
+#ifndef FFTX_K4
+#define FFTX_K4 1
+#endif
+template <int L, bool FIRST, int U, bool INV>
+__device__ __forceinline__ void fftx_stages(float2 *__restrict__ t, int s0, unsigned colbase, const double2 *__restrict__ tw)
+{
+    if constexpr (FFTX_K4 && L >= 7) {
+        // radix-16 groups (one per thread): two round trips instead of three, the index arithmetic once per 32 butterflies
+        fftx_chunk<4, L, FIRST, 1, INV>(t, 0, s0, colbase, tw);
+        fftx_chunk<L - 4, L, FIRST, 1, INV>(t, 4, s0, colbase, tw);
+        return;
+    }
+    if (L >= 3) fftx_chunk<3, L, FIRST, U, INV>(t, 0, s0, colbase, tw);
+    if (L >= 6) fftx_chunk<3, L, FIRST, U, INV>(t, 3, s0, colbase, tw);
+    if (L == 5) fftx_chunk<2, L, FIRST, U, INV>(t, 3, s0, colbase, tw);
+    if (L == 7) fftx_chunk<1, L, FIRST, 2 * U, INV>(t, 6, s0, colbase, tw);
+    if (L == 8) fftx_chunk<2, L, FIRST, U, INV>(t, 6, s0, colbase, tw);
+}
+
 template <int L, bool FIRST, int U, bool INV>
 __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src, int src_mode, long long src_stride, float2 *__restrict__ z,
                                                    float *__restrict__ mag, unsigned n, int m, int s0, int batch,
@@ -278,12 +298,7 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
         }
     }
     __syncthreads();
-    // L stages as chunks of 3, 3, rest
-    if (L >= 3) fftx_chunk<3, L, FIRST, U, INV>(t, 0, s0, colbase, tw);
-    if (L >= 6) fftx_chunk<3, L, FIRST, U, INV>(t, 3, s0, colbase, tw);
-    if (L == 5) fftx_chunk<2, L, FIRST, U, INV>(t, 3, s0, colbase, tw);
-    if (L == 7) fftx_chunk<1, L, FIRST, 2 * U, INV>(t, 6, s0, colbase, tw);
-    if (L == 8) fftx_chunk<2, L, FIRST, U, INV>(t, 6, s0, colbase, tw);
+    fftx_stages<L, FIRST, U, INV>(t, s0, colbase, tw);
     const bool filter = keep.on && (int)w != keep.full_w;
     if (FIRST) {
         // column c is block B = rev_{m-L}(r0 + c): R contiguous results per block
@@ -313,6 +328,66 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
             if (epilogue == 1) mag[(long long)w * n + at] = sqrtf(v.x * v.x + v.y * v.y);
             else if (!filter || at == 0ull || (at >= keep.lo0 && at < keep.hi0) || (at >= keep.lo1 && at < keep.hi1)) zb[at] = v;
         }
+    }
+}
+
+// The autocorrelation's MIDDLE trip: the forward transform's last L stages, fft.c:167-175's division, the magnitude
+// (fft.c:49-64) and the inverse transform's first L stages on one tile, without the round trip of the magnitudes over HBM
+// and without two of the six kernel ramps.  It works because the two trips want the SAME elements: the forward's last trip
+// (s0 = m - L) holds rows {colbase + c + row * 2^(m-L)}, and the inverse's first trip gathers, for its row r', the element
+// rev_L(r') * 2^(m-L) + r0 + c — the rows of the tile in bit-reversed order.  So between the two halves the tile is permuted
+// in LDS (new row r' = |old row rev_L(r')|), and the inverse's stages then run with the FIRST trip's twiddle indices and its
+// store (R contiguous results per column).  The inverse therefore takes the forward's plan backwards (L_last first); the
+// stages and the f32 roundings between them are the same sequence whatever the grouping, so the bits do not change.
+// zin and zout are different buffers: a tile's results land in other tiles' inputs.
+template <int L, int U>
+__global__ __launch_bounds__(256) void k_fftx_mid(const float2 *__restrict__ zin, float2 *__restrict__ zout, unsigned n, int m, int batch,
+                                                  const double2 *__restrict__ tw, float inv_nf)
+{
+    constexpr unsigned R = 1u << L, C = 4096u >> L, Cp = C + 1u;
+    constexpr int LOGC = 12 - L;
+    __shared__ float2 t[R * Cp];
+    const unsigned tid = threadIdx.x;
+    const unsigned per_oct = 8u * (unsigned)batch;
+    const unsigned oct = blockIdx.x / per_oct, rem = blockIdx.x % per_oct;
+    const unsigned w = rem >> 3, tile = oct * 8u + (rem & 7u);
+    const float2 *zi = zin + (long long)w * n;
+    float2 *zo = zout + (long long)w * n;
+    const int s0 = m - L;                 // the forward's last trip: one group, 2^s0 columns
+    const unsigned colbase = tile << LOGC;
+#pragma unroll FFTX_LOAD_UNROLL
+    for (unsigned e = tid; e < 4096u; e += 256u) {
+        const unsigned row = e >> LOGC, c = e & (C - 1u);
+        t[row * Cp + c] = zi[(unsigned long long)colbase + ((unsigned long long)row << s0) + c];
+    }
+    __syncthreads();
+    fftx_stages<L, false, U, false>(t, s0, colbase, tw);
+    // (the chunk ends with a barrier)  division, magnitude, rows into bit-reversed order
+    float mg[16];
+#pragma unroll
+    for (unsigned k = 0; k < 16u; k++) {
+        const unsigned e = tid + 256u * k;
+        const unsigned row = e >> LOGC, c = e & (C - 1u);
+        float2 v = t[fftx_rev(row, L) * Cp + c];
+        v.x = v.x * inv_nf;  // fft.c:167-175 (see k_fftx_fast)
+        v.y = v.y * inv_nf;
+        mg[k] = sqrtf(v.x * v.x + v.y * v.y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned k = 0; k < 16u; k++) {
+        const unsigned e = tid + 256u * k;
+        const unsigned row = e >> LOGC, c = e & (C - 1u);
+        t[row * Cp + c] = make_float2(mg[k], 0.f);  // real_to_complex, fft.c:14-22
+    }
+    __syncthreads();
+    fftx_stages<L, true, U, true>(t, 0, 0u, tw);
+    // the inverse's first-trip store: column c is block B = rev_{m-L}(r0 + c), R contiguous results
+#pragma unroll 4
+    for (unsigned e = tid; e < 4096u; e += 256u) {
+        const unsigned c = e >> L, row = e & (R - 1u);
+        const unsigned long long B = fftx_rev(colbase + c, m - L);
+        zo[B * R + row] = t[row * Cp + c];
     }
 }
 
@@ -488,8 +563,55 @@ static int fftx_transform(tsdrgpu_t *g, hipStream_t st, const float *src, int sr
     return TSDRGPU_OK;
 }
 
+template <int U>
+static bool fftx_launch_mid(tsdrgpu_t *g, hipStream_t st, int L, unsigned blocks, const float2 *zin, float2 *zout, uint32_t n, int m, int batch,
+                            const double2 *d_tw)
+{
+    const float inv_nf = 1.0f / (float)n;  // exact: n is a power of two
+    switch (L) {
+        case 5: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_mid<5, U>), blocks, 256, zin, zout, n, m, batch, d_tw, inv_nf); return true;
+        case 6: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_mid<6, U>), blocks, 256, zin, zout, n, m, batch, d_tw, inv_nf); return true;
+        case 7: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_mid<7, U>), blocks, 256, zin, zout, n, m, batch, d_tw, inv_nf); return true;
+        case 8: TSDR_LAUNCH(g, PROF_FFT_PASS, st, (k_fftx_mid<8, U>), blocks, 256, zin, zout, n, m, batch, d_tw, inv_nf); return true;
+        default: return false;
+    }
+}
+
+// The five-trip form of the autocorrelation (k_fftx_mid): forward trips but the last in `work`, the middle trip from `work`
+// into z, the inverse's remaining trips — the forward's plan backwards — in place in z.  Returns false (nothing queued) when
+// the plan does not qualify; the caller then runs the six-trip form.
+static bool fftx_correlate_fused(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n, int m,
+                                 const double2 *d_tw, float2 *z, float2 *work, const FftxKeep &keep)
+{
+    static const int off = (getenv("TSDRGPU_FFTX_GENERIC") || (getenv("TSDRGPU_FFTX_FUSED") && getenv("TSDRGPU_FFTX_FUSED")[0] == '0')) ? 1 : 0;
+    if (off || n < (1u << 15)) return false;
+    FftxTrip trips[8];
+    const int nt = fftx_plan(m, trips);
+    if (nt < 2) return false;
+    for (int k = 0; k < nt; k++) {
+        const unsigned width = trips[k].s0 == 0 ? (n >> trips[k].L) : (1u << trips[k].s0);
+        if (trips[k].L < 5 || trips[k].L > 8 || (4096u >> trips[k].L) > width) return false;
+    }
+    for (int j = nt - 2, s0 = trips[nt - 1].L; j >= 0; s0 += trips[j].L, j--)  // the same plan backwards: do its tiles fit too?
+        if ((4096u >> trips[j].L) > (1u << s0)) return false;
+    const unsigned blocks = (n / 4096u) * (unsigned)cnt;
+    const int src_mode = in_is_iq ? 1 : 0;
+    for (int k = 0; k < nt - 1; k++)
+        if (!fftx_launch_fast_u<1>(g, st, trips[k].L, blocks, d_in, src_mode, stride, work, nullptr, n, m, trips[k].s0, cnt, d_tw, 0, 0, FFTX_KEEP_ALL))
+            return false;
+    const int Lm = trips[nt - 1].L;
+    if (!fftx_launch_mid<1>(g, st, Lm, blocks, work, z, n, m, cnt, d_tw)) return false;
+    int s0 = Lm;
+    for (int j = nt - 2; j >= 0; j--) {  // the inverse: L_last was the middle trip's, then the forward's plan backwards
+        const int L = trips[j].L;
+        (void)fftx_launch_fast_u<1>(g, st, L, blocks, nullptr, 0, 0, z, nullptr, n, m, s0, cnt, d_tw, 1, 0, j == 0 ? keep : FFTX_KEEP_ALL);
+        s0 += L;
+    }
+    return true;
+}
+
 // fft_autocorrelation for `cnt` windows, exactly: answer = IFFT( | FFT(x) / N | ), fft.c:49-64.
-// z: cnt*n complex (the result), mag: cnt*n floats.
+// z: cnt*n complex (the result), mag: cnt*n COMPLEX points of scratch (the six-trip form keeps its cnt*n magnitudes there).
 static int fftx_correlate_keep(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
                                const double2 *d_tw, float2 *z, float *mag, const FftxKeep &keep)
 {
@@ -497,6 +619,10 @@ static int fftx_correlate_keep(tsdrgpu_t *g, hipStream_t st, const float *d_in, 
     while ((1u << m) < n) m++;
     int rc;
     if (m == 0) return tsdr_fail(g, TSDRGPU_EINVAL, "exact FFT", "transform too short");
+    if (fftx_correlate_fused(g, st, d_in, in_is_iq, stride, cnt, n, m, d_tw, z, reinterpret_cast<float2 *>(mag), keep)) {
+        if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "exact FFT", "launch");
+        return TSDRGPU_OK;
+    }
     if ((rc = fftx_transform(g, st, d_in, in_is_iq ? 1 : 0, stride, z, mag, n, m, cnt, d_tw, 0, 1))) return rc;
     return fftx_transform(g, st, mag, 0, (long long)n, z, mag, n, m, cnt, d_tw, 1, 0, keep);
 }
@@ -507,7 +633,7 @@ int fftx_correlate(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq
     return fftx_correlate_keep(g, st, d_in, in_is_iq, stride, cnt, n, d_tw, z, mag, FFTX_KEEP_ALL);
 }
 
-// fft_autocorrelation + accummulate for `cnt` windows, exactly.  z: cnt*n complex, mag: cnt*n floats.  Only the lag
+// fft_autocorrelation + accummulate for `cnt` windows, exactly.  z: cnt*n complex, mag: cnt*n complex points of scratch.  Only the lag
 // windows (and lag 0) of the correlations are stored, except for window `full_w` of the batch (-1: none), kept whole.
 int fftx_autocorr(tsdrgpu_t *g, hipStream_t st, const float *d_in, int in_is_iq, long long stride, int cnt, uint32_t n,
                   const double2 *d_tw, float2 *z, float *mag, int frame_lo, int frame_len, int line_lo, int line_len, double *d_plots,
