@@ -149,6 +149,9 @@ __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src
 #ifndef FFTX_LOAD_UNROLL
 #define FFTX_LOAD_UNROLL 16
 #endif
+#ifndef FFTX_TW_FIRST
+#define FFTX_TW_FIRST 0
+#endif
 struct FftxKeep {
     int on;       // 0: store everything
     int full_w;   // window of the batch stored whole (-1: none)
@@ -171,16 +174,15 @@ __device__ __forceinline__ void fftx_groups(float2 *__restrict__ t, unsigned Cp,
                                             unsigned colbase, const double2 *__restrict__ tw)
 {
     constexpr int NP = 1 << K;
-    float2 v[U][NP];
-#pragma unroll
-    for (int u = 0; u < U; u++)
-#pragma unroll
-        for (int j = 0; j < NP; j++) v[u][j] = t[(base[u] + ((unsigned)j << a)) * Cp + c[u]];
+    // The chunk's twiddles (2^K - 1 per group), w[u][(1 << st) - 1 + jl] = stage st, butterfly jl.  Left to itself the scheduler
+    // sinks every request next to its use (K waits per chunk); FFTX_TW_FIRST=1 pins all of them above the arithmetic (one wait
+    // per chunk, +20 VGPRs).  Measured: 123.0 vs 123.7 us per 2^22 window — the trips are not waiting for their twiddles — so
+    // the default is the scheduler's order.
+    double2 w[U][NP - 1];
 #pragma unroll
     for (int st = 0; st < K; st++) {
         const int s = s0 + a + st;
         const unsigned sbase = (1u << s) - 1u;  // this stage's u[q], q < 2^s, start here (the whole table has n - 1 < 2^32 entries)
-        double2 w[U][1 << (K - 1)];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const unsigned low = base[u] & ((1u << a) - 1u);
@@ -188,19 +190,32 @@ __device__ __forceinline__ void fftx_groups(float2 *__restrict__ t, unsigned Cp,
             for (int jl = 0; jl < (1 << st); jl++) {
                 const unsigned rowlow = low + ((unsigned)jl << a);
                 const unsigned q = sbase + (FIRST ? rowlow : ((rowlow << s0) + colbase + c[u]));
-                w[u][jl] = tw[q];
-                if (INV) w[u][jl].y = -w[u][jl].y;  // the inverse recurrence yields exactly the conjugates
+                w[u][(1 << st) - 1 + jl] = tw[q];
             }
         }
+    }
+    float2 v[U][NP];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int j = 0; j < NP; j++) v[u][j] = t[(base[u] + ((unsigned)j << a)) * Cp + c[u]];
+#if FFTX_TW_FIRST
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests above the arithmetic (the scheduler would sink each next to its use)
+#endif
+#pragma unroll
+    for (int st = 0; st < K; st++) {
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int jl = 0; jl < (1 << st); jl++)
+            for (int jl = 0; jl < (1 << st); jl++) {
+                double2 wq = w[u][(1 << st) - 1 + jl];
+                if (INV) wq.y = -wq.y;  // the inverse recurrence yields exactly the conjugates
 #pragma unroll
                 for (int jh = 0; jh < (NP >> (st + 1)); jh++) {
                     const int j0 = (jh << (st + 1)) | jl;
-                    fftx_bfly(v[u][j0], v[u][j0 | (1 << st)], w[u][jl]);
+                    fftx_bfly(v[u][j0], v[u][j0 | (1 << st)], wq);
                 }
+            }
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
 // stages and the f32 roundings between them are the same sequence whatever the grouping, so the bits do not change.
 // zin and zout are different buffers: a tile's results land in other tiles' inputs.
 template <int L, int U>
-__global__ __launch_bounds__(256) void k_fftx_mid(const float2 *__restrict__ zin, float2 *__restrict__ zout, unsigned n, int m, int batch,
+__global__ __launch_bounds__(256, 4) void k_fftx_mid(const float2 *__restrict__ zin, float2 *__restrict__ zout, unsigned n, int m, int batch,
                                                   const double2 *__restrict__ tw, float inv_nf)
 {
     constexpr unsigned R = 1u << L, C = 4096u >> L, Cp = C + 1u;
