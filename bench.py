@@ -176,13 +176,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--seconds", type=float, default=1.0, help="signal seconds per batch")
+    ap.add_argument("--seconds", type=float, default=None,
+                    help="signal seconds per HBM-resident batch.  Default 4 for the 25 and 100 MS/s configurations (3.2 GB of IQ and 240 "
+                         "frames per pass at 100 MS/s: every pass ends with a plot update, a certificate and a join of the lanes, fixed costs "
+                         "of ~0.06 ms that a 1 s batch pays four times as often; 288 GB of HBM are there to be used), 1 for configs[4] and "
+                         "for --bands.  The 1 s batch of rounds 1-3 is the `batch_1s` leg")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
                     help="BASELINE.json configs index (0-based): 2 = 100 MS/s 1080p60 (the headline metric, default), "
                          "1 = 25 MS/s 1024x768, 4 = 200 MS/s 2160p with 15/16 motion blur (use --seconds 0.5)")
-    ap.add_argument("--passes", type=int, default=50,
-                    help="passes over the HBM-resident batch per step (a step = passes x seconds of signal), so that "
-                         "the default 20-30 steps give a timed region of more than a second")
+    ap.add_argument("--passes", type=int, default=None,
+                    help="passes over the HBM-resident batch per step (a step = passes x seconds of signal; default: ~50 s of signal "
+                         "per step), so that the default 20-30 steps give a timed region of more than a second")
     ap.add_argument("--fast-sync", action="store_true",
                     help="opt out of the contract-exact sync detector (tsdrgpu_postproc_set_exact_ties(0)); the default "
                          "— and what the library ships — redoes toss-up decisions with the reference's own strip sums")
@@ -245,6 +249,10 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="(default now; kept so that old command lines still parse)")
     args = ap.parse_args()
 
+    if args.seconds is None:
+        args.seconds = 4.0 if args.config in (1, 2) and not args.bands else 1.0
+    if args.passes is None:
+        args.passes = max(1, int(round(50.0 / args.seconds)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -783,16 +791,19 @@ def main():
                 return {"error": repr(ex)}
 
         legs = {
-            "configs[1]": leg(["--config", "1", "--steps", "4", "--passes", "100"], "25 MS/s, 1024x768@60 (1033x806 frames), 1 s batches"),
+            "batch_1s": leg(["--config", "2", "--seconds", "1", "--steps", "8", "--passes", "50"],
+                            "the headline configuration in 1 s batches (60 frames, 17 windows per pass): the workload of rounds 1-3's lines"),
+            "configs[1]": leg(["--config", "1", "--steps", "4", "--passes", "25"], "25 MS/s, 1024x768@60 (1033x806 frames), 4 s batches"),
+            "configs[1]_batch_1s": leg(["--config", "1", "--seconds", "1", "--steps", "4", "--passes", "100"], "25 MS/s, 1024x768@60 (1033x806 frames), 1 s batches"),
             "configs[4]": leg(["--config", "4", "--steps", "4", "--passes", "25"], "200 MS/s, 3840x2160@60 (2962x2250 frames), motion blur 15/16, 1 s batches"),
-            "frame_path_blur": leg(["--config", "2", "--blur", "0.5", "--no-fuse", "--steps", "4", "--passes", "40"],
+            "frame_path_blur": leg(["--config", "2", "--blur", "0.5", "--no-fuse", "--steps", "4", "--passes", "10"],
                                    "the headline configuration with motion blur 0.5 through the split run: the IIR is live, every batch takes "
                                    "the frame-by-frame k_frame_pass (state in registers across the batch's frames: 8P bytes moved per frame = "
                                    "8P credited)"),
-            "frame_path_blur_fused": leg(["--config", "2", "--blur", "0.5", "--steps", "4", "--passes", "40"],
+            "frame_path_blur_fused": leg(["--config", "2", "--blur", "0.5", "--steps", "4", "--passes", "10"],
                                          "... and through the fused run, the default: one trip walks the batch's frames tile by tile "
                                          "(k_frame_tile_pass: statistics + normalise + IIR, 8P moved, 12P credited)"),
-            "frame_path_unfused": leg(["--config", "2", "--no-fuse", "--steps", "4", "--passes", "40"],
+            "frame_path_unfused": leg(["--config", "2", "--no-fuse", "--steps", "4", "--passes", "10"],
                                       "the headline configuration with the split run instead of the fused one: k_frame_stats, then the "
                                       "normalise/IIR pass (16P bytes per frame moved); the autocorrelation beside the pass of its own batch"),
         }
@@ -975,7 +986,7 @@ def main():
                        "frame_path": (("fused run (tsdrgpu_postproc_begin_minmax / _finish): per-frame min/max from the resampler's frame "
                                        "tracking, one trip over the raw frames for statistics + normalise/IIR (12P bytes per frame moved)")
                                       if args.fuse else "split run (tsdrgpu_postproc_begin / _finish): statistics kernel, then the normalise/IIR pass")
-                                     + "; batches of one second (60 frames).  Every form of the run gives the same frames and state bit "
+                                     + f"; batches of {args.seconds:g} s ({int(round(args.seconds * fv))} frames).  Every form of the run gives the same frames and state bit "
                                        "for bit (tests/test_gpu_postproc.py); the streaming engine behind tsdr_readasync takes frames as "
                                        "they arrive (batches of 1-2) through tsdrgpu_postproc_run",
                        "sync_detector": "fast (toss-ups not redone)" if args.fast_sync else

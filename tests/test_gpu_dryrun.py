@@ -45,7 +45,7 @@ def _common(d, world, scaling):
 
 
 def test_bench_gpus8_strong_scaling_dry_run():
-    d = _run(["--scaling", "strong"])
+    d = _run(["--scaling", "strong", "--seconds", "1"])
     _common(d, 8, "strong")
     assert [r["windows_per_pass"] for r in d["ranks"]] == [3, 2, 2, 2, 2, 2, 2, 2] and all(r["of"] == 17 for r in d["ranks"])
     # the merged plots' detection is the single-GPU run's on this stream (BENCH_r03.json `detected`: the reference's own
@@ -54,7 +54,7 @@ def test_bench_gpus8_strong_scaling_dry_run():
 
 
 def test_bench_gpus8_weak_scaling_dry_run():
-    d = _run(["--scaling", "weak"])
+    d = _run(["--scaling", "weak", "--seconds", "1"])
     _common(d, 8, "weak")
     assert all(r["windows_per_pass"] == 17 and r["of"] == 8 * 17 for r in d["ranks"])
     assert d["config"]["samples_per_step_per_gpu"] == 2 * 99_999_600
