@@ -177,10 +177,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--seconds", type=float, default=None,
-                    help="signal seconds per HBM-resident batch.  Default 4 for the 25 and 100 MS/s configurations (3.2 GB of IQ and 240 "
-                         "frames per pass at 100 MS/s: every pass ends with a plot update, a certificate and a join of the lanes, fixed costs "
-                         "of ~0.06 ms that a 1 s batch pays four times as often; 288 GB of HBM are there to be used), 1 for configs[4] and "
-                         "for --bands.  The 1 s batch of rounds 1-3 is the `batch_1s` leg")
+                    help="signal seconds per HBM-resident batch.  Default: 1 (100 M samples at the headline's 100 MS/s); 4 for "
+                         "configs[1], the same 100 M samples at 25 MS/s — a 1 s batch there is 60 frames of 0.8 Mpixel and 17 windows "
+                         "of 2^20, too little per launch to fill 256 CUs (66 vs 78-79 GS/s; the 1 s form is the `configs[1]_batch_1s` "
+                         "leg).  The headline in 4 s batches is the `batch_4s` leg (+0 to +5 %% between boxes)")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
                     help="BASELINE.json configs index (0-based): 2 = 100 MS/s 1080p60 (the headline metric, default), "
                          "1 = 25 MS/s 1024x768, 4 = 200 MS/s 2160p with 15/16 motion blur (use --seconds 0.5)")
@@ -250,7 +250,7 @@ def main():
     args = ap.parse_args()
 
     if args.seconds is None:
-        args.seconds = 4.0 if args.config in (1, 2) and not args.bands else 1.0
+        args.seconds = 4.0 if args.config == 1 and not args.bands else 1.0
     if args.passes is None:
         args.passes = max(1, int(round(50.0 / args.seconds)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -573,8 +573,9 @@ def main():
         torch.cuda.synchronize()
 
     if args.pmc_calibrate:
-        cal = torch.empty(nsamples, dtype=torch.float32, device=dev)
-        g.am_demod(d_iq, DevPtr(cal), nsamples)
+        ncal = min(nsamples, 99_999_600)  # scripts/pmc_summarize.py calibrates on exactly this many samples, whatever the batch
+        cal = torch.empty(ncal, dtype=torch.float32, device=dev)
+        g.am_demod(d_iq, DevPtr(cal), ncal)
         g.sync()
         del cal
     for _ in range(args.warmup):
@@ -791,19 +792,20 @@ def main():
                 return {"error": repr(ex)}
 
         legs = {
-            "batch_1s": leg(["--config", "2", "--seconds", "1", "--steps", "8", "--passes", "50"],
-                            "the headline configuration in 1 s batches (60 frames, 17 windows per pass): the workload of rounds 1-3's lines"),
+            "batch_4s": leg(["--config", "2", "--seconds", "4", "--steps", "8", "--passes", "12"],
+                            "the headline configuration in 4 s batches (240 frames, 70 windows per pass): a pass's fixed costs (plot update, "
+                            "certificate, joins of the lanes, ~0.06 ms) paid a quarter as often"),
             "configs[1]": leg(["--config", "1", "--steps", "4", "--passes", "25"], "25 MS/s, 1024x768@60 (1033x806 frames), 4 s batches"),
             "configs[1]_batch_1s": leg(["--config", "1", "--seconds", "1", "--steps", "4", "--passes", "100"], "25 MS/s, 1024x768@60 (1033x806 frames), 1 s batches"),
             "configs[4]": leg(["--config", "4", "--steps", "4", "--passes", "25"], "200 MS/s, 3840x2160@60 (2962x2250 frames), motion blur 15/16, 1 s batches"),
-            "frame_path_blur": leg(["--config", "2", "--blur", "0.5", "--no-fuse", "--steps", "4", "--passes", "10"],
+            "frame_path_blur": leg(["--config", "2", "--blur", "0.5", "--no-fuse", "--steps", "4", "--passes", "40"],
                                    "the headline configuration with motion blur 0.5 through the split run: the IIR is live, every batch takes "
                                    "the frame-by-frame k_frame_pass (state in registers across the batch's frames: 8P bytes moved per frame = "
                                    "8P credited)"),
-            "frame_path_blur_fused": leg(["--config", "2", "--blur", "0.5", "--steps", "4", "--passes", "10"],
+            "frame_path_blur_fused": leg(["--config", "2", "--blur", "0.5", "--steps", "4", "--passes", "40"],
                                          "... and through the fused run, the default: one trip walks the batch's frames tile by tile "
                                          "(k_frame_tile_pass: statistics + normalise + IIR, 8P moved, 12P credited)"),
-            "frame_path_unfused": leg(["--config", "2", "--no-fuse", "--steps", "4", "--passes", "10"],
+            "frame_path_unfused": leg(["--config", "2", "--no-fuse", "--steps", "4", "--passes", "40"],
                                       "the headline configuration with the split run instead of the fused one: k_frame_stats, then the "
                                       "normalise/IIR pass (16P bytes per frame moved); the autocorrelation beside the pass of its own batch"),
         }

@@ -60,7 +60,7 @@ def main():
         r["fetch_kib"] += sum(f)
         r["write_kib"] += sum(w)
     # calibration on the demod kernel of bench.py --pmc-calibrate: nsamples = 99 999 600
-    nsamp = 99_999_600
+    nsamp = 99_999_600  # bench.py --pmc-calibrate demodulates exactly this many, whatever the batch length
     cal_f = cal_w = None
     if "k_demod_vec4" in rows and rows["k_demod_vec4"]["launches"]:
         r = rows["k_demod_vec4"]

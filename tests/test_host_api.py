@@ -145,3 +145,12 @@ def test_sweep_tool_is_built_and_has_no_cpu_path(libs, tmp_path):
         np.zeros(2 * 450909 + 16, np.float32).tofile(f)
         out = subprocess.run([tool, str(f), "8000000"], capture_output=True, text=True)
         assert out.returncode == 1 and "no usable HIP device" in out.stderr
+
+
+def test_bench_help_renders():
+    """argparse formats every help string with %: a bare percent sign in one of them breaks `bench.py --help` (it did, twice)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "--seconds" in out.stdout, out.stderr[-500:]
