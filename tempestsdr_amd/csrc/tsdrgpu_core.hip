@@ -998,11 +998,19 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
             const bool real = lane >= 2 && id < sB;
             if (real && fired && id > 0 && !fired_prev) contrib = rs_contrib_before(g, id, c_in, ld);  // the exception when r >= 1
             const float first = rs_up_first(a, pind, contrib, val);
+            // the sample's pixels [pin, pin + cnt) that lie below PE: `lim` of them, at consecutive tile slots.  maxc (uniform:
+            // (int)r + 2) bounds cnt; the reference's geometry has r ~ 2, i.e. maxc = 3 or 4, so the first four stores are
+            // straight-line — one compare each and an immediate offset — instead of a counted loop with the index arithmetic and
+            // both comparisons per pixel (the kernel's time is its VALU count)
             const int cnt = real ? pnext - pin : 0;
-            for (int c = 0; c < maxc; c++) {
-                const int p = pin + c;
-                if (c < cnt && p < PE) tile[p + toff] = (c == 0 && fired) ? first : vf;
-            }
+            const int lim = min(cnt, PE - pin);
+            float *tp = tile + (pin + toff);
+            if (__builtin_expect(lim > 0, 1)) tp[0] = fired ? first : vf;
+            if (__builtin_expect(lim > 1, 1)) tp[1] = vf;
+            if (__builtin_expect(lim > 2, 1)) tp[2] = vf;
+            if (lim > 3) tp[3] = vf;
+            for (int c = 4; c < maxc; c++)  // r >= 3 only
+                if (c < lim) tp[c] = vf;
         }
     }
     __syncthreads();

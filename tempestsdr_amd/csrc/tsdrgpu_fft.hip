@@ -19,17 +19,20 @@
 #include <thread>
 #include <vector>
 
-// windows per launch of the float32 plan (TSDRGPU_AC_SUBBATCH overrides for experiments: 1..32)
-static int ac_subbatch()
+// windows per launch of the float32 plan: 9 of 2^22 points or more (see ac_run_fast), 18 of shorter ones — 9 windows of 2^20
+// points are a quarter of the workgroups, launches that are mostly ramp and drain.  Measured on bench.py --config 1 (25 MS/s,
+// 70 windows of 2^20 per pass): 9 -> 79.0 GS/s, 18 -> 84.5, 36 -> 81.8, 64 -> 81.6 (longer launches starve the sync chain on
+// the side lane, as at 2^22).  TSDRGPU_AC_SUBBATCH overrides for experiments: 1..64
+static int ac_subbatch(uint32_t n)
 {
-    static const int v = [] {
+    static const int forced = [] {
         const char *e = getenv("TSDRGPU_AC_SUBBATCH");
-        const int n = e ? atoi(e) : 9;
-        return n < 1 ? 1 : (n > 32 ? 32 : n);
+        const int v = e ? atoi(e) : 0;
+        return v < 1 ? 0 : (v > 64 ? 64 : v);
     }();
-    return v;
+    if (forced) return forced;
+    return n < (1u << 22) ? 18 : 9;
 }
-#define AC_SUBBATCH (ac_subbatch())
 
 // one tsdrgpu_autocorr_run call of the current epoch, as the certified mode remembers it for an exact replay
 struct AcLogRec {
@@ -1139,6 +1142,7 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
     // 6+6+5 -> group at 0.565 of the roofline, 9+8 -> 0.585, one launch of 17 -> 0.62 — but a caller's small kernels on
     // another lane (the sync chain in bench.py's split run) then find free CUs less often (0.31 -> 0.49 ms) and become
     // the critical path; 9 is where the whole pass is fastest
+    const int AC_SUBBATCH = ac_subbatch(ac->n);
     const int sub = nwindows < AC_SUBBATCH ? nwindows : AC_SUBBATCH;
     if (ac->cap_windows < sub) {
         (void)hipStreamSynchronize(g->stream);
@@ -1157,7 +1161,8 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
     const int L = ac->frame_len + ac->line_len + 1;  // + the lag-0 entry
     float2 *corr = nullptr;
     int last_count = 0;
-    const int parts = (nwindows + AC_SUBBATCH - 1) / AC_SUBBATCH;
+    int parts = (nwindows + AC_SUBBATCH - 1) / AC_SUBBATCH;
+    if (parts < 2 && nwindows > 9) parts = 2;             // a pass of 17 short windows stays 9 + 8: one launch of 17 measured 7 % slower for the pass
     const int per_part = (nwindows + parts - 1) / parts;  // equal sub-batches (17 -> 9,8)
     for (int w0 = 0; w0 < nwindows; w0 += per_part) {
         const int cnt = (nwindows - w0 < per_part) ? (nwindows - w0) : per_part;
