@@ -146,12 +146,72 @@ struct StatsStore {
     const float *screen;
     int *odd;
 };
+// (v - lastmin) / span for a whole frame's pixels: the divisor is the same 3.3 million times.  hipcc expands an IEEE f32
+// division into  s = div_scale(d), r = rcp(s), r += (1 - s r) r  |  q = n r, q += (n - s q) r, div_fmas(n - s q, r, q), div_fixup
+// — eleven instructions of which the first half depend on the divisor alone, and the scalings / fix-ups act only at the ends
+// of the exponent range (v_div_scale_f32: divisor subnormal or above 2^126, exponents 96 apart, quotient subnormal, numerator
+// below 2^-103).  NormDiv keeps the divisor's half per frame and runs the numerator's half bare: the SAME instructions on the
+// same values, so the same bits as the `/` it replaces, provided nothing would have been scaled — `ok` says so from the frame's
+// two scalars alone: 2^-20 <= span <= 2^20 and 2^-20 <= |lastmin| <= 2^10.  Then a pixel |v| <= 250 gives n = v - lastmin
+// with |n| <= 2^11 and, unless it is zero, |n| >= 2^-44 (two distinct floats one of which is at least 2^-20 in magnitude differ by at
+// least an ulp of that one), quotients between 2^-64 and 2^31: far inside.  n = 0 gives 0 either way.  Pixels above 250 in
+// magnitude (sentinels, dsp.c:80-86) are not divided; non-finite results send the batch to the literal pass (`odd`).
+struct NormDiv {
+    float d, r;
+    bool ok;
+};
+__device__ __forceinline__ NormDiv norm_div_setup(float lastmin, float span)
+{
+    NormDiv nd;
+    nd.d = span;
+    nd.ok = span >= 0x1p-20f && span <= 0x1p20f && fabsf(lastmin) >= 0x1p-20f && fabsf(lastmin) <= 0x1p10f;
+    const float r0 = __builtin_amdgcn_rcpf(span);
+    const float e = __builtin_fmaf(-span, r0, 1.0f);
+    nd.r = __builtin_fmaf(e, r0, r0);
+    return nd;
+}
+__device__ __forceinline__ float norm_div(const NormDiv &nd, float n)
+{
+    float q = n * nd.r;
+    q = __builtin_fmaf(__builtin_fmaf(-nd.d, q, n), nd.r, q);
+    return __builtin_fmaf(__builtin_fmaf(-nd.d, q, n), nd.r, q);
+}
+
+// what the frame-parallel IIR at coefficient 0 cannot reproduce: a non-finite value (it sticks to its pixel in the reference)
+// and -0.0 (the reference's sum with the old state's +0 gives +0).  One v_cmp_class: sNaN | qNaN | -inf | -0 | +inf.
+__device__ __forceinline__ bool px_odd(float o) { return __builtin_amdgcn_classf(o, 0x1 | 0x2 | 0x4 | 0x20 | 0x200); }
+__device__ __forceinline__ bool px_nonfinite(float o) { return __builtin_amdgcn_classf(o, 0x1 | 0x2 | 0x4 | 0x200); }
+
 __device__ __forceinline__ void stats_store_tile(const float (&val)[TILE_H / 4][4], const StatsStore &st, int f, int W, int H, int x0, int y0,
                                                  int lane, int wave)
 {
     const float lastmin = st.chain[f].lastmin, span = st.chain[f].span;
     float *outp = st.dst + (long long)f * st.dstride;
     bool bad = false;
+    const NormDiv nd = norm_div_setup(lastmin, span);
+    if (nd.ok && x0 + TILE_W <= W && y0 + TILE_H <= H) {
+        // the rule: a tile inside the frame, a divisor in range — no bounds, no branches, five instructions per division
+#pragma unroll
+        for (int r = 0; r < TILE_H / 4; r++) {
+            const int y = y0 + wave + 4 * r;
+            float4_a4 t;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float v = val[r][j];
+                const float o = (v > 250.0f || v < -250.0f) ? v : norm_div(nd, v - lastmin);
+                t[j] = o;
+                bad |= px_odd(o);
+            }
+            const long long at = (long long)y * W + x0 + 4 * lane;
+            *reinterpret_cast<float4_a4 *>(outp + at) = t;
+            if (f == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) bad |= px_nonfinite(st.screen[at + j]);  // the incoming state has to be finite
+            }
+        }
+        if (__any(bad) && lane == 0) atomicOr(st.odd, 1);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < TILE_H / 4; r++) {
         const int y = y0 + wave + 4 * r;
@@ -173,10 +233,8 @@ __device__ __forceinline__ void stats_store_tile(const float (&val)[TILE_H / 4][
             const int x = xl + j;
             if (y < H && x < W) {
                 if (xl + 4 > W) outp[(long long)y * W + x] = o[j];
-                // what the frame-parallel IIR at coefficient 0 cannot reproduce: a non-finite value (it sticks to its pixel
-                // in the reference) and -0.0 (the reference's sum with the old state's +0 gives +0)
-                bad |= !(fabsf(o[j]) <= 3.4028234664e38f) || __float_as_uint(o[j]) == 0x80000000u;
-                if (f == 0) bad |= !(fabsf(st.screen[(long long)y * W + x]) <= 3.4028234664e38f);  // the incoming state has to be finite
+                bad |= px_odd(o[j]);
+                if (f == 0) bad |= px_nonfinite(st.screen[(long long)y * W + x]);  // the incoming state has to be finite
             }
         }
     }
@@ -210,9 +268,16 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
     // so that 32 requests per lane are in flight (one dwordx4 per row measured 4 % slower here)
     constexpr int ROWS = TILE_H / 4;
     float val[ROWS][4];
+    const bool interior = (x0 + TILE_W <= W) && (y0 + TILE_H <= H);  // workgroup-uniform, and the rule
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int y = y0 + wave + 4 * r;
+        if (STORE && interior) {  // no bounds to test: eight dwordx4 requests back to back
+            const float4_a4 t = *reinterpret_cast<const float4_a4 *>(src + (long long)y * W + x0 + 4 * lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) val[r][j] = t[j];
+            continue;
+        }
         const float *row = src + (long long)(y < H ? y : 0) * W;
         if (STORE && y < H && x0 + 4 * lane + 4 <= W) {  // the storing form: a lane's four columns are neighbours, one dwordx4
             const float4_a4 t = *reinterpret_cast<const float4_a4 *>(row + x0 + 4 * lane);
@@ -234,7 +299,7 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
     // a wave whose 32 x 256 pixels are all inside the frame and hold no sentinel (the rule, decided with one
     // max3 per two pixels and a ballot) only needs the plain sums and min/max: same additions in the same
     // order as the general form below, whose sentinel accumulators would all stay zero
-    bool plain = (x0 + TILE_W <= W) && (y0 + TILE_H <= H);  // workgroup-uniform
+    bool plain = interior;
     if (plain) {
         float m = 0.f;
 #pragma unroll
@@ -1126,7 +1191,13 @@ template <> struct VecT<4> { typedef float4_a4 type; };
 __device__ __forceinline__ float pass_one(int flags, float v, float &s, float a, double one_minus_a, float lastmin, float span,
                                           bool on_line)
 {
-    if (flags & PASS_NORMALISE) v = (v > 250.0f || v < -250.0f) ? v : ((v - lastmin) / span);
+    if (flags & PASS_NORMALISE) {
+        // the frame's divisor prepared once (NormDiv; lastmin and span are uniform and loop invariant, so the set-up is hoisted
+        // out of the caller's pixel loop), `/` where the guard does not hold
+        const NormDiv nd = norm_div_setup(lastmin, span);
+        const float q = nd.ok ? norm_div(nd, v - lastmin) : ((v - lastmin) / span);
+        v = (v > 250.0f || v < -250.0f) ? v : q;
+    }
     if ((flags & PASS_LINES) && on_line) v = PIX_G;
     if (flags & PASS_IIR) {
         s = (float)((double)(s * a) + (double)v * one_minus_a);

@@ -570,3 +570,39 @@ def test_snr_by_product_of_the_run(orc, cfg, form):
     pp.run(d_in, 4, w, h, d_out, mb, 0.1, lbs, aap, ash, pll, 0)
     with pytest.raises(gpu.TsdrGpuError):
         pp.snr(1)
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.125), (2.0 ** -25, 2.0 ** -26), (2.0 ** -19, 2.0 ** -21), (2.0 ** -18, 0.0), (100.0, -120.0),
+                                          (2.0 ** -30, 3.0), (1.0, 2.0 ** -21), (3.0e-39, 0.0), (1.0, -0.0)])
+def test_fused_run_divides_like_the_plain_run(scale, offset):
+    """The fused trip normalises with the frame's divisor prepared once (NormDiv: the compiler's own division sequence with the
+    divisor's half hoisted, valid while nothing would be scaled: 2^-20 <= span <= 2^20, 2^-20 <= |lastmin| <= 2^10) and falls
+    back to `/` outside that range.  Frames whose span / minimum sit inside, at and far outside the guard — down to subnormal
+    amplitudes — must come out of the fused run bit-identical to the plain run's (which divides with `/`), sentinels included."""
+    g = ctx()
+    w, h = 301, 67
+    n = w * h
+    rng = np.random.default_rng(int(abs(np.log2(scale)) * 10) + 3)
+    frames = []
+    for k in range(6):
+        f = (rng.random(n).astype(np.float32) * np.float32(scale) + np.float32(offset)).astype(np.float32)
+        f[rng.integers(0, n, 5)] = np.float32(offset)                 # pixels equal to the minimum: numerator 0
+        if k == 2:
+            f[rng.integers(0, n, 7)] = np.float32(512.0)             # sentinels pass through undivided
+        if k == 4:
+            f[rng.integers(0, n, 3)] = np.float32(offset) + np.float32(scale) * np.float32(2.0 ** -24)  # a numerator of one ulp
+        frames.append(f)
+    cfg = (0, 0, 0, 0, 0.0)
+    want, infos_a, _ = run_gpu(g, frames, w, h, cfg, 3)
+    pp = gpu.PostProcess(g)
+    d_in = g.to_device(np.concatenate(frames))
+    d_out = g.empty(len(frames) * n)
+    mn, mx = _minmax(frames)
+    d_mn, d_mx = g.to_device(mn), g.to_device(mx)
+    infos_b = []
+    for s in range(0, len(frames), 3):
+        pp.begin_minmax(d_in, 3, w, h, d_mn.at(s), d_mx.at(s), d_out, 0.0, 0.1, 0, 0, 0, 0, 0, frames_offset=s * n, out_offset=s * n)
+        infos_b += pp.finish(d_out, out_offset=s * n)
+    got = d_out.download().reshape(len(frames), n)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert [(i.lastmin, i.lastmax) for i in infos_a] == [(i.lastmin, i.lastmax) for i in infos_b]
