@@ -492,7 +492,27 @@ int staging_release(tsdrgpu_t *g, StagingRing *r, int slot)
 // pointers allow; products, sum and sqrt are separate correctly-rounded f32
 // operations (-ffp-contract=off), so the result is bit-identical to the CPU's.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float demod1(float re, float im) { return sqrtf(re * re + im * im); }
+// am_demod's sqrtf(re*re + im*im), TSDRLibrary.c:244-262.  hipcc's correctly rounded sqrtf is 21 instructions: v_sqrt_f32 (1 ulp),
+// the two-sided correction (the neighbours' residuals by fma, two selects), a rescaling by 2^32 for arguments below 2^-96 and
+// a class test for 0 / inf — the last two a third of it, for arguments a sample stream practically never holds.  When every
+// lane of the wave has 2^-96 <= x < inf (one subtract and one unsigned compare on the bits, one ballot) the same correction
+// runs bare: the same instructions on the same values as the library routine, so the same bits (the resampler's time is its
+// VALU count).  Any other wave — zeros of an int8 recording, subnormal amplitudes, infinities — takes sqrtf as before.
+__device__ __forceinline__ float demod1(float re, float im)
+{
+    const float x = re * re + im * im;
+    const unsigned b = __float_as_uint(x);
+    const bool plain = (b - 0x0f800000u) < (0x7f800000u - 0x0f800000u);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!plain) == 0ull, 1)) {
+        float s = __builtin_amdgcn_sqrtf(x);
+        const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+        const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+        s = (rm <= 0.0f) ? sm : s;
+        s = (rp > 0.0f) ? sp : s;
+        return s;
+    }
+    return sqrtf(x);
+}
 
 __global__ __launch_bounds__(256) void k_demod_vec4(const float4 *__restrict__ iq, float4 *__restrict__ out, long long nquads)
 {
@@ -970,12 +990,14 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
     const int toff = mis - PA;
     // rounds go in batches of RSU_BATCH: all of a batch's samples are requested before the first one is used
     for (int j0 = 0; j0 < rounds; j0 += RSU_BATCH) {
-        float vfs[RSU_BATCH];
+        // (the raw samples: demod1 holds a wave-uniform branch, and a branch between the requests would serialise them)
+        float2 raw[RSU_BATCH];
 #pragma unroll
         for (int jj = 0; jj < RSU_BATCH; jj++) {
             const int id = sA + (wave * rounds + j0 + jj) * RSU_LANES + lane - 2;
             const int idc = id < 0 ? 0 : (id >= size ? size - 1 : id);
-            vfs[jj] = ld(idc);
+            if (IQ) raw[jj] = ((const float2 *)ld.base)[idc];
+            else raw[jj] = make_float2(ld.base[idc], 0.f);
         }
 #pragma unroll
         for (int jj = 0; jj < RSU_BATCH; jj++) {
@@ -984,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
             const int id = base + lane - 2;
             const RsUpGeom a = rs_up_geom(g, id);
             const int pnext = (int)a.pnext;
-            const float vf = vfs[jj];
+            const float vf = IQ ? demod1(raw[jj].x, raw[jj].y) : raw[jj].x;
             const double val = (double)vf;
             const double tail = rs_up_tail(g, a, val);
             int pin = rsu_shr1(pnext);
