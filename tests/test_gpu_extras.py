@@ -254,3 +254,21 @@ def test_wave_reductions_equal_the_shuffle_tree(tmp_path):
                    check=True, timeout=300)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
+def test_division_and_square_root_on_the_device(tmp_path):
+    """scripts/micro/arith_check.hip: on this GPU the compiler's f32 `/` and sqrtf are the host's (correctly rounded) results on
+    the hard cases — divisors with an all-ones mantissa under powers of two, every float of two binades for the root — and the
+    bare sequences the kernels run (NormDiv, demod1) give the same bits as `/` and sqrtf."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "arith_check")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-w", "-ffp-contract=off", "-o", exe, os.path.join(root, "scripts", "micro", "arith_check.hip")],
+                   check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("0 mismatches"), r.stdout + r.stderr
