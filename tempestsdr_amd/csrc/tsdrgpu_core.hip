@@ -986,7 +986,9 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
 
     SampleLoad<IQ> ld{in + (IQ ? 2 : 1) * ch.in_off};
     const double c_in = cin[blockIdx.y];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: the compiler then keeps everything derived from it — a round's base sample, the
+    // tests that only a chunk's first wave needs — on the scalar unit)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int toff = mis - PA;
     // rounds go in batches of RSU_BATCH: all of a batch's samples are requested before the first one is used
     for (int j0 = 0; j0 < rounds; j0 += RSU_BATCH) {
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
 #pragma unroll
         for (int jj = 0; jj < RSU_BATCH; jj++) {
             const int id = sA + (wave * rounds + j0 + jj) * RSU_LANES + lane - 2;
-            const int idc = id < 0 ? 0 : (id >= size ? size - 1 : id);
+            const unsigned idc = (unsigned)max(0, min(id, size - 1));  // (size >= 1 here; an unsigned index spares the sign extension)
             if (IQ) raw[jj] = ((const float2 *)ld.base)[idc];
             else raw[jj] = make_float2(ld.base[idc], 0.f);
         }
@@ -1010,13 +1012,18 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
             const double val = (double)vf;
             const double tail = rs_up_tail(g, a, val);
             int pin = rsu_shr1(pnext);
-            pin = (id <= 0) ? 0 : pin;
+            const double tail_prev = rsu_shr1(tail);
+            // dsp.c:299-302 leaves contrib = 0.0 + tail; a demodulated sample is a square root, never -0.0, so its tail term is
+            // never -0.0 either and the addition of 0.0 changes nothing (magnitude input keeps it)
+            double contrib = IQ ? tail_prev : 0.0 + tail_prev;
+            if (__builtin_expect(base == 0, 0)) {  // wave-uniform: only a chunk's first wave holds the samples id <= 0 (ghost lanes) and id == 0
+                asm volatile("" ::: "memory");     // (a real branch: as selects these tests cost every round eight instructions)
+                pin = (id <= 0) ? 0 : pin;
+                if (id == 0) contrib = c_in;
+            }
             const double pind = (double)pin;
             const bool fired = rs_up_fired(a, pind);
             const int fired_prev = rsu_shr1(fired ? 1 : 0);
-            const double tail_prev = rsu_shr1(tail);
-            double contrib = 0.0 + tail_prev;
-            if (id == 0) contrib = c_in;
             const bool real = lane >= 2 && id < sB;
             if (real && fired && id > 0 && !fired_prev) contrib = rs_contrib_before(g, id, c_in, ld);  // the exception when r >= 1
             const float first = rs_up_first(a, pind, contrib, val);
