@@ -182,8 +182,9 @@ __device__ __forceinline__ float norm_div(const NormDiv &nd, float n)
 __device__ __forceinline__ bool px_odd(float o) { return __builtin_amdgcn_classf(o, 0x1 | 0x2 | 0x4 | 0x20 | 0x200); }
 __device__ __forceinline__ bool px_nonfinite(float o) { return __builtin_amdgcn_classf(o, 0x1 | 0x2 | 0x4 | 0x200); }
 
+// no_sentinel: the caller knows (wave-uniformly) that none of the wave's pixels exceeds 250 in magnitude
 __device__ __forceinline__ void stats_store_tile(const float (&val)[TILE_H / 4][4], const StatsStore &st, int f, int W, int H, int x0, int y0,
-                                                 int lane, int wave)
+                                                 int lane, int wave, bool no_sentinel)
 {
     const float lastmin = st.chain[f].lastmin, span = st.chain[f].span;
     float *outp = st.dst + (long long)f * st.dstride;
@@ -198,7 +199,8 @@ __device__ __forceinline__ void stats_store_tile(const float (&val)[TILE_H / 4][
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float v = val[r][j];
-                const float o = (v > 250.0f || v < -250.0f) ? v : norm_div(nd, v - lastmin);
+                const float q = norm_div(nd, v - lastmin);
+                const float o = (no_sentinel || !(v > 250.0f || v < -250.0f)) ? q : v;  // (no_sentinel is uniform: the tests fold away)
                 t[j] = o;
                 bad |= px_odd(o);
             }
@@ -291,14 +293,10 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
             val[r][j] = (y < H && x < W) ? row[x] : NAN;  // NaN = outside the frame (neither branch below takes it)
         }
     }
-    if (STORE) stats_store_tile(val, st, f, W, H, x0, y0, lane, wave);
-    // phase 2.  Sentinel pixels (|v| > 250) are rare — raw resampler output has none — so their partial
-    // sums are only reduced and written when the tile holds any (tflag), which saves two thirds of the
-    // partial-sum traffic; k_frame_reduce reads them under the same flag.
-    float prs[ROWS], prc[ROWS];
     // a wave whose 32 x 256 pixels are all inside the frame and hold no sentinel (the rule, decided with one
     // max3 per two pixels and a ballot) only needs the plain sums and min/max: same additions in the same
-    // order as the general form below, whose sentinel accumulators would all stay zero
+    // order as the general form below, whose sentinel accumulators would all stay zero — and, in the storing form, no
+    // sentinel test per pixel
     bool plain = interior;
     if (plain) {
         float m = 0.f;
@@ -309,6 +307,14 @@ __global__ __launch_bounds__(256) void k_frame_stats(const float *__restrict__ f
         }
         plain = __builtin_amdgcn_ballot_w64(m > 250.0f) == 0ull;  // wave-uniform
     }
+    if (STORE) {
+        if (plain) stats_store_tile(val, st, f, W, H, x0, y0, lane, wave, true);
+        else stats_store_tile(val, st, f, W, H, x0, y0, lane, wave, false);
+    }
+    // phase 2.  Sentinel pixels (|v| > 250) are rare — raw resampler output has none — so their partial
+    // sums are only reduced and written when the tile holds any (tflag), which saves two thirds of the
+    // partial-sum traffic; k_frame_reduce reads them under the same flag.
+    float prs[ROWS], prc[ROWS];
     if (plain) {
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
