@@ -68,9 +68,10 @@ typedef void (*tsdrplugin_readasync_raw_function)(const void *buf, uint64_t item
  * The return value is a set of bits: TSDRX_MEMORY_MAPPED is the promise above (any non-zero value of older plugins is
  * read as this bit alone... so they keep returning 1).  TSDRX_MEMORY_IMMUTABLE adds that the CONTENTS of a block
  * handed to the tsdrplugin_readasync callback do not change for as long as tsdrplugin_readasync runs (a recording, not a
- * ring that hardware refills), TSDRX_MEMORY_IMMUTABLE_RAW the same for tsdrplugin_readasync_raw: only then may the library
+ * ring that hardware refills), TSDRX_MEMORY_IMMUTABLE_RAW the same for tsdrplugin_readasync_raw: only then MAY the library
  * return from the callback while its DMA out of the block is still in flight, so that consecutive blocks' transfers
- * overlap (TSDR_GPU_ASYNC_UPLOAD=0 makes it wait regardless). */
+ * overlap — which it does only when the host opts in with TSDR_GPU_ASYNC_UPLOAD=1: by default every DMA is waited for
+ * (measured faster on MI355X: 35-41 against 20-25 GB/s through the upload lane), and the promise changes nothing. */
 #define TSDRX_MEMORY_MAPPED 1
 #define TSDRX_MEMORY_IMMUTABLE 2
 #define TSDRX_MEMORY_IMMUTABLE_RAW 4

@@ -76,7 +76,32 @@ def build(force=False, verbose=True):
     mem_so = os.path.join(HERE, "libTSDRPlugin_Mem.so")
     if force or _newer(mem_so, [mem_src] + _headers()):
         subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", mem_so, mem_src], check=True)
+    build_checks(force=force, verbose=verbose)
     return LIB
+
+
+# Device self-checks (scripts/micro/*.hip) that the GPU suite RUNS: the GPU boxes have no hipcc, so the binaries are built here,
+# in-tree, and travel with the snapshot like the libraries (git-ignored, not gpurun-ignored).
+# (arith_check with the flags of the bit-exact stages it vouches for)
+CHECKS = [("arith_check", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]), ("wave_reduce_check", [])]
+
+
+def build_checks(force=False, verbose=True):
+    micro = os.path.join(ROOT, "scripts", "micro")
+    procs = []
+    for name, extra in CHECKS:
+        src = os.path.join(micro, name + ".hip")
+        exe = os.path.join(micro, name)
+        if not os.path.exists(src):
+            continue
+        if force or _newer(exe, [src] + _headers()):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-w"] + extra + ["-o", exe, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("compile failed: " + " ".join(cmd))
 
 
 if __name__ == "__main__":

@@ -222,6 +222,7 @@ static int exact_wanted(const char *name)
 /* A failing device call ends the session: the first failure is remembered, the workers stop, the plugin is told to
  * stop, and tsdr_readasync returns TSDR_CANNOT_OPEN_DEVICE with this text (the reference surfaces its failures the
  * same way, through the return value of tsdr_readasync and tsdr_getlasterrortext).  Nothing is retried. */
+static __thread int in_plugin_callback; /* this thread is inside on_block_any */
 static int gpu_ok(struct engine *e, int rc, const char *what)
 {
     if (rc == 0) return 1;
@@ -229,7 +230,11 @@ static int gpu_ok(struct engine *e, int rc, const char *what)
         snprintf(e->fail_msg, sizeof(e->fail_msg), "GPU stage '%s' failed (%d): %s", what, rc, tsdrgpu_last_error(e->g));
         fprintf(stderr, "tsdr: %s\n", e->fail_msg);
         e->t->running = 0;
-        (void)tsdr_plugin_stop_once(e->t); /* (tsdr_stop on the host's thread may be doing the same right now) */
+        /* On the plugin's own thread — inside its readasync callback — the plugin is NOT told to stop from here: a plugin
+         * whose tsdrplugin_stop waits for its streaming thread would wait for itself.  The device thread sees running == 0
+         * within its 30 ms poll and makes the call (device_thread's last lines).  From any other thread the call is made at
+         * once (tsdr_stop on the host's thread may be doing the same right now: tsdr_plugin_stop_once). */
+        if (!in_plugin_callback) (void)tsdr_plugin_stop_once(e->t);
     }
     return 0;
 }
@@ -347,21 +352,27 @@ static size_t sample_bytes(int type)
  * own thread — more than the DMA that follows it — so a helper takes the second half.  The helper spins for a short while
  * after a job (blocks of a free-running source follow each other within ~100 us) and sleeps on a condition variable
  * otherwise (a live source's blocks are milliseconds apart: the wake-up latency does not matter there). */
+#if defined(__x86_64__) || defined(__i386__)
+#define cpu_relax() __builtin_ia32_pause()
+#elif defined(__aarch64__) || defined(__arm__)
+#define cpu_relax() __asm__ __volatile__("yield" ::: "memory")
+#else
+#define cpu_relax() sched_yield()
+#endif
+/* copy_state: 0 idle, 1 job posted (copy_dst / copy_src / copy_n valid), 2 done — handed over with acquire / release */
 static void *copy_thread(void *arg)
 {
     struct engine *e = (struct engine *)arg;
     double last = now_s();
     for (;;) {
-        if (e->copy_state == 1) {
-            __sync_synchronize();
+        if (__atomic_load_n(&e->copy_state, __ATOMIC_ACQUIRE) == 1) {
             memcpy(e->copy_dst, e->copy_src, e->copy_n);
-            __sync_synchronize();
-            e->copy_state = 2;
+            __atomic_store_n(&e->copy_state, 2, __ATOMIC_RELEASE);
             last = now_s();
             continue;
         }
         if (e->copy_quit) break;
-        if (now_s() - last < 300e-6) { __builtin_ia32_pause(); continue; }
+        if (now_s() - last < 300e-6) { cpu_relax(); continue; }
         pthread_mutex_lock(&e->cm);
         while (e->copy_state != 1 && !e->copy_quit) pthread_cond_wait(&e->c_wake, &e->cm);
         pthread_mutex_unlock(&e->cm);
@@ -379,20 +390,27 @@ static void bounce_copy(struct engine *e, void *dst, const void *src, size_t n)
     /* posted under the helper's mutex: a flag read outside it ("is the helper asleep?") can miss a helper that is just
      * going to sleep (store-load reordering on both sides) — that was a deadlock */
     pthread_mutex_lock(&e->cm);
-    e->copy_state = 1;
+    __atomic_store_n(&e->copy_state, 1, __ATOMIC_RELEASE);
     pthread_cond_signal(&e->c_wake);
     pthread_mutex_unlock(&e->cm);
     memcpy(dst, src, half);
-    while (e->copy_state != 2) __builtin_ia32_pause();
-    __sync_synchronize();
-    e->copy_state = 0;
+    while (__atomic_load_n(&e->copy_state, __ATOMIC_ACQUIRE) != 2) cpu_relax();
+    __atomic_store_n(&e->copy_state, 0, __ATOMIC_RELAXED);
 }
 
+static void on_block_inner(const void *buf, uint64_t items, int type, struct engine *e, int64_t dropped);
 static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, int64_t dropped)
 {
     struct engine *e = (struct engine *)ctx;
     if (!e->t->running || (items & 1)) return;
     if (!e->plugin_thread_bound) { tsdrgpu_bind_thread(e->g); e->plugin_thread_bound = 1; }
+    in_plugin_callback = 1;
+    on_block_inner(buf, items, type, e, dropped);
+    in_plugin_callback = 0;
+}
+
+static void on_block_inner(const void *buf, uint64_t items, int type, struct engine *e, int64_t dropped)
+{
     const double t0 = e->stats ? now_s() : 0.0;
     /* device thread is behind: lose the whole block.  Decided without the queue's mutex — a free-running source whose DMAs we
      * no longer wait for comes here tens of millions of times per second, and a plugin thread spinning on the mutex starved
@@ -661,8 +679,8 @@ static void detector_rebuild(struct engine *e, uint32_t fs)
     /* Detector mode.  Default: CERTIFIED — the float32 three-trip transform; every plot that leaves carries an argmax
      * certificate (tsdrgpu_autocorr_set_certify), and an epoch whose certificate fails is replayed in the reference's own
      * FFT arithmetic before its plot is delivered, so the argmax the host takes (PlotVisualizer.java:233-236) is always
-     * the CPU library's; such an epoch (and any epoch that outgrows the retention ring, TSDR_GPU_AUTOCORR_RETAIN_MB,
-     * default 1024) continues bit-identical.  TSDR_GPU_AUTOCORR=exact (or TSDR_GPU_EXACT_AUTOCORR=1 / TSDR_GPU_EXACT=1): every window in the
+     * the CPU library's; such an epoch (and any epoch that outgrows the retention ring — TSDR_GPU_AUTOCORR_RETAIN_MB;
+     * unset: a quarter of the free HBM, at most 32 GiB, allocated in segments in the background —) continues bit-identical.  TSDR_GPU_AUTOCORR=exact (or TSDR_GPU_EXACT_AUTOCORR=1 / TSDR_GPU_EXACT=1): every window in the
      * reference's arithmetic, plots bit-identical always.  TSDR_GPU_AUTOCORR=fast (or TSDR_GPU_EXACT_AUTOCORR=0 /
      * TSDR_GPU_EXACT=0): plain float32 form, plots within 1e-4*max, no guarantee on ties. */
     {
@@ -864,6 +882,8 @@ static void deliver_frames(struct engine *e, out_buf_t *ob, int F, int W, int H)
     }
 }
 
+static void track_off(struct engine *e);
+
 /* parameter sets the fused run handles itself (the others silently take its split path: nothing gained) */
 static int fused_wanted(const tsdrgpu_pp_params_t *p)
 {
@@ -923,7 +943,12 @@ static void run_frames(struct engine *e)
          * detector's sums and writes the normalised frames (12 instead of 16 bytes per pixel moved).  Frames and state are
          * bit-identical to tsdrgpu_postproc_run's (tests/test_gpu_postproc.py).  Frames that arrive one or two at a time
          * — a live source — take the plain run: there the launches, not the bytes, are what costs. */
-        const int fuse = e->mm_nohead == 0 && F >= FUSE_MIN_FRAMES && e->mm_n >= F && fused_wanted(&prm);
+        /* the min / max entries belong to the frame grid the resampler tracked (track_P pixels per frame): a
+         * tsdr_setresolution between the resampler call and this turn makes them another grid's — those frames take the plain
+         * run and the tracking restarts at the next resampler call */
+        if (e->track_P && (int64_t)P != e->track_P) track_off(e);
+        if (e->mm_nohead > 0 && F > e->mm_nohead) F = e->mm_nohead;
+        const int fuse = e->mm_nohead == 0 && (int64_t)P == e->track_P && F >= FUSE_MIN_FRAMES && e->mm_n >= F && fused_wanted(&prm);
         if (fuse) {
             if (!gpu_ok(e, tsdrgpu_postproc_begin_minmax(e->pp, e->pix.d + e->pix.rd, F, W, H, &prm, e->d_mm_min + e->mm_off, e->d_mm_max + e->mm_off, ob->d),
                         "postproc (fused)") ||
@@ -932,10 +957,6 @@ static void run_frames(struct engine *e)
             e->n_fused_batches++;
             e->n_fused_frames += F;
         } else if (!gpu_ok(e, tsdrgpu_postproc_run(e->pp, e->pix.d + e->pix.rd, F, W, H, &prm, ob->d, prm.pll ? &info : NULL), "postproc")) return;
-        /* the frames' min/max entries go with them */
-        if (e->mm_nohead > 0) e->mm_nohead -= F; /* (F was capped to the head frames above) */
-        else if (e->mm_n >= F) { e->mm_off += F; e->mm_n -= F; if (!e->mm_n) e->mm_off = 0; }
-        else { e->mm_off = e->mm_n = 0; }
         if (t->rgb_cb) {
             /* the JNI shim's pixel loop (TSDRLibraryNDK.c:222-276) on the device: frame after frame into the viewer's
              * persistent pixel buffer (transparent pixels keep their colour), a copy of which goes home */
@@ -962,6 +983,10 @@ static void run_frames(struct engine *e)
             !gpu_ok(e, tsdrgpu_event_record(e->g, ob->done, TSDRGPU_LANE_COMPUTE), "event"))
             return;
         e->pix.rd += P * (size_t)F;
+        /* the frames' min/max entries go with them (together with the read position: an early return above leaves both alone) */
+        if (e->mm_nohead > 0) e->mm_nohead -= F; /* (F was capped to the head frames above) */
+        else if (e->mm_n >= F) { e->mm_off += F; e->mm_n -= F; if (!e->mm_n) e->mm_off = 0; }
+        else { e->mm_off = e->mm_n = 0; }
         if (prm.pll && info.pll_fired) { /* syncdetector.c:149-151: the one place the host has to see a result at once */
             pthread_mutex_lock(&t->lock);
             t->refreshrate -= info.frameratediff;
@@ -1293,6 +1318,8 @@ static void *device_thread(void *arg)
             e->s_dev_det += t3 - t2;
         }
     }
+    /* a device call that failed on the plugin's thread left the stop to us (gpu_ok) */
+    if (e->failed) (void)tsdr_plugin_stop_once(t);
     return NULL;
 }
 
@@ -1360,7 +1387,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
         else e->zero_copy = (promise & TSDRX_MEMORY_MAPPED) != 0;
         /* ... and its DMAs overlap the plugin's next blocks only when the plugin also promises that a block's contents stay
          * untouched while it streams (decided below, once it is known which of its two entry points is used);
-         * TSDR_GPU_ASYNC_UPLOAD=0 waits for every DMA like round 3 did */
+         * and only with TSDR_GPU_ASYNC_UPLOAD=1 — the default waits for every DMA: measured faster, see below) */
         e->immutable = promise;
     }
     {   /* the helper for bounce-buffer copies (only plugins without the promise need it); TSDR_GPU_COPY_THREAD=0: off */

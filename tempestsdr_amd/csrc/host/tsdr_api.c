@@ -242,10 +242,21 @@ int tsdr_plugin_stop_once(tsdr_lib_t *t)
     if (!t->plugin.loaded || !t->plugin.stop) return TSDR_OK;
     pthread_mutex_lock(&t->lock);
     const int first = !t->stop_sent;
-    t->stop_sent = 1;
+    if (first) {
+        t->stop_sent = 1; /* 1: the call is being made, 2: its status is known */
+        pthread_mutex_unlock(&t->lock);
+        const int status = t->plugin.stop();
+        pthread_mutex_lock(&t->lock);
+        t->stop_status = status;
+        t->stop_sent = 2;
+        pthread_cond_broadcast(&t->stopped);
+    } else {
+        /* the second caller reports what the first one's call RETURNED, not what stop_status held before it did */
+        while (t->stop_sent == 1) pthread_cond_wait(&t->stopped, &t->lock);
+    }
+    const int status = t->stop_status;
     pthread_mutex_unlock(&t->lock);
-    if (first) t->stop_status = t->plugin.stop();
-    return t->stop_status;
+    return status;
 }
 
 int tsdr_stop(tsdr_lib_t *t) /* TSDRLibrary.c:213-224 */

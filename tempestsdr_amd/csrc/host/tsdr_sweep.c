@@ -50,7 +50,6 @@ typedef struct {
     int use_comm;
     const unsigned char *id;
     pthread_barrier_t *bar;
-    volatile int *abort_all; /* a rank failed while loading: nobody enters the collectives */
     /* per rank */
     int rank, device;
     int rc;
@@ -65,6 +64,7 @@ typedef struct {
     uint32_t capture, fft_n;
     double *plots; /* flen + llen, malloc'ed by rank 0 when asked for */
     int want_plots;
+    volatile int *votes; /* one slot per rank: how the ranks agree before every step that leads into a collective (agree()) */
 } rank_t;
 
 static double now_ms(void)
@@ -73,6 +73,34 @@ static double now_ms(void)
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
+
+/* Every rank contributes flag bits; all of them get the OR.  The ranks are threads of this process, so the exchange is shared
+ * memory between two barriers.  The ranks meet like this before every step that leads into a collective (ncclCommInitRank,
+ * the all-reduces): a rank that failed on its own, or whose certificate alone was refused (the premise check looks at the
+ * rank's OWN newest window), would otherwise enter — or skip — a collective the others do not, and they would wait for ever.
+ * AGREE_FAILED is raised by a rank that has given up: everybody leaves at that meeting point. */
+#define AGREE_FAILED 2
+static int agree(rank_t *r, int flags)
+{
+    if (r->world == 1) return flags;
+    r->votes[r->rank] = flags;
+    pthread_barrier_wait(r->bar);
+    int any = 0;
+    for (int k = 0; k < r->world; k++) any |= r->votes[k];
+    pthread_barrier_wait(r->bar); /* everybody has read: the slots may be written again */
+    return any;
+}
+/* a meeting point of the healthy path: leaves through `out` when some rank has failed */
+#define MEET(r_, flags_, result_)                                                                   \
+    do {                                                                                            \
+        (result_) = agree((r_), (flags_));                                                          \
+        if ((result_) & AGREE_FAILED) {                                                             \
+            snprintf((r_)->err, sizeof((r_)->err), "another rank failed");                          \
+            (r_)->rc = 2;                                                                           \
+            announced = 1;                                                                          \
+            goto out;                                                                               \
+        }                                                                                           \
+    } while (0)
 
 #define FAIL(r_, g_, what_)                                                                                    \
     do {                                                                                                       \
@@ -90,10 +118,9 @@ static void *rank_main(void *arg)
     float *d_win = NULL;
     void *d_raw = NULL, *h_buf = NULL;
     int fd = -1;
-    int created = 0;
+    int announced = 0, met = 0; /* announced: the others know that this rank is leaving (or it learnt of a failure from them) */
 
     if (tsdrgpu_create(&g, r->device)) { snprintf(r->err, sizeof(r->err), "tsdrgpu_create(device %d) failed: no usable HIP device (this tool has no CPU path)", r->device); r->rc = 1; g = NULL; goto out; }
-    created = 1;
     if (tsdrgpu_autocorr_create(g, &ac, r->rate)) FAIL(r, g, "tsdrgpu_autocorr_create");
     uint32_t capture = 0, n = 0;
     int32_t flo, flen, llo, llen;
@@ -101,6 +128,8 @@ static void *rank_main(void *arg)
     if (r->detector == 2 && tsdrgpu_autocorr_set_exact(ac, 1)) FAIL(r, g, "tsdrgpu_autocorr_set_exact");
     /* certified: the windows stay where they are in this device's memory until the sweep is over (mode 2: no copy) */
     if (r->detector == 1 && tsdrgpu_autocorr_set_certify(ac, 2, 0)) FAIL(r, g, "tsdrgpu_autocorr_set_certify");
+    /* ncclCommInitRank is itself a collective: only enter it once every rank has its context and its detector */
+    MEET(r, 0, met);
     if (r->use_comm && tsdrgpu_comm_create(g, &comm, r->world, r->rank, r->id)) FAIL(r, g, "tsdrgpu_comm_create");
 
     /* this rank's windows: k = rank, rank + world, ... -> contiguous in its own buffer */
@@ -136,13 +165,12 @@ static void *rank_main(void *arg)
     }
     const double t1 = now_ms();
     r->ms_upload = t1 - t0;
-    if (r->bar) pthread_barrier_wait(r->bar); /* the timed part starts together */
-    created = 2;
-    if (*r->abort_all) { snprintf(r->err, sizeof(r->err), "another rank failed"); r->rc = 1; goto out; }
+    MEET(r, 0, met); /* the timed part starts together */
 
     const double t2 = now_ms();
     const int sums = r->world > 1 || r->use_comm;
     if (mine && tsdrgpu_autocorr_run(ac, d_win, 1, (int64_t)capture, mine, sums ? 1 : 0)) FAIL(r, g, "tsdrgpu_autocorr_run");
+    MEET(r, 0, met); /* nobody enters the exchange alone */
     if (sums) {
         if (comm ? tsdrgpu_autocorr_allreduce(ac, comm, (uint64_t)r->nwin) : tsdrgpu_autocorr_finalize_sums(ac, (uint64_t)r->nwin)) FAIL(r, g, "exchange");
     }
@@ -150,9 +178,13 @@ static void *rank_main(void *arg)
     tsdrgpu_ac_certificate_t c;
     tsdrgpu_autocorr_certificate(ac, &c);
     r->certified = (c.frame_certified && c.line_certified) || c.exact_epoch;
-    if (r->detector == 1 && !r->certified) {
-        /* identical plots on every rank -> every rank takes this branch or none does */
+    /* The merged plots are identical on every rank, but a certificate also folds in the premise check of the rank's OWN newest
+     * window (ac_premise_check), so one rank alone may be refused: the ranks agree first, and one refusal sends all of them
+     * through the replay and the second exchange. */
+    MEET(r, (r->detector == 1 && !r->certified) ? 1 : 0, met);
+    if (r->detector == 1 && (met & 1)) {
         if (tsdrgpu_autocorr_promote(ac)) FAIL(r, g, "tsdrgpu_autocorr_promote");
+        MEET(r, 0, met);
         if (sums && (comm ? tsdrgpu_autocorr_allreduce(ac, comm, (uint64_t)r->nwin) : tsdrgpu_autocorr_finalize_sums(ac, (uint64_t)r->nwin)))
             FAIL(r, g, "second exchange");
         if (tsdrgpu_autocorr_argmax(ac, &r->fi, &r->li)) FAIL(r, g, "tsdrgpu_autocorr_argmax");
@@ -173,9 +205,11 @@ static void *rank_main(void *arg)
             if (!r->plots || tsdrgpu_autocorr_plots(ac, r->plots, r->plots + flen, &calls)) FAIL(r, g, "tsdrgpu_autocorr_plots");
         }
     }
+    MEET(r, 0, met); /* the last meeting point: a rank that failed behind the exchanges finds the others here */
 out:
-    /* a rank that failed before the barrier still has to meet the others there */
-    if (r->bar && created < 2) { *r->abort_all = 1; pthread_barrier_wait(r->bar); }
+    /* a rank that failed on its own tells the others at their next meeting point, whichever that is; they all leave there.
+     * (What cannot be announced: a device fault INSIDE a collective the others have already entered.) */
+    if (r->rc && !announced) (void)agree(r, AGREE_FAILED);
     if (fd >= 0) close(fd);
     if (g) {
         tsdrgpu_sync(g);
@@ -249,19 +283,20 @@ int main(int argc, char **argv)
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, NULL, (unsigned)ndev);
     static rank_t ranks[MAX_DEV];
-    static volatile int abort_all;
+    static volatile int votes[MAX_DEV];
     pthread_t th[MAX_DEV];
     for (int r = 0; r < ndev; r++) {
         rank_t *k = &ranks[r];
         memset(k, 0, sizeof(*k));
         k->path = path; k->rate = rate; k->type = type; k->elem = elem; k->world = ndev; k->nwin = nwin; k->detector = detector;
-        k->use_comm = use_comm; k->id = id; k->bar = &bar; k->abort_all = &abort_all; k->rank = r; k->device = devs[r]; k->want_plots = plots_path != NULL;
+        k->use_comm = use_comm; k->id = id; k->bar = &bar; k->votes = votes; k->rank = r; k->device = devs[r]; k->want_plots = plots_path != NULL;
         pthread_create(&th[r], NULL, rank_main, k);
     }
     for (int r = 0; r < ndev; r++) pthread_join(th[r], NULL);
     pthread_barrier_destroy(&bar);
-    for (int r = 0; r < ndev; r++)
-        if (ranks[r].rc) { fprintf(stderr, "rank %d (device %d): %s\n", r, ranks[r].device, ranks[r].err); return 1; }
+    for (int pass = 1; pass <= 2; pass++) /* the rank that failed first (rc 1) before those that left because of it (rc 2) */
+        for (int r = 0; r < ndev; r++)
+            if (ranks[r].rc == pass) { fprintf(stderr, "rank %d (device %d): %s\n", r, ranks[r].device, ranks[r].err); return 1; }
     /* every rank holds the same merged plots: they must agree on the argmax and on what they did about the certificate */
     for (int r = 1; r < ndev; r++)
         if (ranks[r].fi != ranks[0].fi || ranks[r].li != ranks[0].li || ranks[r].promoted != ranks[0].promoted) {

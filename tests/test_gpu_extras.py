@@ -239,36 +239,40 @@ def test_frame_snr_matches_dsp_autogain_run(orc, n, sentinels):
         assert abs(got.value - want) <= 1e-9 * abs(want) + np.spacing(want)
 
 
-def test_wave_reductions_equal_the_shuffle_tree(tmp_path):
+def _device_check_binary(name):
+    """scripts/micro/<name>: built for gfx950 by tempestsdr_amd.build.build_checks() (the GPU boxes have no hipcc, so the
+    binary travels with the snapshot like the libraries); rebuilt here when a compiler is present and the binary is not."""
+    import os
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "scripts", "micro", name + ".hip")
+    exe = os.path.join(root, "scripts", "micro", name)
+    if not os.path.exists(src):
+        pytest.skip("scripts/micro/%s.hip is not in this tree" % name)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        from tempestsdr_amd import build as b
+        if os.path.exists(b.HIPCC):
+            b.build_checks(verbose=False)
+    assert os.path.exists(exe), "scripts/micro/%s was not built (python -m tempestsdr_amd.build) and there is no hipcc here" % name
+    return exe
+
+
+def test_wave_reductions_equal_the_shuffle_tree():
     """tempestsdr_amd/csrc/wave_reduce.h (permlane swaps + DPP row shifts) must give lane 0 the shuffle tree's result bit
     for bit — the partial sums of the frame statistics, and with them the strips, depend on the order of additions."""
-    import os
-    import shutil
     import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc on this box")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "wave_reduce_check")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-w", "-o", exe, os.path.join(root, "scripts", "micro", "wave_reduce_check.hip")],
-                   check=True, timeout=300)
+    exe = _device_check_binary("wave_reduce_check")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr
 
 
-def test_division_and_square_root_on_the_device(tmp_path):
+def test_division_and_square_root_on_the_device():
     """scripts/micro/arith_check.hip: on this GPU the compiler's f32 `/` and sqrtf are the host's (correctly rounded) results on
     the hard cases — divisors with an all-ones mantissa under powers of two, every float of two binades for the root — and the
     bare sequences the kernels run (NormDiv, demod1) give the same bits as `/` and sqrtf."""
-    import os
-    import shutil
     import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc on this box")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "arith_check")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-w", "-ffp-contract=off", "-o", exe, os.path.join(root, "scripts", "micro", "arith_check.hip")],
-                   check=True, timeout=300)
+    exe = _device_check_binary("arith_check")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
     assert r.returncode == 0 and r.stdout.strip().endswith("0 mismatches"), r.stdout + r.stderr

@@ -136,15 +136,18 @@ def test_pipeline_matches_oracle(orc, iq_file, cfg):
     s.close()
 
 
-def test_dropped_samples_keep_alignment(orc, iq_file):
+@pytest.mark.parametrize("as_empty_block", [0, 1])
+def test_dropped_samples_keep_alignment(orc, iq_file, as_empty_block):
     """A plugin-reported drop: the library skips whole `block`s' worth so the
     raster stays aligned (dsp.c:313-368).  Expected frames are built by applying
-    the oracle's bookkeeping to the same block sequence."""
+    the oracle's bookkeeping to the same block sequence.  as_empty_block: the drop arrives as the reference's UHD plugin
+    sends an overflow, cb(buf, 0, ctx, dropped) (TSDRPlugin_UHD.cpp:294) — process() shifts the bookkeeping by the count
+    and adds nothing (TSDRLibrary.c:283-295), so the frames must be the very same ones."""
     path, iq = iq_file
     plugin = hu.build_test_plugin()
     geo = orc.geometry(FS, H, FV)
     drop_at, drop_n = 3, 100_000
-    s, ok, rc = run_session(plugin, f"{path} {FS} {BLOCK} 8000 {drop_at} {drop_n}", nframes=20)
+    s, ok, rc = run_session(plugin, f"{path} {FS} {BLOCK} 8000 {drop_at} {drop_n} {as_empty_block}", nframes=20)
     assert rc == 0
     # what the pipeline forwards to the resampler
     per = BLOCK // 2
