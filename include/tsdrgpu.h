@@ -471,12 +471,19 @@ int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t *c, uint64
 /* ---- a13/a14: super-bandwidth stitch --------------------------------------------- */
 /* superb_ondataready, superbandwidth.c:121-152 (complex_to_abs_diff :67-81,
  * superb_bestfit :83-119, fft_crosscorrelation fft.c:69-93).  d_hops: nhops
- * device buffers of 2*gathered floats (modified in place like the reference).
- * d_out: nhops*2*n floats with n = largest 2^m <= gathered.  h_offsets[nhops]:
- * best offsets in floats.  Synchronises (the offsets steer the rotation). */
+ * device buffers of 2*gathered floats.  d_out: nhops*2*n floats with n = largest
+ * 2^m <= gathered.  h_offsets[nhops]: best offsets in floats.  Synchronises.
+ * Four hops (the reference's SUPER_HOPS_TO_MAKE) of 2^16 .. 2^23 points take the THREE-TRIP plan (csrc/fft4step.h): the
+ * hop buffers are read only.  Other shapes, and tsdrgpu_superb_set_plan(g, 0), take the pass-per-radix plan, which — like
+ * the reference, superbandwidth.c:138-144 — leaves every hop buffer holding its spectrum (values the reference never
+ * reads again: the next gather overwrites them, superbandwidth.c:225-236).  Same results either way: offsets identical,
+ * the stitched signal within 1e-4 * max. */
 int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered,
                           int samples_in_frame, float *d_out, int32_t *h_offsets,
                           uint32_t *h_total);
+/* trips = 3 (default): the three-trip plan where it applies; 0: the pass-per-radix plan always (A/B, and what the sharded
+ * form below is bit-identical to). */
+int tsdrgpu_superb_set_plan(tsdrgpu_t *g, int trips);
 /* SURVEY 8(e) row 3 — the stitch with ONE HOP PER GPU (rank r holds hop r; superbandwidth.c:121-152).  Everything but
  * two steps is per hop; the two steps are exchanges the caller makes between the phases:
  *   _reference   hop 0's rank transforms its abs-diff signal; *d_ref (n floats) is broadcast from that rank

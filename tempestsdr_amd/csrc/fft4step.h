@@ -159,22 +159,27 @@ __device__ __forceinline__ void dft_reg<16>(float2 (&v)[16])
 // ---------------------------------------------------------------------------
 // twiddles: exp(-2 pi i e / span) for a power-of-two span, from an exactly representable dyadic fraction
 // ---------------------------------------------------------------------------
+// WIDE: spans above 2^24 (the 2^25-point stitch transform, column length 2048): r itself may not be a float, r - span
+// (|.| <= 2^24) is, and the angle differs by a whole turn
+template <bool WIDE = false>
 __device__ __forceinline__ float2 tw_exact(unsigned e, unsigned mask, float inv)
 {
     float sn, cs;
-    sincospif((float)(e & mask) * inv, &sn, &cs);
+    const unsigned r = e & mask;
+    const float f = (WIDE && r > (mask >> 1)) ? -(float)(mask - r + 1u) : (float)r;
+    sincospif(f * inv, &sn, &cs);
     return make_float2(cs, sn);
 }
 
 // pw[i] = w^(e1*i), i < M (a power of two): log2(M) accurate evaluations, the rest complex products of
 // depth <= log2(M)-1 (a few f32 ulps)
-template <int M>
+template <int M, bool WIDE = false>
 __device__ __forceinline__ void tw_powers(float2 (&pw)[M], unsigned e1, unsigned mask, float inv)
 {
     pw[0] = make_float2(1.f, 0.f);
 #pragma unroll
     for (int bit = 1; bit < M; bit <<= 1) {
-        pw[bit] = tw_exact(e1 * (unsigned)bit, mask, inv);
+        pw[bit] = tw_exact<WIDE>(e1 * (unsigned)bit, mask, inv);
 #pragma unroll
         for (int i = bit + 1; i < 2 * bit; i++) pw[i] = cmul(pw[bit], pw[i - bit]);
     }
@@ -241,6 +246,8 @@ __device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, un
 template <int LOGN1>
 struct ColGeom {
     static constexpr unsigned N1 = 1u << LOGN1;
+    // (column length 2048 — the super-bandwidth stitch of hops of 2^23 points — keeps 8 columns: 128 KiB, one workgroup of
+    // 1024 threads per CU)
     static constexpr unsigned C = (N1 >= AC4_C8_FROM) ? 8u : (N1 >= 256u) ? 16u : 4096u / N1;
     static constexpr unsigned NT = N1 * C / 16u;  // threads per workgroup
     static constexpr unsigned Q = N1 / 16u;
@@ -248,13 +255,73 @@ struct ColGeom {
     static constexpr int NP = (LOGN1 + 3) / 4;                       // passes
 };
 
-template <int IN_MODE>
-__device__ __forceinline__ float2 ac4_load(const void *__restrict__ base, long long at, bool al16)
+// am_demod (TSDRLibrary.c:244-262) with the reference's bits: separate products and sum (no contraction), correctly rounded
+// root.  For the side store of trip 1 into the retention ring — what an epoch is replayed from must be the reference's own
+// demodulated samples.  The two-sided correction runs bare where every lane's argument is an ordinary number (see demod1,
+// tsdrgpu_core.hip: the same instructions on the same values as the library routine).
+__device__ __forceinline__ float ac4_demod_exact(float re, float im)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float x = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    const unsigned bts = __float_as_uint(x);
+    const bool plain = (bts - 0x0f800000u) < (0x7f800000u - 0x0f800000u);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!plain) == 0ull, 1)) {
+        float r = __builtin_amdgcn_sqrtf(x);
+        const float rm1 = __uint_as_float(__float_as_uint(r) - 1u), rp1 = __uint_as_float(__float_as_uint(r) + 1u);
+        const float em = __builtin_fmaf(-rm1, r, x), ep = __builtin_fmaf(-rp1, r, x);
+        r = (em <= 0.0f) ? rm1 : r;
+        r = (ep > 0.0f) ? rp1 : r;
+        return r;
+    }
+    return sqrtf(x);
+#else
+    volatile float a = re * re, b = im * im;  // (volatile: no fused multiply-add on the host either)
+    return sqrtf(a + b);
+#endif
+}
+
+// What the column kernels' variants beyond the autocorrelation's own need (all unused, and compiled away, there):
+//   retain  EPI 1: the ring slot of window 0 (2 nh floats per window): trip 1 leaves the demodulated samples it has in
+//           registers anyway (tsdrgpu_autocorr_set_certify mode 1; frameratedetector.c:87-126 keeps one copy too)
+//   shift   IN_MODE 6: the input rotated left by that many complex points (superbandwidth.c:135-137)
+//   pval / pidx  EPI 2: per workgroup the first maximum of |re| and of |im| of the results (superb_bestfit's search,
+//           superbandwidth.c:100-116, over correlations that are real sequences packed two per transform)
+struct AcColsAux {
+    float *retain;
+    unsigned shift;
+    float *pval;
+    int *pidx;
+};
+
+template <int IN_MODE>
+__device__ __forceinline__ float2 ac4_load(const void *__restrict__ base, long long at, bool al16, unsigned nh, unsigned shift)
+{
+    (void)nh;
+    (void)shift;
     if (IN_MODE == 0) return ((const float2 *)base)[at];
     if (IN_MODE == 3) {
         const float *x = (const float *)base;
         return make_float2(x[2 * at], x[2 * at + 1]);
+    }
+    if (IN_MODE == 5) {
+        // complex_to_abs_diff (superbandwidth.c:67-81): the first difference of the magnitudes, element 0 seeded with
+        // |z0|^2 (kept literally), imaginary part 0.  Hardware square root: this feeds a float32 correlation whose peak
+        // position is all that is read.
+        const float2 *z = (const float2 *)base;
+        const float2 c = z[at];
+        const float cur = AC_SQRT(c.x * c.x + c.y * c.y);
+        float prev;
+        if (at == 0) prev = c.x * c.x + c.y * c.y;
+        else {
+            const float2 p = z[at - 1];
+            prev = AC_SQRT(p.x * p.x + p.y * p.y);
+        }
+        return make_float2(cur - prev, 0.f);
+    }
+    if (IN_MODE == 6) {
+        unsigned src = (unsigned)at + shift;
+        if (src >= nh) src -= nh;
+        return ((const float2 *)base)[src];
     }
     // two IQ samples = 16 bytes; a window starts on an 8-byte boundary only (capture lengths are odd), and gfx950
     // moves an under-aligned dwordx4 in one instruction all the same
@@ -273,17 +340,190 @@ __device__ __forceinline__ float2 ac4_load(const void *__restrict__ base, long l
 }
 
 // rtw[i] = w_nh^(ebase + estep i), i < 16
+template <bool WIDE = false>
 __device__ __forceinline__ void ac4_col_twiddles(float2 (&rtw)[16], unsigned estep, unsigned ebase, unsigned nh)
 {
     const unsigned mask = nh - 1u;
     const float inv = -2.0f / (float)nh;
-    tw_powers<16>(rtw, estep, mask, inv);
-    const float2 rbase = tw_exact(ebase, mask, inv);
+    tw_powers<16, WIDE>(rtw, estep, mask, inv);
+    const float2 rbase = tw_exact<WIDE>(ebase, mask, inv);
     rtw[0] = rbase;
 #pragma unroll
     for (int i = 1; i < 16; i++) rtw[i] = cmul(rbase, rtw[i]);
 }
 
+// EPI 0: results stored (trip 3: filtered by `keep`); 1: as 0, and IN_MODE 4's samples also go to aux.retain, demodulated
+// with the reference's bits; 2: LAST only — nothing stored, per workgroup the first maxima of |re| and |im| to aux.pval / pidx
+template <int LOGN1, int IN_MODE, bool LAST, int EPI>
+__device__ __forceinline__ void ac4_cols_body(const void *__restrict__ xb, float2 *__restrict__ yb, unsigned nh, const FftKeep &keep,
+                                              const unsigned b, const AcColsAux &aux)
+{
+    typedef ColGeom<LOGN1> G;
+    constexpr unsigned N1 = G::N1, C = G::C, NT = G::NT, Q = G::Q;
+    constexpr int R0 = G::R0, NP = G::NP, G0 = 16 / R0;
+    constexpr bool WIDE = LOGN1 >= 11;  // only there can nh (4 x 4096 x N1 in the stitch's last trip) exceed 2^24
+    __shared__ float2 L[N1 * C];
+    __shared__ float2 twN[N1];
+    // C == 16 (column lengths >= 256): the powers (w_nh^(col Q))^i, i < 16, of the workgroup's 16 columns are shared by
+    // the 32 threads of a column — one accurate evaluation each instead of four evaluations and eleven products per
+    // thread (rows padded to 17 entries: sixteen columns' reads hit sixteen different bank pairs)
+    constexpr bool PTAB = (C == 16u);
+    __shared__ float2 ptw[PTAB ? 16 * 17 : 1];
+    const unsigned N2 = nh / N1;
+    const unsigned tid = threadIdx.x;
+    const unsigned c = tid % C, q = tid / C;
+    // consecutive tiles go to the same XCD (workgroups are dealt round-robin to the 8 XCDs): the IQ rows
+    // of a window start on 8-byte boundaries only, so neighbouring tiles share a cache line at each end
+    const unsigned gx = gridDim.x;
+    const unsigned tile = (gx % 8u == 0u) ? (blockIdx.x % 8u) * (gx / 8u) + blockIdx.x / 8u : blockIdx.x;
+    const unsigned col = tile * C + c;
+    for (unsigned e = tid; e < N1; e += NT) {
+        float sn, cs;
+        sincospif(-2.0f * (float)e / (float)N1, &sn, &cs);
+        twN[e] = make_float2(cs, sn);
+    }
+    if (PTAB && tid < 256u) {
+        const unsigned cc = tid >> 4, i = tid & 15u;
+        ptw[cc * 17u + i] = tw_exact<WIDE>((tile * C + cc) * Q * i, nh - 1u, -2.0f / (float)nh);
+    }
+    const bool al16 = (IN_MODE == 4) && (((unsigned long long)xb) & 15ull) == 0ull;
+
+    float2 v[16];
+    // ---- pass 0 (Ns = 1, radix R0): butterfly a of this thread is column point jb = q + Q*a
+#pragma unroll
+    for (int a = 0; a < G0; a++)
+#pragma unroll
+        for (int t = 0; t < R0; t++) {
+            const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
+            if (EPI == 1 && IN_MODE == 4) {
+                // the two samples of the point demodulated with the reference's bits: into the ring, and into the transform
+                const float2 *p = (const float2 *)xb + 2 * ((long long)row * N2 + col);
+                const float2 s0 = p[0], s1 = p[1];
+                const float2 m = make_float2(ac4_demod_exact(s0.x, s0.y), ac4_demod_exact(s1.x, s1.y));
+                ((float2 *)(aux.retain + (long long)b * (2ll * nh)))[(long long)row * N2 + col] = m;
+                v[a * R0 + t] = m;
+            } else {
+                v[a * R0 + t] = ac4_load<IN_MODE>(xb, (long long)row * N2 + col, al16, nh, aux.shift);
+            }
+        }
+    // The twiddle between the column and the row transforms, w_nh^(k1 n2), lives here (trip 2 is the one
+    // short of VALU time): on trip 1's results and on trip 3's inputs the thread's 16 rows are q + Q i, so
+    // the factors are w^(n2 q) * (w^(n2 Q))^i: five accurate evaluations and products of depth <= 4.
+    if (LAST) {
+        float2 rtw[16];
+        if (PTAB) {
+            __syncthreads();  // ptw[] complete (the loads above are in flight meanwhile)
+            const float2 rbase = tw_exact<WIDE>(col * q, nh - 1u, -2.0f / (float)nh);
+            rtw[0] = rbase;
+#pragma unroll
+            for (int i = 1; i < 16; i++) rtw[i] = cmul(rbase, ptw[c * 17u + (unsigned)i]);
+        } else {
+            ac4_col_twiddles<WIDE>(rtw, col * Q, col * q, nh);
+        }
+#pragma unroll
+        for (int a = 0; a < G0; a++)
+#pragma unroll
+            for (int t = 0; t < R0; t++) v[a * R0 + t] = cmul(v[a * R0 + t], rtw[a + G0 * t]);
+    }
+#pragma unroll
+    for (int a = 0; a < G0; a++) dft_reg<R0>(*reinterpret_cast<float2(*)[R0]>(&v[a * R0]));
+
+    if (NP > 1) {
+#pragma unroll
+        for (int a = 0; a < G0; a++)
+#pragma unroll
+            for (int u = 0; u < R0; u++) L[((q + Q * (unsigned)a) * (unsigned)R0 + (unsigned)u) * C + c] = v[a * R0 + u];
+        __syncthreads();  // tile and twN[] complete
+        unsigned Ns = (unsigned)R0;
+#pragma unroll
+        for (int pass = 1; pass < NP; pass++) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) v[t] = L[(q + (unsigned)t * Q) * C + c];
+            const unsigned k = q & (Ns - 1u);
+            const unsigned unit = N1 / (Ns * 16u);
+#pragma unroll
+            for (int t = 1; t < 16; t++) v[t] = cmul(v[t], twN[((unsigned)t * k * unit) & (N1 - 1u)]);
+            dft_reg<16>(v);
+            if (pass < NP - 1) {
+                __syncthreads();  // every read of this pass done before the tile is overwritten
+#pragma unroll
+                for (int u = 0; u < 16; u++) L[((q - k) * 16u + k + (unsigned)u * Ns) * C + c] = v[u];
+                __syncthreads();
+                Ns *= 16u;
+            }
+        }
+    }
+    // ---- store: the last pass has Ns*R = N1, so thread q holds rows q + u*(N1/16) (R0 outputs per
+    // butterfly when the only pass is pass 0)
+    constexpr int RL = (NP > 1) ? 16 : R0;  // radix of the last pass
+    constexpr int GL = 16 / RL;
+    if (EPI == 2) {
+        // superb_bestfit's search (superbandwidth.c:100-116) over what this workgroup computed: the first maximum of |re| and
+        // of |im| (two real correlations per transform), lowest index on ties; one (value, index) pair each per workgroup
+        float bre = -1.f, bim = -1.f;
+        unsigned are = 0x7fffffffu, aim = 0x7fffffffu;
+#pragma unroll
+        for (int a = 0; a < GL; a++)
+#pragma unroll
+            for (int u = 0; u < RL; u++) {
+                const unsigned row = q + Q * (unsigned)a + (unsigned)u * (N1 / (unsigned)RL);
+                const unsigned m = row * N2 + col;
+                const float re = fabsf(v[a * RL + u].x), im = fabsf(v[a * RL + u].y);
+                if (re > bre || (re == bre && m < are)) { bre = re; are = m; }
+                if (im > bim || (im == bim && m < aim)) { bim = im; aim = m; }
+            }
+        __syncthreads();  // the tile is free: it carries the tree
+        float *rv = (float *)L;
+        unsigned *ri = (unsigned *)(rv + 2 * NT);
+        rv[tid] = bre; rv[NT + tid] = bim; ri[tid] = are; ri[NT + tid] = aim;
+        __syncthreads();
+        for (unsigned s = NT / 2u; s > 0u; s >>= 1) {
+            if (tid < s) {
+#pragma unroll
+                for (int w = 0; w < 2; w++) {
+                    const float ov = rv[w * NT + tid + s];
+                    const unsigned oi = ri[w * NT + tid + s];
+                    if (ov > rv[w * NT + tid] || (ov == rv[w * NT + tid] && oi < ri[w * NT + tid])) { rv[w * NT + tid] = ov; ri[w * NT + tid] = oi; }
+                }
+            }
+            __syncthreads();
+        }
+        if (tid < 2u) {
+            const unsigned slot = (2u * b + tid) * gridDim.x + tile;
+            aux.pval[slot] = rv[tid * NT];
+            aux.pidx[slot] = (int)ri[tid * NT];
+        }
+        return;
+    }
+    float2 rtw[16];
+    if (!LAST) {
+        if (PTAB) {  // (NP > 1 here: the passes' barriers lie between the table's writes and these reads)
+            const float2 rbase = tw_exact<WIDE>(col * q, nh - 1u, -2.0f / (float)nh);
+            rtw[0] = rbase;
+#pragma unroll
+            for (int i = 1; i < 16; i++) rtw[i] = cmul(rbase, ptw[c * 17u + (unsigned)i]);
+        } else {
+            ac4_col_twiddles<WIDE>(rtw, col * Q, col * q, nh);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < GL; a++)
+#pragma unroll
+        for (int u = 0; u < RL; u++) {
+            const unsigned row = q + Q * (unsigned)a + (unsigned)u * (N1 / (unsigned)RL);
+            const unsigned m = row * N2 + col;
+            float2 o = v[a * RL + u];
+            if (!LAST) o = cmul(o, rtw[a + GL * u]);
+            if (LAST) {
+                o.y = -o.y;
+                if (keep.on && (int)b != keep.full_b && !((m >= keep.lo0 && m < keep.hi0) || (m >= keep.lo1 && m < keep.hi1) || m == 0u)) continue;
+            }
+            yb[m] = o;
+        }
+}
+
+#if defined(AC4_COLS_R4)
+// (A/B build: round 4's kernel text, verbatim, for the autocorrelation's own three instantiations; -DAC4_COLS_R4)
 template <int LOGN1, int IN_MODE, bool LAST>
 __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *__restrict__ xin, long long in_stride,
                                                                 float2 *__restrict__ y, unsigned nh, FftKeep keep)
@@ -333,7 +573,7 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *_
 #pragma unroll
         for (int t = 0; t < R0; t++) {
             const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
-            v[a * R0 + t] = ac4_load<IN_MODE>(xb, (long long)row * N2 + col, al16);
+            v[a * R0 + t] = ac4_load<IN_MODE>(xb, (long long)row * N2 + col, al16, nh, 0u);
         }
     // The twiddle between the column and the row transforms, w_nh^(k1 n2), lives here (trip 2 is the one
     // short of VALU time): on trip 1's results and on trip 3's inputs the thread's 16 rows are q + Q i, so
@@ -411,6 +651,75 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *_
             }
             yb[m] = o;
         }
+}
+#else
+template <int LOGN1, int IN_MODE, bool LAST>
+__global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *__restrict__ xin, long long in_stride,
+                                                                float2 *__restrict__ y, unsigned nh, FftKeep keep)
+{
+    const unsigned b = blockIdx.y;
+    const void *xb;
+    if (IN_MODE == 3) xb = (const void *)((const float *)xin + (long long)b * in_stride);
+    else xb = (const void *)((const float2 *)xin + (long long)b * in_stride);
+    const AcColsAux none = {nullptr, 0u, nullptr, nullptr};
+    ac4_cols_body<LOGN1, IN_MODE, LAST, 0>(xb, y + (long long)b * nh, nh, keep, b, none);
+}
+
+#endif
+
+// trip 1 from interleaved IQ that also fills the retention ring (tsdrgpu_autocorr_set_certify mode 1): see AcColsAux.retain
+template <int LOGN1>
+__global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols_retain(const void *__restrict__ xin, long long in_stride,
+                                                                       float2 *__restrict__ y, unsigned nh, float *__restrict__ retain)
+{
+    const unsigned b = blockIdx.y;
+    const FftKeep all = {0, -1, 0u, 0u, 0u, 0u};
+    const AcColsAux aux = {retain, 0u, nullptr, nullptr};
+    ac4_cols_body<LOGN1, 4, false, 1>((const void *)((const float2 *)xin + (long long)b * in_stride), y + (long long)b * nh, nh, all, b, aux);
+}
+
+// ---------------------------------------------------------------------------
+// The super-bandwidth stitch on the same three trips (superb_ondataready / superb_bestfit, superbandwidth.c:83-152;
+// fft_crosscorrelation, fft.c:69-93).  Four hops of M = N1 * 4096 complex points each.
+//
+// alignment (hops 1..3 against hop 0, over bn points each): d_h = complex_to_abs_diff(hop_h) is real, so the three
+//   correlations c_i = IFFT(conj(D_0) D_i) are real sequences:
+//     trip 1  k_sb_cols<.., 5>      column DFTs of the four d_h (abs-diff fused into the load)
+//     trip 2  k_sb_rows<XCORR>      row k1 of the four: DFT-4096 each, Q = D_0 conj(D_2) and P = D_0 conj(D_1 - i D_3)
+//                                   at the same k in registers, DFT-4096 of both (the inverse's row half): TWO arrays out
+//     trip 3  k_sb_cols_argmax      column DFTs of P and Q: F(P) = c_1 + i c_3, F(Q) = c_2; nothing is stored but each
+//                                   workgroup's first maxima of |re| and |im|
+// stitch: x = IFFT_4M([X_0 X_1 X_2 X_3]), X_h = FFT_M(rot_h(hop_h)) / M.  As the three-trip plan of ONE 4M-point transform
+//   with rows of 16384 = 4 x 4096 points (input index K = k1 + N1 (k2 + 4096 h), output n = 16384 q1 + 4 q2 + s):
+//     trip 1  k_sb_cols<.., 6>      column DFTs of the four rotated hops (the rotation is the load's index)
+//     trip 2  k_sb_rows<STITCH>     row k1 of the four: DFT-4096 each (the forward transforms' row half); then the 16384-point
+//                                   row transform of the inverse as radix 4 across the hops at the same k (registers + one
+//                                   exchange), the twiddle w_16384^(k2 s), DFT-4096 for each residue s; stored [q2][s]
+//     trip 3  k_ac_cols<.., 0, true> with nh = 4M: exactly the autocorrelation's last trip (twiddle, column DFTs, conjugate),
+//                                   natural order
+//   = 3 trips over 4M points where the pass-per-radix plan made 4 x 3 + 4.
+// ---------------------------------------------------------------------------
+struct SbHops {
+    const void *p[4];
+};
+
+template <int LOGN1, int IN_MODE>
+__global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_sb_cols(SbHops hops, float2 *__restrict__ y, unsigned nh, const int *__restrict__ off_floats)
+{
+    const unsigned b = blockIdx.y;
+    const FftKeep all = {0, -1, 0u, 0u, 0u, 0u};
+    // rotation: the reference's offset is in floats and even (2 * maxlength, superbandwidth.c:118)
+    const AcColsAux aux = {nullptr, (IN_MODE == 6 && off_floats) ? ((unsigned)off_floats[b] >> 1) & (nh - 1u) : 0u, nullptr, nullptr};
+    ac4_cols_body<LOGN1, IN_MODE, false, 0>(hops.p[b], y + (long long)b * nh, nh, all, b, aux);
+}
+
+template <int LOGN1>
+__global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_sb_cols_argmax(const float2 *__restrict__ x, unsigned nh, float *__restrict__ pval, int *__restrict__ pidx)
+{
+    const unsigned b = blockIdx.y;
+    const FftKeep all = {0, -1, 0u, 0u, 0u, 0u};
+    const AcColsAux aux = {nullptr, 0u, pval, pidx};
+    ac4_cols_body<LOGN1, 0, true, 2>((const void *)(x + (long long)b * nh), nullptr, nh, all, b, aux);
 }
 
 // ---------------------------------------------------------------------------
@@ -565,4 +874,151 @@ __global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsi
     // loads and the conjugation that completes the inverse after its forward column transform
 #pragma unroll
     for (int u = 0; u < 16; u++) zrow[j2 + 256u * (unsigned)u] = v[u];
+}
+
+// ---------------------------------------------------------------------------
+// trip 2 of the super-bandwidth stitch's two phases (see k_sb_cols above).  One workgroup of 512 threads per row k1 of the
+// FOUR hop arrays w[h][k1][.] (trip 1's output, already times w_nh^(k1 n2)): threads 0..255 take hops 0 and 2 one after
+// the other, threads 256..511 hops 1 and 3 — thread j of either half ends up holding X_h[k1 + N1 (j + 256 u)], u < 16,
+// of its two hops, so everything that combines the hops AT THE SAME k is register arithmetic plus one exchange of 16
+// values per thread between the halves.
+//   XCORR   (fft_crosscorrelation, fft.c:69-93, for the three pairs (0, i) at once): half 0 forms Q = D0 conj(D2), half 1
+//           P = D0 conj(D1 - i D3) (D0 handed over through LDS); each half transforms its one row; out[a][k1][q2], a = half
+//   STITCH  (superbandwidth.c:138-146): U_h = conj(X_h) / M; half 0: U0 +- U2, half 1: U1 +- U3; half 0 gets U1 + U3 and
+//           forms T0, T2, half 1 gets U0 - U2 and forms T1, T3 (T_s = sum_h (-i)^(h s) U_h); times w_16384^(s k2);
+//           DFT-4096 per residue; out[k1][4 q2 + s]
+// `scale`: 1/n of the forward transforms (fft.c:167-175), a power of two.
+// ---------------------------------------------------------------------------
+#define SB_ROWS_XCORR 0
+#define SB_ROWS_STITCH 1
+
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void k_sb_rows(const float2 *__restrict__ w, float2 *__restrict__ out, unsigned nh, float scale)
+{
+    __shared__ float2 buf[2][AC4_ROWBUF];
+    __shared__ float2 tw256[256], tw4k[256];
+    const unsigned tid = threadIdx.x, half = tid >> 8, j = tid & 255u;
+    const unsigned k1 = blockIdx.x;
+    float2 *Lr = buf[half];
+    const float2 *rowA = w + (long long)half * nh + (long long)k1 * AC4_ROW;  // hop `half`
+    const float2 *rowB = rowA + 2ll * nh;                                      // hop `half + 2`
+    float2 va[16], vb[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) va[t] = rowA[j + 256u * (unsigned)t];
+#pragma unroll
+    for (int t = 0; t < 16; t++) vb[t] = rowB[j + 256u * (unsigned)t];
+    {
+        float sn, cs;
+        if (half == 0u) {
+            sincospif(-(float)j * (1.0f / 128.0f), &sn, &cs);
+            tw256[j] = make_float2(cs, sn);
+        } else {
+            sincospif(-(float)j * (1.0f / 2048.0f), &sn, &cs);
+            tw4k[j] = make_float2(cs, sn);
+        }
+    }
+    __syncthreads();  // tables ready
+    ac4_fft4096(va, Lr, j, tw256, tw4k);  // va[u] = X_a[k1 + N1 (j + 256 u)]
+    __syncthreads();
+    unsigned j2 = j;
+    AC4_LAUNDER(j2);
+    ac4_fft4096(vb, Lr, j2, tw256, tw4k);
+    __syncthreads();  // both buffers free
+    float2 *const Lown = Lr + (j2 + (j2 >> 4));               // own element u sits at Lown[272 u]
+    float2 *const Loth = buf[1u - half] + (j2 + (j2 >> 4));    // the same (j, u) of the other half
+    if (MODE == SB_ROWS_XCORR) {
+        const float s2 = scale * scale;
+        if (half == 0u) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) Lown[272 * u] = va[u];  // D0 for the other half
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {  // conj(D1 - i D3)
+                const float2 e = cadd_mi(va[u], vb[u]);
+                vb[u] = make_float2(e.x * s2, -e.y * s2);
+            }
+        }
+        __syncthreads();
+        if (half == 0u) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {  // Q = D0 conj(D2)
+                const float2 c = make_float2(vb[u].x * s2, -vb[u].y * s2);
+                va[u] = cmul(va[u], c);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; u++) va[u] = cmul(Loth[272 * u], vb[u]);  // P = D0 conj(D1 - i D3)
+        }
+        __syncthreads();  // the exchange's reads are done before the buffers carry the next transform
+        unsigned j3 = j2;
+        AC4_LAUNDER(j3);
+        ac4_fft4096(va, Lr, j3, tw256, tw4k);
+        float2 *orow = out + (long long)half * nh + (long long)k1 * AC4_ROW;
+#pragma unroll
+        for (int u = 0; u < 16; u++) orow[j3 + 256u * (unsigned)u] = va[u];
+    } else {
+        // U = conj(X) * scale; e = Ua + Ub, o = Ua - Ub
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const float2 a = make_float2(va[u].x * scale, -va[u].y * scale), b = make_float2(vb[u].x * scale, -vb[u].y * scale);
+            va[u] = cadd(a, b);
+            vb[u] = csub(a, b);
+        }
+        // half 0 publishes its o (U0 - U2) and needs the other's e (U1 + U3); half 1 the other way round
+        if (half == 0u) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) Lown[272 * u] = vb[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; u++) Lown[272 * u] = va[u];
+        }
+        __syncthreads();
+        if (half == 0u) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float2 be = Loth[272 * u];
+                const float2 ae = va[u];
+                va[u] = cadd(ae, be);  // T0
+                vb[u] = csub(ae, be);  // T2
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float2 ao = Loth[272 * u];
+                const float2 bo = vb[u];
+                va[u] = cadd_mi(ao, bo);  // T1 = (U0 - U2) - i (U1 - U3)
+                vb[u] = csub_mi(ao, bo);  // T3 = (U0 - U2) + i (U1 - U3)
+            }
+        }
+        // residues: va is s = half, vb is s = half + 2; times w_16384^(s (j + 256 u)) = w_16384^(s j) * w_64^(s u)
+        const unsigned sa = half, sb = half + 2u;
+        {
+            float sn, cs;
+            if (sa) {
+                sincospif(-(float)(sa * j2) * (1.0f / 8192.0f), &sn, &cs);
+                const float2 base = make_float2(cs, sn);
+                va[0] = cmul(va[0], base);
+#pragma unroll
+                for (int u = 1; u < 16; u++) va[u] = cmul(va[u], cmul(base, tw256[(4u * sa * (unsigned)u) & 255u]));
+            }
+            sincospif(-(float)(sb * j2) * (1.0f / 8192.0f), &sn, &cs);
+            const float2 base = make_float2(cs, sn);
+            vb[0] = cmul(vb[0], base);
+#pragma unroll
+            for (int u = 1; u < 16; u++) vb[u] = cmul(vb[u], cmul(base, tw256[(4u * sb * (unsigned)u) & 255u]));
+        }
+        __syncthreads();  // the exchange's reads are done before the buffers carry the next transform
+        float2 *orow = out + (long long)k1 * (4ll * AC4_ROW);
+        unsigned j3 = j2;
+        AC4_LAUNDER(j3);
+        ac4_fft4096(va, Lr, j3, tw256, tw4k);
+#pragma unroll
+        for (int u = 0; u < 16; u++) orow[4u * (j3 + 256u * (unsigned)u) + sa] = va[u];
+        __syncthreads();
+        unsigned j4 = j3;
+        AC4_LAUNDER(j4);
+        ac4_fft4096(vb, Lr, j4, tw256, tw4k);
+#pragma unroll
+        for (int u = 0; u < 16; u++) orow[4u * (j4 + 256u * (unsigned)u) + sb] = vb[u];
+    }
 }

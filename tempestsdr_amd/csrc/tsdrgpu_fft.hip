@@ -965,29 +965,31 @@ static bool ac4_supported(uint32_t nh) { return nh >= 4096u * 16u && nh <= 4096u
 
 template <int LOGN1>
 static void launch_ac4_n1(tsdrgpu_t *g, hipStream_t st, const float *src, int in_is_iq, long long stride, int cnt, uint32_t nh, float2 *work,
-                          float2 *out, const FftKeep &keep)
+                          float2 *out, const FftKeep &keep, float *retain)
 {
     typedef ColGeom<LOGN1> G;
     const dim3 cgrid(AC4_ROW / G::C, cnt);
-    if (in_is_iq) TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 4, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
+    // retain (certified mode, library retention, IQ input): trip 1 also leaves the demodulated windows in the ring
+    if (in_is_iq && retain) TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols_retain<LOGN1>), cgrid, G::NT, (const void *)src, stride, work, nh, retain);
+    else if (in_is_iq) TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 4, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
     else TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 3, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
     TSDR_LAUNCH(g, PROF_AC_ROWS, st, k_ac_rows, dim3((1u << LOGN1) / 2u, cnt), 512, work, nh);
     TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 0, true>), cgrid, G::NT, (const void *)work, (long long)nh, out, nh, keep);
 }
 
 static void launch_ac4(tsdrgpu_t *g, hipStream_t st, const float *src, int in_is_iq, long long stride, int cnt, uint32_t nh, float2 *work,
-                       float2 *out, const FftKeep &keep)
+                       float2 *out, const FftKeep &keep, float *retain = nullptr)
 {
     int logn1 = 0;
     while ((4096u << logn1) < nh) logn1++;
     switch (logn1) {
-        case 4: launch_ac4_n1<4>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
-        case 5: launch_ac4_n1<5>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
-        case 6: launch_ac4_n1<6>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
-        case 7: launch_ac4_n1<7>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
-        case 8: launch_ac4_n1<8>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
-        case 9: launch_ac4_n1<9>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
-        default: launch_ac4_n1<10>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep); break;
+        case 4: launch_ac4_n1<4>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 5: launch_ac4_n1<5>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 6: launch_ac4_n1<6>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 7: launch_ac4_n1<7>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 8: launch_ac4_n1<8>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 9: launch_ac4_n1<9>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        default: launch_ac4_n1<10>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
     }
 }
 
@@ -1134,7 +1136,10 @@ static int ac_run_exact(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq,
 }
 
 // `nwindows` windows through the float32 transform (three-trip plan where it applies), accumulated into the plots
-static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, long long stride, int nwindows, int mode)
+// retain_to (IQ input on the three-trip plan only, see ac_retain_fused): where trip 1 leaves the windows' demodulated samples,
+// n floats per window
+static bool ac_retain_fused(const tsdrgpu_autocorr_t *ac, int in_is_iq);
+static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, long long stride, int nwindows, int mode, float *retain_to = nullptr)
 {
     tsdrgpu_t *g = ac->g;
     // windows are transformed at most AC_SUBBATCH at a time.  A launch of the three-trip plan is only ~3 rounds of
@@ -1184,7 +1189,7 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
         keep.hi1 = (unsigned)(ac->line_lo + ac->line_len + 1) / 2;
         if (ac4_supported(nh) && !ac->plan5) {
             // three trips (fft4step.h): columns -> row pairs (in place) -> columns
-            launch_ac4(g, ac->st, src, in_is_iq, stride, cnt, nh, ac->d_a, ac->d_b, keep);
+            launch_ac4(g, ac->st, src, in_is_iq, stride, cnt, nh, ac->d_a, ac->d_b, keep, retain_to ? retain_to + (size_t)w0 * ac->n : nullptr);
             corr_ = ac->d_b;
         } else if (fused) {
             // forward passes but the last ...
@@ -1225,6 +1230,12 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
     ac->d_last = corr + (size_t)(nwindows_last - 1) * nh;
     ac->last_exact = 0;
     return TSDRGPU_OK;
+}
+
+static bool ac_retain_fused(const tsdrgpu_autocorr_t *ac, int in_is_iq)
+{
+    static const bool off = [] { const char *e = getenv("TSDRGPU_RETAIN_COPY"); return e && e[0] == '1'; }();  // A/B: the copy kernel
+    return in_is_iq && !off && ac4_supported(ac->n / 2) && !ac->plan5;
 }
 
 // Replays the epoch's windows (every run since the last reset) in the reference's own arithmetic: the plots then hold
@@ -1339,11 +1350,18 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
             if ((rc = tsdrgpu_autocorr_promote(ac))) return rc;
             return ac_run_exact(ac, src, in_is_iq, stride, nwindows - done, mode);
         }
-        if ((rc = fftx_retain(g, ac->st, src, in_is_iq, (long long)stride, take, ac->n, slot))) return rc;
+        // From interleaved IQ on the three-trip plan, trip 1 itself leaves the demodulated samples in the ring (it holds every
+        // one of them in registers: k_ac_cols_retain) — 8N read + 4N + 4N written per window where a copy kernel in front
+        // (k_fftx_retain) read the IQ twice and the ring once more: 8N + 4N, then 4N + 4N.  Magnitude input, and sizes outside
+        // the plan, keep the copy.
+        const bool fused = ac_retain_fused(ac, in_is_iq);
+        if (!fused && (rc = fftx_retain(g, ac->st, src, in_is_iq, (long long)stride, take, ac->n, slot))) return rc;
         const AcLogRec r = {slot, 0, (long long)ac->n, take, mode};
         ac->log[ac->log_count++] = r;
         ac->ring_count = pos + take;
-        if ((rc = ac_run_fast(ac, slot, 0, (long long)ac->n, take, mode))) return rc;
+        if (fused) rc = ac_run_fast(ac, src, 1, (long long)stride, take, mode, slot);
+        else rc = ac_run_fast(ac, slot, 0, (long long)ac->n, take, mode);
+        if (rc) return rc;
         done += take;
     }
     return TSDRGPU_OK;
@@ -1842,6 +1860,107 @@ static int superb_scratch(tsdrgpu_t *g, size_t bytes, char **out)
     return TSDRGPU_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The stitch on the three-trip plan (fft4step.h, "The super-bandwidth stitch on the same three trips"): four hops (the
+// reference's SUPER_HOPS_TO_MAKE, superbandwidth.c:22) whose length and correlated length are N1 * 4096 points,
+// N1 = 16 .. 2048.  Seven launches: columns / rows / columns+argmax / peaks for the alignment, columns / rows / columns
+// for the transforms; 3 trips over the 4 bn and 3 over the 4 M points where the pass-per-radix plan below makes 7 x 3
+// and 4 x 3 + 4.
+// ---------------------------------------------------------------------------
+static bool sb3_size_ok(uint32_t n) { return n >= 4096u * 16u && n <= 4096u * 2048u && (n & (n - 1u)) == 0u; }
+
+// the three peaks from the partials of k_sb_cols_argmax: slots (array 0 |re|, array 0 |im|, array 1 |re|, array 1 |im|) of
+// T partials each; correlation i (hop i + 1 against hop 0) is slot {2, 0, 3}[i] (k_sb_rows<XCORR>: F(P) = c_1 + i c_3, F(Q) = c_2)
+__global__ __launch_bounds__(64) void k_sb_argmax_final(const float *__restrict__ pval, const int *__restrict__ pidx, int T, int *__restrict__ out_floats)
+{
+    const int slot = blockIdx.x == 0 ? 2 : (blockIdx.x == 1 ? 0 : 3);
+    float best = -1.f;
+    int at = 0x7fffffff;
+    for (int b = threadIdx.x; b < T; b += 64) {
+        const float ob = pval[slot * T + b];
+        const int oi = pidx[slot * T + b];
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(at, o, 64);
+        if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
+    }
+    // (nothing compared greater than the start value: all NaN — the reference's scan then keeps index 0, superbandwidth.c:104-113)
+    if (threadIdx.x == 0) out_floats[blockIdx.x] = (at == 0x7fffffff) ? 0 : 2 * at;  // the reference returns the offset in floats
+}
+
+template <int LOGN1>
+static void launch_sb3_align(tsdrgpu_t *g, hipStream_t st, const SbHops &hops, uint32_t bn, float2 *W, float2 *V, float *pval, int *pidx, int *d_off)
+{
+    typedef ColGeom<LOGN1> G;
+    const unsigned T = AC4_ROW / G::C;
+    TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_sb_cols<LOGN1, 5>), dim3(T, 4), G::NT, hops, W, bn, (const int *)nullptr);
+    TSDR_LAUNCH(g, PROF_AC_ROWS, st, (k_sb_rows<SB_ROWS_XCORR>), dim3(1u << LOGN1), 512, (const float2 *)W, V, bn, 1.0f / (float)bn);
+    TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_sb_cols_argmax<LOGN1>), dim3(T, 2), G::NT, (const float2 *)V, bn, pval, pidx);
+    TSDR_LAUNCH(g, PROF_ARGMAX, st, k_sb_argmax_final, 3, 64, (const float *)pval, (const int *)pidx, (int)T, d_off + 1);
+}
+
+template <int LOGN1>
+static void launch_sb3_stitch(tsdrgpu_t *g, hipStream_t st, const SbHops &hops, uint32_t per, float2 *W, float2 *V, float2 *out, const int *d_off)
+{
+    typedef ColGeom<LOGN1> G;
+    const unsigned T = AC4_ROW / G::C;
+    TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_sb_cols<LOGN1, 6>), dim3(T, 4), G::NT, hops, W, per, d_off);
+    TSDR_LAUNCH(g, PROF_AC_ROWS, st, (k_sb_rows<SB_ROWS_STITCH>), dim3(1u << LOGN1), 512, (const float2 *)W, V, per, 1.0f / (float)per);
+    // the last trip of ONE transform of 4 * per points with rows of 4 * 4096: the autocorrelation's own kernel
+    TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 0, true>), dim3(4u * T, 1), G::NT, (const void *)V, 4ll * per, out, 4u * per, KEEP_ALL);
+}
+
+#define SB3_DISPATCH(fn_, n_, ...)                                  \
+    do {                                                            \
+        int l_ = 0;                                                 \
+        while ((4096u << l_) < (n_)) l_++;                          \
+        switch (l_) {                                               \
+            case 4: fn_<4>(__VA_ARGS__); break;                     \
+            case 5: fn_<5>(__VA_ARGS__); break;                     \
+            case 6: fn_<6>(__VA_ARGS__); break;                     \
+            case 7: fn_<7>(__VA_ARGS__); break;                     \
+            case 8: fn_<8>(__VA_ARGS__); break;                     \
+            case 9: fn_<9>(__VA_ARGS__); break;                     \
+            case 10: fn_<10>(__VA_ARGS__); break;                   \
+            default: fn_<11>(__VA_ARGS__); break;                   \
+        }                                                           \
+    } while (0)
+
+static int superb_stitch3(tsdrgpu_t *g, float *const *d_hops, uint32_t per, uint32_t bn, float *d_out, int32_t *h_offsets)
+{
+    const uint32_t wn = per > bn ? per : bn;
+    const unsigned tmax = AC4_ROW / 8u;  // at most 512 column tiles per array
+    const size_t bytes = sizeof(float2) * (size_t)wn * 8 + sizeof(int) * 4 + (sizeof(float) + sizeof(int)) * 4 * (size_t)tmax;
+    char *ws = nullptr;
+    int rc = superb_scratch(g, bytes + 64, &ws);
+    if (rc) return rc;
+    float2 *W = (float2 *)ws, *V = W + 4 * (size_t)wn;
+    int *d_off = (int *)(V + 4 * (size_t)wn);
+    float *pval = (float *)(d_off + 4);
+    int *pidx = (int *)(pval + 4 * (size_t)tmax);
+    hipStream_t st = g->stream;
+    SbHops hops;
+    for (int i = 0; i < 4; i++) hops.p[i] = d_hops[i];
+    HIP_TRY(g, hipMemsetAsync(d_off, 0, sizeof(int) * 4, st));
+    SB3_DISPATCH(launch_sb3_align, bn, g, st, hops, bn, W, V, pval, pidx, d_off);
+    KERNEL_CHECK(g, "hop alignment");
+    SB3_DISPATCH(launch_sb3_stitch, per, g, st, hops, per, W, V, (float2 *)d_out, (const int *)d_off);
+    KERNEL_CHECK(g, "stitch transform");
+    if (h_offsets) HIP_TRY(g, hipMemcpyAsync(h_offsets, d_off, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(g, hipStreamSynchronize(st));
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_superb_set_plan(tsdrgpu_t *g, int trips)
+{
+    if (!g || (trips != 3 && trips != 0)) return g ? tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_superb_set_plan", "trips must be 3 or 0") : TSDRGPU_EINVAL;
+    g->superb_passes = trips == 0 ? 1 : 0;
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered, int samples_in_frame,
                                      float *d_out, int32_t *h_offsets, uint32_t *h_total)
 {
@@ -1857,6 +1976,12 @@ extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nho
     const uint32_t bn = bfl / 2;  // complex samples cross-correlated
     const uint32_t nfft = pow2_floor(total);  // fft_perform truncates, fft.c:101-105
     const int nb = nhops - 1;              // correlations against hop 0
+    if (nhops == 4 && !g->superb_passes && sb3_size_ok(per) && sb3_size_ok(bn)) {
+        const int rc3 = superb_stitch3(g, d_hops, per, bn, d_out, h_offsets);
+        if (rc3) return rc3;
+        if (h_total) *h_total = total;
+        return TSDRGPU_OK;
+    }
 
     // [A bn][FA 2 bn][B nb bn][FB 2 nb bn][R total][S 2 total][BIG 2 nfft] float2, then offsets and argmax partials
     const size_t f2 = (size_t)bn * 3 + (size_t)bn * nb * 3 + (size_t)total * 3 + (size_t)nfft * 2;

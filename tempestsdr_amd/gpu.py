@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtsdrgpu.so")
+# TSDRGPU_LIB: another build of the SAME library (same-box A/B of two kernel versions in one gpurun call); never a fallback
+LIB_PATH = os.environ.get("TSDRGPU_LIB") or os.path.join(_HERE, "libtsdrgpu.so")
 
 vp = C.c_void_p
 
@@ -178,6 +179,7 @@ _SIGS = {
     "tsdrgpu_autocorr_argmax_certified": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     "tsdrgpu_superb_stitch": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
+    "tsdrgpu_superb_set_plan": (C.c_int, [vp, C.c_int]),
     "tsdrgpu_superb_stitch_exact": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     "tsdrgpu_decode_samples": (C.c_int, [vp, vp, C.c_int, vp, C.c_int64]),
@@ -362,6 +364,10 @@ class TsdrGpu:
     def fft_perform(self, d_iq, n, inverse, offset=0, exact=False):
         fn = self.lib.tsdrgpu_fft_exact if exact else self.lib.tsdrgpu_fft
         self._ck(fn(self.h, d_iq.at(offset), n, int(inverse)))
+
+    def superb_set_plan(self, trips):
+        """3: the three-trip plan where it applies (default); 0: the pass-per-radix plan always"""
+        self._ck(self.lib.tsdrgpu_superb_set_plan(self.h, int(trips)))
 
     def superb_stitch(self, d_hops, gathered, samples_in_frame, d_out, exact=False):
         ptrs = (vp * len(d_hops))(*[h.ptr for h in d_hops])

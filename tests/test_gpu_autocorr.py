@@ -223,6 +223,56 @@ def test_superb_stitch_vs_oracle(orc):
     assert np.max(np.abs(got[:2048] - gold["superb_out_head"])) <= 1e-4 * np.max(np.abs(want))
 
 
+def _stitch_hops(fs_like_sif, gathered, seed):
+    """four hops of one periodic 'raster' magnitude (period sif) seen at four random delays, on a rotating carrier"""
+    sif = fs_like_sif
+    rng = np.random.default_rng(seed)
+    t = np.arange(gathered + 2 * sif)
+    base = (0.4 + 0.5 * ((t % sif) < sif // 7) + 0.1 * np.sin(t * 0.01)).astype(np.float32)
+    hops = []
+    for k in range(4):
+        d = int(rng.integers(0, sif))
+        mag = base[d:d + gathered] + rng.standard_normal(gathered).astype(np.float32) * np.float32(0.01)
+        ph = 0.21 * np.arange(gathered) + k
+        h = np.empty(2 * gathered, np.float32)
+        h[0::2] = mag * np.cos(ph)
+        h[1::2] = mag * np.sin(ph)
+        hops.append(h)
+    return hops
+
+
+# (gathered, samples_in_frame): hop length 2^17 with 2^16 correlated points; the same with all 2^17 correlated
+# (samples_in_frame divides the hop); hop length 2^18 / 2^17; and — BASELINE configs[2]'s rate, what bench.py times —
+# 10 frames of 100 MS/s: hops of 2^23 points (column length 2048), 2^22 correlated
+@pytest.mark.parametrize("gathered,sif", [(133_330, 13_333), (140_000, 8_192), (270_000, 27_000), (16_666_660, 1_666_666)])
+def test_superb_stitch_three_trip_plan_vs_oracle(orc, gathered, sif):
+    """tsdrgpu_superb_stitch on the three-trip plan (four hops of 2^16 .. 2^23 points: k_sb_cols / k_sb_rows / k_sb_cols_argmax /
+    k_ac_cols) against the oracle's superb_ondataready (superbandwidth.c:83-152): hop offsets identical, the stitched signal
+    within 1e-4 * max; the hop buffers are read only; the pass-per-radix plan (tsdrgpu_superb_set_plan(0)) agrees."""
+    g = ctx()
+    hops = _stitch_hops(sif, gathered, gathered % 1000)
+    want, offs = orc.superb_stitch(hops, sif)
+    d_hops = [g.to_device(h) for h in hops]
+    d_out = g.empty(want.size)
+    got_offs, total = g.superb_stitch(d_hops, gathered, sif, d_out)
+    assert 2 * total == want.size
+    assert np.array_equal(got_offs, offs), (got_offs, offs)
+    got = d_out.download()
+    tol = 1e-4 * np.max(np.abs(want))
+    assert np.max(np.abs(got - want)) <= tol
+    for d, h in zip(d_hops, hops):
+        assert np.array_equal(d.download(), h)  # three-trip plan: the hops are inputs only
+    if gathered < 1_000_000:
+        g.superb_set_plan(0)
+        try:
+            d_out2 = g.empty(want.size)
+            offs2, total2 = g.superb_stitch(d_hops, gathered, sif, d_out2)
+        finally:
+            g.superb_set_plan(3)
+        assert total2 == total and np.array_equal(offs2, offs)
+        assert np.max(np.abs(d_out2.download() - want)) <= tol
+
+
 def test_argmax_async_result(orc):
     """tsdrgpu_autocorr_argmax_async / _result == tsdrgpu_autocorr_argmax, with other work queued in between;
     one outstanding request per object."""

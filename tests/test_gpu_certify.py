@@ -365,3 +365,33 @@ def test_plain_mode_reports_a_certificate(orc):
     with pytest.raises(gpu.TsdrGpuError):
         ac.promote()
     ac.destroy()
+
+
+@pytest.mark.parametrize("fs", sorted(RATES))
+def test_trip1_retention_replays_to_the_oracle_bits(orc, fs):
+    """Library retention from interleaved IQ (mode 1): trip 1 of the float32 transform leaves the demodulated samples in the
+    ring itself (k_ac_cols_retain) — they must be am_demod's bits (TSDRLibrary.c:244-262), for ordinary samples and for the
+    waves that leave the bare square-root sequence (zeros, amplitudes whose squares underflow), because a replay of the
+    epoch must reproduce the reference's plots bit for bit (frameratedetector.c:34-62,87-126).  Every column length of the
+    plan (8 / 25 / 100 / 200 MS/s: 32 / 128 / 512 / 1024)."""
+    g = ctx()
+    ac = gpu.Autocorr(g, fs)
+    ac.set_certify(1)
+    nwin = 3 if fs <= 25_000_000 else 2
+    data, is_iq = _windows("raster", fs, nwin, ac.capture, 77)
+    assert is_iq
+    data = data.copy()
+    data[2 * 1000:2 * 1200] = 0.0                       # an int8 recording's zeros
+    data[2 * 5000:2 * 5300] *= np.float32(1e-25)        # squares underflow to 0 / subnormals
+    data[2 * ac.capture + 2 * 17:2 * ac.capture + 2 * 90] = 0.0
+    d_in = g.to_device(data)
+    o, _ = _oracle_plots(orc, fs, data, 1, nwin, ac.capture)
+    ac.run(d_in, 1, ac.capture, 1)
+    ac.run(d_in, 1, ac.capture, nwin - 1, in_offset=2 * ac.capture)
+    f, l, calls = ac.plots()
+    assert calls == nwin
+    assert np.max(np.abs(f - o.frame)) <= 1e-4 * np.max(o.frame) and np.max(np.abs(l - o.line)) <= 1e-4 * np.max(o.line)
+    ac.promote()   # replay from the ring, in the reference's arithmetic
+    f, l, calls = ac.plots()
+    assert calls == nwin and np.array_equal(f, o.frame) and np.array_equal(l, o.line)
+    ac.destroy()
