@@ -248,7 +248,11 @@ struct ColGeom {
     static constexpr unsigned N1 = 1u << LOGN1;
     // (column length 2048 — the super-bandwidth stitch of hops of 2^23 points — keeps 8 columns: 128 KiB, one workgroup of
     // 1024 threads per CU)
-    static constexpr unsigned C = (N1 >= AC4_C8_FROM) ? 8u : (N1 >= 256u) ? 16u : 4096u / N1;
+    // AC4_C4_FROM (experiment): 4 columns from that column length on — 64 KiB again at 2048, but runs of 32 bytes
+#ifndef AC4_C4_FROM
+#define AC4_C4_FROM 0x7fffffffu
+#endif
+    static constexpr unsigned C = (N1 >= AC4_C4_FROM) ? 4u : (N1 >= AC4_C8_FROM) ? 8u : (N1 >= 256u) ? 16u : 4096u / N1;
     static constexpr unsigned NT = N1 * C / 16u;  // threads per workgroup
     static constexpr unsigned Q = N1 / 16u;
     static constexpr int R0 = (LOGN1 % 4) ? (1 << (LOGN1 % 4)) : 16;  // radix of the first pass
@@ -257,26 +261,47 @@ struct ColGeom {
 
 // am_demod (TSDRLibrary.c:244-262) with the reference's bits: separate products and sum (no contraction), correctly rounded
 // root.  For the side store of trip 1 into the retention ring — what an epoch is replayed from must be the reference's own
-// demodulated samples.  The two-sided correction runs bare where every lane's argument is an ordinary number (see demod1,
-// tsdrgpu_core.hip: the same instructions on the same values as the library routine).
-__device__ __forceinline__ float ac4_demod_exact(float re, float im)
+// demodulated samples.  In three pieces, so that a wave decides ONCE for all its roots whether the two-sided correction may
+// run bare (every argument an ordinary number; see demod1, tsdrgpu_core.hip: the same instructions on the same values as the
+// library routine).
+__device__ __forceinline__ float ac4_sumsq_exact(float re, float im)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const float x = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
-    const unsigned bts = __float_as_uint(x);
-    const bool plain = (bts - 0x0f800000u) < (0x7f800000u - 0x0f800000u);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!plain) == 0ull, 1)) {
-        float r = __builtin_amdgcn_sqrtf(x);
-        const float rm1 = __uint_as_float(__float_as_uint(r) - 1u), rp1 = __uint_as_float(__float_as_uint(r) + 1u);
-        const float em = __builtin_fmaf(-rm1, r, x), ep = __builtin_fmaf(-rp1, r, x);
-        r = (em <= 0.0f) ? rm1 : r;
-        r = (ep > 0.0f) ? rp1 : r;
-        return r;
+    // (HIP's __fmul_rn / __fadd_rn are plain operators, and this translation unit is built with contraction on: the pragma
+    // is what keeps re*re + im*im from becoming fma(re, re, im*im))
+    float x;
+    {
+#pragma clang fp contract(off)
+        const float rr = re * re, ii = im * im;
+        x = rr + ii;
     }
-    return sqrtf(x);
+    return x;
 #else
     volatile float a = re * re, b = im * im;  // (volatile: no fused multiply-add on the host either)
-    return sqrtf(a + b);
+    return a + b;
+#endif
+}
+// 2^-96 <= x < inf: where the correctly rounded root is the hardware's (1 ulp) plus the two-sided correction and nothing else
+__device__ __forceinline__ bool ac4_sqrt_plain(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__float_as_uint(x) - 0x0f800000u) < (0x7f800000u - 0x0f800000u);
+#else
+    (void)x;
+    return false;
+#endif
+}
+__device__ __forceinline__ float ac4_sqrt_bare(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_sqrtf(x);
+    const float rm1 = __uint_as_float(__float_as_uint(r) - 1u), rp1 = __uint_as_float(__float_as_uint(r) + 1u);
+    const float em = __builtin_fmaf(-rm1, r, x), ep = __builtin_fmaf(-rp1, r, x);
+    r = (em <= 0.0f) ? rm1 : r;
+    r = (ep > 0.0f) ? rp1 : r;
+    return r;
+#else
+    return sqrtf(x);
 #endif
 }
 
@@ -308,6 +333,14 @@ __device__ __forceinline__ float2 ac4_load(const void *__restrict__ base, long l
         // |z0|^2 (kept literally), imaginary part 0.  Hardware square root: this feeds a float32 correlation whose peak
         // position is all that is read.
         const float2 *z = (const float2 *)base;
+#if defined(__HIPCC__)
+        // z[at - 1] and z[at] as one (under-aligned) 16-byte request; point 0 has no predecessor: it reads (z0, z1)
+        typedef float float4_d8 __attribute__((ext_vector_type(4), aligned(8)));
+        const float4_d8 t = *reinterpret_cast<const float4_d8 *>(z + (at ? at - 1 : 0));
+        const float2 c = at ? make_float2(t[2], t[3]) : make_float2(t[0], t[1]);
+        const float cur = AC_SQRT(c.x * c.x + c.y * c.y);
+        const float prev = at ? AC_SQRT(t[0] * t[0] + t[1] * t[1]) : c.x * c.x + c.y * c.y;
+#else
         const float2 c = z[at];
         const float cur = AC_SQRT(c.x * c.x + c.y * c.y);
         float prev;
@@ -316,6 +349,7 @@ __device__ __forceinline__ float2 ac4_load(const void *__restrict__ base, long l
             const float2 p = z[at - 1];
             prev = AC_SQRT(p.x * p.x + p.y * p.y);
         }
+#endif
         return make_float2(cur - prev, 0.f);
     }
     if (IN_MODE == 6) {
@@ -363,12 +397,15 @@ __device__ __forceinline__ void ac4_cols_body(const void *__restrict__ xb, float
     constexpr int R0 = G::R0, NP = G::NP, G0 = 16 / R0;
     constexpr bool WIDE = LOGN1 >= 11;  // only there can nh (4 x 4096 x N1 in the stitch's last trip) exceed 2^24
     __shared__ float2 L[N1 * C];
-    __shared__ float2 twN[N1];
     // C == 16 (column lengths >= 256): the powers (w_nh^(col Q))^i, i < 16, of the workgroup's 16 columns are shared by
     // the 32 threads of a column — one accurate evaluation each instead of four evaluations and eleven products per
-    // thread (rows padded to 17 entries: sixteen columns' reads hit sixteen different bank pairs)
+    // thread (rows padded to 17 entries: sixteen columns' reads hit sixteen different bank pairs).  The table sits behind
+    // twN[] in one array so that it costs no byte where it is not used (column length 2048 in tiles of 4 columns: two
+    // workgroups of 64 + 16 KiB fill a CU's LDS exactly).
     constexpr bool PTAB = (C == 16u);
-    __shared__ float2 ptw[PTAB ? 16 * 17 : 1];
+    __shared__ float2 twtab[N1 + (PTAB ? 16u * 17u : 0u)];
+    float2 *const twN = twtab;
+    float2 *const ptw = twtab + N1;
     const unsigned N2 = nh / N1;
     const unsigned tid = threadIdx.x;
     const unsigned c = tid % C, q = tid / C;
@@ -390,22 +427,64 @@ __device__ __forceinline__ void ac4_cols_body(const void *__restrict__ xb, float
 
     float2 v[16];
     // ---- pass 0 (Ns = 1, radix R0): butterfly a of this thread is column point jb = q + Q*a
+    if (EPI == 1 && IN_MODE == 4) {
+        // the two samples of every point demodulated with the reference's bits: into the ring, and into the transform.
+        // All sixteen requests first, then the arithmetic with one wave-uniform branch.
+#if defined(__HIPCC__)
+        typedef float float4_r8 __attribute__((ext_vector_type(4), aligned(8)));
+        float4_r8 raw[16];
 #pragma unroll
-    for (int a = 0; a < G0; a++)
+        for (int a = 0; a < G0; a++)
 #pragma unroll
-        for (int t = 0; t < R0; t++) {
-            const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
-            if (EPI == 1 && IN_MODE == 4) {
-                // the two samples of the point demodulated with the reference's bits: into the ring, and into the transform
-                const float2 *p = (const float2 *)xb + 2 * ((long long)row * N2 + col);
-                const float2 s0 = p[0], s1 = p[1];
-                const float2 m = make_float2(ac4_demod_exact(s0.x, s0.y), ac4_demod_exact(s1.x, s1.y));
-                ((float2 *)(aux.retain + (long long)b * (2ll * nh)))[(long long)row * N2 + col] = m;
-                v[a * R0 + t] = m;
-            } else {
+            for (int t = 0; t < R0; t++) {
+                const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
+                raw[a * R0 + t] = *reinterpret_cast<const float4_r8 *>((const float2 *)xb + 2 * ((long long)row * N2 + col));
+            }
+#endif
+        float2 *ring = (float2 *)(aux.retain + (long long)b * (2ll * nh));
+        bool plain = true;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+#if defined(__HIPCC__)
+            v[i] = make_float2(ac4_sumsq_exact(raw[i][0], raw[i][1]), ac4_sumsq_exact(raw[i][2], raw[i][3]));
+#else
+            const unsigned row = q + Q * (unsigned)(i / R0) + (unsigned)(i % R0) * (N1 / (unsigned)R0);
+            const float2 *p = (const float2 *)xb + 2 * ((long long)row * N2 + col);
+            v[i] = make_float2(ac4_sumsq_exact(p[0].x, p[0].y), ac4_sumsq_exact(p[1].x, p[1].y));
+#endif
+            plain = plain && ac4_sqrt_plain(v[i].x) && ac4_sqrt_plain(v[i].y);
+        }
+        // ONE decision per wave for its 32 x 64 roots: the bare correction (the library routine's instructions on the same
+        // values, see demod1 in tsdrgpu_core.hip) when every argument is an ordinary number, sqrtf otherwise (zeros of an int8
+        // recording, subnormal squares, infinities)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool all_plain = __builtin_amdgcn_ballot_w64(!plain) == 0ull;
+#else
+        const bool all_plain = false;
+#endif
+        if (__builtin_expect(all_plain, 1)) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = make_float2(ac4_sqrt_bare(v[i].x), ac4_sqrt_bare(v[i].y));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = make_float2(sqrtf(v[i].x), sqrtf(v[i].y));
+        }
+#pragma unroll
+        for (int a = 0; a < G0; a++)
+#pragma unroll
+            for (int t = 0; t < R0; t++) {
+                const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
+                ring[(long long)row * N2 + col] = v[a * R0 + t];
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < G0; a++)
+#pragma unroll
+            for (int t = 0; t < R0; t++) {
+                const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
                 v[a * R0 + t] = ac4_load<IN_MODE>(xb, (long long)row * N2 + col, al16, nh, aux.shift);
             }
-        }
+    }
     // The twiddle between the column and the row transforms, w_nh^(k1 n2), lives here (trip 2 is the one
     // short of VALU time): on trip 1's results and on trip 3's inputs the thread's 16 rows are q + Q i, so
     // the factors are w^(n2 q) * (w^(n2 Q))^i: five accurate evaluations and products of depth <= 4.
@@ -532,12 +611,15 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *_
     constexpr unsigned N1 = G::N1, C = G::C, NT = G::NT, Q = G::Q;
     constexpr int R0 = G::R0, NP = G::NP, G0 = 16 / R0;
     __shared__ float2 L[N1 * C];
-    __shared__ float2 twN[N1];
     // C == 16 (column lengths >= 256): the powers (w_nh^(col Q))^i, i < 16, of the workgroup's 16 columns are shared by
     // the 32 threads of a column — one accurate evaluation each instead of four evaluations and eleven products per
-    // thread (rows padded to 17 entries: sixteen columns' reads hit sixteen different bank pairs)
+    // thread (rows padded to 17 entries: sixteen columns' reads hit sixteen different bank pairs).  The table sits behind
+    // twN[] in one array so that it costs no byte where it is not used (column length 2048 in tiles of 4 columns: two
+    // workgroups of 64 + 16 KiB fill a CU's LDS exactly).
     constexpr bool PTAB = (C == 16u);
-    __shared__ float2 ptw[PTAB ? 16 * 17 : 1];
+    __shared__ float2 twtab[N1 + (PTAB ? 16u * 17u : 0u)];
+    float2 *const twN = twtab;
+    float2 *const ptw = twtab + N1;
     const unsigned N2 = nh / N1;
     const unsigned tid = threadIdx.x;
     const unsigned c = tid % C, q = tid / C;
@@ -1011,14 +1093,61 @@ __global__ __launch_bounds__(512, 4) void k_sb_rows(const float2 *__restrict__ w
         float2 *orow = out + (long long)k1 * (4ll * AC4_ROW);
         unsigned j3 = j2;
         AC4_LAUNDER(j3);
-        ac4_fft4096(va, Lr, j3, tw256, tw4k);
-#pragma unroll
-        for (int u = 0; u < 16; u++) orow[4u * (j3 + 256u * (unsigned)u) + sa] = va[u];
+        ac4_fft4096(va, Lr, j3, tw256, tw4k);  // va[u] = y_sa[q2 = j + 256 u]
         __syncthreads();
         unsigned j4 = j3;
         AC4_LAUNDER(j4);
-        ac4_fft4096(vb, Lr, j4, tw256, tw4k);
+        ac4_fft4096(vb, Lr, j4, tw256, tw4k);  // vb[u] = y_sb[q2]
+        // The four residues of one q2 are 32 contiguous bytes of the output (index 4 q2 + s), and each half holds two of them
+        // for all of its 16 points: half 0 keeps the points of even u and hands the odd ones' (y0, y2) over, half 1 keeps the
+        // odd ones and hands the even ones' (y1, y3) over — 16 values each way through the (free) row buffers — so that every
+        // thread stores 8 x 32 contiguous bytes.  (8-byte stores 32 bytes apart, what the registers allow without the exchange,
+        // quarter the efficiency of every store instruction: 254 -> measured below.)
+        __syncthreads();  // the transform's last reads of the row buffers are done
+        float2 *const Lo = Lr + (j4 + (j4 >> 4));
+        float2 *const Lp = buf[1u - half] + (j4 + (j4 >> 4));
+        // (two explicit branches on the wave-uniform `half`: every register index a constant)
+        if (half == 0u) {
 #pragma unroll
-        for (int u = 0; u < 16; u++) orow[4u * (j4 + 256u * (unsigned)u) + sb] = vb[u];
+            for (int i = 0; i < 8; i++) {  // gives away its odd u
+                Lo[272 * (2 * i)] = va[2 * i + 1];
+                Lo[272 * (2 * i + 1)] = vb[2 * i + 1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {  // gives away its even u
+                Lo[272 * (2 * i)] = va[2 * i];
+                Lo[272 * (2 * i + 1)] = vb[2 * i];
+            }
+        }
+        __syncthreads();
+#if defined(__HIPCC__)
+        typedef float sb_f4 __attribute__((ext_vector_type(4)));
+#define SB_STORE4(dst_, y0_, y1_, y2_, y3_)                                        \
+    do {                                                                           \
+        sb_f4 lo_ = {(y0_).x, (y0_).y, (y1_).x, (y1_).y}, hi_ = {(y2_).x, (y2_).y, (y3_).x, (y3_).y}; \
+        *reinterpret_cast<sb_f4 *>(dst_) = lo_;                                    \
+        *reinterpret_cast<sb_f4 *>((dst_) + 2) = hi_;                              \
+    } while (0)
+#else
+#define SB_STORE4(dst_, y0_, y1_, y2_, y3_) \
+    do { (dst_)[0] = (y0_); (dst_)[1] = (y1_); (dst_)[2] = (y2_); (dst_)[3] = (y3_); } while (0)
+#endif
+        if (half == 0u) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {  // keeps even u: holds s = 0, 2; receives s = 1, 3
+                const float2 y1 = Lp[272 * (2 * i)], y3 = Lp[272 * (2 * i + 1)];
+                float2 *dst = orow + 4u * (j4 + 256u * (unsigned)(2 * i));
+                SB_STORE4(dst, va[2 * i], y1, vb[2 * i], y3);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {  // keeps odd u: holds s = 1, 3; receives s = 0, 2
+                const float2 y0 = Lp[272 * (2 * i)], y2 = Lp[272 * (2 * i + 1)];
+                float2 *dst = orow + 4u * (j4 + 256u * (unsigned)(2 * i + 1));
+                SB_STORE4(dst, y0, va[2 * i + 1], y2, vb[2 * i + 1]);
+            }
+        }
+#undef SB_STORE4
     }
 }

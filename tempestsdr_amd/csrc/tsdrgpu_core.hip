@@ -75,6 +75,7 @@ extern "C" void tsdrgpu_destroy(tsdrgpu_t *g)
     free(g->spans);
     if (g->fft_ws) hipFree(g->fft_ws);
     if (g->superb_ws) hipFree(g->superb_ws);
+    if (g->superb_h_off) hipHostFree(g->superb_h_off);
     if (g->fftx_tw) hipFree(g->fftx_tw);
     hipEventDestroy(g->t0);
     hipEventDestroy(g->t1);

@@ -1871,7 +1871,10 @@ static bool sb3_size_ok(uint32_t n) { return n >= 4096u * 16u && n <= 4096u * 20
 
 // the three peaks from the partials of k_sb_cols_argmax: slots (array 0 |re|, array 0 |im|, array 1 |re|, array 1 |im|) of
 // T partials each; correlation i (hop i + 1 against hop 0) is slot {2, 0, 3}[i] (k_sb_rows<XCORR>: F(P) = c_1 + i c_3, F(Q) = c_2)
-__global__ __launch_bounds__(64) void k_sb_argmax_final(const float *__restrict__ pval, const int *__restrict__ pidx, int T, int *__restrict__ out_floats)
+// out_floats[0..3]: the four hops' offsets (hop 0: 0), on the device for the rotation and — h_out, pinned — for the host, so
+// that neither a memset in front nor a copy behind is queued
+__global__ __launch_bounds__(64) void k_sb_argmax_final(const float *__restrict__ pval, const int *__restrict__ pidx, int T, int *__restrict__ out_floats,
+                                                        int *__restrict__ h_out)
 {
     const int slot = blockIdx.x == 0 ? 2 : (blockIdx.x == 1 ? 0 : 3);
     float best = -1.f;
@@ -1888,18 +1891,23 @@ __global__ __launch_bounds__(64) void k_sb_argmax_final(const float *__restrict_
         if (ob > best || (ob == best && oi < at)) { best = ob; at = oi; }
     }
     // (nothing compared greater than the start value: all NaN — the reference's scan then keeps index 0, superbandwidth.c:104-113)
-    if (threadIdx.x == 0) out_floats[blockIdx.x] = (at == 0x7fffffff) ? 0 : 2 * at;  // the reference returns the offset in floats
+    if (threadIdx.x == 0) {
+        const int off = (at == 0x7fffffff) ? 0 : 2 * at;  // the reference returns the offset in floats
+        out_floats[blockIdx.x + 1] = off;
+        h_out[blockIdx.x + 1] = off;
+        if (blockIdx.x == 0) { out_floats[0] = 0; h_out[0] = 0; }
+    }
 }
 
 template <int LOGN1>
-static void launch_sb3_align(tsdrgpu_t *g, hipStream_t st, const SbHops &hops, uint32_t bn, float2 *W, float2 *V, float *pval, int *pidx, int *d_off)
+static void launch_sb3_align(tsdrgpu_t *g, hipStream_t st, const SbHops &hops, uint32_t bn, float2 *W, float2 *V, float *pval, int *pidx, int *d_off, int *h_off)
 {
     typedef ColGeom<LOGN1> G;
     const unsigned T = AC4_ROW / G::C;
     TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_sb_cols<LOGN1, 5>), dim3(T, 4), G::NT, hops, W, bn, (const int *)nullptr);
     TSDR_LAUNCH(g, PROF_AC_ROWS, st, (k_sb_rows<SB_ROWS_XCORR>), dim3(1u << LOGN1), 512, (const float2 *)W, V, bn, 1.0f / (float)bn);
     TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_sb_cols_argmax<LOGN1>), dim3(T, 2), G::NT, (const float2 *)V, bn, pval, pidx);
-    TSDR_LAUNCH(g, PROF_ARGMAX, st, k_sb_argmax_final, 3, 64, (const float *)pval, (const int *)pidx, (int)T, d_off + 1);
+    TSDR_LAUNCH(g, PROF_ARGMAX, st, k_sb_argmax_final, 3, 64, (const float *)pval, (const int *)pidx, (int)T, d_off, h_off);
 }
 
 template <int LOGN1>
@@ -1942,15 +1950,19 @@ static int superb_stitch3(tsdrgpu_t *g, float *const *d_hops, uint32_t per, uint
     float *pval = (float *)(d_off + 4);
     int *pidx = (int *)(pval + 4 * (size_t)tmax);
     hipStream_t st = g->stream;
+    if (!g->superb_h_off && hipHostMalloc((void **)&g->superb_h_off, sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) {
+        g->superb_h_off = nullptr;
+        return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_superb_stitch", "pinned offsets");
+    }
     SbHops hops;
     for (int i = 0; i < 4; i++) hops.p[i] = d_hops[i];
-    HIP_TRY(g, hipMemsetAsync(d_off, 0, sizeof(int) * 4, st));
-    SB3_DISPATCH(launch_sb3_align, bn, g, st, hops, bn, W, V, pval, pidx, d_off);
+    SB3_DISPATCH(launch_sb3_align, bn, g, st, hops, bn, W, V, pval, pidx, d_off, g->superb_h_off);
     KERNEL_CHECK(g, "hop alignment");
     SB3_DISPATCH(launch_sb3_stitch, per, g, st, hops, per, W, V, (float2 *)d_out, (const int *)d_off);
     KERNEL_CHECK(g, "stitch transform");
-    if (h_offsets) HIP_TRY(g, hipMemcpyAsync(h_offsets, d_off, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(g, hipStreamSynchronize(st));
+    if (h_offsets)
+        for (int i = 0; i < 4; i++) h_offsets[i] = g->superb_h_off[i];
     return TSDRGPU_OK;
 }
 

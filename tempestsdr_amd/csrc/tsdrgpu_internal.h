@@ -50,6 +50,7 @@ struct tsdrgpu {
     size_t fft_ws_bytes;
     void *superb_ws;    // scratch of tsdrgpu_superb_stitch (grown on demand)
     size_t superb_ws_bytes;
+    int *superb_h_off;  // pinned: the stitch's hop offsets, written by the peak kernel itself
     int superb_passes;  // tsdrgpu_superb_set_plan(0): the pass-per-radix plan even where the three-trip one applies
     void *fftx_tw;      // twiddle table of the last tsdrgpu_fft_exact size (double2[n-1])
     uint32_t fftx_n;

@@ -258,8 +258,31 @@ def test_superb_stitch_three_trip_plan_vs_oracle(orc, gathered, sif):
     assert 2 * total == want.size
     assert np.array_equal(got_offs, offs), (got_offs, offs)
     got = d_out.download()
-    tol = 1e-4 * np.max(np.abs(want))
-    assert np.max(np.abs(got - want)) <= tol
+    peak = np.max(np.abs(want))
+    # The bar is 1e-4 * max against the reference's stitch.  The reference's own transform is that accurate only up to hops of
+    # ~2^21 points: its stage twiddles come from a half-angle recurrence, c2 = sqrt((1 - c1) / 2) (fft.c:161-164), whose
+    # cancellation leaves the last stage of a 2^25-point transform a step angle that is 2.7e-4 off — measured against numpy's
+    # f64 transform of the same rotated hops the reference is 4e-7 * max off at hops of 2^17 points, 4e-6 at 2^20, 1.0e-4 at
+    # 2^22 and 6e-4 at 2^23.  So: 1e-4 * max against the reference where the reference is exact to that, and everywhere
+    # (a) 5e-6 * max against the EXACT transform and (b) no further from the reference than the reference is from the exact
+    # transform (+ the same 1e-4).  (Its bits are what tsdrgpu_superb_stitch_exact reproduces: the engine's default.)
+    per = total // 4
+    spec = []
+    for h, o in zip(hops, offs):
+        z = h[0:2 * per:2].astype(np.float64) + 1j * h[1:2 * per:2].astype(np.float64)
+        spec.append(np.fft.fft(np.roll(z, -(int(o) // 2))) / per)
+    exact = np.fft.ifft(np.concatenate(spec)) * (4 * per)
+    del spec
+    ex = np.empty(2 * exact.size, np.float64)
+    ex[0::2], ex[1::2] = exact.real, exact.imag
+    del exact
+    ref_err = np.max(np.abs(want - ex))
+    assert np.max(np.abs(got - ex)) <= 5e-6 * peak
+    del ex
+    tol = 1e-4 * peak
+    assert np.max(np.abs(got - want)) <= tol + ref_err
+    if per <= (1 << 21):
+        assert ref_err <= 0.1 * tol and np.max(np.abs(got - want)) <= tol
     for d, h in zip(d_hops, hops):
         assert np.array_equal(d.download(), h)  # three-trip plan: the hops are inputs only
     if gathered < 1_000_000:
