@@ -248,11 +248,9 @@ struct ColGeom {
     static constexpr unsigned N1 = 1u << LOGN1;
     // (column length 2048 — the super-bandwidth stitch of hops of 2^23 points — keeps 8 columns: 128 KiB, one workgroup of
     // 1024 threads per CU)
-    // AC4_C4_FROM (experiment): 4 columns from that column length on — 64 KiB again at 2048, but runs of 32 bytes
-#ifndef AC4_C4_FROM
-#define AC4_C4_FROM 0x7fffffffu
-#endif
-    static constexpr unsigned C = (N1 >= AC4_C4_FROM) ? 4u : (N1 >= AC4_C8_FROM) ? 8u : (N1 >= 256u) ? 16u : 4096u / N1;
+    // (measured and dropped: 4 columns at column length 2048 — 64 + 16 KiB, two workgroups of 512 threads per CU again, but runs
+    // of 32 bytes: the stitch's three big trips 155 / 175 -> 177 / 237 us)
+    static constexpr unsigned C = (N1 >= AC4_C8_FROM) ? 8u : (N1 >= 256u) ? 16u : 4096u / N1;
     static constexpr unsigned NT = N1 * C / 16u;  // threads per workgroup
     static constexpr unsigned Q = N1 / 16u;
     static constexpr int R0 = (LOGN1 % 4) ? (1 << (LOGN1 % 4)) : 16;  // radix of the first pass
@@ -279,16 +277,6 @@ __device__ __forceinline__ float ac4_sumsq_exact(float re, float im)
 #else
     volatile float a = re * re, b = im * im;  // (volatile: no fused multiply-add on the host either)
     return a + b;
-#endif
-}
-// 2^-96 <= x < inf: where the correctly rounded root is the hardware's (1 ulp) plus the two-sided correction and nothing else
-__device__ __forceinline__ bool ac4_sqrt_plain(float x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (__float_as_uint(x) - 0x0f800000u) < (0x7f800000u - 0x0f800000u);
-#else
-    (void)x;
-    return false;
 #endif
 }
 __device__ __forceinline__ float ac4_sqrt_bare(float x)
@@ -442,7 +430,11 @@ __device__ __forceinline__ void ac4_cols_body(const void *__restrict__ xb, float
             }
 #endif
         float2 *ring = (float2 *)(aux.retain + (long long)b * (2ll * nh));
-        bool plain = true;
+        // ONE decision per wave for its 32 x 64 roots: the bare correction (the library routine's instructions on the same
+        // values, see demod1 in tsdrgpu_core.hip) when every argument is 0 or an ordinary number >= 2^-96 — two unsigned
+        // min / max trees over the bit patterns —, sqrtf otherwise (subnormal squares, infinities, NaN).  Zero takes the bare
+        // sequence too: sqrt(0) = 0, the lower neighbour's residual is NaN (compares false), the upper one's is 0 (not > 0).
+        unsigned lo = 0xffffffffu, hi = 0u;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
 #if defined(__HIPCC__)
@@ -452,12 +444,16 @@ __device__ __forceinline__ void ac4_cols_body(const void *__restrict__ xb, float
             const float2 *p = (const float2 *)xb + 2 * ((long long)row * N2 + col);
             v[i] = make_float2(ac4_sumsq_exact(p[0].x, p[0].y), ac4_sumsq_exact(p[1].x, p[1].y));
 #endif
-            plain = plain && ac4_sqrt_plain(v[i].x) && ac4_sqrt_plain(v[i].y);
-        }
-        // ONE decision per wave for its 32 x 64 roots: the bare correction (the library routine's instructions on the same
-        // values, see demod1 in tsdrgpu_core.hip) when every argument is an ordinary number, sqrtf otherwise (zeros of an int8
-        // recording, subnormal squares, infinities)
 #if defined(__HIP_DEVICE_COMPILE__)
+            const unsigned bx = __float_as_uint(v[i].x), by = __float_as_uint(v[i].y);
+            const unsigned l2 = (bx - 1u) < (by - 1u) ? (bx - 1u) : (by - 1u);  // (0 - 1 wraps to the top: zero never is the minimum)
+            const unsigned h2 = bx > by ? bx : by;
+            lo = lo < l2 ? lo : l2;
+            hi = hi > h2 ? hi : h2;
+#endif
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool plain = lo >= 0x0f7fffffu && hi < 0x7f800000u;
         const bool all_plain = __builtin_amdgcn_ballot_w64(!plain) == 0ull;
 #else
         const bool all_plain = false;

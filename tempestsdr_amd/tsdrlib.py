@@ -52,15 +52,19 @@ def load(path=LIB):
 RGB_CB = C.CFUNCTYPE(None, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p)
 
 
-def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, setup=None, free=True, rgb=False):
+def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, setup=None, free=True, rgb=False, dump=None, dump_frames=0, dump_skip=0):
     """Loads `plugin` into the library at `libpath`, lets it stream for `seconds` and counts what reaches the
     callbacks.  Both the reference's pipeline and ours are lossy by design (whole blocks / frames are dropped when a
     stage cannot keep up), so frames delivered per wall second x samples per frame is the effective rate."""
     lib = load(libpath)
     vp = C.c_void_p
     cnt = {"frames": 0, "plots": 0, "w": 0, "h": 0}
+    kept = []  # dump: dump_frames float frames as they reach the callback, after the first dump_skip (bench.py's configs[0] leg)
 
     def on_frame(buf, w, h, ctx):
+        if dump and not rgb and cnt["frames"] >= dump_skip and len(kept) < dump_frames:
+            import numpy as np
+            kept.append(np.ctypeslib.as_array(buf, shape=(w * h,)).copy())
         cnt["frames"] += 1
         cnt["w"], cnt["h"] = w, h
 
@@ -75,7 +79,7 @@ def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, set
     if rc != 0:
         raise RuntimeError(f"tsdr_loadplugin: {rc} {lib.tsdr_getlasterrortext(h)}")
     lib.tsdr_setgain(h, 0.5)
-    lib.tsdr_motionblur(h, 0.0)
+    lib.tsdr_motionblur(h, float(os.environ.get("TSDR_BENCH_MOTIONBLUR", "0")))  # (bench.py's configs[4] leg: 15/16)
     if lib.tsdr_setresolution(h, height, fv) != 0:
         raise RuntimeError("tsdr_setresolution")
     if setup:
@@ -96,11 +100,16 @@ def throughput_run(libpath, plugin, params, height, fv, seconds, warmup=1.0, set
     th.join(30)
     if free:  # the reference's own tsdr_free() frees an uninitialised pointer: callers skip it there
         lib.tsdr_free(C.byref(h))
+    if dump and kept:
+        import numpy as np
+        sizes = {k.size for k in kept}
+        np.save(dump, np.stack([k for k in kept if k.size == max(sizes)]))
     return {"frames_per_s": (f1 - f0) / (t1 - t0), "plots_per_s": (p1 - p0) / (t1 - t0), "width": cnt["w"], "height": cnt["h"],
             "status": status.get("rc")}
 
 
-def throughput_subprocess(libpath, plugin, params, height, fv, seconds, env=None, timeout=120, set_int=(), free=True, rgb=False):
+def throughput_subprocess(libpath, plugin, params, height, fv, seconds, env=None, timeout=120, set_int=(), free=True, rgb=False, dump=None, dump_frames=0,
+                          dump_skip=0):
     """throughput_run in a process of its own — what a host application is — started with GPU_MAX_HW_QUEUES=2 like a
     launcher script would (tsdrgpu_core.hip says why) instead of inheriting the caller's runtime state."""
     import json
@@ -111,7 +120,8 @@ def throughput_subprocess(libpath, plugin, params, height, fv, seconds, env=None
     # optimum on MI355X (tsdrgpu_core.hip); a caller's env overrides
     e["GPU_MAX_HW_QUEUES"] = "2"
     e.update(env or {})
-    extra = [("free" if free else "nofree") + ("+rgb" if rgb else "")] + [str(v) for pair in set_int for v in pair]  # tsdr_setparameter_int(id, value) pairs
+    extra = [("free" if free else "nofree") + ("+rgb" if rgb else "") + (f"+dump={dump}:{int(dump_frames)}:{int(dump_skip)}" if dump else "")]
+    extra += [str(v) for pair in set_int for v in pair]  # tsdr_setparameter_int(id, value) pairs
     out = subprocess.run([sys.executable, "-m", "tempestsdr_amd.tsdrlib", libpath, plugin, params, str(height), str(fv), str(seconds)] + extra,
                          env=e, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -127,6 +137,9 @@ if __name__ == "__main__":
     import sys
     a = sys.argv[1:]
     pairs = [(int(a[i]), int(a[i + 1])) for i in range(7, len(a) - 1, 2)]
-    print(json.dumps(throughput_run(a[0], a[1], a[2], int(a[3]), float(a[4]), float(a[5]), free=(len(a) < 7 or a[6].startswith("free")),
-                                    rgb=(len(a) >= 7 and a[6].endswith("+rgb")),
+    flags = a[6].split("+") if len(a) >= 7 else ["free"]
+    dump_arg = [f for f in flags if f.startswith("dump=")]
+    dump_path, dump_n, dump_sk = dump_arg[0][5:].rsplit(":", 2) if dump_arg else (None, "0", "0")
+    print(json.dumps(throughput_run(a[0], a[1], a[2], int(a[3]), float(a[4]), float(a[5]), free=(flags[0] == "free"),
+                                    rgb=("rgb" in flags), dump=dump_path, dump_frames=int(dump_n), dump_skip=int(dump_sk),
                                     setup=(lambda lib, h: [lib.tsdr_setparameter_int(h, i, v) for i, v in pairs]) if pairs else None)))
