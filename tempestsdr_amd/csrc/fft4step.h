@@ -955,6 +955,113 @@ __global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsi
 }
 
 // ---------------------------------------------------------------------------
+// trip 2, second form: the same row pair per workgroup of 256 threads — thread j holds the 16 points j + 256 t of BOTH rows,
+// one after the other through ONE row buffer (39 KB of LDS with the tables: four workgroups per CU instead of two of 74 KB, i.e.
+// the same 16 waves per CU in four barrier domains instead of two, so that one workgroup's loads and stores overlap another's
+// butterflies more often).  Every pair Z[k] <-> Z[nh-k] has exactly one element in row k1: its owner evaluates it and hands
+// the partner's half back through the buffer.  (k_ac_rows evaluates half of the pairs from the other row's side — the same
+// formula with the roles of the two elements exchanged — so the two forms agree to rounding, not to the bit; both are the
+// float32, tolerance-stated transform.)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void k_ac_rows256(float2 *__restrict__ z, unsigned nh)
+{
+    __shared__ float2 buf[AC4_ROWBUF];
+    __shared__ float2 tw256[256], tw4k[256];
+    const unsigned N1 = nh / AC4_ROW;
+    const unsigned j = threadIdx.x;
+    const unsigned wg = blockIdx.x;
+    const bool selfpair = wg == 0;
+    const unsigned kA = selfpair ? 0u : wg, kB = selfpair ? N1 / 2u : N1 - wg;
+    float2 *rowA = z + (long long)blockIdx.y * nh + (long long)kA * AC4_ROW;
+    float2 *rowB = z + (long long)blockIdx.y * nh + (long long)kB * AC4_ROW;
+    float2 va[16], vb[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) va[t] = rowA[j + 256u * (unsigned)t];
+#pragma unroll
+    for (int t = 0; t < 16; t++) vb[t] = rowB[j + 256u * (unsigned)t];
+    {
+        float sn, cs;
+        sincospif(-(float)j * (1.0f / 128.0f), &sn, &cs);
+        tw256[j] = make_float2(cs, sn);
+        sincospif(-(float)j * (1.0f / 2048.0f), &sn, &cs);
+        tw4k[j] = make_float2(cs, sn);
+    }
+    __syncthreads();  // tables ready
+    ac4_fft4096(va, buf, j, tw256, tw4k);  // va[u] = Z[kA + N1 (j + 256 u)]
+    __syncthreads();
+    unsigned j2 = j;
+    AC4_LAUNDER(j2);
+    ac4_fft4096(vb, buf, j2, tw256, tw4k);  // vb[u] = Z[kB + N1 (j + 256 u)]
+    __syncthreads();
+    float2 *const Lj = buf + (j2 + (j2 >> 4));  // own element u sits at Lj[272 u]
+    if (!selfpair) {
+        float sn0, cs0;
+        sincospif(-(float)(kA + N1 * j2) * (1.0f / (float)nh), &sn0, &cs0);  // exp(-i pi k/nh), k = kA + N1 (j + 256 u)
+        const float2 w0 = make_float2(cs0, sn0);
+#pragma unroll
+        for (int u = 0; u < 16; u++) Lj[272 * u] = vb[u];
+        __syncthreads();
+        const unsigned pb = AC4_ROW - 1u - j2;  // partner of k2 = j + 256 u in row kB: pb - 256 u
+        float2 *const Lq = buf + (pb + (pb >> 4)) - 272u * 15u;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const float2 bm = Lq[272 * (15 - u)];
+            const float2 wk = u ? cmul(w0, tw256[8u * (unsigned)u]) : w0;  // times exp(-i pi u/16)
+            float2 zk, zkm;
+            ac_split_pair(va[u], bm, wk, nh, &zk, &zkm);
+            va[u] = make_float2(zk.x, -zk.y);  // conjugated input: inverse = conj(FFT(conj(.)))
+            Lq[272 * (15 - u)] = make_float2(zkm.x, -zkm.y);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; u++) vb[u] = Lj[272 * u];
+    } else {
+        // rows 0 and N1/2 mirror onto themselves: every element evaluates its own pair; one row after the other
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            float2(&v)[16] = r ? vb : va;
+            const unsigned k1 = r ? kB : kA;
+            float sn0, cs0;
+            sincospif(-(float)(k1 + N1 * j2) * (1.0f / (float)nh), &sn0, &cs0);
+            const float2 w0 = make_float2(cs0, sn0);
+#pragma unroll
+            for (int u = 0; u < 16; u++) Lj[272 * u] = v[u];
+            __syncthreads();
+            // row 0: partner of k2 is 4096 - k2 (k2 = 0 would wrap, but takes the special formula below)
+            const unsigned pb = (r == 0 ? AC4_ROW : AC4_ROW - 1u) - j2;
+            const float2 *const Lq = buf + (pb + (pb >> 4)) - 272u * 15u;
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float2 bm = Lq[272 * (15 - u)];
+                const float2 wk = u ? cmul(w0, tw256[8u * (unsigned)u]) : w0;
+                float2 zk, zkm;
+                ac_split_pair(v[u], bm, wk, nh, &zk, &zkm);
+                if (u == 0 && r == 0 && j2 == 0u) {
+                    const float inv_n = 1.0f / (float)(2u * nh);
+                    const float m0 = fabsf(v[0].x + v[0].y) * inv_n;  // X[0]  = Re Z0 + Im Z0
+                    const float mh = fabsf(v[0].x - v[0].y) * inv_n;  // X[nh] = Re Z0 - Im Z0
+                    zk = make_float2(m0 + mh, m0 - mh);
+                }
+                v[u] = make_float2(zk.x, -zk.y);
+            }
+            __syncthreads();  // this row's reads are done before the buffer carries the next
+        }
+    }
+    __syncthreads();  // exchange reads done before the buffer is reused
+    unsigned j3 = j2;
+    AC4_LAUNDER(j3);
+    ac4_fft4096(va, buf, j3, tw256, tw4k);
+#pragma unroll
+    for (int u = 0; u < 16; u++) rowA[j3 + 256u * (unsigned)u] = va[u];
+    __syncthreads();
+    unsigned j4 = j3;
+    AC4_LAUNDER(j4);
+    ac4_fft4096(vb, buf, j4, tw256, tw4k);
+#pragma unroll
+    for (int u = 0; u < 16; u++) rowB[j4 + 256u * (unsigned)u] = vb[u];
+}
+
+// ---------------------------------------------------------------------------
 // trip 2 of the super-bandwidth stitch's two phases (see k_sb_cols above).  One workgroup of 512 threads per row k1 of the
 // FOUR hop arrays w[h][k1][.] (trip 1's output, already times w_nh^(k1 n2)): threads 0..255 take hops 0 and 2 one after
 // the other, threads 256..511 hops 1 and 3 — thread j of either half ends up holding X_h[k1 + N1 (j + 256 u)], u < 16,

@@ -963,6 +963,17 @@ __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ 
 // ---------------------------------------------------------------------------
 static bool ac4_supported(uint32_t nh) { return nh >= 4096u * 16u && nh <= 4096u * 1024u; }
 
+// trip 2's form: TSDRGPU_ROWS256=1 / =0 picks k_ac_rows256 (256 threads, both rows per thread, four workgroups per CU) or
+// k_ac_rows (512 threads, two per CU); the default is what measured faster
+static bool ac_rows256()
+{
+    static const bool v = [] {
+        const char *e = getenv("TSDRGPU_ROWS256");
+        return e ? e[0] == '1' : false;
+    }();
+    return v;
+}
+
 template <int LOGN1>
 static void launch_ac4_n1(tsdrgpu_t *g, hipStream_t st, const float *src, int in_is_iq, long long stride, int cnt, uint32_t nh, float2 *work,
                           float2 *out, const FftKeep &keep, float *retain)
@@ -973,7 +984,8 @@ static void launch_ac4_n1(tsdrgpu_t *g, hipStream_t st, const float *src, int in
     if (in_is_iq && retain) TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols_retain<LOGN1>), cgrid, G::NT, (const void *)src, stride, work, nh, retain);
     else if (in_is_iq) TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 4, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
     else TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 3, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
-    TSDR_LAUNCH(g, PROF_AC_ROWS, st, k_ac_rows, dim3((1u << LOGN1) / 2u, cnt), 512, work, nh);
+    if (ac_rows256()) TSDR_LAUNCH(g, PROF_AC_ROWS, st, k_ac_rows256, dim3((1u << LOGN1) / 2u, cnt), 256, work, nh);
+    else TSDR_LAUNCH(g, PROF_AC_ROWS, st, k_ac_rows, dim3((1u << LOGN1) / 2u, cnt), 512, work, nh);
     TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 0, true>), cgrid, G::NT, (const void *)work, (long long)nh, out, nh, keep);
 }
 

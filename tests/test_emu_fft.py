@@ -195,3 +195,28 @@ def test_stitch_transform_on_three_trips_matches_numpy(emu5, logn1, offs):
     want = np.fft.ifft(np.concatenate(spec)) * (4 * per)
     got = out[0::2] + 1j * out[1::2]
     assert np.max(np.abs(got - want)) <= 2e-6 * np.max(np.abs(want))
+
+
+def test_trip2_256_thread_form(emu):
+    """k_ac_rows256 (one workgroup of 256 threads per row pair, both rows per thread) against k_ac_rows (512 threads) and numpy:
+    the same plan; half of the pairs are evaluated from the other row's side, so the two agree to rounding."""
+    logn1, cnt = 5, 2
+    nh = 4096 << logn1
+    n = 2 * nh
+    rng = np.random.default_rng(256)
+    x = rng.random(cnt * n + 8).astype(np.float32)
+    work = np.zeros(cnt * nh * 2, np.float32)
+    a = np.zeros(cnt * nh * 2, np.float32)
+    b = np.zeros(cnt * nh * 2, np.float32)
+    emu.emu_set_rows256.argtypes = [C.c_int]
+    assert emu.emu_autocorr4(x, 0, n, cnt, nh, work, a, 0, -1, 0, 0, 0, 0) == 0
+    emu.emu_set_rows256(1)
+    try:
+        assert emu.emu_autocorr4(x, 0, n, cnt, nh, work, b, 0, -1, 0, 0, 0, 0) == 0
+    finally:
+        emu.emu_set_rows256(0)
+    want = _want(x, n, 0)
+    assert np.max(np.abs(a - b)) <= 3e-7 * want[0]
+    for k in range(cnt):
+        want = _want(x[k * n:], n, 0)
+        assert np.max(np.abs(b[k * n:(k + 1) * n] - want)) <= 5e-7 * want[0]
