@@ -353,7 +353,8 @@ int tsdrgpu_autocorr_set_exact(tsdrgpu_autocorr_t *ac, int on);
  * frame-lag window), noise-like or flat plots — the windows of the epoch (everything run since the last
  * tsdrgpu_autocorr_reset) are replayed through the exact form (tsdrgpu_autocorr_promote): plots, argmax and
  * last correlation are then bit-identical to the reference's, and the rest of the epoch runs exact.
- *   mode 1: the library retains the windows — the first fft_n samples of each, demodulated, in a ring of
+ *   mode 1: the library retains the windows — the first fft_n samples of each, 4 bytes a sample (magnitudes; from IQ input
+ *           the sum of squares am_demod forms, left there by the transform's own first trip), in a ring of
  *           retain_bytes in HBM (0 = a quarter of the device's free memory at the time of the call, at most 32 GiB: 2048
  *           windows of 2^22 samples, 116 s of real-time signal at 100 MS/s), allocated in segments of >= 32 windows ahead of need
  *           by a thread of the library's own (tsdrgpu_autocorr_retention); the float32 transform reads the ring.  An

@@ -257,11 +257,10 @@ struct ColGeom {
     static constexpr int NP = (LOGN1 + 3) / 4;                       // passes
 };
 
-// am_demod (TSDRLibrary.c:244-262) with the reference's bits: separate products and sum (no contraction), correctly rounded
-// root.  For the side store of trip 1 into the retention ring — what an epoch is replayed from must be the reference's own
-// demodulated samples.  In three pieces, so that a wave decides ONCE for all its roots whether the two-sided correction may
-// run bare (every argument an ordinary number; see demod1, tsdrgpu_core.hip: the same instructions on the same values as the
-// library routine).
+// am_demod's re*re + im*im (TSDRLibrary.c:244-262) with the reference's bits: two rounded products and their rounded sum, no
+// contraction.  For the side store of trip 1 into the retention ring: what an epoch is replayed from must lead to the
+// reference's own demodulated samples, and the correctly rounded root of THIS value (taken by the replay's first trip,
+// tsdrgpu_fftx.hip src_mode 3) is exactly that.
 __device__ __forceinline__ float ac4_sumsq_exact(float re, float im)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -279,23 +278,9 @@ __device__ __forceinline__ float ac4_sumsq_exact(float re, float im)
     return a + b;
 #endif
 }
-__device__ __forceinline__ float ac4_sqrt_bare(float x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    float r = __builtin_amdgcn_sqrtf(x);
-    const float rm1 = __uint_as_float(__float_as_uint(r) - 1u), rp1 = __uint_as_float(__float_as_uint(r) + 1u);
-    const float em = __builtin_fmaf(-rm1, r, x), ep = __builtin_fmaf(-rp1, r, x);
-    r = (em <= 0.0f) ? rm1 : r;
-    r = (ep > 0.0f) ? rp1 : r;
-    return r;
-#else
-    return sqrtf(x);
-#endif
-}
-
 // What the column kernels' variants beyond the autocorrelation's own need (all unused, and compiled away, there):
-//   retain  EPI 1: the ring slot of window 0 (2 nh floats per window): trip 1 leaves the demodulated samples it has in
-//           registers anyway (tsdrgpu_autocorr_set_certify mode 1; frameratedetector.c:87-126 keeps one copy too)
+//   retain  EPI 1: the ring slot of window 0 (2 nh floats per window): trip 1 leaves every sample's re*re + im*im there
+//           (tsdrgpu_autocorr_set_certify mode 1; frameratedetector.c:87-126 keeps one copy too)
 //   shift   IN_MODE 6: the input rotated left by that many complex points (superbandwidth.c:135-137)
 //   pval / pidx  EPI 2: per workgroup the first maximum of |re| and of |im| of the results (superb_bestfit's search,
 //           superbandwidth.c:100-116, over correlations that are real sequences packed two per transform)
@@ -416,8 +401,8 @@ __device__ __forceinline__ void ac4_cols_body(const void *__restrict__ xb, float
     float2 v[16];
     // ---- pass 0 (Ns = 1, radix R0): butterfly a of this thread is column point jb = q + Q*a
     if (EPI == 1 && IN_MODE == 4) {
-        // the two samples of every point demodulated with the reference's bits: into the ring, and into the transform.
-        // All sixteen requests first, then the arithmetic with one wave-uniform branch.
+        // the two samples of every point: am_demod's sum of squares in the reference's roundings into the ring, its (hardware)
+        // root into the transform.  All sixteen requests first.
 #if defined(__HIPCC__)
         typedef float float4_r8 __attribute__((ext_vector_type(4), aligned(8)));
         float4_r8 raw[16];
@@ -430,47 +415,20 @@ __device__ __forceinline__ void ac4_cols_body(const void *__restrict__ xb, float
             }
 #endif
         float2 *ring = (float2 *)(aux.retain + (long long)b * (2ll * nh));
-        // ONE decision per wave for its 32 x 64 roots: the bare correction (the library routine's instructions on the same
-        // values, see demod1 in tsdrgpu_core.hip) when every argument is 0 or an ordinary number >= 2^-96 — two unsigned
-        // min / max trees over the bit patterns —, sqrtf otherwise (subnormal squares, infinities, NaN).  Zero takes the bare
-        // sequence too: sqrt(0) = 0, the lower neighbour's residual is NaN (compares false), the upper one's is 0 (not > 0).
-        unsigned lo = 0xffffffffu, hi = 0u;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-#if defined(__HIPCC__)
-            v[i] = make_float2(ac4_sumsq_exact(raw[i][0], raw[i][1]), ac4_sumsq_exact(raw[i][2], raw[i][3]));
-#else
-            const unsigned row = q + Q * (unsigned)(i / R0) + (unsigned)(i % R0) * (N1 / (unsigned)R0);
-            const float2 *p = (const float2 *)xb + 2 * ((long long)row * N2 + col);
-            v[i] = make_float2(ac4_sumsq_exact(p[0].x, p[0].y), ac4_sumsq_exact(p[1].x, p[1].y));
-#endif
-#if defined(__HIP_DEVICE_COMPILE__)
-            const unsigned bx = __float_as_uint(v[i].x), by = __float_as_uint(v[i].y);
-            const unsigned l2 = (bx - 1u) < (by - 1u) ? (bx - 1u) : (by - 1u);  // (0 - 1 wraps to the top: zero never is the minimum)
-            const unsigned h2 = bx > by ? bx : by;
-            lo = lo < l2 ? lo : l2;
-            hi = hi > h2 ? hi : h2;
-#endif
-        }
-#if defined(__HIP_DEVICE_COMPILE__)
-        const bool plain = lo >= 0x0f7fffffu && hi < 0x7f800000u;
-        const bool all_plain = __builtin_amdgcn_ballot_w64(!plain) == 0ull;
-#else
-        const bool all_plain = false;
-#endif
-        if (__builtin_expect(all_plain, 1)) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = make_float2(ac4_sqrt_bare(v[i].x), ac4_sqrt_bare(v[i].y));
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = make_float2(sqrtf(v[i].x), sqrtf(v[i].y));
-        }
 #pragma unroll
         for (int a = 0; a < G0; a++)
 #pragma unroll
             for (int t = 0; t < R0; t++) {
+                const int i = a * R0 + t;
                 const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
-                ring[(long long)row * N2 + col] = v[a * R0 + t];
+#if defined(__HIPCC__)
+                const float2 x = make_float2(ac4_sumsq_exact(raw[i][0], raw[i][1]), ac4_sumsq_exact(raw[i][2], raw[i][3]));
+#else
+                const float2 *p = (const float2 *)xb + 2 * ((long long)row * N2 + col);
+                const float2 x = make_float2(ac4_sumsq_exact(p[0].x, p[0].y), ac4_sumsq_exact(p[1].x, p[1].y));
+#endif
+                ring[(long long)row * N2 + col] = x;                    // the replay takes the (correctly rounded) root
+                v[i] = make_float2(AC_SQRT(x.x), AC_SQRT(x.y));         // the float32 transform the hardware's, as ever
             }
     } else {
 #pragma unroll
@@ -868,6 +826,9 @@ __device__ __forceinline__ void ac4_fft4096(float2 (&v)[16], float2 *Lr, unsigne
     dft_reg<16>(v);
 }
 
+// (Round 5 built the form the review suggested — one row pair per workgroup of 256 threads, both rows per thread through one
+// 39 KB buffer, four workgroups per CU instead of two — and measured it SLOWER in two same-box A/B pairs: 0.146 / 0.168 against
+// 0.127 / 0.132 ms per pass; it needs all 128 registers plus 24 bytes of scratch where this one takes 81.  Dropped.)
 __global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsigned nh)
 {
     __shared__ float2 buf[2][AC4_ROWBUF];
@@ -952,113 +913,6 @@ __global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsi
     // loads and the conjugation that completes the inverse after its forward column transform
 #pragma unroll
     for (int u = 0; u < 16; u++) zrow[j2 + 256u * (unsigned)u] = v[u];
-}
-
-// ---------------------------------------------------------------------------
-// trip 2, second form: the same row pair per workgroup of 256 threads — thread j holds the 16 points j + 256 t of BOTH rows,
-// one after the other through ONE row buffer (39 KB of LDS with the tables: four workgroups per CU instead of two of 74 KB, i.e.
-// the same 16 waves per CU in four barrier domains instead of two, so that one workgroup's loads and stores overlap another's
-// butterflies more often).  Every pair Z[k] <-> Z[nh-k] has exactly one element in row k1: its owner evaluates it and hands
-// the partner's half back through the buffer.  (k_ac_rows evaluates half of the pairs from the other row's side — the same
-// formula with the roles of the two elements exchanged — so the two forms agree to rounding, not to the bit; both are the
-// float32, tolerance-stated transform.)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void k_ac_rows256(float2 *__restrict__ z, unsigned nh)
-{
-    __shared__ float2 buf[AC4_ROWBUF];
-    __shared__ float2 tw256[256], tw4k[256];
-    const unsigned N1 = nh / AC4_ROW;
-    const unsigned j = threadIdx.x;
-    const unsigned wg = blockIdx.x;
-    const bool selfpair = wg == 0;
-    const unsigned kA = selfpair ? 0u : wg, kB = selfpair ? N1 / 2u : N1 - wg;
-    float2 *rowA = z + (long long)blockIdx.y * nh + (long long)kA * AC4_ROW;
-    float2 *rowB = z + (long long)blockIdx.y * nh + (long long)kB * AC4_ROW;
-    float2 va[16], vb[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) va[t] = rowA[j + 256u * (unsigned)t];
-#pragma unroll
-    for (int t = 0; t < 16; t++) vb[t] = rowB[j + 256u * (unsigned)t];
-    {
-        float sn, cs;
-        sincospif(-(float)j * (1.0f / 128.0f), &sn, &cs);
-        tw256[j] = make_float2(cs, sn);
-        sincospif(-(float)j * (1.0f / 2048.0f), &sn, &cs);
-        tw4k[j] = make_float2(cs, sn);
-    }
-    __syncthreads();  // tables ready
-    ac4_fft4096(va, buf, j, tw256, tw4k);  // va[u] = Z[kA + N1 (j + 256 u)]
-    __syncthreads();
-    unsigned j2 = j;
-    AC4_LAUNDER(j2);
-    ac4_fft4096(vb, buf, j2, tw256, tw4k);  // vb[u] = Z[kB + N1 (j + 256 u)]
-    __syncthreads();
-    float2 *const Lj = buf + (j2 + (j2 >> 4));  // own element u sits at Lj[272 u]
-    if (!selfpair) {
-        float sn0, cs0;
-        sincospif(-(float)(kA + N1 * j2) * (1.0f / (float)nh), &sn0, &cs0);  // exp(-i pi k/nh), k = kA + N1 (j + 256 u)
-        const float2 w0 = make_float2(cs0, sn0);
-#pragma unroll
-        for (int u = 0; u < 16; u++) Lj[272 * u] = vb[u];
-        __syncthreads();
-        const unsigned pb = AC4_ROW - 1u - j2;  // partner of k2 = j + 256 u in row kB: pb - 256 u
-        float2 *const Lq = buf + (pb + (pb >> 4)) - 272u * 15u;
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const float2 bm = Lq[272 * (15 - u)];
-            const float2 wk = u ? cmul(w0, tw256[8u * (unsigned)u]) : w0;  // times exp(-i pi u/16)
-            float2 zk, zkm;
-            ac_split_pair(va[u], bm, wk, nh, &zk, &zkm);
-            va[u] = make_float2(zk.x, -zk.y);  // conjugated input: inverse = conj(FFT(conj(.)))
-            Lq[272 * (15 - u)] = make_float2(zkm.x, -zkm.y);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 16; u++) vb[u] = Lj[272 * u];
-    } else {
-        // rows 0 and N1/2 mirror onto themselves: every element evaluates its own pair; one row after the other
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            float2(&v)[16] = r ? vb : va;
-            const unsigned k1 = r ? kB : kA;
-            float sn0, cs0;
-            sincospif(-(float)(k1 + N1 * j2) * (1.0f / (float)nh), &sn0, &cs0);
-            const float2 w0 = make_float2(cs0, sn0);
-#pragma unroll
-            for (int u = 0; u < 16; u++) Lj[272 * u] = v[u];
-            __syncthreads();
-            // row 0: partner of k2 is 4096 - k2 (k2 = 0 would wrap, but takes the special formula below)
-            const unsigned pb = (r == 0 ? AC4_ROW : AC4_ROW - 1u) - j2;
-            const float2 *const Lq = buf + (pb + (pb >> 4)) - 272u * 15u;
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const float2 bm = Lq[272 * (15 - u)];
-                const float2 wk = u ? cmul(w0, tw256[8u * (unsigned)u]) : w0;
-                float2 zk, zkm;
-                ac_split_pair(v[u], bm, wk, nh, &zk, &zkm);
-                if (u == 0 && r == 0 && j2 == 0u) {
-                    const float inv_n = 1.0f / (float)(2u * nh);
-                    const float m0 = fabsf(v[0].x + v[0].y) * inv_n;  // X[0]  = Re Z0 + Im Z0
-                    const float mh = fabsf(v[0].x - v[0].y) * inv_n;  // X[nh] = Re Z0 - Im Z0
-                    zk = make_float2(m0 + mh, m0 - mh);
-                }
-                v[u] = make_float2(zk.x, -zk.y);
-            }
-            __syncthreads();  // this row's reads are done before the buffer carries the next
-        }
-    }
-    __syncthreads();  // exchange reads done before the buffer is reused
-    unsigned j3 = j2;
-    AC4_LAUNDER(j3);
-    ac4_fft4096(va, buf, j3, tw256, tw4k);
-#pragma unroll
-    for (int u = 0; u < 16; u++) rowA[j3 + 256u * (unsigned)u] = va[u];
-    __syncthreads();
-    unsigned j4 = j3;
-    AC4_LAUNDER(j4);
-    ac4_fft4096(vb, buf, j4, tw256, tw4k);
-#pragma unroll
-    for (int u = 0; u < 16; u++) rowB[j4 + 256u * (unsigned)u] = vb[u];
 }
 
 // ---------------------------------------------------------------------------

@@ -35,6 +35,10 @@ static int ac_subbatch(uint32_t n)
 }
 
 // one tsdrgpu_autocorr_run call of the current epoch, as the certified mode remembers it for an exact replay
+// (is_iq is the input KIND as the exact form's first trip takes it: 0 real magnitudes, 1 interleaved IQ, AC_KIND_SUMSQ the ring
+// as k_ac_cols_retain fills it — am_demod's re*re + im*im, the root still to be taken; one float per sample like kind 0)
+#define AC_KIND_SUMSQ 3
+#define AC_KIND_FLOATS(kind_) ((kind_) == 1 ? 2 : 1)
 struct AcLogRec {
     const float *src;
     int is_iq;
@@ -963,17 +967,6 @@ __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ 
 // ---------------------------------------------------------------------------
 static bool ac4_supported(uint32_t nh) { return nh >= 4096u * 16u && nh <= 4096u * 1024u; }
 
-// trip 2's form: TSDRGPU_ROWS256=1 / =0 picks k_ac_rows256 (256 threads, both rows per thread, four workgroups per CU) or
-// k_ac_rows (512 threads, two per CU); the default is what measured faster
-static bool ac_rows256()
-{
-    static const bool v = [] {
-        const char *e = getenv("TSDRGPU_ROWS256");
-        return e ? e[0] == '1' : false;
-    }();
-    return v;
-}
-
 template <int LOGN1>
 static void launch_ac4_n1(tsdrgpu_t *g, hipStream_t st, const float *src, int in_is_iq, long long stride, int cnt, uint32_t nh, float2 *work,
                           float2 *out, const FftKeep &keep, float *retain)
@@ -984,8 +977,7 @@ static void launch_ac4_n1(tsdrgpu_t *g, hipStream_t st, const float *src, int in
     if (in_is_iq && retain) TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols_retain<LOGN1>), cgrid, G::NT, (const void *)src, stride, work, nh, retain);
     else if (in_is_iq) TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 4, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
     else TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 3, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
-    if (ac_rows256()) TSDR_LAUNCH(g, PROF_AC_ROWS, st, k_ac_rows256, dim3((1u << LOGN1) / 2u, cnt), 256, work, nh);
-    else TSDR_LAUNCH(g, PROF_AC_ROWS, st, k_ac_rows, dim3((1u << LOGN1) / 2u, cnt), 512, work, nh);
+    TSDR_LAUNCH(g, PROF_AC_ROWS, st, k_ac_rows, dim3((1u << LOGN1) / 2u, cnt), 512, work, nh);
     TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 0, true>), cgrid, G::NT, (const void *)work, (long long)nh, out, nh, keep);
 }
 
@@ -1134,7 +1126,7 @@ static int ac_run_exact(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq,
     if (rc) return rc;
     for (int w0 = 0; w0 < nwindows; w0 += AC_XBATCH) {
         const int cnt = nwindows - w0 < AC_XBATCH ? nwindows - w0 : AC_XBATCH;
-        const float *src = d_in + (size_t)w0 * (size_t)stride * (in_is_iq ? 2 : 1);
+        const float *src = d_in + (size_t)w0 * (size_t)stride * AC_KIND_FLOATS(in_is_iq);
         // (only the call's final window is stored whole: tsdrgpu_autocorr_last_corr; the others keep their lag windows)
         rc = fftx_autocorr(g, ac->st, src, in_is_iq, stride, cnt, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag, ac->frame_lo, ac->frame_len,
                            ac->line_lo, ac->line_len, ac->d_plots, (unsigned long long)(ac->calls + w0), mode,
@@ -1290,7 +1282,7 @@ extern "C" int tsdrgpu_autocorr_promote_step(tsdrgpu_autocorr_t *ac, int max_win
         const AcLogRec &r = ac->log[ac->replay_rec];
         const int left = r.nwindows - ac->replay_win;
         const int take = left < budget ? left : budget;
-        const float *src = r.src + (size_t)ac->replay_win * (size_t)r.stride * (r.is_iq ? 2 : 1);
+        const float *src = r.src + (size_t)ac->replay_win * (size_t)r.stride * AC_KIND_FLOATS(r.is_iq);
         if ((rc = ac_run_exact(ac, src, r.is_iq, r.stride, take, r.mode))) return rc;
         budget -= take;
         ac->replay_win += take;
@@ -1362,13 +1354,15 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
             if ((rc = tsdrgpu_autocorr_promote(ac))) return rc;
             return ac_run_exact(ac, src, in_is_iq, stride, nwindows - done, mode);
         }
-        // From interleaved IQ on the three-trip plan, trip 1 itself leaves the demodulated samples in the ring (it holds every
-        // one of them in registers: k_ac_cols_retain) — 8N read + 4N + 4N written per window where a copy kernel in front
-        // (k_fftx_retain) read the IQ twice and the ring once more: 8N + 4N, then 4N + 4N.  Magnitude input, and sizes outside
-        // the plan, keep the copy.
+        // From interleaved IQ on the three-trip plan, trip 1 itself fills the ring (it holds every sample in registers:
+        // k_ac_cols_retain) — 8N read + 4N + 4N written per window where a copy kernel in front (k_fftx_retain) read the IQ
+        // twice and the ring once more: 8N + 4N, then 4N + 4N.  What it leaves is am_demod's sum of squares, re*re + im*im in the
+        // reference's own roundings, NOT the root: the correctly rounded root costs ten instructions a sample and is only ever
+        // needed by a replay, whose first trip takes it on its loads (AC_KIND_SUMSQ).  Magnitude input, and sizes outside the
+        // plan, keep the copy.
         const bool fused = ac_retain_fused(ac, in_is_iq);
         if (!fused && (rc = fftx_retain(g, ac->st, src, in_is_iq, (long long)stride, take, ac->n, slot))) return rc;
-        const AcLogRec r = {slot, 0, (long long)ac->n, take, mode};
+        const AcLogRec r = {slot, fused ? AC_KIND_SUMSQ : 0, (long long)ac->n, take, mode};
         ac->log[ac->log_count++] = r;
         ac->ring_count = pos + take;
         if (fused) rc = ac_run_fast(ac, src, 1, (long long)stride, take, mode, slot);
@@ -1495,7 +1489,7 @@ static int ac_premise_check(tsdrgpu_autocorr_t *ac)
     if (rc) return rc;
     if (!ac->d_check && hipMalloc(&ac->d_check, 2 * sizeof(unsigned long long)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_autocorr", "premise check");
     const AcLogRec &r = ac->log[ac->log_count - 1];  // its final window is the one d_last holds whole
-    const float *src = r.src + (size_t)(r.nwindows - 1) * (size_t)r.stride * (r.is_iq ? 2 : 1);
+    const float *src = r.src + (size_t)(r.nwindows - 1) * (size_t)r.stride * AC_KIND_FLOATS(r.is_iq);
     if ((rc = fftx_correlate(g, ac->st, src, r.is_iq, r.stride, 1, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag))) return rc;
     if (hipMemsetAsync(ac->d_check, 0, 2 * sizeof(unsigned long long), ac->st) != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_autocorr", "premise check");
     const int L = ac->frame_len + ac->line_len + 1;
@@ -1605,7 +1599,7 @@ extern "C" int tsdrgpu_autocorr_last_corr(tsdrgpu_autocorr_t *ac, const float **
         const AcLogRec &r = ac->log[ac->log_count - 1];
         int rc = ac_ensure_exact(ac);
         if (rc) return rc;
-        const float *src = r.src + (size_t)(r.nwindows - 1) * (size_t)r.stride * (r.is_iq ? 2 : 1);
+        const float *src = r.src + (size_t)(r.nwindows - 1) * (size_t)r.stride * AC_KIND_FLOATS(r.is_iq);
         if ((rc = fftx_correlate(g, ac->st, src, r.is_iq, r.stride, 1, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag))) return rc;
         HIP_TRY(g, hipStreamSynchronize(ac->st));
         if (d_corr) *d_corr = (const float *)ac->d_xz;

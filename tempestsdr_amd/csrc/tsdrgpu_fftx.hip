@@ -34,7 +34,9 @@ __device__ __forceinline__ unsigned fftx_rev(unsigned v, int bits) { return bits
 //  s0 == 0: the rows of column r are the 2^L elements of bit-reversed block B = rev(r), i.e. the source
 //           elements rev_L(t)*S + r, S = n >> L (coalesced in r); results go to z[B*R + t].
 //  s0 >  0: in place on z, element (row, c) of tile (group, c0) is z[group*2^(s0+L) + row*2^s0 + c0 + c].
-// src_mode (s0 == 0 only): 0 real floats, 1 interleaved IQ demodulated on the fly (TSDRLibrary.c:244-262),
+// src_mode (s0 == 0 only): 0 real floats, 1 interleaved IQ demodulated on the fly (TSDRLibrary.c:244-262), 3 real floats
+//           holding re*re + im*im as am_demod forms it (two rounded products, their rounded sum): the root is taken here — what
+//           trip 1 of the float32 transform leaves in the retention ring (k_ac_cols_retain, fft4step.h),
 //           2 complex.
 // epilogue (last trip of a forward transform): 1 = divide by nf, magnitude -> mag[] (real), fft.c:167-175,34-45;
 //           2 = divide by nf only.
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src
     if (s0 == 0) {
         S = n >> L;
         r0 = tile * (unsigned)C;
-        const float *sb = src + (long long)blockIdx.y * src_stride * (src_mode == 0 ? 1 : 2);
+        const float *sb = src + (long long)blockIdx.y * src_stride * ((src_mode == 0 || src_mode == 3) ? 1 : 2);
         for (unsigned e = tid; e < total; e += 256) {
             const unsigned row = e / (unsigned)C, c = e % (unsigned)C;
             const unsigned long long at = (unsigned long long)fftx_rev(row, L) * S + r0 + c;
@@ -66,6 +68,8 @@ __global__ __launch_bounds__(256) void k_fftx_trip(const float *__restrict__ src
             if (src_mode == 1) {
                 const float2 iq = ((const float2 *)sb)[at];
                 v = sqrtf(iq.x * iq.x + iq.y * iq.y);
+            } else if (src_mode == 3) {
+                v = sqrtf(sb[at]);
             } else {
                 v = sb[at];
             }
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
         // the rows of column r are the 2^L elements of bit-reversed block B = rev(r): source elements rev_L(row)*S + r
         const unsigned S = n >> L;
         r0 = tile * C;
-        const float *sb = src + (long long)w * src_stride * (src_mode == 0 ? 1 : 2);
+        const float *sb = src + (long long)w * src_stride * ((src_mode == 0 || src_mode == 3) ? 1 : 2);
         // all 16 gathers of a thread are requested before the first is used: the trip is bound by their latency (SQ counters:
         // 68 % of a wave's cycles waiting, the VALU 12 % busy)
 #pragma unroll FFTX_LOAD_UNROLL
@@ -298,7 +302,8 @@ __global__ __launch_bounds__(256) void k_fftx_fast(const float *__restrict__ src
             else if (src_mode == 1) {
                 const float2 iq = ((const float2 *)sb)[at];
                 v = make_float2(sqrtf(iq.x * iq.x + iq.y * iq.y), 0.f);  // am_demod, TSDRLibrary.c:244-262
-            } else v = make_float2(sb[at], 0.f);  // real_to_complex, fft.c:14-22
+            } else if (src_mode == 3) v = make_float2(sqrtf(sb[at]), 0.f);  // the root of am_demod's retained sum of squares
+            else v = make_float2(sb[at], 0.f);  // real_to_complex, fft.c:14-22
             t[row * Cp + c] = v;
         }
     } else {
@@ -610,7 +615,7 @@ static bool fftx_correlate_fused(tsdrgpu_t *g, hipStream_t st, const float *d_in
     for (int j = nt - 2, s0 = trips[nt - 1].L; j >= 0; s0 += trips[j].L, j--)  // the same plan backwards: do its tiles fit too?
         if ((4096u >> trips[j].L) > (1u << s0)) return false;
     const unsigned blocks = (n / 4096u) * (unsigned)cnt;
-    const int src_mode = in_is_iq ? 1 : 0;
+    const int src_mode = in_is_iq;  // the input kind: 0 real, 1 interleaved IQ, 3 retained sums of squares
     for (int k = 0; k < nt - 1; k++)
         if (!fftx_launch_fast_u<1>(g, st, trips[k].L, blocks, d_in, src_mode, stride, work, nullptr, n, m, trips[k].s0, cnt, d_tw, 0, 0, FFTX_KEEP_ALL))
             return false;
@@ -638,7 +643,7 @@ static int fftx_correlate_keep(tsdrgpu_t *g, hipStream_t st, const float *d_in, 
         if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "exact FFT", "launch");
         return TSDRGPU_OK;
     }
-    if ((rc = fftx_transform(g, st, d_in, in_is_iq ? 1 : 0, stride, z, mag, n, m, cnt, d_tw, 0, 1))) return rc;
+    if ((rc = fftx_transform(g, st, d_in, in_is_iq, stride, z, mag, n, m, cnt, d_tw, 0, 1))) return rc;
     return fftx_transform(g, st, mag, 0, (long long)n, z, mag, n, m, cnt, d_tw, 1, 0, keep);
 }
 

@@ -6,9 +6,6 @@
 
 #include "../../tempestsdr_amd/csrc/fft4step.h"
 
-static int g_rows256 = 0;  // emu_set_rows256: trip 2 in its 256-thread form
-extern "C" void emu_set_rows256(int on) { g_rows256 = on; }
-
 template <int LOGN1>
 static void run_plan(const float *in, int in_is_iq, long long stride, int cnt, unsigned nh, float2 *work, float2 *out, FftKeep keep)
 {
@@ -19,8 +16,7 @@ static void run_plan(const float *in, int in_is_iq, long long stride, int cnt, u
         emu_launch(emu_dim3(N2 / G::C, cnt), G::NT, [&]() { k_ac_cols<LOGN1, 4, false>(in, stride, work, nh, all); });
     else
         emu_launch(emu_dim3(N2 / G::C, cnt), G::NT, [&]() { k_ac_cols<LOGN1, 3, false>(in, stride, work, nh, all); });
-    if (g_rows256) emu_launch(emu_dim3((1u << LOGN1) / 2, cnt), 256, [&]() { k_ac_rows256(work, nh); });
-    else emu_launch(emu_dim3((1u << LOGN1) / 2, cnt), 512, [&]() { k_ac_rows(work, nh); });
+    emu_launch(emu_dim3((1u << LOGN1) / 2, cnt), 512, [&]() { k_ac_rows(work, nh); });
     emu_launch(emu_dim3(N2 / G::C, cnt), G::NT, [&]() { k_ac_cols<LOGN1, 0, true>(work, (long long)nh, out, nh, keep); });
 }
 

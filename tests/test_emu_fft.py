@@ -106,17 +106,18 @@ def emu5(emu):
     return emu
 
 
-def test_trip1_retains_the_reference_demodulation(emu5):
-    """k_ac_cols_retain: the ring holds am_demod's bits (TSDRLibrary.c:244-262: separate products, their sum, a correctly
-    rounded root — numpy's float32 arithmetic is exactly that) for every sample of every window, and the transform of
-    those magnitudes is the autocorrelation."""
+def test_trip1_retains_the_reference_sum_of_squares(emu5):
+    """k_ac_cols_retain: the ring holds am_demod's re*re + im*im with the reference's roundings (TSDRLibrary.c:244-262: two
+    rounded products, their rounded sum — numpy's float32 arithmetic is exactly that) for every sample of every window: the
+    correctly rounded root of it, which a replay takes on its loads, is the reference's demodulated sample.  The transform of
+    the (hardware) roots is the autocorrelation."""
     logn1, cnt = 4, 2
     nh = 4096 << logn1
     n = 2 * nh
     rng = np.random.default_rng(5)
     stride = n + 11
     x = rng.standard_normal((cnt * stride + 8) * 2).astype(np.float32)
-    x[:64] = 0.0                 # zeros (an int8 recording's): the wave leaves the bare sequence
+    x[:64] = 0.0                      # zeros (an int8 recording's)
     x[200:264] *= np.float32(1e-30)   # squares underflow
     work = np.zeros(cnt * nh * 2, np.float32)
     out = np.zeros(cnt * nh * 2, np.float32)
@@ -125,9 +126,10 @@ def test_trip1_retains_the_reference_demodulation(emu5):
     for b in range(cnt):
         seg = x[2 * b * stride:2 * (b * stride + n)]
         re, im = seg[0::2], seg[1::2]
-        want = np.sqrt(re * re + im * im)  # float32 throughout
+        want = re * re + im * im  # float32 throughout
         assert want.dtype == np.float32
         assert np.array_equal(ring[b * n:(b + 1) * n], want)
+        assert np.array_equal(np.sqrt(ring[b * n:(b + 1) * n]), np.sqrt(re * re + im * im))  # (what the replay demodulates to)
         corr = _want(x[2 * b * stride:], n, 1)
         assert np.max(np.abs(out[b * n:(b + 1) * n] - corr)) <= 5e-7 * corr[0]
 
@@ -196,27 +198,3 @@ def test_stitch_transform_on_three_trips_matches_numpy(emu5, logn1, offs):
     got = out[0::2] + 1j * out[1::2]
     assert np.max(np.abs(got - want)) <= 2e-6 * np.max(np.abs(want))
 
-
-def test_trip2_256_thread_form(emu):
-    """k_ac_rows256 (one workgroup of 256 threads per row pair, both rows per thread) against k_ac_rows (512 threads) and numpy:
-    the same plan; half of the pairs are evaluated from the other row's side, so the two agree to rounding."""
-    logn1, cnt = 5, 2
-    nh = 4096 << logn1
-    n = 2 * nh
-    rng = np.random.default_rng(256)
-    x = rng.random(cnt * n + 8).astype(np.float32)
-    work = np.zeros(cnt * nh * 2, np.float32)
-    a = np.zeros(cnt * nh * 2, np.float32)
-    b = np.zeros(cnt * nh * 2, np.float32)
-    emu.emu_set_rows256.argtypes = [C.c_int]
-    assert emu.emu_autocorr4(x, 0, n, cnt, nh, work, a, 0, -1, 0, 0, 0, 0) == 0
-    emu.emu_set_rows256(1)
-    try:
-        assert emu.emu_autocorr4(x, 0, n, cnt, nh, work, b, 0, -1, 0, 0, 0, 0) == 0
-    finally:
-        emu.emu_set_rows256(0)
-    want = _want(x, n, 0)
-    assert np.max(np.abs(a - b)) <= 3e-7 * want[0]
-    for k in range(cnt):
-        want = _want(x[k * n:], n, 0)
-        assert np.max(np.abs(b[k * n:(k + 1) * n] - want)) <= 5e-7 * want[0]

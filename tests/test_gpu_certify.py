@@ -369,11 +369,11 @@ def test_plain_mode_reports_a_certificate(orc):
 
 @pytest.mark.parametrize("fs", sorted(RATES))
 def test_trip1_retention_replays_to_the_oracle_bits(orc, fs):
-    """Library retention from interleaved IQ (mode 1): trip 1 of the float32 transform leaves the demodulated samples in the
-    ring itself (k_ac_cols_retain) — they must be am_demod's bits (TSDRLibrary.c:244-262), for ordinary samples and for the
-    waves that leave the bare square-root sequence (zeros, amplitudes whose squares underflow), because a replay of the
-    epoch must reproduce the reference's plots bit for bit (frameratedetector.c:34-62,87-126).  Every column length of the
-    plan (8 / 25 / 100 / 200 MS/s: 32 / 128 / 512 / 1024)."""
+    """Library retention from interleaved IQ (mode 1): trip 1 of the float32 transform fills the ring itself (k_ac_cols_retain)
+    with am_demod's re*re + im*im in the reference's roundings (TSDRLibrary.c:244-262); the replay's first trip takes the
+    correctly rounded root — for ordinary samples, zeros and amplitudes whose squares underflow alike — and must reproduce the
+    reference's plots bit for bit (frameratedetector.c:34-62,87-126).  Every column length of the plan (8 / 25 / 100 /
+    200 MS/s: 32 / 128 / 512 / 1024)."""
     g = ctx()
     ac = gpu.Autocorr(g, fs)
     ac.set_certify(1)

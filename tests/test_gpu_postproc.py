@@ -518,8 +518,11 @@ def test_frame_parallel_pass_and_its_literal_redo(orc, cfg, negzero, odd):
         assert (info.dx, info.vx, info.stripx, info.dy, info.vy, info.stripy, info.locked) == tuple(si[:7]), f"frame {k}"
 
 
-@pytest.mark.parametrize("cfg", [(0, 0, 0, 0, 0.0), (1, 0, 1, 0, 0.5), (0, 1, 0, 0, 0.0), (1, 1, 0, 0, 0.25)])
-@pytest.mark.parametrize("form", ["run", "split", "fused"])
+_SNR_CFGS = [(0, 0, 0, 0, 0.0), (1, 0, 1, 0, 0.5), (0, 1, 0, 0, 0.0), (1, 1, 0, 0, 0.25)]
+
+
+# (the fused run is the default stage order's: only that order is paired with it)
+@pytest.mark.parametrize("cfg,form", [(c, f) for f in ("run", "split", "fused") for c in _SNR_CFGS if not (f == "fused" and (c[0] or c[1]))])
 def test_snr_by_product_of_the_run(orc, cfg, form):
     """dsp_autogain_t.snr (dsp.c:69-93) of every frame as the run's by-product, in the four stage orders (autogain reads the
     input frames, the low-passed ones or the corrected ones) and the three forms of a run, against the oracle's field after
@@ -534,8 +537,6 @@ def test_snr_by_product_of_the_run(orc, cfg, form):
     _, states, _ = run_orc(orc, frames, fs, h, fv, cfg)
     want = np.array([sd[2] for _, sd in states], np.float32)
     lbs, aap, ash, pll, mb = cfg
-    if form == "fused" and (lbs or aap):
-        pytest.skip("the fused run is the default stage order's")
     pp = gpu.PostProcess(g)
     with pytest.raises(gpu.TsdrGpuError):
         pp.snr(1)                      # not asked for
