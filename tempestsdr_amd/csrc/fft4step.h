@@ -222,13 +222,6 @@ __device__ __forceinline__ void ac_split_pair(float2 a, float2 bm, float2 wk, un
     *zkm = make_float2(s - sn * d, cs * d);
 }
 
-// keeps the compiler from carrying address registers from one transform (or one window of a loop) into the next
-#if defined(__HIP_DEVICE_COMPILE__)
-#define AC4_LAUNDER(x) asm volatile("" : "+v"(x))
-#else
-#define AC4_LAUNDER(x) (void)(x)
-#endif
-
 // ---------------------------------------------------------------------------
 // trips 1 and 3: column DFTs of length N1 = 2^LOGN1 (16..1024), rows N2 = nh/N1 elements apart.
 // A workgroup owns C neighbouring columns (C = 16 for N1 >= 256, else 4096/N1: at least 4096 points);
@@ -722,169 +715,6 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols_retain(const 
 }
 
 // ---------------------------------------------------------------------------
-// trip 3 WITH accummulate (frameratedetector.c:34-62) folded in, for column lengths >= 512.  A workgroup owns a tile of CC
-// columns and walks the launch's windows IN WINDOW ORDER: twiddle, column DFTs, and then — instead of storing the lag windows
-// for a kernel behind to read them back — it folds |re| and |im| of the points that lie in the detector's two lag windows
-// (complex point m holds lags 2m and 2m + 1; point 0 is lag 0, the scale of the argmax certificate) into f64 accumulators it
-// keeps on chip, with the reference's recurrence out = (out (calls - 1) + now) / calls in the reference's order (or plain
-// sums, mode 1).  Which of a thread's 32 lags are wanted does not depend on the window, so the running values are read once
-// before the first window and written once behind the last.  What k_accumulate computed, to the bit (the same values through
-// the same f64 operations in the same order); the lag windows' store and re-load (2 x 30 MB and a launch per 9 windows at
-// N = 2^22) are gone.  The window `full_b` is still stored whole (tsdrgpu_autocorr_last_corr, the premise check).
-// 512 tiles of 8 columns x 256 (512) threads at column length 512 (1024): two workgroups per CU, all resident, no tail; one
-// workgroup's loads run under the other's butterflies.  (The plain kernel + k_accumulate stay for shorter columns — 128 tiles
-// cannot fill 256 CUs — and for the five-trip plan.)
-// ---------------------------------------------------------------------------
-struct AcAccum {
-    double *plots;  // frame_len + line_len + 1 running means (mode 0) or sums (mode 1); the last entry is lag 0
-    int frame_lo, frame_len, line_lo, line_len;
-    unsigned long long calls_before;  // windows folded in before this launch's first
-    int mode;
-    int cnt;     // windows of this launch
-    int full_b;  // window stored whole (-1: none)
-};
-
-// plot index of lag `lag`, or -1
-__device__ __forceinline__ int ac_plot_index(const AcAccum &A, unsigned lag)
-{
-    if (lag == 0u) return A.frame_len + A.line_len;
-    const int l = (int)lag;
-    if (l >= A.frame_lo && l < A.frame_lo + A.frame_len) return l - A.frame_lo;
-    if (l >= A.line_lo && l < A.line_lo + A.line_len) return A.frame_len + (l - A.line_lo);
-    return -1;
-}
-
-// A thread's wanted lags are few (the frame window covers ~16 % of the lags: 2-4 of a thread's 16 rows; the line window one
-// row) but WHICH of its registers hold them depends on the thread, so the running values live in LDS, AC_ACC_SLOTS compact
-// slots per thread filled in register order (the loops over the registers stay unrolled: every register index a constant).
-#define AC_ACC_SLOTS 8
-#if defined(__HIP_DEVICE_COMPILE__)
-#define AC4_WAVES4 __attribute__((amdgpu_num_vgpr(128)))  // two workgroups of 256 (512) threads per CU
-#else
-#define AC4_WAVES4
-#endif
-template <int LOGN1, unsigned CC>
-__global__ __launch_bounds__((1u << LOGN1) * CC / 16u) AC4_WAVES4 void k_ac_cols_acc(const float2 *__restrict__ x, float2 *__restrict__ out, unsigned nh, AcAccum A)
-{
-    constexpr unsigned N1 = 1u << LOGN1, C = CC, NT = N1 * C / 16u, Q = N1 / 16u;
-    constexpr int R0 = (LOGN1 % 4) ? (1 << (LOGN1 % 4)) : 16, NP = (LOGN1 + 3) / 4, G0 = 16 / R0;
-    static_assert(NP > 1, "column lengths >= 32");
-    __shared__ float2 L[N1 * C];
-    __shared__ float2 twN[N1];
-    __shared__ double accs[AC_ACC_SLOTS][NT];
-    const unsigned N2 = nh / N1;
-    const unsigned tid = threadIdx.x;
-    const unsigned c = tid % C, q = tid / C;
-    const unsigned gx = gridDim.x;
-    const unsigned tile = (gx % 8u == 0u) ? (blockIdx.x % 8u) * (gx / 8u) + blockIdx.x / 8u : blockIdx.x;
-    const unsigned col = tile * C + c;
-    for (unsigned e = tid; e < N1; e += NT) {
-        float sn, cs;
-        sincospif(-2.0f * (float)e / (float)N1, &sn, &cs);
-        twN[e] = make_float2(cs, sn);
-    }
-    // w_nh^(k1 n2) on the loads: rows q + Q i -> w^(col q) * (w^(col Q))^i, the same for every window
-    float2 rtw[16];
-    ac4_col_twiddles<false>(rtw, col * Q, col * q, nh);
-    // the thread's outputs: the last pass (radix 16) leaves row q + u N1/16 in register u.  The lags 2m + h (h = 0: re, 1: im) of
-    // those points that have a plot entry get the slots 0, 1, ... in register order; slot s remembers its 2u + h in 5 bits of `codes`
-    unsigned long long codes = 0ull;
-    int nslots = 0;
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-        const unsigned m = (q + (unsigned)u * (N1 / 16u)) * N2 + col;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int i = ac_plot_index(A, 2u * m + (unsigned)h);
-            if (i >= 0 && nslots < AC_ACC_SLOTS) {
-                codes |= (unsigned long long)(2 * u + h) << (5 * nslots);
-                accs[nslots][tid] = A.plots[i];
-                nslots++;
-            }
-        }
-    }
-    __syncthreads();  // twN[] complete
-    for (int b = 0; b < A.cnt; b++) {
-        // (laundered copies of the thread's coordinates: left to itself the compiler hoists every address of the loop body —
-        // 16 global offsets, ~80 LDS positions — out of the loop and needs 224 registers to carry them from window to window)
-        unsigned q_ = q, c_ = c, t_ = tid;
-        AC4_LAUNDER(q_);
-        AC4_LAUNDER(c_);
-        AC4_LAUNDER(t_);
-        const unsigned col_ = tile * C + c_;
-        const float2 *xb = x + (long long)b * nh;
-        float2 v[16];
-#pragma unroll
-        for (int a = 0; a < G0; a++)
-#pragma unroll
-            for (int t = 0; t < R0; t++) {
-                const unsigned row = q_ + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
-                v[a * R0 + t] = xb[(long long)row * N2 + col_];
-            }
-#pragma unroll
-        for (int a = 0; a < G0; a++)
-#pragma unroll
-            for (int t = 0; t < R0; t++) v[a * R0 + t] = cmul(v[a * R0 + t], rtw[a + G0 * t]);
-#pragma unroll
-        for (int a = 0; a < G0; a++) dft_reg<R0>(*reinterpret_cast<float2(*)[R0]>(&v[a * R0]));
-        if (b) __syncthreads();  // the previous window's stash has been read
-#pragma unroll
-        for (int a = 0; a < G0; a++)
-#pragma unroll
-            for (int u = 0; u < R0; u++) L[((q_ + Q * (unsigned)a) * (unsigned)R0 + (unsigned)u) * C + c_] = v[a * R0 + u];
-        __syncthreads();
-        unsigned Ns = (unsigned)R0;
-#pragma unroll
-        for (int pass = 1; pass < NP; pass++) {
-#pragma unroll
-            for (int t = 0; t < 16; t++) v[t] = L[(q_ + (unsigned)t * Q) * C + c_];
-            const unsigned k = q_ & (Ns - 1u);
-            const unsigned unit = N1 / (Ns * 16u);
-#pragma unroll
-            for (int t = 1; t < 16; t++) v[t] = cmul(v[t], twN[((unsigned)t * k * unit) & (N1 - 1u)]);
-            dft_reg<16>(v);
-            if (pass < NP - 1) {
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < 16; u++) L[((q_ - k) * 16u + k + (unsigned)u * Ns) * C + c_] = v[u];
-                __syncthreads();
-                Ns *= 16u;
-            }
-        }
-        // register u = row q_ + u N1/16 of this window's correlation (conjugate: only |.| is read below)
-        if (b == A.full_b) {
-            float2 *ob = out + (long long)b * nh;
-#pragma unroll
-            for (int u = 0; u < 16; u++) ob[(q_ + (unsigned)u * (N1 / 16u)) * N2 + col_] = make_float2(v[u].x, -v[u].y);
-        }
-        // The wanted values are a few of the 16 registers, WHICH ones differs from thread to thread: the registers go through the
-        // (now free) tile — every thread reads back only what it wrote itself — and a short loop over the slots picks them up.
-        __syncthreads();  // the last pass's reads of the tile are done
-        float *stash = (float *)L;
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-            stash[(2 * u) * NT + t_] = v[u].x;
-            stash[(2 * u + 1) * NT + t_] = v[u].y;
-        }
-        const unsigned long long calls = A.calls_before + (unsigned long long)b + 1ull;
-        const double cm1 = (double)(calls - 1ull), cd = (double)calls;
-#pragma unroll 1
-        for (int sl = 0; sl < nslots; sl++) {
-            const unsigned code = (unsigned)(codes >> (5 * sl)) & 31u;
-            const double now = fabs((double)stash[code * NT + t_]);
-            const double o = accs[sl][t_];
-            accs[sl][t_] = A.mode == 0 ? (o * cm1 + now) / cd : o + now;
-        }
-    }
-#pragma unroll 1
-    for (int sl = 0; sl < nslots; sl++) {
-        const unsigned code = (unsigned)(codes >> (5 * sl)) & 31u;
-        const unsigned m = (q + (code >> 1) * (N1 / 16u)) * N2 + col;
-        A.plots[ac_plot_index(A, 2u * m + (code & 1u))] = accs[sl][tid];
-    }
-}
-
-// ---------------------------------------------------------------------------
 // The super-bandwidth stitch on the same three trips (superb_ondataready / superb_bestfit, superbandwidth.c:83-152;
 // fft_crosscorrelation, fft.c:69-93).  Four hops of M = N1 * 4096 complex points each.
 //
@@ -940,6 +770,12 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_sb_cols_argmax(const 
 // (e.g. pad(j + 256 t) = j + (j >> 4) + 272 t) so that they become immediate offsets of the DS instructions.
 #define AC4_ROWBUF (4096 + 256 + 16)
 
+// keeps the compiler from carrying the first transform's address registers through to the second one
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AC4_LAUNDER(x) asm volatile("" : "+v"(x))
+#else
+#define AC4_LAUNDER(x) (void)(x)
+#endif
 
 // in: v[t] = x[j + 256 t]; out: v[u] = X[j + 256 u].  All threads of the workgroup must call it (barriers);
 // Lr is the caller's row buffer, which must not be in use on entry.  Twiddles come from two 256-entry

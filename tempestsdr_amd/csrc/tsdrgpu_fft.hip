@@ -967,32 +967,9 @@ __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ 
 // ---------------------------------------------------------------------------
 static bool ac4_supported(uint32_t nh) { return nh >= 4096u * 16u && nh <= 4096u * 1024u; }
 
-// trip 3 with the accumulation folded in (k_ac_cols_acc, fft4step.h): column lengths >= 512; TSDRGPU_FOLD_ACC=0 keeps the
-// separate k_accumulate (A/B)
-static bool ac_fold_ok(uint32_t nh, int frame_lo, int frame_len, int line_lo, int line_len)
-{
-    static const bool off = [] { const char *e = getenv("TSDRGPU_FOLD_ACC"); return e && e[0] == '0'; }();
-    if (off || nh < 4096u * 512u) return false;
-    // a thread holds rows q + Q u (u < 16, Q = N1 / 16) of its column and keeps AC_ACC_SLOTS running values: count, for the worst q,
-    // the rows that touch the frame window's points, the line window's and point 0 (two lags a point)
-    const unsigned N1 = nh / 4096u, Q = N1 / 16u;
-    const unsigned f0 = ((unsigned)frame_lo / 2u) / 4096u, f1 = ((unsigned)(frame_lo + frame_len - 1) / 2u) / 4096u;
-    const unsigned l0 = ((unsigned)line_lo / 2u) / 4096u, l1 = ((unsigned)(line_lo + line_len - 1) / 2u) / 4096u;
-    unsigned worst = 0;
-    for (unsigned q = 0; q < Q; q++) {
-        unsigned n = 0;
-        for (unsigned u = 0; u < 16u; u++) {
-            const unsigned r = q + Q * u;
-            if ((r >= f0 && r <= f1) || (r >= l0 && r <= l1) || r == 0u) n += 2u;
-        }
-        worst = n > worst ? n : worst;
-    }
-    return worst <= (unsigned)AC_ACC_SLOTS;
-}
-
 template <int LOGN1>
 static void launch_ac4_n1(tsdrgpu_t *g, hipStream_t st, const float *src, int in_is_iq, long long stride, int cnt, uint32_t nh, float2 *work,
-                          float2 *out, const FftKeep &keep, float *retain, const AcAccum *fold)
+                          float2 *out, const FftKeep &keep, float *retain)
 {
     typedef ColGeom<LOGN1> G;
     const dim3 cgrid(AC4_ROW / G::C, cnt);
@@ -1001,31 +978,22 @@ static void launch_ac4_n1(tsdrgpu_t *g, hipStream_t st, const float *src, int in
     else if (in_is_iq) TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 4, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
     else TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 3, false>), cgrid, G::NT, (const void *)src, stride, work, nh, KEEP_ALL);
     TSDR_LAUNCH(g, PROF_AC_ROWS, st, k_ac_rows, dim3((1u << LOGN1) / 2u, cnt), 512, work, nh);
-    if constexpr (LOGN1 >= 9) {
-        if (fold) {
-            AcAccum A = *fold;
-            A.cnt = cnt;
-            A.full_b = keep.full_b;
-            TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols_acc<LOGN1, 8u>), dim3(AC4_ROW / 8u, 1), (1u << LOGN1) / 2u, (const float2 *)work, out, nh, A);
-            return;
-        }
-    }
     TSDR_LAUNCH(g, PROF_AC_COLS, st, (k_ac_cols<LOGN1, 0, true>), cgrid, G::NT, (const void *)work, (long long)nh, out, nh, keep);
 }
 
 static void launch_ac4(tsdrgpu_t *g, hipStream_t st, const float *src, int in_is_iq, long long stride, int cnt, uint32_t nh, float2 *work,
-                       float2 *out, const FftKeep &keep, float *retain = nullptr, const AcAccum *fold = nullptr)
+                       float2 *out, const FftKeep &keep, float *retain = nullptr)
 {
     int logn1 = 0;
     while ((4096u << logn1) < nh) logn1++;
     switch (logn1) {
-        case 4: launch_ac4_n1<4>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain, fold); break;
-        case 5: launch_ac4_n1<5>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain, fold); break;
-        case 6: launch_ac4_n1<6>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain, fold); break;
-        case 7: launch_ac4_n1<7>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain, fold); break;
-        case 8: launch_ac4_n1<8>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain, fold); break;
-        case 9: launch_ac4_n1<9>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain, fold); break;
-        default: launch_ac4_n1<10>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain, fold); break;
+        case 4: launch_ac4_n1<4>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 5: launch_ac4_n1<5>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 6: launch_ac4_n1<6>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 7: launch_ac4_n1<7>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 8: launch_ac4_n1<8>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        case 9: launch_ac4_n1<9>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
+        default: launch_ac4_n1<10>(g, st, src, in_is_iq, stride, cnt, nh, work, out, keep, retain); break;
     }
 }
 
@@ -1214,7 +1182,6 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
         const unsigned Ns_last = nh / R_last;
         const bool fused = nh >= 4096 && plan.count >= 2 && Ns_last >= 2u * (2048u / R_last);
         float2 *corr_;
-        bool folded = false;  // the accumulation happened inside the last trip
         // lags stored by the last pass: complex point m holds lags 2m, 2m+1 (point 0, i.e. lag 0, always); the call's
         // final window is stored whole for tsdrgpu_autocorr_last_corr
         FftKeep keep;
@@ -1226,12 +1193,8 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
         keep.hi1 = (unsigned)(ac->line_lo + ac->line_len + 1) / 2;
         if (ac4_supported(nh) && !ac->plan5) {
             // three trips (fft4step.h): columns -> row pairs (in place) -> columns
-            const bool fold = ac_fold_ok(nh, ac->frame_lo, ac->frame_len, ac->line_lo, ac->line_len);
-            const AcAccum A = {ac->d_plots, ac->frame_lo, ac->frame_len, ac->line_lo, ac->line_len, (unsigned long long)(ac->calls + w0), mode, cnt, keep.full_b};
-            launch_ac4(g, ac->st, src, in_is_iq, stride, cnt, nh, ac->d_a, ac->d_b, keep, retain_to ? retain_to + (size_t)w0 * ac->n : nullptr,
-                       fold ? &A : nullptr);
+            launch_ac4(g, ac->st, src, in_is_iq, stride, cnt, nh, ac->d_a, ac->d_b, keep, retain_to ? retain_to + (size_t)w0 * ac->n : nullptr);
             corr_ = ac->d_b;
-            folded = fold;
         } else if (fused) {
             // forward passes but the last ...
             float2 *z = run_fft_range(g, src, in_is_iq ? 4 : 3, stride, ac->d_a, ac->d_b, nh, cnt, plan.radix, plan.count, 0,
@@ -1261,7 +1224,7 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
         }
         corr = corr_;
         KERNEL_CHECK(g, "fft passes");
-        if (!folded) TSDR_LAUNCH(g, PROF_ACCUMULATE, ac->st, k_accumulate, (L + 255) / 256, 256, (const float *)corr, ac->n, cnt, ac->frame_lo, ac->frame_len, ac->line_lo,
+        TSDR_LAUNCH(g, PROF_ACCUMULATE, ac->st, k_accumulate, (L + 255) / 256, 256, (const float *)corr, ac->n, cnt, ac->frame_lo, ac->frame_len, ac->line_lo,
                                                           ac->line_len, ac->d_plots, (unsigned long long)(ac->calls + w0), mode);
         KERNEL_CHECK(g, "k_accumulate");
         last_count = cnt;

@@ -122,30 +122,3 @@ extern "C" int emu_sb_stitch(const float *h0, const float *h1, const float *h2, 
     }
     return 0;
 }
-
-// ---- trip 3 with the accumulation folded in (k_ac_cols_acc) -------------------------------------------------------------
-template <int LOGN1>
-static void run_plan_acc(const float *in, long long stride, int cnt, unsigned nh, float2 *work, float2 *out, AcAccum A)
-{
-    typedef ColGeom<LOGN1> G;
-    const unsigned N2 = nh >> LOGN1;
-    const FftKeep all = {0, -1, 0u, 0u, 0u, 0u};
-    emu_launch(emu_dim3(N2 / G::C, cnt), G::NT, [&]() { k_ac_cols<LOGN1, 3, false>(in, stride, work, nh, all); });
-    emu_launch(emu_dim3((1u << LOGN1) / 2, cnt), 512, [&]() { k_ac_rows(work, nh); });
-    emu_launch(emu_dim3(N2 / G::C, 1), G::NT, [&]() { k_ac_cols_acc<LOGN1, G::C>(work, out, nh, A); });
-}
-
-extern "C" int emu_autocorr4_acc(const float *in, long long stride, int cnt, unsigned nh, float *work, float *out, double *plots, int frame_lo,
-                                 int frame_len, int line_lo, int line_len, unsigned long long calls_before, int mode, int full_b)
-{
-    unsigned logn1 = 0;
-    while ((4096u << logn1) < nh) logn1++;
-    if ((4096u << logn1) != nh) return -1;
-    AcAccum A = {plots, frame_lo, frame_len, line_lo, line_len, calls_before, mode, cnt, full_b};
-    switch (logn1) {
-        case 5: run_plan_acc<5>(in, stride, cnt, nh, (float2 *)work, (float2 *)out, A); break;
-        case 6: run_plan_acc<6>(in, stride, cnt, nh, (float2 *)work, (float2 *)out, A); break;
-        default: return -1;
-    }
-    return 0;
-}

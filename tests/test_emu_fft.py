@@ -198,42 +198,3 @@ def test_stitch_transform_on_three_trips_matches_numpy(emu5, logn1, offs):
     got = out[0::2] + 1j * out[1::2]
     assert np.max(np.abs(got - want)) <= 2e-6 * np.max(np.abs(want))
 
-
-
-f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
-
-
-@pytest.mark.parametrize("logn1,mode", [(5, 0), (6, 0), (5, 1)])
-def test_trip3_with_the_accumulation_folded_in(emu, logn1, mode):
-    """k_ac_cols_acc: a workgroup walks the launch's windows in window order and keeps accummulate's running means
-    (frameratedetector.c:34-62: out = (out (calls - 1) + now) / calls) — or plain sums — of its lags in registers: the same
-    plots as the stored correlations folded by the recurrence afterwards, bit for bit, across two launches of one epoch;
-    the window asked for is still stored whole."""
-    emu.emu_autocorr4_acc.restype = C.c_int
-    emu.emu_autocorr4_acc.argtypes = [f32p, C.c_longlong, C.c_int, C.c_uint, f32p, f32p, f64p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.c_ulonglong, C.c_int, C.c_int]
-    nh = 4096 << logn1
-    n = 2 * nh
-    cnt = 3
-    rng = np.random.default_rng(900 + logn1)
-    x = rng.random(2 * cnt * n + 8).astype(np.float32)
-    flo, flen, llo, llen = n // 5 + 1, n // 7, 37, 211  # odd starts: a point's two lags straddle a window's edge
-    L = flen + llen + 1
-    plots = np.zeros(L, np.float64)
-    work = np.zeros(cnt * nh * 2, np.float32)
-    full = np.zeros(cnt * nh * 2, np.float32)
-    want = np.zeros(L, np.float64)
-    calls = 0
-    for launch in range(2):
-        xin = x[launch * cnt * n:]
-        assert emu.emu_autocorr4(xin, 0, n, cnt, nh, work, full, 0, -1, 0, 0, 0, 0) == 0  # every window whole
-        part = np.full(cnt * nh * 2, -7.0, np.float32)
-        assert emu.emu_autocorr4_acc(xin, n, cnt, nh, work, part, plots, flo, flen, llo, llen, calls, mode, cnt - 1) == 0
-        for b in range(cnt):
-            corr = full[b * n:(b + 1) * n].astype(np.float64)
-            now = np.abs(np.concatenate([corr[flo:flo + flen], corr[llo:llo + llen], corr[0:1]]))
-            calls += 1
-            want = (want * float(calls - 1) + now) / float(calls) if mode == 0 else want + now
-        assert np.array_equal(part[(cnt - 1) * n:], full[(cnt - 1) * n:])      # the window kept whole
-        assert np.all(part[:(cnt - 1) * n] == -7.0)                             # nothing else is stored
-    assert np.array_equal(plots, want)
