@@ -189,6 +189,12 @@ __device__ __forceinline__ void tw_powers(float2 (&pw)[M], unsigned e1, unsigned
 // ranges are stored (the autocorrelation reads nothing but its two lag windows, frameratedetector.c:
 // 115-118) plus point 0 (lag 0, the scale of the argmax certificate), except for transform `full_b`
 // of the batch, which is stored whole.
+// (Round 5 also built the fold the review asked for — accummulate inside trip 3: a workgroup per column tile walking the launch's
+// windows in window order, the running means of its lags in LDS slots, bit-identical plots, no lag-window store / re-load, no
+// k_accumulate launch — and measured it SLOWER: 0.2672 / 0.2695 ms per pass for the two column trips against 0.2399 + 0.0221
+// with the separate kernel at N = 2^22, 0.70 against 0.59 + 0.04 at 2^23.  A workgroup that walks the windows leaves a CU
+// (N1 tiles x threads) / CUs = 8 waves where the flat grid keeps 16 resident, and trip 3 lives on memory-level parallelism.
+// Commit 0de10d1 has the kernel.)
 struct FftKeep {
     int on;
     int full_b;
