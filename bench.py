@@ -539,7 +539,15 @@ def main():
         if args.uncertified:
             return fi_li
         c = a.certificate()
-        if c.frame_certified and c.line_certified:
+        uncertified = 0 if (c.frame_certified and c.line_certified) else 1
+        if sharded and c.premise_checked:
+            # The merged plots are the same on every rank, but an update that carried the runtime premise check also folds in
+            # the check of the rank's OWN newest window: the ranks agree before any of them enters the replay's collective
+            # (the checks fall on the same updates everywhere, so every rank comes here together)
+            t = torch.tensor([uncertified], dtype=torch.int32, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            uncertified = int(t.item())
+        if not uncertified:
             return fi_li
         promoted_passes[0] += 1
         a.promote()

@@ -24,9 +24,16 @@ for k in range(4):
     hops.append(h.astype(np.float32))
 d_hops = [g.to_device(h) for h in hops]
 d_st = g.empty(2 * 4 * per)
+if "--pmc-calibrate" in sys.argv:
+    # a launch whose traffic is known exactly (8 B read + 4 B written per sample): scripts/pmc_summarize.py calibrates the
+    # FETCH_SIZE / WRITE_SIZE counters of the same rocprofv3 run on it
+    ncal = 99_999_600
+    d_cal_in = g.to_device(np.zeros(2 * ncal, np.float32))
+    d_cal_out = g.empty(ncal)
+    for _ in range(3):
+        g.am_demod(d_cal_in, d_cal_out, ncal)
+    g.sync()
 for rep in range(6):
-    for k in range(4):
-        d_hops[k].upload(hops[k])
     g.sync()
     t = time.perf_counter()
     offs, total = g.superb_stitch(d_hops, gathered, sif, d_st)

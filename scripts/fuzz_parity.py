@@ -339,7 +339,9 @@ def fuzz_tracking(g, rng):
 
 def fuzz_superb(g, rng):
     # four hops of a periodic signal, each delayed by a random amount (superbandwidth.c:121-152)
-    fs = int(rng.integers(20_000, 400_000))
+    # (two cases in five with hops of 2^16 .. 2^19 points: the three-trip plan of tsdrgpu_superb_stitch; the others take the
+    # pass-per-radix plan)
+    fs = int(rng.integers(600_000, 3_000_000)) if rng.random() < 0.4 else int(rng.integers(20_000, 400_000))
     fv = float(rng.choice([50.0, 60.0, 75.0]))
     sif = int(fs / fv)
     gathered = int(rng.integers(2 * sif + 8, 10 * sif))

@@ -40,6 +40,10 @@ def short(name):
         k = "k_frame_stats_store"
     if k == "k_ac_cols":  # one kernel template, two trips: <log2 N1, input mode, LAST>
         k += "_trip3" if re.search(r"k_ac_cols<[^>]*true>", name) else "_trip1"
+    if k == "k_sb_cols":  # the stitch's first trips: <log2 N1, 5> abs-diff of the hops (alignment), <log2 N1, 6> the rotated hops
+        k += "_absdiff" if re.search(r"k_sb_cols<\d+, 5>", name) else "_rotated"
+    if k == "k_sb_rows":
+        k += "_xcorr" if re.search(r"k_sb_rows<0>", name) else "_stitch"
     return k
 
 

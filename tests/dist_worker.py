@@ -59,7 +59,11 @@ def main():
     if kind != "plain":
         arg = ac.argmax()
         c = ac.certificate()
-        if not (c.frame_certified and c.line_certified):
+        # the ranks AGREE before any of them enters the replay's collective: the certificate also folds in the premise check of
+        # the rank's own newest window, which one rank alone may fail (bench.py's settle() does the same)
+        flag = torch.tensor([0 if (c.frame_certified and c.line_certified) else 1], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
             ac.promote()   # this rank's windows once more, in the reference's arithmetic (sums)
             exchange()     # the second exchange
             arg = ac.argmax()
