@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B build of libtsdrgpu.so: the same tree with extra flags for tsdrgpu_fft.hip (e.g. -DAC4_COLS_R4), into tempestsdr_amd/ab/<name>.so.
+# A/B build of libtsdrgpu.so: the same tree with extra flags for tsdrgpu_fft.hip (e.g. -DSOME_EXPERIMENT), into tempestsdr_amd/ab/<name>.so.
 # Use with TSDRGPU_LIB=tempestsdr_amd/ab/<name>.so (tempestsdr_amd/gpu.py).  usage: scripts/build_ab.sh <name> <flags...>
 set -e
 name=$1; shift

@@ -561,140 +561,10 @@ __device__ __forceinline__ void ac4_cols_body(const void *__restrict__ xb, float
         }
 }
 
-#if defined(AC4_COLS_R4)
-// (A/B build: round 4's kernel text, verbatim, for the autocorrelation's own three instantiations; -DAC4_COLS_R4)
-template <int LOGN1, int IN_MODE, bool LAST>
-__global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *__restrict__ xin, long long in_stride,
-                                                                float2 *__restrict__ y, unsigned nh, FftKeep keep)
-{
-    typedef ColGeom<LOGN1> G;
-    constexpr unsigned N1 = G::N1, C = G::C, NT = G::NT, Q = G::Q;
-    constexpr int R0 = G::R0, NP = G::NP, G0 = 16 / R0;
-    __shared__ float2 L[N1 * C];
-    // C == 16 (column lengths >= 256): the powers (w_nh^(col Q))^i, i < 16, of the workgroup's 16 columns are shared by
-    // the 32 threads of a column — one accurate evaluation each instead of four evaluations and eleven products per
-    // thread (rows padded to 17 entries: sixteen columns' reads hit sixteen different bank pairs).  The table sits behind
-    // twN[] in one array so that it costs no byte where it is not used (column length 2048 in tiles of 4 columns: two
-    // workgroups of 64 + 16 KiB fill a CU's LDS exactly).
-    constexpr bool PTAB = (C == 16u);
-    __shared__ float2 twtab[N1 + (PTAB ? 16u * 17u : 0u)];
-    float2 *const twN = twtab;
-    float2 *const ptw = twtab + N1;
-    const unsigned N2 = nh / N1;
-    const unsigned tid = threadIdx.x;
-    const unsigned c = tid % C, q = tid / C;
-    const unsigned b = blockIdx.y;
-    // consecutive tiles go to the same XCD (workgroups are dealt round-robin to the 8 XCDs): the IQ rows
-    // of a window start on 8-byte boundaries only, so neighbouring tiles share a cache line at each end
-    const unsigned gx = gridDim.x;
-    const unsigned tile = (gx % 8u == 0u) ? (blockIdx.x % 8u) * (gx / 8u) + blockIdx.x / 8u : blockIdx.x;
-    const unsigned col = tile * C + c;
-    for (unsigned e = tid; e < N1; e += NT) {
-        float sn, cs;
-        sincospif(-2.0f * (float)e / (float)N1, &sn, &cs);
-        twN[e] = make_float2(cs, sn);
-    }
-    if (PTAB && tid < 256u) {
-        const unsigned cc = tid >> 4, i = tid & 15u;
-        ptw[cc * 17u + i] = tw_exact((tile * C + cc) * Q * i, nh - 1u, -2.0f / (float)nh);
-    }
-    const void *xb;
-    bool al16 = false;
-    if (IN_MODE == 0) xb = (const void *)((const float2 *)xin + (long long)b * in_stride);
-    else if (IN_MODE == 3) xb = (const void *)((const float *)xin + (long long)b * in_stride);
-    else {
-        xb = (const void *)((const float2 *)xin + (long long)b * in_stride);
-        al16 = (((unsigned long long)xb) & 15ull) == 0ull;
-    }
-    float2 *yb = y + (long long)b * nh;
-
-    float2 v[16];
-    // ---- pass 0 (Ns = 1, radix R0): butterfly a of this thread is column point jb = q + Q*a
-#pragma unroll
-    for (int a = 0; a < G0; a++)
-#pragma unroll
-        for (int t = 0; t < R0; t++) {
-            const unsigned row = q + Q * (unsigned)a + (unsigned)t * (N1 / (unsigned)R0);
-            v[a * R0 + t] = ac4_load<IN_MODE>(xb, (long long)row * N2 + col, al16, nh, 0u);
-        }
-    // The twiddle between the column and the row transforms, w_nh^(k1 n2), lives here (trip 2 is the one
-    // short of VALU time): on trip 1's results and on trip 3's inputs the thread's 16 rows are q + Q i, so
-    // the factors are w^(n2 q) * (w^(n2 Q))^i: five accurate evaluations and products of depth <= 4.
-    if (LAST) {
-        float2 rtw[16];
-        if (PTAB) {
-            __syncthreads();  // ptw[] complete (the loads above are in flight meanwhile)
-            const float2 rbase = tw_exact(col * q, nh - 1u, -2.0f / (float)nh);
-            rtw[0] = rbase;
-#pragma unroll
-            for (int i = 1; i < 16; i++) rtw[i] = cmul(rbase, ptw[c * 17u + (unsigned)i]);
-        } else {
-            ac4_col_twiddles(rtw, col * Q, col * q, nh);
-        }
-#pragma unroll
-        for (int a = 0; a < G0; a++)
-#pragma unroll
-            for (int t = 0; t < R0; t++) v[a * R0 + t] = cmul(v[a * R0 + t], rtw[a + G0 * t]);
-    }
-#pragma unroll
-    for (int a = 0; a < G0; a++) dft_reg<R0>(*reinterpret_cast<float2(*)[R0]>(&v[a * R0]));
-
-    if (NP > 1) {
-#pragma unroll
-        for (int a = 0; a < G0; a++)
-#pragma unroll
-            for (int u = 0; u < R0; u++) L[((q + Q * (unsigned)a) * (unsigned)R0 + (unsigned)u) * C + c] = v[a * R0 + u];
-        __syncthreads();  // tile and twN[] complete
-        unsigned Ns = (unsigned)R0;
-#pragma unroll
-        for (int pass = 1; pass < NP; pass++) {
-#pragma unroll
-            for (int t = 0; t < 16; t++) v[t] = L[(q + (unsigned)t * Q) * C + c];
-            const unsigned k = q & (Ns - 1u);
-            const unsigned unit = N1 / (Ns * 16u);
-#pragma unroll
-            for (int t = 1; t < 16; t++) v[t] = cmul(v[t], twN[((unsigned)t * k * unit) & (N1 - 1u)]);
-            dft_reg<16>(v);
-            if (pass < NP - 1) {
-                __syncthreads();  // every read of this pass done before the tile is overwritten
-#pragma unroll
-                for (int u = 0; u < 16; u++) L[((q - k) * 16u + k + (unsigned)u * Ns) * C + c] = v[u];
-                __syncthreads();
-                Ns *= 16u;
-            }
-        }
-    }
-    // ---- store: the last pass has Ns*R = N1, so thread q holds rows q + u*(N1/16) (R0 outputs per
-    // butterfly when the only pass is pass 0)
-    constexpr int RL = (NP > 1) ? 16 : R0;  // radix of the last pass
-    constexpr int GL = 16 / RL;
-    float2 rtw[16];
-    if (!LAST) {
-        if (PTAB) {  // (NP > 1 here: the passes' barriers lie between the table's writes and these reads)
-            const float2 rbase = tw_exact(col * q, nh - 1u, -2.0f / (float)nh);
-            rtw[0] = rbase;
-#pragma unroll
-            for (int i = 1; i < 16; i++) rtw[i] = cmul(rbase, ptw[c * 17u + (unsigned)i]);
-        } else {
-            ac4_col_twiddles(rtw, col * Q, col * q, nh);
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < GL; a++)
-#pragma unroll
-        for (int u = 0; u < RL; u++) {
-            const unsigned row = q + Q * (unsigned)a + (unsigned)u * (N1 / (unsigned)RL);
-            const unsigned m = row * N2 + col;
-            float2 o = v[a * RL + u];
-            if (!LAST) o = cmul(o, rtw[a + GL * u]);
-            if (LAST) {
-                o.y = -o.y;
-                if (keep.on && (int)b != keep.full_b && !((m >= keep.lo0 && m < keep.hi0) || (m >= keep.lo1 && m < keep.hi1) || m == 0u)) continue;
-            }
-            yb[m] = o;
-        }
-}
-#else
+// (Until round 4 this kernel held the body itself.  The restructuring into ac4_cols_body changed its schedule — 102 registers
+// instead of 76, the loads further ahead — and a same-box A/B against the old text, kept behind a macro for that purpose and
+// removed since, measured the new form 1-2 % FASTER: 0.2387 / 0.2389 against 0.2414 / 0.2430 ms per pass for the two column
+// trips, profiles/round5_ab_runs.txt.)
 template <int LOGN1, int IN_MODE, bool LAST>
 __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *__restrict__ xin, long long in_stride,
                                                                 float2 *__restrict__ y, unsigned nh, FftKeep keep)
@@ -707,7 +577,6 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols(const void *_
     ac4_cols_body<LOGN1, IN_MODE, LAST, 0>(xb, y + (long long)b * nh, nh, keep, b, none);
 }
 
-#endif
 
 // trip 1 from interleaved IQ that also fills the retention ring (tsdrgpu_autocorr_set_certify mode 1): see AcColsAux.retain
 template <int LOGN1>

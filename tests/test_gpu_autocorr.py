@@ -244,7 +244,9 @@ def _stitch_hops(fs_like_sif, gathered, seed):
 # (gathered, samples_in_frame): hop length 2^17 with 2^16 correlated points; the same with all 2^17 correlated
 # (samples_in_frame divides the hop); hop length 2^18 / 2^17; and — BASELINE configs[2]'s rate, what bench.py times —
 # 10 frames of 100 MS/s: hops of 2^23 points (column length 2048), 2^22 correlated
-@pytest.mark.parametrize("gathered,sif", [(133_330, 13_333), (140_000, 8_192), (270_000, 27_000), (16_666_660, 1_666_666)])
+# (also: the plan's smallest shape, 2^16 / 2^16 = column length 16; and 2^20 / 2^19 = column lengths 256 / 128, radix-16 first pass)
+@pytest.mark.parametrize("gathered,sif", [(70_000, 4_096), (133_330, 13_333), (140_000, 8_192), (270_000, 27_000), (1_100_000, 110_000),
+                                          (16_666_660, 1_666_666)])
 def test_superb_stitch_three_trip_plan_vs_oracle(orc, gathered, sif):
     """tsdrgpu_superb_stitch on the three-trip plan (four hops of 2^16 .. 2^23 points: k_sb_cols / k_sb_rows / k_sb_cols_argmax /
     k_ac_cols) against the oracle's superb_ondataready (superbandwidth.c:83-152): hop offsets identical, the stitched signal
@@ -285,7 +287,7 @@ def test_superb_stitch_three_trip_plan_vs_oracle(orc, gathered, sif):
         assert ref_err <= 0.1 * tol and np.max(np.abs(got - want)) <= tol
     for d, h in zip(d_hops, hops):
         assert np.array_equal(d.download(), h)  # three-trip plan: the hops are inputs only
-    if gathered < 1_000_000:
+    if gathered < 1_000_000:  # (the pass-per-radix plan beside it: not timed here, so not at every size)
         g.superb_set_plan(0)
         try:
             d_out2 = g.empty(want.size)
