@@ -1,13 +1,13 @@
 #!/bin/bash
 # SQ counters for the bench kernels (instruction mix / stall picture).  Run through gpurun.
-# usage: pmc_sq.sh [out_dir_under_gpurun_out]
+# usage: pmc_sq.sh [out_dir_under_gpurun_out]      PMC_SQ_CMD="python scripts/exp_stitch_prof.py" profiles another workload (the stitch)
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/${1:-pmc_sq}
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES \
-   --output-format csv -d $OUT -o sq -- python $R/bench.py --steps 1 --warmup 1 --passes 4 --no-cpu-baseline --no-e2e --no-legs --serial --no-profile > $OUT/run.log 2>&1
+   --output-format csv -d $OUT -o sq -- ${PMC_SQ_CMD:-python $R/bench.py --steps 1 --warmup 1 --passes 4 --no-cpu-baseline --no-e2e --no-legs --serial --no-profile} > $OUT/run.log 2>&1
 cd $R
 python - <<PY
 import csv, glob, collections, re
