@@ -830,6 +830,9 @@ __global__ __launch_bounds__(256) void k_ac_expand(const float2 *__restrict__ zo
 // accummulate (frameratedetector.c:34-62) over a batch of windows, in window
 // order, so the running mean's f64 rounding matches the reference's recurrence.
 // ---------------------------------------------------------------------------
+// (Round 5 tried requesting all of a launch's windows' values before the sequential recurrence — on the theory that nine
+// load-wait-divide round trips are what its 12 us per launch of nine windows are: 13.1 us, no gain; the kernel is at what 36 MB in
+// 2 600 short workgroups behind a launch ramp cost.)
 __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ corr, unsigned n, int nwindows, int frame_lo,
                                                     int frame_len, int line_lo, int line_len, double *__restrict__ plots,
                                                     unsigned long long calls_before, int mode)
