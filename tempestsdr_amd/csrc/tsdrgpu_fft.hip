@@ -1174,7 +1174,11 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
     float2 *corr = nullptr;
     int last_count = 0;
     int parts = (nwindows + AC_SUBBATCH - 1) / AC_SUBBATCH;
-    if (parts < 2 && nwindows > 9) parts = 2;             // a pass of 17 short windows stays 9 + 8: one launch of 17 measured 7 % slower for the pass
+    // (A/B switch.  Re-measured in round 5 with the fused frame path, same box: 9 + 8 -> 91.8 / 92.0 GS/s, group 0.3926 / 0.3912 ms;
+    // one launch of 17 -> 92.4 / 91.9, 0.3898 / 0.3893 (rows 0.118 instead of 0.127 ms, columns 0.250 instead of 0.243);
+    // 6 + 6 + 5 -> 90.3, 0.403; 12 + 5 -> 91.9, 0.395: nothing to choose between 9 + 8 and 17, so 9 + 8 stays)
+    static const bool one_launch = [] { const char *e = getenv("TSDRGPU_AC_ONE_LAUNCH"); return e && e[0] == '1'; }();
+    if (parts < 2 && nwindows > 9 && !one_launch) parts = 2;  // a pass of 17 short windows stays 9 + 8: one launch of 17 measured 7 % slower for the pass
     const int per_part = (nwindows + parts - 1) / parts;  // equal sub-batches (17 -> 9,8)
     for (int w0 = 0; w0 < nwindows; w0 += per_part) {
         const int cnt = (nwindows - w0 < per_part) ? (nwindows - w0) : per_part;
