@@ -1458,12 +1458,15 @@ extern "C" int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t t
 // of this update fails — the caller promotes the epoch like for any other uncertified plot.  A plot is a mean over
 // windows of per-window values and R0 the same mean of the per-window lag-0 values, so the per-window bound carries over.
 // ---------------------------------------------------------------------------
+// (PREMISE_BLOCKS workgroups stride over the lags and each ends in ONE atomic: one 64-bit atomicMax per wave — 10 500 of them on a
+// single address for the 671 000 lags of a 100 MS/s detector — took 122 us, as long as the exact transform the check runs.)
+#define PREMISE_BLOCKS 256
 __global__ __launch_bounds__(256) void k_premise_diff(const float *__restrict__ fast, const float2 *__restrict__ exact, int frame_lo, int frame_len,
                                                       int line_lo, int line_len, unsigned long long *__restrict__ check)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double d = 0.0;
-    if (i <= frame_len + line_len) {
+    bool nan = false;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= frame_len + line_len; i += gridDim.x * blockDim.x) {
         const int lag = (i < frame_len) ? (frame_lo + i) : (i < frame_len + line_len ? line_lo + (i - frame_len) : 0);
         const float2 v = exact[lag];
         const double re = v.x, im = v.y;
@@ -1472,10 +1475,12 @@ __global__ __launch_bounds__(256) void k_premise_diff(const float *__restrict__ 
         if (i == frame_len + line_len) {
             check[1] = (unsigned long long)__double_as_longlong(want);  // lag 0: the scale of the bound, not one of the plots' lags
         } else {
-            d = fabs(got - want);
-            if (!(d == d)) d = __longlong_as_double(0x7ff8000000000000LL);  // NaN: larger than everything below, fails the bound
+            const double e = fabs(got - want);
+            if (!(e == e)) nan = true;
+            else d = e > d ? e : d;
         }
     }
+    if (nan) d = __longlong_as_double(0x7ff8000000000000LL);  // NaN: larger than everything below, fails the bound
     // non-negative doubles order like their bit patterns (NaN above infinity)
     unsigned long long bits = (unsigned long long)__double_as_longlong(d);
 #pragma unroll
@@ -1483,7 +1488,13 @@ __global__ __launch_bounds__(256) void k_premise_diff(const float *__restrict__ 
         const unsigned long long ob = __shfl_down(bits, o, 64);
         bits = ob > bits ? ob : bits;
     }
-    if ((threadIdx.x & 63) == 0 && bits) atomicMax(check, bits);
+    __shared__ unsigned long long wb[4];
+    if ((threadIdx.x & 63) == 0) wb[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) bits = wb[w] > bits ? wb[w] : bits;
+        if (bits) atomicMax(check, bits);
+    }
 }
 
 // queues the check behind the last run; 0 = not due / not possible, 1 = queued (d_check is valid behind it), < 0 error
@@ -1500,7 +1511,7 @@ static int ac_premise_check(tsdrgpu_autocorr_t *ac)
     if ((rc = fftx_correlate(g, ac->st, src, r.is_iq, r.stride, 1, ac->n, ac->d_tw, ac->d_xz, ac->d_xmag))) return rc;
     if (hipMemsetAsync(ac->d_check, 0, 2 * sizeof(unsigned long long), ac->st) != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_autocorr", "premise check");
     const int L = ac->frame_len + ac->line_len + 1;
-    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_premise_diff, (L + 255) / 256, 256, (const float *)ac->d_last, (const float2 *)ac->d_xz, ac->frame_lo, ac->frame_len,
+    TSDR_LAUNCH(g, PROF_ARGMAX, ac->st, k_premise_diff, ((L + 255) / 256 < PREMISE_BLOCKS ? (L + 255) / 256 : PREMISE_BLOCKS), 256, (const float *)ac->d_last, (const float2 *)ac->d_xz, ac->frame_lo, ac->frame_len,
                 ac->line_lo, ac->line_len, ac->d_check);
     if (hipGetLastError() != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_autocorr", "k_premise_diff");
     ac->since_check = 0;
