@@ -610,6 +610,11 @@ __global__ __launch_bounds__(ColGeom<LOGN1>::NT, 4) void k_ac_cols_retain(const 
 //                                   natural order
 //   = 3 trips over 4M points where the pass-per-radix plan made 4 x 3 + 4.
 // ---------------------------------------------------------------------------
+// (Measured and not kept: the alignment with the hops PAIRED — two real abs-diff signals per complex transform, the four spectra
+// out of the pairs Z[k], Z[bn - k] in a row-pair kernel like k_ac_rows; two column trips instead of four, N1/2 x (4 + 4) row
+// transforms instead of N1 x (4 + 2).  Offsets identical, but the first trip still reads all four hops (85 -> 68 us) and the row
+// kernel gains nothing (48 us either way, 128 registers + 80 bytes of scratch): 0.672 -> 0.665 ms per stitch.  Not worth a second
+// form of the row kernel.)
 struct SbHops {
     const void *p[4];
 };
