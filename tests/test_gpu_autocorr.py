@@ -298,6 +298,45 @@ def test_superb_stitch_three_trip_plan_vs_oracle(orc, gathered, sif):
         assert np.max(np.abs(d_out2.download() - want)) <= tol
 
 
+@pytest.mark.parametrize("kind", ["zeros", "constant_magnitude", "identical_hops", "impulse"])
+def test_superb_stitch_three_trip_degenerate_hops(orc, kind):
+    """The three-trip stitch where the alignment has nothing to hold on to: silent hops (every correlation is 0 everywhere: the
+    reference's scan keeps lag 0, superbandwidth.c:104-113), a carrier of constant magnitude (the abs-diff signal is its seed
+    element and rounding noise), four identical hops (offset 0), one impulse per hop (the correlation IS one point).  Offsets
+    identical to the oracle's, the signal within 1e-4 * max (or exactly 0)."""
+    g = ctx()
+    gathered, sif = 140_000, 8_192
+    rng = np.random.default_rng(11)
+    n = np.arange(gathered)
+    if kind == "zeros":
+        hops = [np.zeros(2 * gathered, np.float32) for _ in range(4)]
+    elif kind == "constant_magnitude":
+        hops = []
+        for k in range(4):
+            h = np.empty(2 * gathered, np.float32)
+            h[0::2] = (0.5 * np.cos(0.21 * n + k)).astype(np.float32)
+            h[1::2] = (0.5 * np.sin(0.21 * n + k)).astype(np.float32)
+            hops.append(h)
+    elif kind == "identical_hops":
+        one = rng.standard_normal(2 * gathered).astype(np.float32)
+        hops = [one.copy() for _ in range(4)]
+    else:
+        hops = []
+        for k in range(4):
+            h = np.zeros(2 * gathered, np.float32)
+            h[2 * (1000 + 777 * k)] = 1.0
+            hops.append(h)
+    want, offs = orc.superb_stitch(hops, sif)
+    d_hops = [g.to_device(h) for h in hops]
+    d_out = g.empty(want.size)
+    got_offs, total = g.superb_stitch(d_hops, gathered, sif, d_out)
+    assert 2 * total == want.size
+    assert np.array_equal(got_offs, offs), (kind, got_offs, offs)
+    got = d_out.download()
+    peak = np.max(np.abs(want))
+    assert np.max(np.abs(got - want)) <= 1e-4 * peak if peak > 0 else not got.any()
+
+
 def test_argmax_async_result(orc):
     """tsdrgpu_autocorr_argmax_async / _result == tsdrgpu_autocorr_argmax, with other work queued in between;
     one outstanding request per object."""

@@ -288,10 +288,15 @@ def simulate_superb(orc, iq, fs, fv, block_floats):
     return outs
 
 
-def test_superresolution_frames_match_oracle(orc, tmp_path):
+@pytest.mark.parametrize("stitch", ["exact", "fast"])
+def test_superresolution_frames_match_oracle(orc, tmp_path, monkeypatch, stitch):
     """a13/a14 end to end: the frames delivered in super-resolution mode against the oracle's stitch +
     demod + resample + post-process of the same hop data.  Tolerance: the stitched signal carries the
-    FFT tolerance (1e-4 of its maximum), so frames (0..1 after autogain) are compared to 2e-3."""
+    FFT tolerance (1e-4 of its maximum), so frames (0..1 after autogain) are compared to 2e-3.
+    exact: the library's default (tsdrgpu_superb_stitch_exact); fast: TSDR_GPU_EXACT_AUTOCORR=0 — the float32 stitch, which at
+    this rate (hops of 2^18 points, 2^17 correlated) is the three-trip plan."""
+    if stitch == "fast":
+        monkeypatch.setenv("TSDR_GPU_EXACT_AUTOCORR", "0")
     fs, h, fv = 2_000_000, 131, 60.0
     mode = (200, 131, 160, 120)
     block = 65536
