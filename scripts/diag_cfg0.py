@@ -35,3 +35,19 @@ for tag, lib, free in (("reference", reflib, False), ("mi355x", tsdrlib.LIB, Tru
         d = [float(np.mean(np.abs(fr[i] - w)[(np.abs(fr[i]) < 250) & (np.abs(w) < 250)])) for w in want]
         j = int(np.argmin(d))
         print("   frame", 10 + i, "nearest oracle frame", j, "mean |diff|", round(d[j], 6), "exact pixels", int(np.sum(fr[i] == want[j])), "of", P)
+
+# Does "the first n blocks were refused by the ring" (dsp_dropped_compensation_add's failure branch, dsp.c:338-345: every refused
+# block of 262 144 samples becomes a skip of block = round(2 S) = 266 667 samples) explain the reference's frames?
+ref_frames = np.load("/tmp/diag_cfg0_reference.npy")
+rk = {hash(f.tobytes()): i for i, f in enumerate(ref_frames)}
+block = int(round(((geo.width * h) << 1) * geo.pixeltimeoversampletime))
+for n in range(0, 13):
+    start = n * block
+    pix_n, _ = orc.demod_resample_stream(iq[2 * start:], geo)
+    pp_n = orc.PostProcess(geo)
+    hits = []
+    for k in range(min(40, pix_n.size // P)):
+        f = pp_n.run(pix_n[k * P:(k + 1) * P].copy(), 0.0)
+        hits.append(rk.get(hash(f.tobytes())))
+    found = [(k, v) for k, v in enumerate(hits) if v is not None]
+    print("skipped", n, "blocks of", block, "samples at the start ->", len(found), "of the driver's first 40 frames are frames the reference delivered", found[:3])
