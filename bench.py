@@ -219,10 +219,10 @@ def config0_leg():
     Frame comparison.  The yardstick is the DETERMINISTIC DRIVER: the reference's own functions called in order on the same
     samples with nothing dropped (what SURVEY 8(c) names as the reproducible form of the reference).  Measured on MI355X boxes:
     our library behind the reference's plugin delivers exactly the driver's frames — bit for bit, in order, none missing (its engine
-    loses no block at 8 MS/s) — while the reference's own threaded library delivers none of them: it loses blocks while its threads
-    start, compensates in units of block = round(2 S) samples (TSDRLibrary.c:283-284; 2 S = 266 666.67, block = 266 667) and so
-    moves the raster by a third of a sample per lost block: the same picture, every pixel a different blend of the recording's
-    noise (mean |difference| 0.03 at frame 10).  It does so consistently from run to run when the timing repeats (two reference
+    loses no block at 8 MS/s) — while the reference's own threaded library delivers none of them: the same picture, every pixel a
+    different blend of the recording's noise (mean |difference| 0.03 at frame 10).  The likely cause are its lossy rings: a block
+    a ring refuses becomes a skip of block = round(2 S) samples (dsp.c:338-345, TSDRLibrary.c:283-284; 2 S = 266 666.67,
+    block = 266 667), a third of a sample off the raster each.  It does so consistently from run to run when the timing repeats (two reference
     runs: up to 30 of 30 frames with a bit-identical twin; none on a loaded host).  All three numbers are in the leg."""
     from tempestsdr_amd import tsdrlib, synth
     import resource
@@ -285,10 +285,10 @@ def config0_leg():
                 "reference_vs_reference": {"frames": 30, "bit_identical_twin_found": twins_rr},
                 "how": "the deterministic driver = the reference's own functions called in order on the same samples with nothing dropped "
                        "(oracle/: am_demod, dsp_resample_process per chunk, dsp_post_process per frame); a delivered frame counts when its "
-                       "266 175 floats equal a driver frame's.  The reference's threaded library loses blocks while its threads start and "
-                       "skips in units of round(2 S) samples (TSDRLibrary.c:283-284), a third of a sample off the raster per block, so its "
-                       "frames are the driver's picture with every pixel a different blend of the recording's noise — consistently from run "
-                       "to run when the timing repeats (reference_vs_reference)"}
+                       "266 175 floats equal a driver frame's.  The reference's threaded library delivers the driver's picture with every pixel a "
+                       "different blend of the recording's noise (likely blocks its lossy rings refuse, each compensated by a skip of round(2 S) "
+                       "samples, a third of a sample off the raster: dsp.c:338-345, TSDRLibrary.c:283-284) — consistently from run to run when "
+                       "the timing repeats (reference_vs_reference)"}
         return {"workload": "BASELINE configs[0]: 8 MS/s float32 IQ, TSDRPlugin_RawFile (the reference's binary, real-time paced), 640x480@60 -> 507x525 frames",
                 "runs": runs, "frames": cmp_, "cores_on_box": os.cpu_count(),
                 "note": "both libraries behind the same plugin binary on the same 2 s recording; the plugin paces to real time, so both deliver "
