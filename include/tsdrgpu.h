@@ -493,8 +493,9 @@ int tsdrgpu_superb_set_plan(tsdrgpu_t *g, int trips);
  *                slot my_hop of *d_spectra, which is all-gathered in place (tsdrgpu_comm_allgather_f32, n floats per hop);
  *                the hop buffer is left holding the spectrum like the reference's
  *   _finish      the inverse transform of the concatenated spectra (on every rank that calls it) -> d_out
- * The kernels and their order are tsdrgpu_superb_stitch's, so offsets and the stitched signal are bit-identical to the
- * single-GPU call.  Measured worth: the exchanges (32 + 256 MB at 4 x 2^23 samples) cost more than
+ * The kernels and their order are those of tsdrgpu_superb_stitch's pass-per-radix plan (tsdrgpu_superb_set_plan(g, 0)), so
+ * offsets and the stitched signal are bit-identical to the single-GPU call on that plan; against its three-trip plan the
+ * offsets are identical and the signal agrees to rounding (within 1e-4 * max of the reference either way).  Measured worth: the exchanges (32 + 256 MB at 4 x 2^23 samples) cost more than
  * the 1.5 ms the whole stitch takes on one GPU — the form exists for hosts whose hops already live on different GPUs. */
 typedef struct tsdrgpu_superb_shard tsdrgpu_superb_shard_t;
 int tsdrgpu_superb_shard_create(tsdrgpu_t *g, tsdrgpu_superb_shard_t **out, int nhops, int my_hop, int gathered, int samples_in_frame);

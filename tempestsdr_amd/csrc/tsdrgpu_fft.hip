@@ -2105,8 +2105,10 @@ extern "C" int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nho
 // to hop 0 (abs-diff, cross-correlation, peak), rotates them, transforms every hop and inverse-transforms the
 // concatenated spectra.  All of it but two things is per hop: the reference spectrum of hop 0 (needed by everybody:
 // one broadcast of bn complex values) and the final transform (needs everybody's spectrum: one all-gather of
-// nhops * per complex values).  The phases below run the single-GPU call's kernels on this rank's hop, so offsets and
-// the stitched signal are bit-identical to tsdrgpu_superb_stitch; the exchanges are the caller's (tsdrgpu_comm_broadcast_f32
+// nhops * per complex values).  The phases below run the kernels of the single-GPU call's pass-per-radix plan
+// (tsdrgpu_superb_set_plan(g, 0); also what it takes below 2^16 points per hop) on this rank's hop, so offsets and the
+// stitched signal are bit-identical to that plan's; against the three-trip plan the offsets are identical and the signal
+// agrees to rounding.  The exchanges are the caller's (tsdrgpu_comm_broadcast_f32
 // / _allgather_f32 over RCCL), which is how the two-process tests run them through gloo on one device.
 // ---------------------------------------------------------------------------
 struct tsdrgpu_superb_shard {
