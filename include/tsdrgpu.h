@@ -496,7 +496,7 @@ int tsdrgpu_superb_set_plan(tsdrgpu_t *g, int trips);
  * The kernels and their order are those of tsdrgpu_superb_stitch's pass-per-radix plan (tsdrgpu_superb_set_plan(g, 0)), so
  * offsets and the stitched signal are bit-identical to the single-GPU call on that plan; against its three-trip plan the
  * offsets are identical and the signal agrees to rounding (within 1e-4 * max of the reference either way).  Measured worth: the exchanges (32 + 256 MB at 4 x 2^23 samples) cost more than
- * the 1.5 ms the whole stitch takes on one GPU — the form exists for hosts whose hops already live on different GPUs. */
+ * the 0.65 ms the whole stitch takes on one GPU (three-trip plan; 1.25 ms on the plan the shards run) — the form exists for hosts whose hops already live on different GPUs. */
 typedef struct tsdrgpu_superb_shard tsdrgpu_superb_shard_t;
 int tsdrgpu_superb_shard_create(tsdrgpu_t *g, tsdrgpu_superb_shard_t **out, int nhops, int my_hop, int gathered, int samples_in_frame);
 void tsdrgpu_superb_shard_destroy(tsdrgpu_superb_shard_t *sh);
