@@ -77,6 +77,7 @@ def build(force=False, verbose=True):
     if force or _newer(mem_so, [mem_src] + _headers()):
         subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", mem_so, mem_src], check=True)
     build_checks(force=force, verbose=verbose)
+    build_host_stress(force=force)
     return LIB
 
 
@@ -102,6 +103,20 @@ def build_checks(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("compile failed: " + " ".join(cmd))
+
+
+def build_host_stress(force=False):
+    """tests/sanitize/host_stress_*: the host library's C files compiled WITH their stress driver, plain and under
+    ThreadSanitizer / AddressSanitizer (scripts/build_sanitized.sh).  Test infrastructure; built here so that the GPU box finds
+    the plain variant (tests/test_gpu_host_pipeline.py::test_host_stress_on_the_device) like it finds the libraries."""
+    san = os.path.join(ROOT, "tests", "sanitize")
+    script = os.path.join(ROOT, "scripts", "build_sanitized.sh")
+    if not os.path.exists(script):
+        return
+    host = os.path.join(CSRC, "host")
+    srcs = [os.path.join(san, "host_stress.c"), os.path.join(san, "stub_tsdrgpu.c"), script] + [os.path.join(host, f) for f in os.listdir(host)] + _headers()
+    if force or any(_newer(os.path.join(san, exe), srcs) for exe in ("host_stress_plain", "host_stress_tsan_stub", "host_stress_asan_stub")):
+        subprocess.run(["bash", script], check=True, capture_output=True)
 
 
 if __name__ == "__main__":

@@ -120,7 +120,7 @@ struct engine {
     tsdrgpu_event_t *det_read; /* the detector's lane (when it has its own) is done reading the detector's sample stream */
     int det_read_valid;
     int ac_certified;          /* the detector runs in its certified mode (default): plots leave only with a certificate */
-    volatile int det_promote;  /* plot thread -> device thread: the last plot's argmax was not certified, replay the epoch exactly */
+    int det_promote;  /* (A_LD / A_ST) plot thread -> device thread: the last plot's argmax was not certified, replay the epoch exactly */
     int det_replaying;         /* an epoch is being replayed in the reference's arithmetic, DET_REPLAY_STEP windows per turn */
     long n_promotions, n_plots_held;
 
@@ -141,8 +141,8 @@ struct engine {
     int copy_thread_on;
     pthread_mutex_t cm;
     pthread_cond_t c_wake;
-    volatile int copy_state; /* 0 idle, 1 job posted, 2 done */
-    volatile int copy_quit;
+    int copy_state; /* 0 idle, 1 job posted, 2 done (atomic) */
+    int copy_quit;  /* (atomic) */
     void *copy_dst; const void *copy_src; size_t copy_n;
     /* per-frame min/max out of the resampler (frame tracking) for the frames that wait in the pixel stream: what the
      * fused run needs instead of a statistics read of its own */
@@ -185,8 +185,8 @@ struct engine {
     pthread_mutex_t pm;
     pthread_cond_t p_nonempty;
 
-    volatile int alive; /* delivery threads keep going */
-    volatile int failed; /* a device call failed: the session is being torn down (gpu_ok) */
+    int alive;  /* delivery threads keep going (A_LD / A_ST) */
+    int failed; /* (atomic) a device call failed: the session is being torn down (gpu_ok) */
     char fail_msg[400];
 
     /* TSDR_GPU_STATS=1: where the host threads spend their time (printed to stderr when the run ends) */
@@ -210,6 +210,9 @@ struct engine {
 };
 
 /* ---- small helpers ----------------------------------------------------------- */
+/* the counters tsdrx_get_stats may read while their one writer counts (a snapshot, not a barrier): relaxed atomics */
+#define STAT_ADD(x, n) ((void)__atomic_fetch_add(&(x), (n), __ATOMIC_RELAXED))
+#define STAT_GET(x) __atomic_load_n(&(x), __ATOMIC_RELAXED)
 /* Contract-exact modes are the default; `name`=0 (or TSDR_GPU_EXACT=0 for all of them) switches one off. */
 static int exact_wanted(const char *name)
 {
@@ -226,10 +229,10 @@ static __thread int in_plugin_callback; /* this thread is inside on_block_any */
 static int gpu_ok(struct engine *e, int rc, const char *what)
 {
     if (rc == 0) return 1;
-    if (!__sync_lock_test_and_set(&e->failed, 1)) {
+    if (!__atomic_exchange_n(&e->failed, 1, __ATOMIC_ACQ_REL)) {
         snprintf(e->fail_msg, sizeof(e->fail_msg), "GPU stage '%s' failed (%d): %s", what, rc, tsdrgpu_last_error(e->g));
         fprintf(stderr, "tsdr: %s\n", e->fail_msg);
-        e->t->running = 0;
+        A_ST(e->t->running, 0);
         /* On the plugin's own thread — inside its readasync callback — the plugin is NOT told to stop from here: a plugin
          * whose tsdrplugin_stop waits for its streaming thread would wait for itself.  The device thread sees running == 0
          * within its 30 ms poll and makes the call (device_thread's last lines).  From any other thread the call is made at
@@ -371,10 +374,10 @@ static void *copy_thread(void *arg)
             last = now_s();
             continue;
         }
-        if (e->copy_quit) break;
+        if (A_LD(e->copy_quit)) break;
         if (now_s() - last < 300e-6) { cpu_relax(); continue; }
         pthread_mutex_lock(&e->cm);
-        while (e->copy_state != 1 && !e->copy_quit) pthread_cond_wait(&e->c_wake, &e->cm);
+        while (A_LD(e->copy_state) != 1 && !A_LD(e->copy_quit)) pthread_cond_wait(&e->c_wake, &e->cm);
         pthread_mutex_unlock(&e->cm);
     }
     return NULL;
@@ -402,7 +405,7 @@ static void on_block_inner(const void *buf, uint64_t items, int type, struct eng
 static void on_block_any(const void *buf, uint64_t items, int type, void *ctx, int64_t dropped)
 {
     struct engine *e = (struct engine *)ctx;
-    if (!e->t->running || (items & 1)) return;
+    if (!A_LD(e->t->running) || (items & 1)) return;
     if (!e->plugin_thread_bound) { tsdrgpu_bind_thread(e->g); e->plugin_thread_bound = 1; }
     in_plugin_callback = 1;
     on_block_inner(buf, items, type, e, dropped);
@@ -416,13 +419,13 @@ static void on_block_inner(const void *buf, uint64_t items, int type, struct eng
      * no longer wait for comes here tens of millions of times per second, and a plugin thread spinning on the mutex starved
      * the device thread of it (measured: 95 % of the device thread's time went into getting it).  Only this thread raises
      * q_count, so a queue seen full here can only have become emptier; pending_drop and n_blocks_lost are this thread's own. */
-    if (*(volatile int *)&e->q_count == NSLOT) {
+    if (A_LD(e->q_count) == NSLOT) {
         e->pending_drop += (int64_t)(items / 2) + dropped;
-        e->n_blocks_lost++;
+        STAT_ADD(e->n_blocks_lost, 1);
         return;
     }
     pthread_mutex_lock(&e->qm);
-    in_slot_t *s = &e->slot[(e->q_head + e->q_count) % NSLOT]; /* only this thread produces: the slot stays ours */
+    in_slot_t *s = &e->slot[(e->q_head + A_LD(e->q_count)) % NSLOT]; /* only this thread produces: the slot stays ours */
     pthread_mutex_unlock(&e->qm);
     int ok = 1;
     if (items) {
@@ -487,8 +490,8 @@ static void on_block_inner(const void *buf, uint64_t items, int type, struct eng
     s->nfloats = items;
     s->dropped = dropped + e->pending_drop;
     e->pending_drop = 0;
-    e->q_count++;
-    e->n_blocks++;
+    __atomic_fetch_add(&e->q_count, 1, __ATOMIC_RELEASE);
+    STAT_ADD(e->n_blocks, 1);
     pthread_cond_signal(&e->q_nonempty);
     pthread_mutex_unlock(&e->qm);
     if (e->stats) e->s_plugin_busy += now_s() - t0;
@@ -512,7 +515,7 @@ static void *video_thread(void *arg)
     tsdr_lib_t *t = e->t;
     tsdrgpu_bind_thread(e->g);
     pthread_mutex_lock(&e->fm);
-    while (e->alive || e->fq_count) {
+    while (A_LD(e->alive) || e->fq_count) {
         if (!e->fq_issued) {
             struct timespec ts;
             deadline_ms(&ts, 30);
@@ -524,7 +527,7 @@ static void *video_thread(void *arg)
         const double t0 = e->stats ? now_s() : 0.0;
         const int arrived = tsdrgpu_event_sync(e->g, f->ready) == 0;
         const double t1 = e->stats ? now_s() : 0.0;
-        if (arrived && t->running) {
+        if (arrived && A_LD(t->running)) {
             /* dsp.c:231-235: autogain values every 7th frame */
             if (f->announce_autogain) tsdr_announce_value(t, VALUE_ID_AUTOGAIN_VALUES, f->h_info->lastmin, f->h_info->lastmax);
             if (t->rgb_cb) t->rgb_cb((int32_t *)(void *)f->h, f->width, f->height, e->cbctx);
@@ -551,7 +554,7 @@ static void *download_thread(void *arg)
     struct engine *e = (struct engine *)arg;
     tsdrgpu_bind_thread(e->g);
     pthread_mutex_lock(&e->fm);
-    while (e->alive || e->fq_issued < e->fq_count) {
+    while (A_LD(e->alive) || e->fq_issued < e->fq_count) {
         if (e->fq_issued == e->fq_count) {
             struct timespec ts;
             deadline_ms(&ts, 30);
@@ -584,7 +587,7 @@ static void *plot_thread(void *arg)
     tsdr_lib_t *t = e->t;
     tsdrgpu_bind_thread(e->g);
     pthread_mutex_lock(&e->pm);
-    while (e->alive) {
+    while (A_LD(e->alive)) {
         if (!e->plot_pending && !e->plot_reset_announce && !e->plot_dumped_announce) {
             struct timespec ts;
             deadline_ms(&ts, 30);
@@ -610,8 +613,8 @@ static void *plot_thread(void *arg)
             if (!got) deliver = 0; /* no certificate, no delivery */
             else if (deliver && !(c.frame_certified && c.line_certified)) {
                 deliver = 0;
-                e->n_plots_held++;
-                e->det_promote = 1;
+                STAT_ADD(e->n_plots_held, 1);
+                A_ST(e->det_promote, 1);
             }
         }
         if (deliver &&
@@ -619,7 +622,7 @@ static void *plot_thread(void *arg)
             tsdrgpu_download_lane(e->g, e->plot.h_line, e->plot.d_snapshot + e->plot.flen, sizeof(double) * (size_t)e->plot.llen) == 0 &&
             tsdrgpu_event_record(e->g, e->plot_home, TSDRGPU_LANE_DOWNLOAD) == 0 && tsdrgpu_event_sync(e->g, e->plot_home) == 0) {
             const plot_msg_t *m = &e->plot;
-            tsdr_on_plot_ready_callback pcb = t->plotready_callback;
+            tsdr_on_plot_ready_callback pcb = A_LD(t->plotready_callback);
             if (pcb) { /* frameratedetector.c:121-124 */
                 pcb(PLOT_ID_FRAME, m->flo, m->h_frame, m->flen, m->rate, t->callbackctx);
                 pcb(PLOT_ID_LINE, m->llo, m->h_line, m->llen, m->rate, t->callbackctx);
@@ -661,7 +664,7 @@ static void detector_rebuild(struct engine *e, uint32_t fs)
 {
     /* the plot thread may still be copying the old detector's snapshot home */
     pthread_mutex_lock(&e->pm);
-    while (e->plot_pending && e->alive) {
+    while (e->plot_pending && A_LD(e->alive)) {
         pthread_mutex_unlock(&e->pm);
         struct timespec ts = {0, 1000000};
         nanosleep(&ts, NULL);
@@ -698,7 +701,7 @@ static void detector_rebuild(struct engine *e, uint32_t fs)
             else (void)tsdrgpu_autocorr_set_exact(e->ac, 1); /* no room for the ring: the exact form needs none */
         }
     }
-    e->det_promote = 0;
+    A_ST(e->det_promote, 0);
     e->det_replaying = 0;
     /* The detector's transforms run in line on the COMPUTE lane.  On its own (BACKGROUND) lane they would overlap the
      * frame path, but every window then needs two device-side waits between the lanes, and a barrier packet parked in
@@ -724,7 +727,7 @@ static void detector_rebuild(struct engine *e, uint32_t fs)
     }
     /* swap the message inside the critical section, once the host is done with the previous plots */
     pthread_mutex_lock(&e->pm);
-    while (e->plot_pending && e->alive) {
+    while (e->plot_pending && A_LD(e->alive)) {
         pthread_mutex_unlock(&e->pm);
         struct timespec ts = {0, 1000000};
         nanosleep(&ts, NULL);
@@ -769,23 +772,23 @@ static void publish_plot(struct engine *e)
 static void run_detector(struct engine *e, uint32_t fs)
 {
     tsdr_lib_t *t = e->t;
-    if (t->params_int[PARAM_AUTOCORR_PLOTS_OFF] || e->iq_is_mag) { e->det.rd = e->det.wr = 0; return; } /* nothing is fed in super mode */
+    if (A_LD(t->params_int[PARAM_AUTOCORR_PLOTS_OFF]) || e->iq_is_mag) { e->det.rd = e->det.wr = 0; return; } /* nothing is fed in super mode */
     if (fs == e->ac_failed_rate) { e->det.rd = e->det.wr = 0; return; } /* no detector exists for this rate */
     if (!e->ac || e->ac_rate != fs) {
         detector_rebuild(e, fs);
         if (!e->ac) { e->det.rd = e->det.wr = 0; return; }
     }
     const uint32_t capture = e->ac_capture;
-    if (e->det_promote && !e->det_replaying) { /* the plot thread held a plot back: its epoch once more, in the reference's arithmetic */
+    if (A_LD(e->det_promote) && !e->det_replaying) { /* the plot thread held a plot back: its epoch once more, in the reference's arithmetic */
         pthread_mutex_lock(&e->pm);
         const int busy = e->plot_pending; /* (the plot thread clears it right after raising the request) */
         pthread_mutex_unlock(&e->pm);
         if (!busy) {
-            e->det_promote = 0;
+            A_ST(e->det_promote, 0);
             e->det_replaying = 1;
         }
     }
-    if (e->det_replaying && !t->detector_purge && !t->params_int[PARAM_AUTOCORR_PLOTS_RESET]) {
+    if (e->det_replaying && !A_LD(t->detector_purge) && !A_LD(t->params_int[PARAM_AUTOCORR_PLOTS_RESET])) {
         /* DET_REPLAY_STEP windows per device-thread turn, the frame path's launches in between; the capture windows that
          * arrive meanwhile are skipped, like the reference's detector thread skips what arrives while it is busy
          * (frameratedetector.c:128-187).  (A pending reset cancels the replay: the loop below sees to it.) */
@@ -794,21 +797,20 @@ static void run_detector(struct engine *e, uint32_t fs)
         e->det.rd += ((e->det.wr - e->det.rd) / 2 / capture) * (size_t)capture * 2;
         if (remaining > 0) return;
         e->det_replaying = 0;
-        e->n_promotions++;
+        STAT_ADD(e->n_promotions, 1);
         publish_plot(e);
     }
-    while ((e->det.wr - e->det.rd) / 2 >= capture && t->running) {
-        if (t->detector_purge) { /* frameratedetector.c:171-176 */
-            t->detector_purge = 0;
+    while ((e->det.wr - e->det.rd) / 2 >= capture && A_LD(t->running)) {
+        if (A_LD(t->detector_purge)) { /* frameratedetector.c:171-176 */
+            A_ST(t->detector_purge, 0);
             tsdrgpu_autocorr_reset(e->ac);
-            e->det_promote = 0;
+            A_ST(e->det_promote, 0);
             e->det_replaying = 0;
         }
-        if (t->params_int[PARAM_AUTOCORR_PLOTS_RESET]) { /* frameratedetector.c:97-104 */
-            const uint32_t orig = t->params_int[PARAM_AUTOCORR_PLOTS_RESET];
-            t->params_int[PARAM_AUTOCORR_PLOTS_RESET] = 0;
+        if (A_LD(t->params_int[PARAM_AUTOCORR_PLOTS_RESET])) { /* frameratedetector.c:97-104 */
+            const uint32_t orig = __atomic_exchange_n(&t->params_int[PARAM_AUTOCORR_PLOTS_RESET], 0, __ATOMIC_ACQ_REL);
             tsdrgpu_autocorr_reset(e->ac);
-            e->det_promote = 0;
+            A_ST(e->det_promote, 0);
             e->det_replaying = 0;
             if (orig == 1) {
                 pthread_mutex_lock(&e->pm);
@@ -826,14 +828,14 @@ static void run_detector(struct engine *e, uint32_t fs)
         if (e->det_replaying) return; /* (the next turn starts stepping, above) */
         if (!gpu_ok(e, tsdrgpu_autocorr_run(e->ac, e->det.d + e->det.rd, 1, capture, 1, 0), "autocorr")) return;
         e->det.rd += (size_t)capture * 2;
-        e->n_windows++;
+        STAT_ADD(e->n_windows, 1);
         /* the window is read on the detector's lane; the COMPUTE lane must not recycle that memory before (process_block) */
         if (tsdrgpu_autocorr_lane(e->ac) != TSDRGPU_LANE_COMPUTE) { /* (in line, the lane's own order does it) */
             if (tsdrgpu_event_record(e->g, e->det_read, tsdrgpu_autocorr_lane(e->ac)) == 0) e->det_read_valid = 1;
             else tsdrgpu_sync(e->g);
         }
-        if (t->params_int[PARAM_AUTOCORR_DUMP]) {
-            t->params_int[PARAM_AUTOCORR_DUMP] = 0;
+        if (A_LD(t->params_int[PARAM_AUTOCORR_DUMP])) {
+            A_ST(t->params_int[PARAM_AUTOCORR_DUMP], 0);
             dump_autocorr(e);
             pthread_mutex_lock(&e->pm);
             e->plot_dumped_announce = 1;
@@ -853,11 +855,11 @@ static void deliver_frames(struct engine *e, out_buf_t *ob, int F, int W, int H)
     for (int f = 0; f < F; f++) {
         const int announce = e->pp_runs++ > AUTOGAIN_REPORT_EVERY_FRAMES;
         if (announce) e->pp_runs = 0;
-        e->n_frames_made++;
+        STAT_ADD(e->n_frames_made, 1);
         pthread_mutex_lock(&e->fm);
         if (e->fq_count == NFRAMEQ) {
             pthread_mutex_unlock(&e->fm);
-            e->n_frames_lost++;
+            STAT_ADD(e->n_frames_lost, 1);
             continue;
         }
         frame_slot_t *s = &e->fq[(e->fq_head + e->fq_count) % NFRAMEQ]; /* free: only this thread produces */
@@ -893,9 +895,10 @@ static int fused_wanted(const tsdrgpu_pp_params_t *p)
 static void run_frames(struct engine *e)
 {
     tsdr_lib_t *t = e->t;
-    while (t->running) {
+    while (A_LD(t->running)) {
         pthread_mutex_lock(&t->lock);
         const int W = t->width, H = t->height;
+        const float blur = t->motionblur;
         pthread_mutex_unlock(&t->lock);
         if (W <= 0 || H <= 0) return;
         const size_t P = (size_t)W * H;
@@ -904,12 +907,12 @@ static void run_frames(struct engine *e)
         int F = (int)(avail / P);
         if (F > MAX_FRAME_BATCH) F = MAX_FRAME_BATCH;
         tsdrgpu_pp_params_t prm;
-        prm.lowpass_before_sync = (int)t->params_int[PARAM_LOW_PASS_BEFORE_SYNC];
-        prm.autogain_after_proc = (int)t->params_int[PARAM_AUTOGAIN_AFTER_PROCESSING];
-        prm.autoshift = (int)t->params_int[PARAM_INT_AUTOSHIFT];
-        prm.pll = (int)t->params_int[PARAM_INT_FRAMERATE_PLL];
-        prm.superresolution = (int)t->params_int[PARAM_AUTOCORR_SUPERRESOLUTION];
-        prm.motionblur = t->motionblur;
+        prm.lowpass_before_sync = (int)A_LD(t->params_int[PARAM_LOW_PASS_BEFORE_SYNC]);
+        prm.autogain_after_proc = (int)A_LD(t->params_int[PARAM_AUTOGAIN_AFTER_PROCESSING]);
+        prm.autoshift = (int)A_LD(t->params_int[PARAM_INT_AUTOSHIFT]);
+        prm.pll = (int)A_LD(t->params_int[PARAM_INT_FRAMERATE_PLL]);
+        prm.superresolution = (int)A_LD(t->params_int[PARAM_AUTOCORR_SUPERRESOLUTION]);
+        prm.motionblur = blur;
         prm.lowpasscoeff = NORMALISATION_LOWPASS_COEFF;
         if (prm.pll) F = 1; /* the PLL's nudge feeds back into the geometry between frames */
         if (e->mm_nohead > 0 && F > e->mm_nohead) F = e->mm_nohead; /* frames from before the tracking started go on their own */
@@ -918,7 +921,7 @@ static void run_frames(struct engine *e)
         if (ob->busy) { /* its frames have left the device? */
             const double t0 = e->stats ? now_s() : 0.0;
             pthread_mutex_lock(&e->fm);
-            while (ob->pending && e->alive) {
+            while (ob->pending && A_LD(e->alive)) {
                 struct timespec ts;
                 deadline_ms(&ts, 30);
                 pthread_cond_timedwait(&e->f_queued, &e->fm, &ts);
@@ -955,7 +958,7 @@ static void run_frames(struct engine *e)
                 !gpu_ok(e, tsdrgpu_postproc_finish(e->pp, ob->d, NULL), "postproc (fused)"))
                 return;
             e->n_fused_batches++;
-            e->n_fused_frames += F;
+            STAT_ADD(e->n_fused_frames, F);
         } else if (!gpu_ok(e, tsdrgpu_postproc_run(e->pp, e->pix.d + e->pix.rd, F, W, H, &prm, ob->d, prm.pll ? &info : NULL), "postproc")) return;
         if (t->rgb_cb) {
             /* the JNI shim's pixel loop (TSDRLibraryNDK.c:222-276) on the device: frame after frame into the viewer's
@@ -1030,9 +1033,9 @@ static void run_resampler(struct engine *e)
         int nchunks = (int)(have / (size_t)chunk);
         if (nchunks <= 0) break;
         /* while pixels are being skipped or a manual shift is pending go chunk by chunk like the reference */
-        if (e->pix_difference != 0 || t->syncoffset != 0) nchunks = 1;
+        if (e->pix_difference != 0 || A_LD(t->syncoffset) != 0) nchunks = 1;
         else if (nchunks > MAX_CHUNKS_PER_CALL) nchunks = MAX_CHUNKS_PER_CALL;
-        if (nchunks > 1 && t->params_int[PARAM_INT_FRAMERATE_PLL]) {
+        if (nchunks > 1 && A_LD(t->params_int[PARAM_INT_FRAMERATE_PLL])) {
             /* PLL on: a frame completed by a chunk may nudge the refresh rate, which the NEXT chunk's ratio must already
              * see (TSDRLibrary.c:335-340 re-reads the geometry per chunk) — so one call takes the chunks up to and
              * including the one that completes the frame being filled, no further */
@@ -1048,16 +1051,16 @@ static void run_resampler(struct engine *e)
         const int64_t count = tsdrgpu_resample_count(e->rs, (uint32_t)chunk, nchunks, up, down);
         if (count < 0) return;
         e->n_resample_calls++;
-        const int nearest = (int)t->params_int[PARAM_NEAREST_NEIGHBOUR_RESAMPLING];
+        const int nearest = (int)A_LD(t->params_int[PARAM_NEAREST_NEIGHBOUR_RESAMPLING]);
         int64_t n = 0;
         if (e->pix_difference == 0) {
             /* the usual case: straight into the pixel stream */
             if (!stream_reserve(e, &e->pix, (size_t)count)) return;
             /* frame tracking for the fused run: on while whole batches can use it (area mode, default stage order, frames
              * of >= 4096 pixels), restarted whenever the frame grid of the pixel stream moved */
-            const int want_track = !nearest && totalpixels >= 4096 && !t->params_int[PARAM_LOW_PASS_BEFORE_SYNC] &&
-                                   !t->params_int[PARAM_AUTOGAIN_AFTER_PROCESSING] && !t->params_int[PARAM_INT_AUTOSHIFT] &&
-                                   !t->params_int[PARAM_INT_FRAMERATE_PLL] && e->d_mm_min != NULL;
+            const int want_track = !nearest && totalpixels >= 4096 && !A_LD(t->params_int[PARAM_LOW_PASS_BEFORE_SYNC]) &&
+                                   !A_LD(t->params_int[PARAM_AUTOGAIN_AFTER_PROCESSING]) && !A_LD(t->params_int[PARAM_INT_AUTOSHIFT]) &&
+                                   !A_LD(t->params_int[PARAM_INT_FRAMERATE_PLL]) && e->d_mm_min != NULL;
             if (!want_track) track_off(e);
             else if (e->track_P != (int64_t)totalpixels) {
                 const size_t live = e->pix.wr - e->pix.rd;
@@ -1106,8 +1109,7 @@ static void run_resampler(struct engine *e)
         }
         e->iq.rd += (size_t)nchunks * chunk * per;
         /* manual sync, TSDRLibrary.c:345-346 */
-        const int so = t->syncoffset;
-        t->syncoffset = 0;
+        const int so = __atomic_exchange_n(&t->syncoffset, 0, __ATOMIC_ACQ_REL); /* (tsdr_sync adds to it atomically: no shift is lost) */
         e->pix_difference = drop_shift_with(e->pix_difference, (uint32_t)totalpixels, -(int64_t)so);
         const double tf = e->stats ? now_s() : 0.0;
         run_frames(e);
@@ -1129,11 +1131,14 @@ static int super_feed(struct engine *e, const float *d_blk, size_t nfloats, int6
     if (e->super_state == SUPER_STARTING) {
         e->super_hop = 0;
         e->super_gathered = 0;
-        if (t->samplerate_real != e->super_rate || !e->d_hops[0]) {
-            e->super_rate = t->samplerate_real;
-            e->super_frame = (int)(t->samplerate_real / t->refreshrate);
+        if (A_LD(t->samplerate_real) != e->super_rate || !e->d_hops[0]) {
+            e->super_rate = A_LD(t->samplerate_real);
+            pthread_mutex_lock(&t->lock);
+            const double refresh = t->refreshrate;
+            pthread_mutex_unlock(&t->lock);
+            e->super_frame = (int)(e->super_rate / refresh);
             e->super_to_gather = SUPER_FRAMES_TO_RECORD * e->super_frame;
-            e->super_to_pause = (int)(SUPER_SECS_TO_PAUSE * t->samplerate_real);
+            e->super_to_pause = (int)(SUPER_SECS_TO_PAUSE * e->super_rate);
             tsdrgpu_sync(e->g);
             for (int i = 0; i < SUPER_HOPS; i++) {
                 tsdrgpu_free(e->g, e->d_hops[i]);
@@ -1183,7 +1188,7 @@ static int super_feed(struct engine *e, const float *d_blk, size_t nfloats, int6
                 return 1;
             }
             /* retune for the next hop, superbandwidth.c:241 */
-            if (t->plugin.loaded) t->plugin.setbasefreq(t->centfreq + (uint32_t)((e->super_hop - SUPER_HOPS / 2) * (int64_t)e->super_rate));
+            if (t->plugin.loaded) t->plugin.setbasefreq(A_LD(t->centfreq) + (uint32_t)((e->super_hop - SUPER_HOPS / 2) * (int64_t)e->super_rate));
             e->super_state = SUPER_PAUSE;
         }
     }
@@ -1211,7 +1216,7 @@ static void process_block(struct engine *e, in_slot_t *slot)
     const int64_t dropped = slot->dropped;
     const size_t size2 = nfloats / 2;
 
-    if (t->params_int[PARAM_AUTOCORR_SUPERRESOLUTION]) { /* TSDRLibrary.c:271-279 */
+    if (A_LD(t->params_int[PARAM_AUTOCORR_SUPERRESOLUTION])) { /* TSDRLibrary.c:271-279 */
         gather_flush(e);
         if (!e->iq_is_mag) { e->iq.rd = e->iq.wr = 0; e->det.rd = e->det.wr = 0; e->iq_is_mag = 1; }
         uint32_t total = 0;
@@ -1224,9 +1229,9 @@ static void process_block(struct engine *e, in_slot_t *slot)
         if (e->iq_is_mag || e->super_state != SUPER_STOPPED) { /* superb_stop, superbandwidth.c:256-264 */
             gather_flush(e);
             super_reset(e);
-            if (t->plugin.loaded) t->plugin.setbasefreq(t->centfreq);
+            if (t->plugin.loaded) t->plugin.setbasefreq(A_LD(t->centfreq));
             pthread_mutex_lock(&t->lock);
-            tsdr_geometry_update(t, t->samplerate_real);
+            tsdr_geometry_update(t, A_LD(t->samplerate_real));
             pthread_mutex_unlock(&t->lock);
             e->iq.rd = e->iq.wr = 0; e->det.rd = e->det.wr = 0; e->iq_is_mag = 0;
         }
@@ -1235,7 +1240,7 @@ static void process_block(struct engine *e, in_slot_t *slot)
         pthread_mutex_unlock(&t->lock);
         e->dev_difference = drop_shift_with(e->dev_difference, (uint32_t)block, dropped);
         const int drop_all = (int64_t)size2 <= e->dev_difference;
-        const int plots_on = !t->params_int[PARAM_AUTOCORR_PLOTS_OFF];
+        const int plots_on = !A_LD(t->params_int[PARAM_AUTOCORR_PLOTS_OFF]);
         /* frameratedetector_run, frameratedetector.c:215-230 */
         if (plots_on && e->det_read_valid) { /* appends may compact the stream into memory an earlier window still occupies */
             tsdrgpu_lane_wait(e->g, TSDRGPU_LANE_COMPUTE, e->det_read);
@@ -1269,9 +1274,9 @@ static void *device_thread(void *arg)
     struct engine *e = (struct engine *)arg;
     tsdr_lib_t *t = e->t;
     tsdrgpu_bind_thread(e->g);
-    while (t->running) {
+    while (A_LD(t->running)) {
         pthread_mutex_lock(&e->qm);
-        if (!e->q_count) {
+        if (!A_LD(e->q_count)) {
             struct timespec ts;
             deadline_ms(&ts, 30);
             pthread_cond_timedwait(&e->q_nonempty, &e->qm, &ts);
@@ -1282,7 +1287,8 @@ static void *device_thread(void *arg)
          * the frame path below then work on several blocks per launch instead of one */
         /* ... but at most half of the slots per turn: the plugin thread refills (and the UPLOAD lane fills) the other half
          * while this one is being worked on */
-        const int head = e->q_head, n = e->q_count > NSLOT / 2 ? NSLOT / 2 : e->q_count;
+        const int queued = A_LD(e->q_count);
+        const int head = e->q_head, n = queued > NSLOT / 2 ? NSLOT / 2 : queued;
         pthread_mutex_unlock(&e->qm);
         const double t0 = e->stats ? now_s() : 0.0;
         /* blocks whose DMA may still be in flight (the plugin thread did not wait for it): the UPLOAD lane is in order,
@@ -1304,12 +1310,15 @@ static void *device_thread(void *arg)
         }
         pthread_mutex_lock(&e->qm);
         e->q_head = (e->q_head + n) % NSLOT;
-        e->q_count -= n;
+        __atomic_fetch_sub(&e->q_count, n, __ATOMIC_RELEASE);
         pthread_mutex_unlock(&e->qm);
         const double t1 = e->stats ? now_s() : 0.0;
         run_resampler(e);
         const double t2 = e->stats ? now_s() : 0.0;
-        run_detector(e, t->samplerate);
+        pthread_mutex_lock(&t->lock);
+        const uint32_t fs_now = t->samplerate;
+        pthread_mutex_unlock(&t->lock);
+        run_detector(e, fs_now);
         if (e->stats) {
             const double t3 = now_s();
             e->s_dev_busy += t3 - t0;
@@ -1319,21 +1328,21 @@ static void *device_thread(void *arg)
         }
     }
     /* a device call that failed on the plugin's thread left the stop to us (gpu_ok) */
-    if (e->failed) (void)tsdr_plugin_stop_once(t);
+    if (A_LD(e->failed)) (void)tsdr_plugin_stop_once(t);
     return NULL;
 }
 
 /* ---- entry ----------------------------------------------------------------------------- */
 void engine_stats(struct engine *e, tsdrx_stats_t *out)
 {
-    out->blocks_in = e->n_blocks;
-    out->blocks_lost = e->n_blocks_lost;
-    out->frames_made = e->n_frames_made;
-    out->frames_lost_to_viewer = e->n_frames_lost;
-    out->windows = e->n_windows;
-    out->plots_held = e->n_plots_held;
-    out->epochs_replayed = e->n_promotions;
-    out->frames_fused = e->n_fused_frames;
+    out->blocks_in = STAT_GET(e->n_blocks);
+    out->blocks_lost = STAT_GET(e->n_blocks_lost);
+    out->frames_made = STAT_GET(e->n_frames_made);
+    out->frames_lost_to_viewer = STAT_GET(e->n_frames_lost);
+    out->windows = STAT_GET(e->n_windows);
+    out->plots_held = STAT_GET(e->n_plots_held);
+    out->epochs_replayed = STAT_GET(e->n_promotions);
+    out->frames_fused = STAT_GET(e->n_fused_frames);
 }
 
 int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
@@ -1398,11 +1407,11 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     pthread_mutex_init(&e->qm, NULL); pthread_cond_init(&e->q_nonempty, NULL);
     pthread_mutex_init(&e->fm, NULL); pthread_cond_init(&e->f_nonempty, NULL); pthread_cond_init(&e->f_queued, NULL);
     pthread_mutex_init(&e->pm, NULL); pthread_cond_init(&e->p_nonempty, NULL);
-    e->alive = 1;
+    A_ST(e->alive, 1);
     t->eng = e;
     /* frameratedetector_startthread flushes the cached estimation, frameratedetector.c:203-209 */
-    t->detector_purge = 1;
-    t->params_int[PARAM_AUTOCORR_PLOTS_RESET] = 2;
+    A_ST(t->detector_purge, 1);
+    A_ST(t->params_int[PARAM_AUTOCORR_PLOTS_RESET], 2);
 
     pthread_t th_dev, th_video, th_plot, th_down;
     pthread_create(&th_dev, NULL, device_thread, e);
@@ -1423,9 +1432,9 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     }
     const int status = use_raw ? t->plugin.readasync_raw(on_block_raw, e) : t->plugin.readasync(on_block, e);
 
-    t->running = 0;
+    A_ST(t->running, 0);
     pthread_join(th_dev, NULL);
-    e->alive = 0;
+    A_ST(e->alive, 0);
     pthread_mutex_lock(&e->fm); pthread_cond_broadcast(&e->f_nonempty); pthread_cond_broadcast(&e->f_queued); pthread_mutex_unlock(&e->fm);
     pthread_mutex_lock(&e->pm); pthread_cond_broadcast(&e->p_nonempty); pthread_mutex_unlock(&e->pm);
     pthread_join(th_down, NULL);
@@ -1433,7 +1442,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     pthread_join(th_plot, NULL);
     if (e->copy_thread_on) {
         pthread_mutex_lock(&e->cm);
-        e->copy_quit = 1;
+        A_ST(e->copy_quit, 1);
         pthread_cond_signal(&e->c_wake);
         pthread_mutex_unlock(&e->cm);
         pthread_join(e->th_copy, NULL);
@@ -1465,7 +1474,7 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     tsdrgpu_sync(e->g);
     tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_UPLOAD);
     tsdrgpu_lane_sync(e->g, TSDRGPU_LANE_DOWNLOAD);
-    if (e->super_state != SUPER_STOPPED && t->plugin.loaded) t->plugin.setbasefreq(t->centfreq);
+    if (e->super_state != SUPER_STOPPED && t->plugin.loaded) t->plugin.setbasefreq(A_LD(t->centfreq));
     /* tsdrplugin_readasync has returned and every DMA out of the plugin's memory is complete (UPLOAD lane drained
      * above): the ranges are unlocked now, before anything can reach tsdrplugin_cleanup / tsdrplugin_init — the memory
      * of a plugin that promised stability (tsdrplugin_memory_stable) is still allocated here */
@@ -1511,12 +1520,11 @@ int engine_run(tsdr_lib_t *t, tsdr_readasync_function cb, void *ctx)
     engine_stats(e, &t->last_stats);
     t->eng = NULL;
     pthread_mutex_unlock(&t->lock);
-    const int failed = e->failed;
+    const int failed = A_LD(e->failed);
     char fail_msg[400];
     memcpy(fail_msg, e->fail_msg, sizeof(fail_msg));
     free(e);
     if (failed) return tsdr_set_error(t, TSDR_CANNOT_OPEN_DEVICE, fail_msg);
     if (status != TSDR_OK) return tsdr_set_error(t, status, t->plugin.getlasterrortext());
-    t->errormsg_code = TSDR_OK;
-    return TSDR_OK;
+    return tsdr_set_error(t, TSDR_OK, NULL);
 }

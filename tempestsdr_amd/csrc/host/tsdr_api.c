@@ -17,26 +17,32 @@
 #define MAX_ARR_SIZE (4000 * 4000) /* TSDRLibrary.c:31 */
 #define MAX_SAMP_RATE (500e6)      /* TSDRLibrary.c:32 */
 
+/* The last error belongs to whichever call set it last — the host's setters on its GUI thread and tsdr_readasync on its
+ * own thread both do (the reference's announceexception, TSDRLibrary.c:622-653, reallocs one shared buffer from all of
+ * them) — so the text changes hands under a lock of its own: two threads failing at once cannot free it twice. */
 int tsdr_set_error(tsdr_lib_t *t, int status, const char *msg)
 {
-    t->errormsg_code = status;
-    if (status == TSDR_OK) return status;
+    if (status == TSDR_OK) {
+        pthread_mutex_lock(&t->errlock);
+        t->errormsg_code = TSDR_OK;
+        pthread_mutex_unlock(&t->errlock);
+        return status;
+    }
     if (!msg)
         msg = "An exception with no detailed explanation cause has occurred. This could as well be a bug in the "
               "TSDRlibrary or in one of its plugins.";
     char *copy = strdup(msg);
+    pthread_mutex_lock(&t->errlock);
+    t->errormsg_code = status;
     if (copy) {
         free(t->errormsg);
         t->errormsg = copy;
     }
+    pthread_mutex_unlock(&t->errlock);
     return status;
 }
 
-static int ok(tsdr_lib_t *t)
-{
-    t->errormsg_code = TSDR_OK;
-    return TSDR_OK;
-}
+static int ok(tsdr_lib_t *t) { return tsdr_set_error(t, TSDR_OK, NULL); }
 
 static int plugin_result(tsdr_lib_t *t, int status)
 {
@@ -46,7 +52,7 @@ static int plugin_result(tsdr_lib_t *t, int status)
 
 void tsdr_announce_value(tsdr_lib_t *t, int id, double a0, double a1)
 {
-    tsdr_value_changed_callback cb = t->callback;
+    tsdr_value_changed_callback cb = A_LD(t->callback);
     if (cb) cb(id, a0, a1, t->callbackctx);
 }
 
@@ -77,6 +83,7 @@ void tsdr_init(tsdr_lib_t **out, tsdr_value_changed_callback callback, tsdr_on_p
     t->callbackctx = ctx;
     t->errormsg_code = TSDR_OK;
     pthread_mutex_init(&t->lock, NULL);
+    pthread_mutex_init(&t->errlock, NULL);
     pthread_cond_init(&t->stopped, NULL);
 }
 
@@ -84,55 +91,62 @@ void tsdr_free(tsdr_lib_t **pt)
 {
     if (!pt || !*pt) return;
     tsdr_lib_t *t = *pt;
-    t->callback = NULL;
-    t->plotready_callback = NULL;
+    A_ST(t->callback, NULL);
+    A_ST(t->plotready_callback, NULL);
     tsdr_stop(t); /* also waits while tsdr_readasync is still tearing the pipeline down on its own */
     plugin_host_close(&t->plugin);
     free(t->errormsg);
     pthread_cond_destroy(&t->stopped);
     pthread_mutex_destroy(&t->lock);
+    pthread_mutex_destroy(&t->errlock);
     free(t);
     *pt = NULL;
 }
 
 void tsdr_reset(tsdr_lib_t *t) /* TSDRLibrary.c:118-133: the DSP state itself lives in the engine and is rebuilt per run */
 {
-    t->syncoffset = 0;
+    A_ST(t->syncoffset, 0);
 }
 
 void *tsdr_getctx(tsdr_lib_t *t) { return t->callbackctx; }
-int tsdr_isrunning(tsdr_lib_t *t) { return t->nativerunning; }
+int tsdr_isrunning(tsdr_lib_t *t) { return A_LD(t->nativerunning); }
 
 char *tsdr_getlasterrortext(tsdr_lib_t *t)
 {
-    return (t->errormsg_code == TSDR_OK) ? NULL : t->errormsg;
+    pthread_mutex_lock(&t->errlock);
+    char *text = (t->errormsg_code == TSDR_OK) ? NULL : t->errormsg; /* (valid until the next failing call, like the reference's) */
+    pthread_mutex_unlock(&t->errlock);
+    return text;
 }
 
 int tsdr_getsamplerate(tsdr_lib_t *t) /* TSDRLibrary.c:181-193 */
 {
     if (!t->plugin.loaded) return tsdr_set_error(t, TSDR_ERR_PLUGIN, "Cannot change sample rate. Plugin not loaded yet.");
-    t->samplerate_real = t->plugin.getsamplerate();
-    if (t->samplerate_real == 0 || t->samplerate_real > MAX_SAMP_RATE)
+    const uint32_t real = t->plugin.getsamplerate();
+    A_ST(t->samplerate_real, real);
+    if (real == 0 || real > MAX_SAMP_RATE)
         return tsdr_set_error(t, TSDR_SAMPLE_RATE_WRONG, "Invalid/unsupported value for sample rate.");
     pthread_mutex_lock(&t->lock);
-    tsdr_geometry_update(t, t->samplerate_real);
+    tsdr_geometry_update(t, real);
     pthread_mutex_unlock(&t->lock);
     return ok(t);
 }
 
 int tsdr_setbasefreq(tsdr_lib_t *t, uint32_t freq) /* TSDRLibrary.c:195-205 */
 {
-    t->centfreq = freq;
+    A_ST(t->centfreq, freq);
     if (!t->plugin.loaded) return ok(t);
     /* frameratedetector_flushcachedestimation, frameratedetector.c:197-201 */
-    t->detector_purge = 1;
-    t->params_int[PARAM_AUTOCORR_PLOTS_RESET] = 2;
-    return plugin_result(t, t->plugin.setbasefreq(t->centfreq));
+    A_ST(t->detector_purge, 1);
+    A_ST(t->params_int[PARAM_AUTOCORR_PLOTS_RESET], 2);
+    return plugin_result(t, t->plugin.setbasefreq(freq));
 }
 
 int tsdr_setgain(tsdr_lib_t *t, float gain) /* TSDRLibrary.c:226-237 */
 {
+    pthread_mutex_lock(&t->lock);
     t->gain = gain;
+    pthread_mutex_unlock(&t->lock);
     if (!t->plugin.loaded) return ok(t);
     return plugin_result(t, t->plugin.setgain(gain));
 }
@@ -140,7 +154,7 @@ int tsdr_setgain(tsdr_lib_t *t, float gain) /* TSDRLibrary.c:226-237 */
 int tsdr_unloadplugin(tsdr_lib_t *t) /* TSDRLibrary.c:425-435 */
 {
     if (!t->plugin.loaded) return tsdr_set_error(t, TSDR_ERR_PLUGIN, "No plugin has been loaded so it can't be unloaded");
-    if (t->nativerunning || t->running)
+    if (A_LD(t->nativerunning) || A_LD(t->running))
         return tsdr_set_error(t, TSDR_ALREADY_RUNNING, "The library is already running in async mode. Stop it first!");
     plugin_host_close(&t->plugin);
     return ok(t);
@@ -148,7 +162,7 @@ int tsdr_unloadplugin(tsdr_lib_t *t) /* TSDRLibrary.c:425-435 */
 
 int tsdr_loadplugin(tsdr_lib_t *t, const char *path, const char *params) /* TSDRLibrary.c:437-465 */
 {
-    if (t->nativerunning || t->running)
+    if (A_LD(t->nativerunning) || A_LD(t->running))
         return tsdr_set_error(t, TSDR_ALREADY_RUNNING, "The library is already running in async mode. Stop it first!");
     plugin_host_close(&t->plugin);
     int status = plugin_host_load(&t->plugin, path);
@@ -185,45 +199,54 @@ int tsdr_setresolution(tsdr_lib_t *t, int height, double refreshrate) /* TSDRLib
 int tsdr_motionblur(tsdr_lib_t *t, float coeff) /* TSDRLibrary.c:568-574 */
 {
     if (coeff < 0.0f || coeff > 1.0f) return TSDR_WRONG_VIDEOPARAMS;
+    pthread_mutex_lock(&t->lock);
     t->motionblur = coeff;
+    pthread_mutex_unlock(&t->lock);
     return ok(t);
 }
 
 int tsdr_sync(tsdr_lib_t *t, int pixels, int direction) /* TSDRLibrary.c:576-602 */
 {
     if (pixels == 0) return TSDR_OK;
+    pthread_mutex_lock(&t->lock);
+    const int width = t->width, height = t->height;
+    pthread_mutex_unlock(&t->lock);
+    int shift = 0;
     switch (direction) {
         case DIRECTION_CUSTOM:
-            t->syncoffset += pixels;
+            shift = pixels;
             break;
         case DIRECTION_UP:
-            if (pixels > t->height || pixels < 0)
+            if (pixels > height || pixels < 0)
                 return tsdr_set_error(t, TSDR_WRONG_VIDEOPARAMS, "Cannot shift up with more pixels than the height of the image or shift is negative!");
-            t->syncoffset += pixels * t->width;
+            shift = pixels * width;
             break;
         case DIRECTION_DOWN:
-            if (pixels > t->height || pixels < 0)
+            if (pixels > height || pixels < 0)
                 return tsdr_set_error(t, TSDR_WRONG_VIDEOPARAMS, "Cannot shift down with more pixels than the height of the image or shift is negative!");
-            t->syncoffset -= pixels * t->width;
+            shift = -pixels * width;
             break;
         case DIRECTION_LEFT:
-            if (pixels > t->width || pixels < 0)
+            if (pixels > width || pixels < 0)
                 return tsdr_set_error(t, TSDR_WRONG_VIDEOPARAMS, "Cannot shift to the left with more pixels than the width of the image or shift is negative!");
-            t->syncoffset += pixels;
+            shift = pixels;
             break;
         case DIRECTION_RIGHT:
-            if (pixels > t->width || pixels < 0)
+            if (pixels > width || pixels < 0)
                 return tsdr_set_error(t, TSDR_WRONG_VIDEOPARAMS, "Cannot shift to the right with more pixels than the width of the image or shift is negative!");
-            t->syncoffset -= pixels;
+            shift = -pixels;
             break;
     }
+    /* the resampler's thread takes the pending shift with an exchange (engine.c): added here in one step, nothing is lost
+     * between the two (the reference's `syncoffset +=` against `syncoffset = 0`, TSDRLibrary.c:345-346, can lose one) */
+    __atomic_fetch_add(&t->syncoffset, shift, __ATOMIC_ACQ_REL);
     return ok(t);
 }
 
 int tsdr_setparameter_int(tsdr_lib_t *t, int parameter, uint32_t value) /* TSDRLibrary.c:604-611 */
 {
     if (parameter < 0 || parameter >= COUNT_PARAM_INT) return tsdr_set_error(t, TSDR_INVALID_PARAMETER, "Invalid integer parameter id");
-    t->params_int[parameter] = value;
+    A_ST(t->params_int[parameter], value);
     return ok(t);
 }
 
@@ -231,7 +254,9 @@ int tsdr_setparameter_double(tsdr_lib_t *t, int parameter, double value) /* TSDR
 {
     if (parameter < 0 || parameter >= COUNT_PARAM_DOUBLE)
         return tsdr_set_error(t, TSDR_INVALID_PARAMETER, "Invalid double floating point parameter id");
+    pthread_mutex_lock(&t->lock);
     t->params_double[parameter] = value; /* the reference validates the id and discards the value */
+    pthread_mutex_unlock(&t->lock);
     return ok(t);
 }
 
@@ -262,15 +287,15 @@ int tsdr_plugin_stop_once(tsdr_lib_t *t)
 int tsdr_stop(tsdr_lib_t *t) /* TSDRLibrary.c:213-224 */
 {
     pthread_mutex_lock(&t->lock);
-    const int was_running = t->running;
+    const int was_running = A_LD(t->running);
     pthread_mutex_unlock(&t->lock);
     const int status = (was_running && t->plugin.loaded) ? tsdr_plugin_stop_once(t) : TSDR_OK;
     /* Wait until tsdr_readasync has torn the pipeline down — also when the plugin's readasync returned on its
      * own and the teardown is merely still in progress (running already 0, nativerunning still 1): nobody may
      * unload the plugin or free the library under it. */
     pthread_mutex_lock(&t->lock);
-    t->running = 0;
-    while (t->nativerunning) pthread_cond_wait(&t->stopped, &t->lock);
+    A_ST(t->running, 0);
+    while (A_LD(t->nativerunning)) pthread_cond_wait(&t->stopped, &t->lock);
     pthread_mutex_unlock(&t->lock);
     if (!was_running) return ok(t);
     return plugin_result(t, status);
@@ -279,7 +304,7 @@ int tsdr_stop(tsdr_lib_t *t) /* TSDRLibrary.c:213-224 */
 static int readasync_common(tsdr_lib_t *t, tsdr_readasync_function cb, tsdrx_readasync_rgb_function rgb_cb, int inverted, void *ctx)
 {
     pthread_mutex_lock(&t->lock);
-    if (t->nativerunning || t->running) {
+    if (A_LD(t->nativerunning) || A_LD(t->running)) {
         pthread_mutex_unlock(&t->lock);
         return tsdr_set_error(t, TSDR_ALREADY_RUNNING, "The library is already running in async mode. Stop it first!");
     }
@@ -290,25 +315,35 @@ static int readasync_common(tsdr_lib_t *t, tsdr_readasync_function cb, tsdrx_rea
     tsdr_reset(t);
     t->rgb_cb = rgb_cb;
     t->rgb_inverted = inverted;
-    t->nativerunning = 1;
-    t->running = 1;
+    A_ST(t->nativerunning, 1);
+    A_ST(t->running, 1);
     t->stop_sent = 0;
     t->stop_status = TSDR_OK;
     pthread_mutex_unlock(&t->lock);
 
     int status = tsdr_getsamplerate(t);
+    double ptost = 0.0;
     if (status == TSDR_OK) {
-        const long long size = (long long)t->width * t->height;
-        if (t->width <= 0 || t->height <= 0 || size > MAX_ARR_SIZE)
+        pthread_mutex_lock(&t->lock);
+        const int width = t->width, height = t->height;
+        ptost = t->pixeltimeoversampletime;
+        pthread_mutex_unlock(&t->lock);
+        const long long size = (long long)width * height;
+        if (width <= 0 || height <= 0 || size > MAX_ARR_SIZE)
             status = tsdr_set_error(t, TSDR_WRONG_VIDEOPARAMS, "The supplied height and the width are invalid!");
     }
-    if (status == TSDR_OK) status = tsdr_setbasefreq(t, t->centfreq);
-    if (status == TSDR_OK) status = tsdr_setgain(t, t->gain);
-    if (status == TSDR_OK && t->pixeltimeoversampletime > 0) status = engine_run(t, cb, ctx);
+    if (status == TSDR_OK) status = tsdr_setbasefreq(t, A_LD(t->centfreq));
+    if (status == TSDR_OK) {
+        pthread_mutex_lock(&t->lock);
+        const float gain = t->gain;
+        pthread_mutex_unlock(&t->lock);
+        status = tsdr_setgain(t, gain);
+    }
+    if (status == TSDR_OK && ptost > 0) status = engine_run(t, cb, ctx);
 
     pthread_mutex_lock(&t->lock);
-    t->running = 0;
-    t->nativerunning = 0;
+    A_ST(t->running, 0);
+    A_ST(t->nativerunning, 0);
     pthread_cond_broadcast(&t->stopped);
     pthread_mutex_unlock(&t->lock);
     return status;

@@ -42,43 +42,56 @@ void plugin_host_close(plugin_host_t *p);
 struct engine;
 void engine_stats(struct engine *e, tsdrx_stats_t *out); /* counters of a running session */
 
+/* Fields that several threads read and write WITHOUT a lock (the reference marks the same ones `volatile`,
+ * internaldefinitions.h:30-65) go through these: acquire loads and release stores — the plain loads and stores `volatile`
+ * gave on x86, the right barriers on other hosts — and read-modify-writes through __atomic_exchange_n / __atomic_fetch_add,
+ * so that a shift or a reset request that arrives between a worker's read and its clear is not lost.  ThreadSanitizer
+ * (tests/sanitize) can then tell them from accidents: everything else is owned by one thread or guarded by a mutex. */
+#define A_LD(x) __atomic_load_n(&(x), __ATOMIC_ACQUIRE)
+#define A_ST(x, v) __atomic_store_n(&(x), (v), __ATOMIC_RELEASE)
+
 struct tsdr_lib {
     plugin_host_t plugin;
 
-    /* geometry — set_internal_samplerate, TSDRLibrary.c:540-550 */
+    /* geometry — set_internal_samplerate, TSDRLibrary.c:540-550; under `lock` */
     uint32_t samplerate;      /* the rate the pipeline runs at (4x in super-bandwidth mode) */
-    uint32_t samplerate_real; /* what the plugin reports */
+    uint32_t samplerate_real; /* what the plugin reports (A_LD / A_ST) */
     int width, height;
     double pixelrate, refreshrate, pixeltimeoversampletime;
+    float motionblur;         /* under `lock` as well (a float: the frame path reads it together with the geometry) */
 
-    volatile int running;       /* workers should keep going */
-    volatile int stop_sent;     /* tsdrplugin_stop was called for this run (tsdr_plugin_stop_once): tsdr_stop and a failing
-                                   engine worker may both want to, the plugin hears it once */
-    int stop_status;            /* what that call returned */
-    volatile int nativerunning; /* tsdr_readasync is on some thread's stack */
+    /* A_LD / A_ST */
+    int running;       /* workers should keep going */
+    int stop_sent;     /* tsdrplugin_stop was called for this run (tsdr_plugin_stop_once): tsdr_stop and a failing
+                          engine worker may both want to, the plugin hears it once (under `lock`) */
+    int stop_status;   /* what that call returned (under `lock`) */
+    int nativerunning; /* tsdr_readasync is on some thread's stack */
     uint32_t centfreq;
-    float gain, motionblur;
-    volatile int syncoffset;
+    float gain;        /* the API threads' own (never read by a worker) */
+    int syncoffset;    /* tsdr_sync adds, the resampler's thread takes it with an exchange */
 
+    /* the last error: any thread that calls into the API sets it, so it has a lock of its own */
+    pthread_mutex_t errlock;
     char *errormsg;
     int errormsg_code;
 
-    volatile uint32_t params_int[COUNT_PARAM_INT];
-    double params_double[COUNT_PARAM_DOUBLE];
+    uint32_t params_int[COUNT_PARAM_INT]; /* A_LD / A_ST */
+    double params_double[COUNT_PARAM_DOUBLE]; /* under `lock` (validated and never read, like the reference's) */
 
-    tsdr_value_changed_callback callback;
+    tsdr_value_changed_callback callback;      /* A_LD / A_ST: tsdr_free clears them while a worker may still announce */
     tsdr_on_plot_ready_callback plotready_callback;
     void *callbackctx;
 
     pthread_mutex_t lock; /* guards geometry + the running/stop handshake */
     pthread_cond_t stopped;
 
-    volatile int detector_purge; /* frameratedetector_flushcachedestimation */
-    struct engine *eng;
+    int detector_purge; /* frameratedetector_flushcachedestimation (A_LD / A_ST) */
+    struct engine *eng; /* under `lock` */
 
-    /* TSDRLibraryExt.h: frames as packed RGB for this run (NULL: float frames through the tsdr_readasync callback) */
+    /* TSDRLibraryExt.h: frames as packed RGB for this run (NULL: float frames through the tsdr_readasync callback); set before
+     * the workers exist */
     tsdrx_readasync_rgb_function rgb_cb;
-    tsdrx_stats_t last_stats; /* of the last session that ended (tsdrx_get_stats) */
+    tsdrx_stats_t last_stats; /* of the last session that ended (tsdrx_get_stats; under `lock`) */
     int rgb_inverted;
 };
 

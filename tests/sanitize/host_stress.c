@@ -1,0 +1,157 @@
+/* tests/sanitize/host_stress.c — the tsdr_* host library (the C files under tempestsdr_amd/csrc/host) compiled together with this driver
+ * under -fsanitize=thread or -fsanitize=address (scripts/build_sanitized.sh) and driven the way the reference's Java GUI
+ * drives TSDRLibrary (JavaGUI/jni/TSDRLibraryNDK.c: one thread blocked in tsdr_readasync, the GUI thread calling the setters
+ * and tsdr_stop while frames and plots arrive on the library's threads).  TEST INFRASTRUCTURE: the product is the plain build.
+ *
+ * usage: host_stress <plugin.so> "<plugin params>" <height> <refresh> <sessions> <seconds_per_session>
+ * Every session: tsdr_readasync on a thread of its own; the main thread changes resolution, gain, motion blur, shifts the
+ * picture, toggles every integer parameter, reads the statistics and stops — once from the main thread and, on odd sessions,
+ * from two threads at the same time (the stop_once path).  Exit code 0 = every call returned what it should; the sanitizer's
+ * own report (and exit code 66) says the rest. */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "TSDRCodes.h"
+#include "TSDRLibrary.h"
+#include "TSDRLibraryExt.h"
+
+static tsdr_lib_t *lib;
+static volatile long frames, plots, values;
+static double frame_sum, plot_sum; /* each written by one of the library's threads only */
+
+static void on_frame(float *buf, int w, int h, void *ctx)
+{
+    (void)ctx;
+    /* touch the first and last pixel like a viewer that copies the frame would */
+    frame_sum += (double)buf[0] + (double)buf[(size_t)w * h - 1];
+    __atomic_add_fetch(&frames, 1, __ATOMIC_RELAXED);
+}
+
+static void on_value(int id, double a0, double a1, void *ctx)
+{
+    (void)id; (void)a0; (void)a1; (void)ctx;
+    __atomic_add_fetch(&values, 1, __ATOMIC_RELAXED);
+}
+
+static void on_plot(int id, int off, double *v, int size, uint32_t rate, void *ctx)
+{
+    (void)id; (void)off; (void)rate; (void)ctx;
+    if (size > 0) plot_sum += v[0] + v[size - 1];
+    __atomic_add_fetch(&plots, 1, __ATOMIC_RELAXED);
+}
+
+static void on_rgb(int32_t *buf, int w, int h, void *ctx)
+{
+    (void)ctx;
+    frame_sum += (double)(buf[0] & 255) + (double)(buf[(size_t)w * h - 1] & 255);
+    __atomic_add_fetch(&frames, 1, __ATOMIC_RELAXED);
+}
+
+static void *reader(void *arg)
+{
+    /* every third session takes its frames as packed RGB (TSDRLibraryExt.h), like the Java GUI's JNI shim would */
+    const int rc = arg ? tsdrx_readasync_rgb(lib, on_rgb, NULL, 1) : tsdr_readasync(lib, on_frame, NULL);
+    return (void *)(intptr_t)rc;
+}
+
+static void *stopper(void *arg)
+{
+    (void)arg;
+    return (void *)(intptr_t)tsdr_stop(lib);
+}
+
+static void nap(double s)
+{
+    struct timespec t = {(time_t)s, (long)((s - (time_t)s) * 1e9)};
+    nanosleep(&t, NULL);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 7) {
+        fprintf(stderr, "usage: %s plugin.so \"params\" height refresh sessions seconds\n", argv[0]);
+        return 2;
+    }
+    const int height = atoi(argv[3]), sessions = atoi(argv[5]);
+    const double refresh = atof(argv[4]), secs = atof(argv[6]);
+    int bad = 0;
+    tsdr_init(&lib, on_value, on_plot, NULL);
+    char params[2048];
+    snprintf(params, sizeof(params), "%s", argv[2]);
+    int rc = tsdr_loadplugin(lib, argv[1], params);
+    if (rc != TSDR_OK) {
+        fprintf(stderr, "tsdr_loadplugin: %d %s\n", rc, tsdr_getlasterrortext(lib) ? tsdr_getlasterrortext(lib) : "");
+        return 3;
+    }
+    for (int s = 0; s < sessions; s++) {
+        const long f0 = frames;
+        tsdr_setgain(lib, 0.5f);
+        tsdr_motionblur(lib, (s & 1) ? 0.5f : 0.0f);
+        if (tsdr_setresolution(lib, height, refresh) != TSDR_OK) bad++;
+        pthread_t th;
+        pthread_create(&th, NULL, reader, (s % 3 == 2) ? (void *)1 : NULL);
+        /* the GUI thread: every setter while the stream runs */
+        const int steps = 12;
+        for (int i = 0; i < steps; i++) {
+            nap(secs / steps);
+            switch (i) {
+                case 1: tsdr_sync(lib, 7, DIRECTION_LEFT); tsdr_sync(lib, 3, DIRECTION_DOWN); break;
+                case 2: tsdr_setparameter_int(lib, PARAM_INT_AUTOSHIFT, 1); break;
+                case 3: tsdr_setresolution(lib, height + 10 * (s + 1), refresh * 1.003); break;
+                case 4: tsdr_setparameter_int(lib, PARAM_INT_FRAMERATE_PLL, 1); tsdr_setparameter_int(lib, PARAM_LOW_PASS_BEFORE_SYNC, 1); break;
+                case 5: tsdr_setparameter_int(lib, PARAM_AUTOCORR_SUPERRESOLUTION, 1); tsdr_setparameter_int(lib, PARAM_AUTOCORR_PLOTS_RESET, 1); break;
+                case 6: tsdr_setparameter_int(lib, PARAM_NEAREST_NEIGHBOUR_RESAMPLING, s & 1); tsdr_motionblur(lib, 0.9f); break;
+                case 7: tsdr_setresolution(lib, height, refresh); tsdr_setgain(lib, 0.25f); tsdr_setbasefreq(lib, 400000000u + (uint32_t)s); break;
+                case 8: tsdr_setparameter_int(lib, PARAM_AUTOGAIN_AFTER_PROCESSING, 1); tsdr_setparameter_double(lib, 0, 0.5); break;
+                case 9: tsdr_setparameter_int(lib, PARAM_AUTOCORR_PLOTS_OFF, 1); tsdr_setparameter_int(lib, PARAM_AUTOCORR_SUPERRESOLUTION, 0); break;
+                case 10: {
+                    tsdrx_stats_t st;
+                    if (tsdrx_get_stats(lib, &st) != TSDR_OK) bad++;
+                    tsdr_setparameter_int(lib, PARAM_AUTOCORR_PLOTS_OFF, 0);
+                    tsdr_setparameter_int(lib, PARAM_INT_AUTOSHIFT, 0);
+                    tsdr_setparameter_int(lib, PARAM_INT_FRAMERATE_PLL, 0);
+                    tsdr_setparameter_int(lib, PARAM_LOW_PASS_BEFORE_SYNC, 0);
+                    tsdr_setparameter_int(lib, PARAM_AUTOGAIN_AFTER_PROCESSING, 0);
+                    break;
+                }
+                default: (void)tsdr_isrunning(lib); (void)tsdr_getsamplerate(lib); break;
+            }
+        }
+        void *r1 = NULL, *r2 = NULL, *rr = NULL;
+        if (s & 1) {  /* two stops racing */
+            pthread_t a, b;
+            pthread_create(&a, NULL, stopper, NULL);
+            pthread_create(&b, NULL, stopper, NULL);
+            pthread_join(a, &r1);
+            pthread_join(b, &r2);
+        } else {
+            r1 = (void *)(intptr_t)tsdr_stop(lib);
+        }
+        pthread_join(th, &rr);
+        if ((intptr_t)rr != TSDR_OK) {
+            fprintf(stderr, "session %d: tsdr_readasync returned %ld (%s)\n", s, (long)(intptr_t)rr, tsdr_getlasterrortext(lib) ? tsdr_getlasterrortext(lib) : "");
+            bad++;
+        }
+        if ((intptr_t)r1 != TSDR_OK || (intptr_t)r2 != TSDR_OK) {
+            fprintf(stderr, "session %d: tsdr_stop returned %ld / %ld\n", s, (long)(intptr_t)r1, (long)(intptr_t)r2);
+            bad++;
+        }
+        if (tsdr_isrunning(lib)) bad++;
+        if (frames == f0) {
+            fprintf(stderr, "session %d: no frame delivered\n", s);
+            bad++;
+        }
+        printf("session %d: frames %ld plots %ld values %ld\n", s, frames, plots, values);
+        fflush(stdout);
+    }
+    if (tsdr_unloadplugin(lib) != TSDR_OK) bad++;
+    tsdr_free(&lib);
+    printf("host_stress: %s (%d bad), checksum %g\n", bad ? "FAILED" : "ok", bad, frame_sum + plot_sum);
+    return bad ? 1 : 0;
+}

@@ -703,3 +703,20 @@ def test_pipeline_config5_matches_oracle(orc, tmp_path):
         assert np.max(np.abs(fp - ac.frame)) <= 1e-4 * np.max(ac.frame) and np.max(np.abs(lp - ac.line)) <= 1e-4 * np.max(ac.line)
         assert int(np.argmax(fp)) == int(np.argmax(ac.frame)) and int(np.argmax(lp)) == int(np.argmax(ac.line))
     s.close()
+
+
+def test_host_stress_on_the_device(iq_file, tmp_path):
+    """tests/sanitize/host_stress.c (what tests/test_host_sanitizers.py runs under ThreadSanitizer against a host-memory
+    stand-in) against the REAL libtsdrgpu.so: every setter from a second thread while the stream runs, resolution changes
+    mid-stream, super-resolution on and off, float and RGB delivery, two tsdr_stop calls racing — every call returns what
+    it should, every session delivers frames and tears down."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "sanitize", "host_stress_plain")
+    if not os.path.exists(exe):
+        subprocess.run(["bash", os.path.join(root, "scripts", "build_sanitized.sh")], check=True, capture_output=True)
+    hu.build_test_plugin()
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="2", TSDR_GPU_STATS="1")
+    for plugin, params in ((hu.MEM_PLUGIN, f"{iq_file[0]} {FS} {BLOCK} 0 2000"), (hu.PLUGIN, f"{iq_file[0]} {FS} {BLOCK} 3000")):
+        out = subprocess.run([exe, plugin, params, str(H), str(FV), "4", "1.5"], capture_output=True, text=True, timeout=120, env=env)
+        assert out.returncode == 0 and "host_stress: ok" in out.stdout, (out.stdout + out.stderr)[-3000:]
