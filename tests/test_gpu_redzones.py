@@ -32,8 +32,7 @@ def test_redzones_catch_one_element_either_side():
     assert not a.redzones_intact("self-test")
     assert any("below" in v for v in conftest._redzone_violations)
     conftest._redzone_violations.clear()
-    # what an out-of-bounds READ would hand a kernel: NaN
-    assert np.isnan(a.download(1, elem_offset=0).view(np.float32)[0]) or True
+    # what an out-of-bounds READ hands a kernel: NaN
     b = g.empty(4)
     g._ck(g.lib.tsdrgpu_copy(g.h, b.ptr, a.ptr + 1000 * 4, 16))  # four floats of the guard above `a`
     g.sync()
@@ -48,8 +47,7 @@ def test_exact_fit_outputs_of_the_elementwise_entry_points(n):
     iq = rng.standard_normal(2 * n).astype(np.float32)
     d_iq, d_m = g.to_device(iq), g.empty(n)
     g.am_demod(d_iq, d_m, n)
-    assert np.array_equal(d_m.download(), np.sqrt(iq[0::2] * iq[0::2] + iq[1::2] * iq[1::2]).astype(np.float32)) or \
-        np.allclose(d_m.download(), np.hypot(iq[0::2], iq[1::2]), rtol=1e-6)
+    assert np.allclose(d_m.download(), np.hypot(iq[0::2], iq[1::2]), rtol=1e-6)  # (bit-exactness: test_gpu_demod_resample.py)
     for fmt, dt in (("int8", np.int8), ("uint8", np.uint8), ("int16", np.int16), ("uint16", np.uint16)):
         raw = rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, 2 * n, dtype=dt, endpoint=True)
         d_raw, d_out = g.to_device(raw, dt), g.empty(2 * n)
@@ -59,5 +57,4 @@ def test_exact_fit_outputs_of_the_elementwise_entry_points(n):
     d_fr, d_rgb = g.to_device(fr), g.empty(n, np.int32)
     d_rgb.zero()
     g.frame_to_rgb(d_fr, d_rgb, n)
-    assert np.all((d_rgb.download() >> 24) & 0xFF == 0xFF) or True
-    g.sync()
+    g.sync()  # (values: test_gpu_extras.py; here only where they land — the fixture checks the guards after the test)
