@@ -95,6 +95,81 @@ extern "C" int tsdrgpu_sync(tsdrgpu_t *g)
     return TSDRGPU_OK;
 }
 
+// ---- TSDRGPU_REDZONES (tsdrgpu_internal.h) --------------------------------------------------------------------------------
+#include <mutex>
+#include <unordered_map>
+namespace {
+constexpr size_t RZ = 4096;
+struct RzRec { void *base; size_t bytes; };
+std::mutex rz_lock;
+std::unordered_map<void *, RzRec> *rz_live;  // (leaked on purpose: frees may come from static destructors)
+int rz_mode = -1;                            // -1 not read yet, 0 off, 1 abort on a violation, 2 report
+int rz_on()
+{
+    if (rz_mode < 0) {
+        const char *e = getenv("TSDRGPU_REDZONES");
+        rz_mode = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
+    }
+    return rz_mode;
+}
+}  // namespace
+
+hipError_t tsdr_redzone_malloc(void **p, size_t n)
+{
+    if (!rz_on()) return (hipMalloc)(p, n);
+    char *base = nullptr;
+    hipError_t rc = (hipMalloc)((void **)&base, n + 2 * RZ);
+    if (rc != hipSuccess) return rc;
+    // (synchronous memsets: a debug mode)
+    if (hipMemset(base, 0xFF, RZ) != hipSuccess || hipMemset(base + RZ + n, 0xFF, RZ) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)(hipFree)(base);
+        return hipErrorOutOfMemory;
+    }
+    std::lock_guard<std::mutex> hold(rz_lock);
+    if (!rz_live) rz_live = new std::unordered_map<void *, RzRec>();
+    (*rz_live)[base + RZ] = RzRec{base, n};
+    *p = base + RZ;
+    return hipSuccess;
+}
+
+hipError_t tsdr_redzone_free(void *p)
+{
+    if (!p || !rz_on()) return (hipFree)(p);
+    RzRec rec{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> hold(rz_lock);
+        if (rz_live) {
+            auto it = rz_live->find(p);
+            if (it != rz_live->end()) { rec = it->second; rz_live->erase(it); }
+        }
+    }
+    if (!rec.base) return (hipFree)(p);  // not ours (allocated before the mode was read: cannot happen) — hand it on
+    static thread_local unsigned char host[2 * RZ];
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(host, rec.base, RZ, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(host + RZ, (char *)rec.base + RZ + rec.bytes, RZ, hipMemcpyDeviceToHost) == hipSuccess) {
+        for (int side = 0; side < 2; side++) {
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < RZ; i++)
+                if (host[side * RZ + i] != 0xFF) { if (!bad) first = i; bad++; }
+            if (bad) {
+                fprintf(stderr, "tsdrgpu: RED ZONE VIOLATION: %zu bytes written %s a device allocation of %zu bytes (first at byte %+ld from that edge)\n",
+                        bad, side ? "above" : "below", rec.bytes, side ? (long)first : (long)first - (long)RZ);
+                fflush(stderr);
+                if (const char *log = getenv("TSDRGPU_REDZONE_LOG")) {  // (a test run collects the reports of all its processes here)
+                    if (FILE *f = fopen(log, "a")) {
+                        fprintf(f, "%zu bytes written %s a device allocation of %zu bytes (first at byte %+ld from that edge)\n", bad,
+                                side ? "above" : "below", rec.bytes, side ? (long)first : (long)first - (long)RZ);
+                        fclose(f);
+                    }
+                }
+                if (rz_on() == 1) abort();
+            }
+        }
+    }
+    return (hipFree)(rec.base);
+}
+
 extern "C" int tsdrgpu_device_name(tsdrgpu_t *g, char *buf, size_t buflen)
 {
     if (!g || !buf || !buflen) return TSDRGPU_EINVAL;

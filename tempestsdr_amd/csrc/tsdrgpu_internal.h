@@ -10,6 +10,22 @@
 
 #define TSDR_WAVE 64
 
+// Debug aid, OFF unless the process sets TSDRGPU_REDZONES=1 (or =2: report and go on): every device allocation the library makes
+// — its own scratch, plots, rings and the buffers behind tsdrgpu_alloc — then sits between two 4 KiB zones of 0xFF bytes (NaN as
+// float32 / float64, -1 as an integer), and tsdrgpu_free / every internal free checks that both are untouched: a kernel that writes
+// outside the scratch the library sized for it is reported on stderr with the allocation's size (and the process aborts unless =2),
+// one that reads outside computes with NaN and fails the parity tests.  tests/conftest.py does the same for the buffers the TESTS
+// allocate; this covers the ones they never see.  Unset, hipMalloc / hipFree below are the runtime's own, one branch away.
+hipError_t tsdr_redzone_malloc(void **p, size_t n);
+hipError_t tsdr_redzone_free(void *p);
+template <class T>
+static inline hipError_t tsdr_malloc_t(T **p, size_t n)
+{
+    return tsdr_redzone_malloc((void **)p, n);
+}
+#define hipMalloc(p_, n_) tsdr_malloc_t((p_), (n_))
+#define hipFree(p_) tsdr_redzone_free((p_))
+
 // stage ids for the optional event profiler (tsdrgpu_profile_*)
 enum ProfStage {
     PROF_DEMOD = 0,
