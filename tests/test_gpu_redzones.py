@@ -58,3 +58,36 @@ def test_exact_fit_outputs_of_the_elementwise_entry_points(n):
     d_rgb.zero()
     g.frame_to_rgb(d_fr, d_rgb, n)
     g.sync()  # (values: test_gpu_extras.py; here only where they land — the fixture checks the guards after the test)
+
+
+def test_library_redzone_mode_reports_an_overrun(tmp_path):
+    """TSDRGPU_REDZONES (tsdrgpu_internal.h): the same for every allocation the LIBRARY makes.  A fresh process with the mode
+    on allocates 100 bytes through the C ABI, copies 104 into them and frees: one report, naming the size and the edge."""
+    import os
+    import subprocess
+    import sys
+    log = tmp_path / "reports.txt"
+    code = (
+        "import ctypes as C\n"
+        "from tempestsdr_amd import gpu\n"
+        "g = gpu.TsdrGpu(0)\n"
+        "a, b = C.c_void_p(), C.c_void_p()\n"
+        "g._ck(g.lib.tsdrgpu_alloc(g.h, C.byref(a), 100)); g._ck(g.lib.tsdrgpu_alloc(g.h, C.byref(b), 4096))\n"
+        "g._ck(g.lib.tsdrgpu_zero(g.h, b, 4096))\n"
+        "g._ck(g.lib.tsdrgpu_copy(g.h, a, b, 100)); g.sync()\n"
+        "g._ck(g.lib.tsdrgpu_free(g.h, a))\n"          # clean: no report
+        "g._ck(g.lib.tsdrgpu_alloc(g.h, C.byref(a), 100))\n"
+        "g._ck(g.lib.tsdrgpu_copy(g.h, a, b, 104)); g.sync()\n"
+        "g._ck(g.lib.tsdrgpu_free(g.h, a)); g._ck(g.lib.tsdrgpu_free(g.h, b))\n"
+        "g.close()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSDRGPU_REDZONES="2", TSDRGPU_REDZONE_LOG=str(log))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = log.read_text().splitlines() if log.exists() else []
+    assert len(lines) == 1 and "4 bytes written above a device allocation of 100 bytes (first at byte +0" in lines[0], (lines, out.stderr[-500:])
+    assert "RED ZONE VIOLATION" in out.stderr
+    # =1 aborts the process at the violation
+    env["TSDRGPU_REDZONES"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "RED ZONE VIOLATION" in out.stderr
