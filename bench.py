@@ -220,10 +220,14 @@ def config0_leg():
     samples with nothing dropped (what SURVEY 8(c) names as the reproducible form of the reference).  Measured on MI355X boxes:
     our library behind the reference's plugin delivers exactly the driver's frames — bit for bit, in order, none missing (its engine
     loses no block at 8 MS/s) — while the reference's own threaded library delivers none of them: the same picture, every pixel a
-    different blend of the recording's noise (mean |difference| 0.03 at frame 10).  The likely cause are its lossy rings: a block
-    a ring refuses becomes a skip of block = round(2 S) samples (dsp.c:338-345, TSDRLibrary.c:283-284; 2 S = 266 666.67,
-    block = 266 667), a third of a sample off the raster each.  It does so consistently from run to run when the timing repeats (two reference
-    runs: up to 30 of 30 frames with a bit-identical twin; none on a loaded host).  All three numbers are in the leg."""
+    different blend of the recording's noise (mean |difference| 0.03 at frame 10).  The cause are its lossy rings at start-up: a
+    ring starts at 2 floats and grows by the adds (circbuff.c:64-110); a block it refuses meanwhile becomes a skip of
+    block = round(2 S) samples (dsp.c:338-345, TSDRLibrary.c:283-284; 2 S = 266 666.67, block = 266 667), a third of a sample off the
+    raster each.  Verified, not assumed: every frame the reference delivers from its 8th on is an EXACT affine image (residual 6e-8;
+    the affine map is the autogain's normalisation) of a raw frame of the deterministic driver run on the recording with
+    2 x 266 667 samples removed, consecutive and in order (`reference_vs_driver_of_the_shortened_stream`; d is searched, so a box
+    with another timing reports its own).  It does so consistently from run to run when the timing repeats (two reference
+    runs: up to 30 of 30 frames with a bit-identical twin; none on a loaded host).  All numbers are in the leg."""
     from tempestsdr_amd import tsdrlib, synth
     import resource
     fs, h, fv = 8_000_000, 525, 60.0
@@ -278,17 +282,59 @@ def config0_leg():
                                             "identical_pixels": int(np.sum(f == driver[int(np.argmin(d))])), "of": P}
             return out
 
+        def against_shortened_stream(frames, iq_all):
+            """What the reference's threaded library delivers INSTEAD: its rings refuse blocks while they grow to their working size
+            (circbuff.c:64-110: a ring starts at 2 floats and is resized by the adds), and a refused block of samples becomes a skip
+            of d x block samples, block = round(2 S) = 266 667 (dsp.c:338-345, TSDRLibrary.c:283-284) — a third of a sample off the
+            raster per block.  So its frames should be the deterministic driver's frames of the recording with d x 266 667 samples
+            REMOVED: the same resampler arithmetic on a shifted stream.  Checked per delivered frame as an exact affine image
+            (frame = a * raw + b: the autogain's normalisation, dsp.c:74, whose state depends on the frames lost before) of a RAW
+            driver frame of the shortened stream; reported: d, how many frames are such images (max residual), whether the raw
+            frames are consecutive."""
+            blk = int(round(((W * H) << 1) * geo.pixeltimeoversampletime))
+            sub = slice(0, P, 11)
+            best = None
+            for d in (2, 1, 3, 0, 4, 5, 6):
+                px, _ = orc.demod_resample_stream(iq_all[2 * d * blk:2 * (d * blk + (skip + nkeep + 40) * int(fs / fv))], geo)
+                raw = [px[k * P:(k + 1) * P][sub].astype(np.float64) for k in range(px.size // P)]
+                hits, worst = [], 0.0
+                for f in frames:
+                    y = f[sub].astype(np.float64)
+                    m = np.abs(y) < 250  # (the sync detector's marker lines are not pixels of the stream)
+                    found = None
+                    for j, x in enumerate(raw):
+                        vx = x[m] - x[m].mean()
+                        a_ = float((vx * (y[m] - y[m].mean())).sum() / (vx * vx).sum())
+                        res = float(np.max(np.abs(a_ * x[m] + (y[m].mean() - a_ * x[m].mean()) - y[m])))
+                        if res < 1e-5:
+                            found, worst = j, max(worst, res)
+                            break
+                    hits.append(found)
+                n_ok = sum(1 for k in hits if k is not None)
+                cand = {"samples_removed": d * blk, "blocks_of_266667": d, "frames": len(frames), "exact_affine_images_of_a_raw_driver_frame": n_ok,
+                        "max_residual": float(f"{worst:.3g}"), "raw_driver_frames": [hits[0], hits[-1]],
+                        "consecutive": all(k is not None for k in hits) and all(b_ - a_ == 1 for a_, b_ in zip(hits, hits[1:]))}
+                if best is None or n_ok > best["exact_affine_images_of_a_raw_driver_frame"]:
+                    best = cand
+                if n_ok > len(frames) // 2:
+                    break
+            return best
+
         twins_rr = sum(1 for f in fr["reference_again"][:30] if any(np.array_equal(f, g_) for g_ in fr["reference"]))
         cmp_ = {"delivered_frames_compared": f"{skip} .. {skip + nkeep - 1} (first pass over the recording)",
                 "mi355x_vs_deterministic_driver": against_driver(fr["mi355x"]),
                 "reference_vs_deterministic_driver": against_driver(fr["reference"]),
                 "reference_vs_reference": {"frames": 30, "bit_identical_twin_found": twins_rr},
+                "reference_vs_driver_of_the_shortened_stream": against_shortened_stream(fr["reference"], np.fromfile(path, np.float32)),
                 "how": "the deterministic driver = the reference's own functions called in order on the same samples with nothing dropped "
                        "(oracle/: am_demod, dsp_resample_process per chunk, dsp_post_process per frame); a delivered frame counts when its "
-                       "266 175 floats equal a driver frame's.  The reference's threaded library delivers the driver's picture with every pixel a "
-                       "different blend of the recording's noise (likely blocks its lossy rings refuse, each compensated by a skip of round(2 S) "
-                       "samples, a third of a sample off the raster: dsp.c:338-345, TSDRLibrary.c:283-284) — consistently from run to run when "
-                       "the timing repeats (reference_vs_reference)"}
+                       "266 175 floats equal a driver frame's.  The reference's threaded library loses blocks while its rings grow to their "
+                       "working size (circbuff.c:64-110), each compensated by a skip of round(2 S) = 266 667 samples, a third of a sample off "
+                       "the raster (dsp.c:338-345, TSDRLibrary.c:283-284): its frames are the driver's frames of the recording with d x 266 667 "
+                       "samples removed, normalised by an autogain whose history lacks the lost frames "
+                       "(reference_vs_driver_of_the_shortened_stream: how many delivered frames are exact affine images of a raw driver frame "
+                       "of that stream, the residual, and whether they are consecutive — a loaded host also loses whole frames later) — "
+                       "consistently from run to run when the timing repeats (reference_vs_reference)"}
         return {"workload": "BASELINE configs[0]: 8 MS/s float32 IQ, TSDRPlugin_RawFile (the reference's binary, real-time paced), 640x480@60 -> 507x525 frames",
                 "runs": runs, "frames": cmp_, "cores_on_box": os.cpu_count(),
                 "note": "both libraries behind the same plugin binary on the same 2 s recording; the plugin paces to real time, so both deliver "
