@@ -36,18 +36,32 @@ for tag, lib, free in (("reference", reflib, False), ("mi355x", tsdrlib.LIB, Tru
         j = int(np.argmin(d))
         print("   frame", 10 + i, "nearest oracle frame", j, "mean |diff|", round(d[j], 6), "exact pixels", int(np.sum(fr[i] == want[j])), "of", P)
 
-# Does "the first n blocks were refused by the ring" (dsp_dropped_compensation_add's failure branch, dsp.c:338-345: every refused
-# block of 262 144 samples becomes a skip of block = round(2 S) = 266 667 samples) explain the reference's frames?
+# What the reference's threaded library delivers instead.  Its rings start at 2 floats and grow by the adds (circbuff.c:64-110); a block
+# a ring refuses meanwhile becomes a skip of d x block samples, block = round(2 S) = 266 667 (dsp.c:338-345, TSDRLibrary.c:283-284): a
+# third of a sample off the raster per block.  Test: is every delivered frame an exact AFFINE image (the autogain's normalisation,
+# dsp.c:74 — its state depends on the frames lost before, so the values differ, the pixels do not) of a RAW driver frame of the recording
+# with d x 266 667 samples removed?  (Round 5, this container: frames 7..59 of a run are images of raw frames 14..66 at d = 2, residual
+# 6e-8, consecutive; frame 2 of raw frame 4 at d = 1; frames 0, 1, 3, 6 straddle a gap.)
 ref_frames = np.load("/tmp/diag_cfg0_reference.npy")
-rk = {hash(f.tobytes()): i for i, f in enumerate(ref_frames)}
 block = int(round(((geo.width * h) << 1) * geo.pixeltimeoversampletime))
-for n in range(0, 13):
-    start = n * block
-    pix_n, _ = orc.demod_resample_stream(iq[2 * start:], geo)
-    pp_n = orc.PostProcess(geo)
-    hits = []
-    for k in range(min(40, pix_n.size // P)):
-        f = pp_n.run(pix_n[k * P:(k + 1) * P].copy(), 0.0)
-        hits.append(rk.get(hash(f.tobytes())))
-    found = [(k, v) for k, v in enumerate(hits) if v is not None]
-    print("skipped", n, "blocks of", block, "samples at the start ->", len(found), "of the driver's first 40 frames are frames the reference delivered", found[:3])
+sub = slice(0, P, 11)
+found = {}
+for d in range(0, 7):
+    px, _ = orc.demod_resample_stream(iq[2 * d * block:2 * (d * block + 9_000_000)], geo)
+    raw = [px[k * P:(k + 1) * P][sub].astype(np.float64) for k in range(px.size // P)]
+    for i, f in enumerate(ref_frames):
+        if i in found:
+            continue
+        y = f[sub].astype(np.float64)
+        m = np.abs(y) < 250
+        for j, x in enumerate(raw):
+            vx = x[m] - x[m].mean()
+            a = float((vx * (y[m] - y[m].mean())).sum() / (vx * vx).sum())
+            b = float(y[m].mean() - a * x[m].mean())
+            res = float(np.max(np.abs(a * x[m] + b - y[m])))
+            if res < 1e-5:
+                found[i] = (d, j, round(a, 5), round(b, 5), res)
+                break
+    print("d =", d, ": delivered frames explained so far:", len(found), "of", len(ref_frames), flush=True)
+for i in range(len(ref_frames)):
+    print("delivered frame", 10 + i, "-> (blocks removed, raw driver frame, a, b, max residual)", found.get(i))
