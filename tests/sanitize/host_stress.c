@@ -82,6 +82,26 @@ int main(int argc, char **argv)
     const double refresh = atof(argv[4]), secs = atof(argv[6]);
     int bad = 0;
     tsdr_init(&lib, on_value, on_plot, NULL);
+    /* the error paths first (TSDRLibrary.c:425-465,552-620): each returns its code and leaves a text; a success clears it */
+#define EXPECT(call_, code_)                                                                     \
+    do {                                                                                         \
+        const int got_ = (call_);                                                                \
+        if (got_ != (code_)) { fprintf(stderr, "%s returned %d, expected %d\n", #call_, got_, (code_)); bad++; } \
+        if (((code_) == TSDR_OK) != (tsdr_getlasterrortext(lib) == NULL)) { fprintf(stderr, "%s: error text does not match the status\n", #call_); bad++; } \
+    } while (0)
+    EXPECT(tsdr_readasync(lib, on_frame, NULL), TSDR_ERR_PLUGIN);
+    EXPECT(tsdr_unloadplugin(lib), TSDR_ERR_PLUGIN);
+    EXPECT(tsdr_getsamplerate(lib), TSDR_ERR_PLUGIN);
+    EXPECT(tsdr_loadplugin(lib, "/nonexistent/libTSDRPlugin_Nothing.so", ""), TSDR_INCOMPATIBLE_PLUGIN);
+    EXPECT(tsdr_loadplugin(lib, argv[1], "/nonexistent/file 0"), TSDR_PLUGIN_PARAMETERS_WRONG);
+    EXPECT(tsdr_setresolution(lib, 0, 60.0), TSDR_WRONG_VIDEOPARAMS);
+    EXPECT(tsdr_setresolution(lib, 100, -1.0), TSDR_WRONG_VIDEOPARAMS);
+    EXPECT(tsdr_setparameter_int(lib, COUNT_PARAM_INT, 1), TSDR_INVALID_PARAMETER);
+    EXPECT(tsdr_setparameter_double(lib, -1, 1.0), TSDR_INVALID_PARAMETER);
+    EXPECT(tsdr_setbasefreq(lib, 400000000u), TSDR_OK); /* no plugin: remembered for the next run */
+    if (tsdr_motionblur(lib, 1.5f) != TSDR_WRONG_VIDEOPARAMS) bad++;
+    if (tsdr_stop(lib) != TSDR_OK) bad++; /* not running: a no-op */
+    if (tsdr_isrunning(lib)) bad++;
     char params[2048];
     snprintf(params, sizeof(params), "%s", argv[2]);
     int rc = tsdr_loadplugin(lib, argv[1], params);
@@ -120,6 +140,11 @@ int main(int argc, char **argv)
                     tsdr_setparameter_int(lib, PARAM_AUTOGAIN_AFTER_PROCESSING, 0);
                     break;
                 }
+                case 11: /* not while it runs (TSDRLibrary.c:425-440,467-475) */
+                    if (tsdr_unloadplugin(lib) != TSDR_ALREADY_RUNNING) bad++;
+                    if (tsdr_loadplugin(lib, argv[1], params) != TSDR_ALREADY_RUNNING) bad++;
+                    if (tsdr_readasync(lib, on_frame, NULL) != TSDR_ALREADY_RUNNING) bad++;
+                    break;
                 default: (void)tsdr_isrunning(lib); (void)tsdr_getsamplerate(lib); break;
             }
         }
