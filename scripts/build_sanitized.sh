@@ -20,4 +20,6 @@ STUB="$OUT/stub_tsdrgpu.o -lpthread -ldl -lm"
 gcc -fsanitize=thread $COMMON -o $OUT/host_stress_tsan_stub $SRCS $STUB
 gcc -fsanitize=address,undefined -fno-sanitize-recover=undefined $COMMON -o $OUT/host_stress_asan_stub $SRCS $STUB
 gcc $COMMON -O2 -o $OUT/host_stress_plain_stub $SRCS $STUB
+# the multi-GPU sweep's C host (one thread and one rank per device) on the stand-in: its meeting points with more than one rank
+gcc -fsanitize=thread $COMMON -o $OUT/host_stress_sweep_tsan_stub $H/tsdr_sweep.c $STUB
 ls -la $OUT/host_stress_*

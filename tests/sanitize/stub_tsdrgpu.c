@@ -11,6 +11,7 @@
  * visible to whoever waited) as a release store / acquire load, so the sanitizer neither sees edges the GPU would not give
  * nor misses the ones it does. */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,7 +19,7 @@
 
 #include "tsdrgpu.h"
 
-struct tsdrgpu { int dummy; };
+struct tsdrgpu { int device; };
 struct tsdrgpu_event { int seq; };
 struct tsdrgpu_resampler { tsdrgpu_t *g; int64_t track_P, phase; int k; float mn[512], mx[512]; };
 struct tsdrgpu_postproc { tsdrgpu_t *g; int open, F; };
@@ -33,10 +34,22 @@ struct tsdrgpu_autocorr {
     long argmaxes;
 };
 
+/* Failure injection for the multi-rank sweep (tests/test_host_sanitizers.py): STUB_FAIL_CREATE_DEVICE=k: tsdrgpu_create(device k)
+ * fails; STUB_FAIL_RUN_DEVICE=k: tsdrgpu_autocorr_run fails on that device's detector; STUB_UNCERTIFIED_DEVICE=k: only that device's
+ * detector refuses its certificate (the premise check of the rank's own newest window); STUB_UNCERTIFIED_DEVICE=all: every rank's. */
+static int stub_env_is(const char *name, int device)
+{
+    const char *e = getenv(name);
+    if (!e || !e[0]) return 0;
+    return (e[0] == 'a') || atoi(e) == device;
+}
+
 int tsdrgpu_create(tsdrgpu_t **out, int device)
 {
-    (void)device;
+    *out = NULL;
+    if (stub_env_is("STUB_FAIL_CREATE_DEVICE", device)) return TSDRGPU_EHIP;
     *out = (tsdrgpu_t *)calloc(1, sizeof(**out));
+    if (*out) (*out)->device = device;
     return *out ? 0 : TSDRGPU_ENOMEM;
 }
 void tsdrgpu_destroy(tsdrgpu_t *g) { free(g); }
@@ -60,6 +73,7 @@ int tsdrgpu_host_unregister(tsdrgpu_t *g, void *p) { (void)g; (void)p; return 0;
 static int cp(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int tsdrgpu_copy(tsdrgpu_t *g, void *d, const void *s, size_t n) { (void)g; if (n) memmove(d, s, n); return 0; }
 int tsdrgpu_download(tsdrgpu_t *g, void *d, const void *s, size_t n) { (void)g; return cp(d, s, n); }
+int tsdrgpu_upload(tsdrgpu_t *g, void *d, const void *s, size_t n) { (void)g; return cp(d, s, n); }
 int tsdrgpu_upload_lane(tsdrgpu_t *g, void *d, const void *s, size_t n) { (void)g; return cp(d, s, n); }
 int tsdrgpu_download_lane(tsdrgpu_t *g, void *d, const void *s, size_t n) { (void)g; return cp(d, s, n); }
 int tsdrgpu_gather2(tsdrgpu_t *g, void *d1, void *d2, const void *const *srcs, const size_t *bytes, int n)
@@ -247,6 +261,7 @@ int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq
 {
     (void)mode;
     if (ac->replay_left) return TSDRGPU_ESTATE;
+    if (stub_env_is("STUB_FAIL_RUN_DEVICE", ac->g->device)) return TSDRGPU_EHIP;
     for (int w = 0; w < nwin; w++) {
         const float *x = d_in + (size_t)w * stride * (in_is_iq ? 2 : 1);
         double acc = 0.0;
@@ -292,7 +307,8 @@ int tsdrgpu_autocorr_certificate(tsdrgpu_autocorr_t *ac, tsdrgpu_ac_certificate_
 {
     memset(c, 0, sizeof(*c));
     /* every seventh plot of a float32 epoch is "not certified": the engine's hold-back and replay path runs */
-    const int okay = ac->exact_epoch || (ac->argmaxes % 7) != 0;
+    int okay = ac->exact_epoch || (ac->argmaxes % 7) != 0;
+    if (getenv("STUB_UNCERTIFIED_DEVICE")) okay = ac->exact_epoch || !stub_env_is("STUB_UNCERTIFIED_DEVICE", ac->g->device);
     c->frame_certified = c->line_certified = okay;
     c->exact_epoch = ac->exact_epoch;
     return 0;
@@ -322,4 +338,81 @@ int tsdrgpu_superb_stitch(tsdrgpu_t *g, float *const *d_hops, int nhops, int gat
 int tsdrgpu_superb_stitch_exact(tsdrgpu_t *g, float *const *d_hops, int nhops, int gathered, int sif, float *d_out, int32_t *h_off, uint32_t *h_total)
 {
     return tsdrgpu_superb_stitch(g, d_hops, nhops, gathered, sif, d_out, h_off, h_total);
+}
+
+/* ---- what tsdr_sweep.c needs on top: the synchronous argmax, the sums' exchange between the ranks (threads of one process) ---- */
+int tsdrgpu_autocorr_argmax(tsdrgpu_autocorr_t *ac, int32_t *fi, int32_t *li)
+{
+    if (tsdrgpu_autocorr_argmax_async(ac)) return TSDRGPU_ESTATE;
+    return tsdrgpu_autocorr_argmax_result(ac, fi, li);
+}
+int tsdrgpu_autocorr_finalize_sums(tsdrgpu_autocorr_t *ac, uint64_t total)
+{
+    const size_t L = (size_t)ac->flen + ac->llen;
+    for (size_t i = 0; i < L; i++) ac->plots[i] /= (double)(total ? total : 1);
+    ac->calls = total;
+    return 0;
+}
+int tsdrgpu_autocorr_promote(tsdrgpu_autocorr_t *ac)
+{
+    ac->exact_epoch = 1; /* (the replayed sums are the same numbers here) */
+    const size_t L = (size_t)ac->flen + ac->llen;
+    for (size_t i = 0; i < L; i++) ac->plots[i] *= (double)(ac->calls ? ac->calls : 1); /* back to this rank's sums */
+    return 0;
+}
+int tsdrgpu_autocorr_plots(tsdrgpu_autocorr_t *ac, double *hf, double *hl, uint64_t *calls)
+{
+    memcpy(hf, ac->plots, sizeof(double) * (size_t)ac->flen);
+    memcpy(hl, ac->plots + ac->flen, sizeof(double) * (size_t)ac->llen);
+    if (calls) *calls = ac->calls;
+    return 0;
+}
+
+/* One communicator per process is enough for the sweep tool.  Creating it is a collective like ncclCommInitRank: every rank
+ * must arrive, or the ones that did wait for ever — which is what tsdr_sweep.c's meeting points are there to prevent. */
+struct tsdrgpu_comm { int world, rank; };
+static pthread_mutex_t comm_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_barrier_t comm_bar;
+static int comm_bar_world;
+static double *comm_acc;
+static size_t comm_acc_n;
+int tsdrgpu_rccl_unique_id(void *id128) { memset(id128, 7, TSDRGPU_RCCL_ID_BYTES); return 0; }
+int tsdrgpu_comm_create(tsdrgpu_t *g, tsdrgpu_comm_t **out, int world, int rank, const void *id128)
+{
+    (void)g; (void)id128;
+    pthread_mutex_lock(&comm_lock);
+    if (comm_bar_world != world) {
+        pthread_barrier_init(&comm_bar, NULL, (unsigned)world);
+        comm_bar_world = world;
+    }
+    pthread_mutex_unlock(&comm_lock);
+    *out = (tsdrgpu_comm_t *)calloc(1, sizeof(**out));
+    if (!*out) return TSDRGPU_ENOMEM;
+    (*out)->world = world; (*out)->rank = rank;
+    pthread_barrier_wait(&comm_bar);
+    return 0;
+}
+void tsdrgpu_comm_destroy(tsdrgpu_comm_t *c) { free(c); }
+int tsdrgpu_autocorr_allreduce(tsdrgpu_autocorr_t *ac, tsdrgpu_comm_t *c, uint64_t total)
+{
+    const size_t L = (size_t)ac->flen + ac->llen;
+    pthread_barrier_wait(&comm_bar);
+    pthread_mutex_lock(&comm_lock);
+    if (comm_acc_n != L) { free(comm_acc); comm_acc = (double *)calloc(L, sizeof(double)); comm_acc_n = L; }
+    for (size_t i = 0; i < L; i++) comm_acc[i] += ac->plots[i];
+    pthread_mutex_unlock(&comm_lock);
+    pthread_barrier_wait(&comm_bar);
+    for (size_t i = 0; i < L; i++) ac->plots[i] = comm_acc[i] / (double)(total ? total : 1);
+    ac->calls = total;
+    pthread_barrier_wait(&comm_bar);
+    if (c->rank == 0) memset(comm_acc, 0, sizeof(double) * L);
+    pthread_barrier_wait(&comm_bar);
+    return 0;
+}
+int tsdrgpu_modedetect_create(tsdrgpu_modedetect_t **out) { *out = NULL; return TSDRGPU_ESTATE; } /* (the tool goes on without it) */
+void tsdrgpu_modedetect_destroy(tsdrgpu_modedetect_t *d) { (void)d; }
+int tsdrgpu_modedetect_feed(tsdrgpu_modedetect_t *d, int fo, int fi, int lo, int li, uint32_t rate, tsdrgpu_detection_t *out)
+{
+    (void)d; (void)fo; (void)fi; (void)lo; (void)li; (void)rate; (void)out;
+    return TSDRGPU_ESTATE;
 }

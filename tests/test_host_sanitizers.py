@@ -66,3 +66,36 @@ def test_host_threads_under_threadsanitizer(built, name, plugin, params):
 def test_host_code_under_addresssanitizer_and_ubsan(built):
     _run("host_stress_asan_stub", MEM, "{f32} 1000000 65536 0 2000".format(**built))
     _run("host_stress_asan_stub", TESTPLUGIN, "{f32} 1000000 524288 20000 3 1000".format(**built), sessions=2)
+
+
+# ---------------------------------------------------------------------------
+# tsdr_sweep (the multi-GPU sweep's C host: one thread and one RCCL rank per device) with MORE THAN ONE rank.  One MI355X box
+# cannot run that (RCCL refuses two ranks on one device), so its meeting points — the ranks agree before every step that leads
+# into a collective, tsdr_sweep.c agree() / MEET — are exercised here, under ThreadSanitizer, on the stand-in, whose communicator
+# creation and all-reduce BLOCK until every rank has arrived, like ncclCommInitRank / ncclAllReduce: a rank that skipped or
+# entered a collective alone would hang the run (the timeout), not fail it.
+# ---------------------------------------------------------------------------
+SWEEP_CASES = [
+    # name, environment, devices, exit code, what the output must hold
+    ("healthy-4-ranks", {}, "0,1,2,3", 0, '"epoch_replayed_exact": 0'),
+    ("healthy-8-ranks", {}, "0,1,2,3,4,5,6,7", 0, '"windows_per_device": [2, 1, 1, 1, 1, 1, 1, 1]'),
+    ("one-rank-alone-is-refused-its-certificate", {"STUB_UNCERTIFIED_DEVICE": "2"}, "0,1,2,3", 0, '"epoch_replayed_exact": 1'),
+    ("every-rank-is-refused", {"STUB_UNCERTIFIED_DEVICE": "all"}, "0,1,2,3", 0, '"epoch_replayed_exact": 1'),
+    ("a-rank-fails-before-the-communicator", {"STUB_FAIL_CREATE_DEVICE": "1"}, "0,1,2,3", 1, "rank 1 (device 1): tsdrgpu_create"),
+    ("a-rank-fails-before-the-exchange", {"STUB_FAIL_RUN_DEVICE": "3"}, "0,1,2,3", 1, "rank 3 (device 3): tsdrgpu_autocorr_run"),
+    ("two-ranks-fail-at-different-points", {"STUB_FAIL_CREATE_DEVICE": "0", "STUB_FAIL_RUN_DEVICE": "2"}, "0,1,2,3", 1, "rank 0 (device 0)"),
+    ("one-rank-with-a-communicator", {}, "0 --force-comm", 0, '"windows_per_device": [9]'),
+]
+
+
+@pytest.mark.parametrize("name,env,devices,rc,needle", SWEEP_CASES, ids=[c[0] for c in SWEEP_CASES])
+def test_sweep_tool_ranks_meet_before_every_collective(built, tmp_path, name, env, devices, rc, needle):
+    rec = tmp_path / "sweep.f32"
+    np.random.default_rng(3).standard_normal(2 * 56363 * 9).astype(np.float32).tofile(rec)  # 9 capture windows at 1 MS/s
+    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", **env)
+    out = subprocess.run([os.path.join(SAN, "host_stress_sweep_tsan_stub"), str(rec), "1000000", "--devices"] + devices.split() + ["--windows", "9"],
+                         capture_output=True, text=True, timeout=60, env=e)  # a rank left alone in a collective = this timeout
+    text = out.stdout + out.stderr
+    assert "ThreadSanitizer" not in text, text[-3000:]
+    assert out.returncode == rc, text[-2000:]
+    assert needle in text, text[-2000:]
