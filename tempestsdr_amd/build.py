@@ -116,7 +116,9 @@ def build_host_stress(force=False):
     host = os.path.join(CSRC, "host")
     srcs = [os.path.join(san, "host_stress.c"), os.path.join(san, "stub_tsdrgpu.c"), script] + [os.path.join(host, f) for f in os.listdir(host)] + _headers()
     if force or any(_newer(os.path.join(san, exe), srcs) for exe in ("host_stress_plain", "host_stress_tsan_stub", "host_stress_asan_stub")):
-        subprocess.run(["bash", script], check=True, capture_output=True)
+        r = subprocess.run(["bash", script], capture_output=True, text=True)
+        if r.returncode != 0:  # test infrastructure: a host without libtsan / libasan still gets the product
+            print("build_host_stress: scripts/build_sanitized.sh failed (the sanitizer tests will rebuild or skip):\n" + r.stderr[-1500:], flush=True)
 
 
 if __name__ == "__main__":
