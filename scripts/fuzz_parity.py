@@ -380,6 +380,11 @@ def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
+    redzones = None
+    if os.environ.get("TSDR_TEST_REDZONES", "0") == "1":  # the GPU suite's red zones (tests/conftest.py) around this script's buffers too
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import conftest as redzones
+        redzones._install_redzones()
     g = gpu.TsdrGpu(0)
     fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0, "plot": 0, "tracking": 0, "superb": 0, "pll": 0, "acmulti": 0}
     for c in range(ncases):
@@ -393,10 +398,18 @@ def main():
         except Exception as e:  # noqa: BLE001
             r = f"{kind} raised {e!r}"
         ran[kind] += 1
+        if redzones is not None:
+            import gc
+            gc.collect()
+            for a in list(redzones._redzone_live):
+                a.redzones_intact(f"case {c} ({kind})")
+            if redzones._redzone_violations:
+                r = (r or "") + " RED ZONE: " + "; ".join(redzones._redzone_violations)
+                redzones._redzone_violations.clear()
         if r:
             fails.append((c, r))
             print("MISMATCH", c, r, flush=True)
-    print(f"fuzz: {ncases} cases {ran}, {len(fails)} mismatches, seed {seed}")
+    print(f"fuzz: {ncases} cases {ran}, {len(fails)} mismatches, seed {seed}" + (", red zones around every buffer" if redzones is not None else ""))
     return 1 if fails else 0
 
 
