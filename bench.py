@@ -223,10 +223,13 @@ def config0_leg():
     different blend of the recording's noise (mean |difference| 0.03 at frame 10).  The cause are its lossy rings at start-up: a
     ring starts at 2 floats and grows by the adds (circbuff.c:64-110); a block it refuses meanwhile becomes a skip of
     block = round(2 S) samples (dsp.c:338-345, TSDRLibrary.c:283-284; 2 S = 266 666.67, block = 266 667), a third of a sample off the
-    raster each.  Verified, not assumed: every frame the reference delivers from its 8th on is an EXACT affine image (residual 6e-8;
-    the affine map is the autogain's normalisation) of a raw frame of the deterministic driver run on the recording with
-    2 x 266 667 samples removed, consecutive and in order (`reference_vs_driver_of_the_shortened_stream`; d is searched, so a box
-    with another timing reports its own).  It does so consistently from run to run when the timing repeats (two reference
+    raster each; a chunk of pixels the NEXT ring refuses costs whole frames (the skip there is a multiple of the frame).  Verified, not
+    assumed: the frames the reference delivers are EXACT affine images (residual 6-9e-8; the affine map is the autogain's
+    normalisation, whose history lacks the lost frames) of raw frames of the deterministic driver run on the recording with
+    d x 266 667 samples removed (`reference_vs_driver_of_the_shortened_stream`; d is searched).  What is lost depends on the host's
+    timing: on the 256-core MI355X box d = 0 and 4 whole frames (60 of 60 compared frames are images of raw frames 13 ... 73: three
+    lost before the 10th delivered, one after); in the 8-core build container d = 2 and delivered frames 7 ... 59 are raw frames
+    14 ... 66 of the shortened recording.  It does so consistently from run to run when the timing repeats (two reference
     runs: up to 30 of 30 frames with a bit-identical twin; none on a loaded host).  All numbers are in the leg."""
     from tempestsdr_amd import tsdrlib, synth
     import resource
@@ -313,6 +316,8 @@ def config0_leg():
                 n_ok = sum(1 for k in hits if k is not None)
                 cand = {"samples_removed": d * blk, "blocks_of_266667": d, "frames": len(frames), "exact_affine_images_of_a_raw_driver_frame": n_ok,
                         "max_residual": float(f"{worst:.3g}"), "raw_driver_frames": [hits[0], hits[-1]],
+                        "whole_frames_lost": ({"before_the_first_compared": hits[0] - skip, "among_the_compared": hits[-1] - hits[0] + 1 - n_ok}
+                                              if hits[0] is not None and hits[-1] is not None else None),
                         "consecutive": all(k is not None for k in hits) and all(b_ - a_ == 1 for a_, b_ in zip(hits, hits[1:]))}
                 if best is None or n_ok > best["exact_affine_images_of_a_raw_driver_frame"]:
                     best = cand
