@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Closing the loop on BASELINE configs[0].  The reference's threaded library delivers frames that are not the deterministic
+driver's (bench.py's configs[0] leg): its rings refuse chunks of pixels — and on slower hosts blocks of samples — while they grow to
+their working size (circbuff.c:64-110), and every refusal is compensated by a skip that keeps the frame grid (dsp.c:313-368): a
+whole multiple of the frame in the pixel ring, d x 266 667 samples in the sample ring.  If that is the WHOLE story, the oracle's
+dsp_post_process run over exactly the pixels the reference kept must reproduce the reference's delivered frames BIT FOR BIT.
+
+This script tests that.  Every delivered frame (from the very first) is decomposed into segments, each an exact affine image (the
+autogain's normalisation, dsp.c:74) of the SAME pixel positions of a raw driver frame of the recording with d x 266 667 samples
+removed — one segment for a frame the rings let through whole, two or more for a frame that straddles a refusal — and the raw
+frames so reconstructed are replayed through the oracle's post-processing in the reference's order.
+CPU only (oracle/ + oracle/_ref); WHAT is lost depends on the host's timing, THAT the replay reproduces the output should not."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tempestsdr_amd import tsdrlib, synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+fs, h, fv = 8_000_000, 525, 60.0
+NF = int(sys.argv[1]) if len(sys.argv) > 1 else 70
+path = "/tmp/diag_cfg0_replay.f32"
+iq = synth.synth_iq(fs, "640x480", fv, 2 * fs, seed=0x5EED0000)
+iq.tofile(path)
+reflib = os.path.join(ROOT, "oracle", "_ref", "libtsdr_ref.so")
+rawfile = os.path.join(ROOT, "oracle", "_ref", "libTSDRPlugin_RawFile.so")
+geo = orc.geometry(fs, h, fv)
+P = geo.width * h
+out = "/tmp/diag_cfg0_replay.npy"
+r = tsdrlib.throughput_subprocess(reflib, rawfile, f"{path} {fs} float", h, fv, 2.0, free=False, timeout=120, dump=out, dump_frames=NF, dump_skip=0)
+fr = np.load(out)
+print("reference:", round(r["frames_per_s"], 2), "frames/s;", len(fr), "delivered frames kept, from the first", flush=True)
+block = int(round(((geo.width * h) << 1) * geo.pixeltimeoversampletime))
+DMAX = 6
+raws = []
+for d in range(DMAX):
+    px, _ = orc.demod_resample_stream(iq[2 * d * block:2 * (d * block + (NF + 40) * int(fs / fv))], geo)
+    raws.append(px)
+TOL = 1e-5
+
+
+def fit(y, x):
+    """max residual of the best affine map x -> y over the pixels that are not marker lines"""
+    m = np.abs(y) < 250
+    if m.sum() < 16:
+        return 0.0
+    xx, yy = x[m].astype(np.float64), y[m].astype(np.float64)
+    vx = xx - xx.mean()
+    den = float((vx * vx).sum())
+    if den == 0.0:
+        return 1.0
+    a = float((vx * (yy - yy.mean())).sum() / den)
+    return float(np.max(np.abs(a * xx + (yy.mean() - a * xx.mean()) - yy)))
+
+
+def decompose(frames, streams, tol_seam=3):
+    """every delivered frame as segments (stream, raw frame, first pixel, end pixel); up to tol_seam pixels between two segments may
+    belong to neither (a pixel that blends the samples either side of a sample gap)"""
+    plan, gd, gj = [], 0, 0
+    for f in frames:
+        pos, segs = 0, []
+        while pos < P:
+            s_ = None
+            for skip_ in range(0, tol_seam + 1 if segs else 1):
+                s_ = segment(f, pos + skip_, gd, gj, streams)
+                if s_ is not None:
+                    if skip_:
+                        segs.append(("seam", None, pos, pos + skip_))
+                    pos += skip_
+                    break
+            if s_ is None:
+                segs = None
+                break
+            d, j, end = s_
+            segs.append((d, j, pos, end))
+            gd, gj = d, j + 1
+            pos = end
+        plan.append(segs)
+    return plan
+
+
+def segment(f, pos, guess_d, guess_j, streams):
+    L = min(4000, P - pos)
+    if L <= 0:
+        return None
+    y = f[pos:pos + L]
+    for d in range(max(0, guess_d), len(streams)):
+        for j in range(max(0, guess_j - 2), guess_j + 14):
+            src = streams[d][j * P:(j + 1) * P]
+            if src.size < P:
+                break
+            if fit(y, src[pos:pos + L]) < TOL:
+                if fit(f[pos:P], src[pos:P]) < TOL:
+                    return d, j, P
+                lo, hi = pos + L, P
+                while hi - lo > 1:
+                    mid = (lo + hi) // 2
+                    if fit(f[pos:mid], src[pos:mid]) < TOL:
+                        lo = mid
+                    else:
+                        hi = mid
+                return d, j, lo
+    return None
+
+
+# pass 1: against the recording shortened FROM THE START by d blocks — tells which d every stretch of the output belongs to, and
+# where the transitions (sample gaps) are
+plan = decompose(fr, raws)
+bad = [i for i, s_ in enumerate(plan) if s_ is None]
+if bad:
+    print("no decomposition for delivered frames", bad, "- giving up")
+    sys.exit(0)
+r_ = P * fv / fs
+gaps = []  # (first sample removed, count) in the ORIGINAL recording
+flat = [(i, sg) for i, segs in enumerate(plan) for sg in segs if sg[0] != "seam"]
+for (i0, a_), (i1, b_) in zip(flat, flat[1:]):
+    if b_[0] == a_[0]:
+        continue
+    # the stream changes between these two segments: a refused plugin block.  Its place is the first block boundary at or after the
+    # last pixel of the earlier segment (inside one delivered frame that is the seam itself — it then falls ON a boundary; when whole
+    # frames were lost in between, any boundary in the lost stretch gives the same pixels afterwards: the chunk grid follows the KEPT
+    # samples)
+    where = a_[0] * block + (a_[1] * P + a_[3]) / r_
+    B = int(np.ceil(where / 262144.0 - 0.01))
+    gaps.append((B * 262144, (b_[0] - a_[0]) * block))
+    print(f"delivered frame {i0}{'' if i0 == i1 else ' .. ' + str(i1)}: the sample stream jumps by {b_[0] - a_[0]} x {block} samples at sample {where:.0f} = plugin block {where / 262144.0:.3f} -> block {B} refused")
+gaps.sort()
+# pass 2: the recording with exactly those samples removed WHERE they were removed, through the oracle's resampler in the reference's
+# chunks: the pixel stream the reference's decimating thread produced, seam pixels and rounding included
+keep = np.ones(iq.size // 2, bool)
+for at, cnt in gaps:
+    keep[at:at + cnt] = False
+iq2 = iq.reshape(-1, 2)[keep].reshape(-1)
+sim, _ = orc.demod_resample_stream(iq2[:2 * (NF + 40) * int(fs / fv)], geo)
+plan2 = decompose(fr, [sim], tol_seam=0)
+bad = [i for i, s_ in enumerate(plan2) if s_ is None]
+print(f"sample gaps: {[(a // 262144, c // block) for a, c in gaps]} (plugin block refused, blocks of {block} samples skipped)")
+if bad:
+    print("against the simulated pixel stream, no decomposition for delivered frames", bad)
+    sys.exit(0)
+whole = sum(1 for s_ in plan2 if len(s_) == 1)
+print(f"against that pixel stream: {whole} delivered frames are one frame of it each; the others straddle a refused chunk of pixels:")
+for i, s_ in enumerate(plan2):
+    if len(s_) > 1:
+        print("   delivered", i, "=", " + ".join(f"frame {j} pixels {a}..{b}" for _, j, a, b in s_))
+print("   frame of the simulated stream per whole delivered frame:", [s_[0][1] if len(s_) == 1 else None for s_ in plan2])
+# The replay.  A frame the reference did not deliver was lost either BEFORE its post-processing (a chunk the pixel ring refused: the
+# frame never existed) or AFTER it (the frame ring towards the video thread refused it: dsp_post_process had run, the autogain and
+# the sync detector had seen it).  For every run of undelivered whole frames the subset that was processed is searched: the one
+# after which the next delivered frame comes out bit for bit.
+from itertools import combinations
+
+
+def run_all(frames_):
+    pp_ = orc.PostProcess(geo)
+    out_ = None
+    for f_ in frames_:
+        out_ = pp_.run(f_.copy(), 0.0)
+    return pp_, out_
+
+
+seq, same, hidden, unexplained = [], 0, [], []
+pp = orc.PostProcess(geo)
+prev_last = -1
+for i, segs in enumerate(plan2):
+    raw = np.concatenate([sim[j * P + a:j * P + b] for _, j, a, b in segs])
+    missing = list(range(prev_last + 1, segs[0][1]))
+    prev_last = segs[-1][1]
+    got = pp.run(raw.copy(), 0.0)
+    if np.array_equal(got, fr[i]):
+        seq.append(raw)
+        same += 1
+        continue
+    found_ = None
+    for k in range(1, len(missing) + 1):
+        for sub in combinations(missing, k):
+            cand = seq + [sim[j * P:(j + 1) * P] for j in sub] + [raw]
+            pp_try, out_try = run_all(cand)
+            if np.array_equal(out_try, fr[i]):
+                found_ = (sub, pp_try, cand)
+                break
+        if found_:
+            break
+    if found_:
+        hidden.append((i, found_[0]))
+        pp, seq = found_[1], found_[2]
+        same += 1
+    else:
+        unexplained.append(i)
+        seq.append(raw)  # (pp has processed it)
+print(f"REPLAY: the oracle's resampler + dsp_post_process over what the reference kept, in its order, reproduce {same} of {len(fr)} delivered frames BIT FOR BIT")
+for i, sub in hidden:
+    print(f"   before delivered frame {i}: frames {list(sub)} of the stream were post-processed but never reached the callback (lost between dsp_post_process and the video thread)")
+if unexplained:
+    print("   not reproduced:", unexplained)
+print(f"lost on the way: {sum(c for _, c in gaps)} samples in {len(gaps)} gap(s) and {plan2[-1][-1][1] + 1 - len(fr)} whole frames of {plan2[-1][-1][1] + 1}")
