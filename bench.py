@@ -325,12 +325,31 @@ def config0_leg():
                     break
             return best
 
+        def replayed_by_the_oracle():
+            """scripts/diag_cfg0_replay.py on a reference session of its own: the oracle's resampler and dsp_post_process over exactly the
+            blocks, chunks and frames the threaded library's rings let through (recovered from its delivered frames) — how many of its
+            delivered frames come out bit for bit"""
+            import re
+            import subprocess
+            try:
+                o = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "diag_cfg0_replay.py"), "60"], capture_output=True, text=True, timeout=400, cwd=ROOT)
+                ln = [x for x in o.stdout.splitlines() if x.startswith("REPLAY:")]
+                lost = [x for x in o.stdout.splitlines() if x.startswith("lost on the way")]
+                if not ln:
+                    return {"error": "this run's loss pattern is outside what the decomposition models", "tail": o.stdout[-300:]}
+                m_ = re.search(r"reproduce (\d+) of (\d+) delivered frames", ln[0])
+                return {"delivered_frames": int(m_.group(2)), "bit_identical_to_the_replay": int(m_.group(1)), "lost": lost[0] if lost else None,
+                        "how": "python scripts/diag_cfg0_replay.py 60 (a reference session of its own; DESIGN.md section 4)"}
+            except Exception as ex_:  # noqa: BLE001
+                return {"error": repr(ex_)}
+
         twins_rr = sum(1 for f in fr["reference_again"][:30] if any(np.array_equal(f, g_) for g_ in fr["reference"]))
         cmp_ = {"delivered_frames_compared": f"{skip} .. {skip + nkeep - 1} (first pass over the recording)",
                 "mi355x_vs_deterministic_driver": against_driver(fr["mi355x"]),
                 "reference_vs_deterministic_driver": against_driver(fr["reference"]),
                 "reference_vs_reference": {"frames": 30, "bit_identical_twin_found": twins_rr},
                 "reference_vs_driver_of_the_shortened_stream": against_shortened_stream(fr["reference"], np.fromfile(path, np.float32)),
+                "threaded_reference_replayed_by_the_oracle": replayed_by_the_oracle(),
                 "how": "the deterministic driver = the reference's own functions called in order on the same samples with nothing dropped "
                        "(oracle/: am_demod, dsp_resample_process per chunk, dsp_post_process per frame); a delivered frame counts when its "
                        "266 175 floats equal a driver frame's.  The reference's threaded library loses blocks while its rings grow to their "
