@@ -3,7 +3,9 @@
  * drives TSDRLibrary (JavaGUI/jni/TSDRLibraryNDK.c: one thread blocked in tsdr_readasync, the GUI thread calling the setters
  * and tsdr_stop while frames and plots arrive on the library's threads).  TEST INFRASTRUCTURE: the product is the plain build.
  *
- * usage: host_stress <plugin.so> "<plugin params>" <height> <refresh> <sessions> <seconds_per_session>
+ * usage: host_stress <plugin.so> "<plugin params>" <height> <refresh> <sessions> <seconds_per_session> [<seed>]
+ * With a seed the resolution changes mid-stream are RANDOM (height 1 .. 20 000, refresh 5 .. 240 Hz: from one-line frames to
+ * geometries whose width truncates to 0) instead of the two fixed ones: the engine's sizing arithmetic under AddressSanitizer.
  * Every session: tsdr_readasync on a thread of its own; the main thread changes resolution, gain, motion blur, shifts the
  * picture, toggles every integer parameter, reads the statistics and stops — once from the main thread and, on odd sessions,
  * from two threads at the same time (the stop_once path).  Exit code 0 = every call returned what it should; the sanitizer's
@@ -80,6 +82,9 @@ int main(int argc, char **argv)
     }
     const int height = atoi(argv[3]), sessions = atoi(argv[5]);
     const double refresh = atof(argv[4]), secs = atof(argv[6]);
+    const int random_geometry = argc > 7;
+    unsigned rnd = random_geometry ? (unsigned)atoi(argv[7]) * 2654435761u + 1u : 0u;
+#define RND() (rnd = rnd * 1664525u + 1013904223u, (rnd >> 8))
     int bad = 0;
     tsdr_init(&lib, on_value, on_plot, NULL);
     /* the error paths first (TSDRLibrary.c:425-465,552-620): each returns its code and leaves a text; a success clears it */
@@ -123,11 +128,22 @@ int main(int argc, char **argv)
             switch (i) {
                 case 1: tsdr_sync(lib, 7, DIRECTION_LEFT); tsdr_sync(lib, 3, DIRECTION_DOWN); break;
                 case 2: tsdr_setparameter_int(lib, PARAM_INT_AUTOSHIFT, 1); break;
-                case 3: tsdr_setresolution(lib, height + 10 * (s + 1), refresh * 1.003); break;
+                case 3:
+                    if (random_geometry) {
+                        const int hh = (RND() % 3 == 0) ? 1 + (int)(RND() % 20000) : 1 + (int)(RND() % 1500);
+                        const double rr = 5.0 + (double)(RND() % 23500) / 100.0;
+                        if (tsdr_setresolution(lib, hh, rr) != TSDR_OK) bad++;
+                    } else tsdr_setresolution(lib, height + 10 * (s + 1), refresh * 1.003);
+                    break;
                 case 4: tsdr_setparameter_int(lib, PARAM_INT_FRAMERATE_PLL, 1); tsdr_setparameter_int(lib, PARAM_LOW_PASS_BEFORE_SYNC, 1); break;
                 case 5: tsdr_setparameter_int(lib, PARAM_AUTOCORR_SUPERRESOLUTION, 1); tsdr_setparameter_int(lib, PARAM_AUTOCORR_PLOTS_RESET, 1); break;
                 case 6: tsdr_setparameter_int(lib, PARAM_NEAREST_NEIGHBOUR_RESAMPLING, s & 1); tsdr_motionblur(lib, 0.9f); break;
-                case 7: tsdr_setresolution(lib, height, refresh); tsdr_setgain(lib, 0.25f); tsdr_setbasefreq(lib, 400000000u + (uint32_t)s); break;
+                case 7:
+                    if (random_geometry && (RND() & 1)) tsdr_setresolution(lib, 1 + (int)(RND() % 3000), 10.0 + (double)(RND() % 11000) / 100.0);
+                    else tsdr_setresolution(lib, height, refresh);
+                    tsdr_setgain(lib, 0.25f);
+                    tsdr_setbasefreq(lib, 400000000u + (uint32_t)s);
+                    break;
                 case 8: tsdr_setparameter_int(lib, PARAM_AUTOGAIN_AFTER_PROCESSING, 1); tsdr_setparameter_double(lib, 0, 0.5); break;
                 case 9: tsdr_setparameter_int(lib, PARAM_AUTOCORR_PLOTS_OFF, 1); tsdr_setparameter_int(lib, PARAM_AUTOCORR_SUPERRESOLUTION, 0); break;
                 case 10: {

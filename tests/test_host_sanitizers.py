@@ -40,9 +40,9 @@ def built(tmp_path_factory):
     return {"f32": str(f32), "u8": str(u8)}
 
 
-def _run(binary, plugin, params, height=100, sessions=3, secs=1.5):
+def _run(binary, plugin, params, height=100, sessions=3, secs=1.5, seed=None):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1", TSDR_GPU_STATS="1")
-    out = subprocess.run([os.path.join(SAN, binary), plugin, params, str(height), "60", str(sessions), str(secs)],
+    out = subprocess.run([os.path.join(SAN, binary), plugin, params, str(height), "60", str(sessions), str(secs)] + ([str(seed)] if seed is not None else []),
                          capture_output=True, text=True, timeout=300, env=env)
     text = out.stdout + out.stderr
     assert "ThreadSanitizer" not in text and "AddressSanitizer" not in text and "runtime error" not in text, text[-4000:]
@@ -63,6 +63,14 @@ CASES = [
 def test_host_threads_under_threadsanitizer(built, name, plugin, params):
     text = _run("host_stress_tsan_stub", MEM if plugin == "mem" else TESTPLUGIN, params.format(**built))
     assert "frames made" in text  # the engine ran (TSDR_GPU_STATS)
+
+
+@pytest.mark.parametrize("seed", [3, 17, 29, 40])
+def test_random_geometry_changes_under_addresssanitizer(built, seed):
+    """resolution changes mid-stream to random geometries — one-line frames, 20 000-line frames whose width truncates to 0, refresh
+    rates from 5 to 240 Hz — : the engine's sizing arithmetic (chunks, pixel counts, stream and batch buffers, the fused run's
+    bookkeeping) with every write of the stand-in's "kernels" checked by AddressSanitizer"""
+    _run("host_stress_asan_stub", MEM, "{f32} 1000000 65536 0 2000".format(**built), sessions=2, secs=1.0, seed=seed)
 
 
 def test_host_code_under_addresssanitizer_and_ubsan(built):
