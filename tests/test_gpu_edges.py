@@ -70,6 +70,33 @@ def test_ragged_frame_geometries(orc, w, h, cfg):
         assert np.array_equal(got[k], want), (k, w, h)
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 1), (1, 2), (3, 1), (1, 7), (2, 2), (3, 2), (4, 3), (1, 300), (300, 1), (2, 4097), (4099, 1)])
+@pytest.mark.parametrize("cfg", [(0, 0, 0, 0.5), (1, 0, 1, 0.0), (0, 1, 0, 0.25), (1, 1, 1, 0.9)])
+def test_degenerate_frame_geometries(orc, w, h, cfg):
+    """one pixel, one row, one column: what the library is handed when a host sets a resolution the stream cannot fill (the
+    reference accepts any height > 0, TSDRLibrary.c:552-565, and derives the width by truncation).  The compiled reference and
+    the oracle agree bit for bit at these sizes (tests/test_oracle_vs_ref.py::test_post_process_degenerate_geometries); so must
+    the kernels, batch of 6 frames, every stage order."""
+    g = ctx()
+    lbs, aap, ash, mb = cfg
+    rng = np.random.default_rng(w * 7919 + h)
+    F = 6
+    frames = [(rng.random(w * h) * 2 - 0.5).astype(np.float32) for _ in range(F)]
+    geo = orc.geometry(1, h, 1.0)
+    geo.width = w
+    opp = orc.PostProcess(geo)
+    pp = gpu.PostProcess(g)
+    d_in = g.to_device(np.concatenate(frames))
+    d_out = g.empty(F * w * h)
+    infos = pp.run(d_in, F, w, h, d_out, mb, 0.1, lbs, aap, ash, 0, 0)
+    got = d_out.download().reshape(F, -1)
+    for k, fr in enumerate(frames):
+        want = opp.run(fr.copy(), mb, 0.1, lbs, aap, ash, 0, 0)
+        si, sd = opp.state()
+        assert (infos[k].dx, infos[k].stripx, infos[k].dy, infos[k].stripy) == (si[0], si[2], si[3], si[5]), (k, w, h)
+        assert np.array_equal(got[k], want, equal_nan=True), (k, w, h)
+
+
 def test_resolution_change_between_calls(orc):
     """dsp_post_process keeps autogain/sync state across a size change and zeroes the screen
     buffer only when it has to grow (dsp.c:152-173)."""

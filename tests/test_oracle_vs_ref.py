@@ -339,3 +339,29 @@ def test_threaded_reference_library_plots_are_the_oracles_running_mean(ref):
     if same != n:
         pytest.skip("a window placement outside the search: " + out.stdout[-400:])
     assert n >= 5
+
+
+@pytest.mark.parametrize("h", [1, 2, 3, 7, 40])
+@pytest.mark.parametrize("w", [1, 2, 3, 4, 5, 9])
+def test_post_process_degenerate_geometries(orc, ref, w, h):
+    """frames of one pixel, one row, one column ...: what a host gets when it sets a resolution the stream cannot fill
+    (width = (int)(2 fs / (fv h)), TSDRLibrary.c:543-546).  The compiled reference neither crashes nor leaves the restatement:
+    bit-identical frames in every stage order, which makes the oracle the yardstick for the GPU path at these sizes too
+    (tests/test_gpu_edges.py::test_degenerate_frame_geometries)."""
+    fv = 10.0
+    fs = next((f for f in range(max(1, int(w * fv * h / 2) - 2), int(w * fv * h / 2) + 40) if int(2 * (f / (fv * h))) == w), None)
+    assert fs is not None
+    rng = np.random.default_rng(100 * w + h)
+    for lbs, aap, ash, mb in ((0, 0, 0, 0.0), (1, 0, 1, 0.5), (0, 1, 0, 0.25), (1, 1, 1, 0.9)):
+        g = orc.geometry(fs, h, fv)
+        assert g.width == w
+        t = ref.ref_new(h, fv, fs, mb, None)
+        ref.ref_setparam(t, 0, ash)
+        pp = orc.PostProcess(g)
+        n = w * h
+        for k in range(8):
+            fr = (rng.random(n) * 2 - 0.5).astype(np.float32)
+            mine = pp.run(fr.copy(), mb, 0.1, lbs, aap, ash, 0, 0)
+            theirs = np.ctypeslib.as_array(ref.ref_post_process(t, fr.copy(), mb, 0.1, lbs, aap), shape=(n,))
+            assert np.array_equal(mine, theirs, equal_nan=True), (lbs, aap, ash, mb, k)
+        ref.ref_free(t)
