@@ -900,7 +900,10 @@ static void run_frames(struct engine *e)
         const int W = t->width, H = t->height;
         const float blur = t->motionblur;
         pthread_mutex_unlock(&t->lock);
-        if (W <= 0 || H <= 0) return;
+        if (W < 2 || H < 2) { /* a geometry the stream cannot fill (tsdrgpu_postproc_run refuses one-row / one-column frames): nothing */
+            e->pix.rd = e->pix.wr; /* to show while it is set, and nothing is kept for later */
+            return;
+        }
         const size_t P = (size_t)W * H;
         size_t avail = e->pix.wr - e->pix.rd;
         if (avail < P) return;
@@ -1024,9 +1027,12 @@ static void run_resampler(struct engine *e)
         const double refresh = t->refreshrate;
         const uint32_t fs = t->samplerate;
         pthread_mutex_unlock(&t->lock);
-        if (W <= 0 || H <= 0 || !(refresh > 0)) return;
-        const int chunk = (int)(FRAMES_TO_POLL * fs / refresh); /* TSDRLibrary.c:335 */
-        if (chunk <= 0) return;
+        const int chunk = (W >= 2 && H >= 2 && refresh > 0) ? (int)(FRAMES_TO_POLL * fs / refresh) : 0; /* TSDRLibrary.c:335 */
+        if (chunk <= 0) { /* no frame can be made of this geometry: the samples are not kept for one (the stream would grow without bound) */
+            e->iq.rd = e->iq.wr;
+            track_off(e);
+            return;
+        }
         const double up = W * H * refresh, down = fs; /* TSDRLibrary.c:340 */
         const int totalpixels = W * H;
         const size_t have = (e->iq.wr - e->iq.rd) / per;

@@ -1923,11 +1923,21 @@ static int pp_copy_info(tsdrgpu_postproc_t *pp, int F, tsdrgpu_pp_frameinfo_t *h
     return TSDRGPU_OK;
 }
 
+// One-row and one-column frames are refused: a strip of ONE entry has no "rest" to compare a window with (syncdetector.c:26-58
+// divides by n - size), and the kernels' tilings assume at least a 2 x 2 raster.  The reference accepts them and shows a line of
+// pixels; here the call fails loudly and the engine shows nothing while a host keeps such a geometry set (engine.c run_frames).
+static int pp_geometry_refused(tsdrgpu_postproc_t *pp, int W, int H, const char *who)
+{
+    if (W >= 2 && H >= 2) return 0;
+    return tsdr_fail(pp->g, TSDRGPU_EINVAL, who, "frames of one row or one column are not supported (width and height must be >= 2)");
+}
+
 extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int F, int W, int H,
                                     const tsdrgpu_pp_params_t *prm, float *d_out, tsdrgpu_pp_frameinfo_t *h_info)
 {
     if (!pp || !d_frames || !d_out || !prm || F < 0 || W <= 0 || H <= 0)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "bad argument") : TSDRGPU_EINVAL;
+    if (pp_geometry_refused(pp, W, H, "tsdrgpu_postproc_run")) return TSDRGPU_EINVAL;
     if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_run", "a split run is open: call tsdrgpu_postproc_finish first");
     if (F == 0) return TSDRGPU_OK;
     tsdrgpu_t *g = pp->g;
@@ -1991,6 +2001,7 @@ extern "C" int tsdrgpu_postproc_begin(tsdrgpu_postproc_t *pp, const float *d_fra
 {
     if (!pp || !d_frames || !prm || F < 0 || W <= 0 || H <= 0)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_begin", "bad argument") : TSDRGPU_EINVAL;
+    if (pp_geometry_refused(pp, W, H, "tsdrgpu_postproc_begin")) return TSDRGPU_EINVAL;
     if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_begin", "a split run is already open");
     tsdrgpu_t *g = pp->g;
     pp->p_frames = d_frames;
@@ -2023,6 +2034,7 @@ extern "C" int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float
 {
     if (!pp || !d_frames || !prm || !d_fmin || !d_fmax || !d_out || F < 0 || W <= 0 || H <= 0)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_begin_minmax", "bad argument") : TSDRGPU_EINVAL;
+    if (pp_geometry_refused(pp, W, H, "tsdrgpu_postproc_begin_minmax")) return TSDRGPU_EINVAL;
     if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_begin_minmax", "a split run is already open");
     tsdrgpu_t *g = pp->g;
     if (F == 0 || prm->lowpass_before_sync || prm->autogain_after_proc || prm->autoshift) {
@@ -2238,6 +2250,7 @@ extern "C" int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *
 {
     if (!pp || !d_band || !prm || F <= 0 || W <= 0 || Htot <= 0 || y0 < 0 || rows <= 0 || y0 + rows > Htot)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_begin", "bad argument") : TSDRGPU_EINVAL;
+    if (pp_geometry_refused(pp, W, Htot, "tsdrgpu_postproc_band_begin")) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
     if (pp->pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_begin", "a split run is already open");
     if (prm->lowpass_before_sync || prm->autogain_after_proc || prm->autoshift || prm->pll)
@@ -2612,6 +2625,7 @@ extern "C" int tsdrgpu_postproc_band_open(tsdrgpu_postproc_t *pp, const float *d
 {
     if (!pp || !d_band || !prm || !edges || F <= 0 || W <= 0 || Htot <= 0 || nbands < 1 || nbands > 64 || band_index < 0 || band_index >= nbands)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_open", "bad argument") : TSDRGPU_EINVAL;
+    if (pp_geometry_refused(pp, W, Htot, "tsdrgpu_postproc_band_open")) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
     if (pp->pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_open", "a split run is already open");
     if (edges[0] != 0 || edges[nbands] != Htot) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_open", "the band edges must run from 0 to the frame height");

@@ -130,7 +130,8 @@ int main(int argc, char **argv)
                 case 2: tsdr_setparameter_int(lib, PARAM_INT_AUTOSHIFT, 1); break;
                 case 3:
                     if (random_geometry) {
-                        const int hh = (RND() % 3 == 0) ? 1 + (int)(RND() % 20000) : 1 + (int)(RND() % 1500);
+                        const unsigned pick = RND() % 6;
+                        const int hh = pick == 0 ? 1 : (pick < 3 ? 1 + (int)(RND() % 20000) : 1 + (int)(RND() % 1500)); /* (one row: a geometry the library refuses) */
                         const double rr = 5.0 + (double)(RND() % 23500) / 100.0;
                         if (tsdr_setresolution(lib, hh, rr) != TSDR_OK) bad++;
                     } else tsdr_setresolution(lib, height + 10 * (s + 1), refresh * 1.003);

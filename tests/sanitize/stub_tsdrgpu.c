@@ -192,6 +192,7 @@ int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int F, i
                          tsdrgpu_pp_frameinfo_t *h_info)
 {
     if (pp->open) return TSDRGPU_ESTATE;
+    if (W < 2 || H < 2) return TSDRGPU_EINVAL; /* like the real one: one-row / one-column frames are refused */
     memcpy(d_out, d_frames, sizeof(float) * (size_t)F * W * H);
     pp->F = F;
     if (h_info) {

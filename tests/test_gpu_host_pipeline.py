@@ -720,3 +720,9 @@ def test_host_stress_on_the_device(iq_file, tmp_path):
     for plugin, params in ((hu.MEM_PLUGIN, f"{iq_file[0]} {FS} {BLOCK} 0 2000"), (hu.PLUGIN, f"{iq_file[0]} {FS} {BLOCK} 3000")):
         out = subprocess.run([exe, plugin, params, str(H), str(FV), "4", "1.5"], capture_output=True, text=True, timeout=120, env=env)
         assert out.returncode == 0 and "host_stress: ok" in out.stdout, (out.stdout + out.stderr)[-3000:]
+    # resolution changes to RANDOM geometries mid-stream, one-row frames (which the library refuses: the engine shows nothing
+    # meanwhile and goes on when a usable geometry is back) and 20 000-line frames among them
+    for seed in (1, 2, 3):
+        out = subprocess.run([exe, hu.MEM_PLUGIN, f"{iq_file[0]} {FS} {BLOCK} 0 2000", str(H), str(FV), "3", "1.2", str(seed)],
+                             capture_output=True, text=True, timeout=120, env=env)
+        assert out.returncode == 0 and "host_stress: ok" in out.stdout, (seed, (out.stdout + out.stderr)[-3000:])
