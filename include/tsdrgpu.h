@@ -212,9 +212,10 @@ int tsdrgpu_postproc_redo_raw(tsdrgpu_postproc_t *pp, int *h, int cap_ints, int 
  * synchronises and fills it.  The refresh-rate PLL's effect on width/refresh
  * is the caller's job (apply h_info[i].frameratediff, TSDRLibrary.c:540-550),
  * so with params->pll the caller should pass one frame at a time.
- * width and height must be >= 2 (and <= 16384): a one-row or one-column "frame" is refused with TSDRGPU_EINVAL by every
+ * width and height must be >= 2 and <= TSDRGPU_MAX_STRIP: a one-row or one-column "frame" is refused with TSDRGPU_EINVAL by every
  * post-processing entry point — the reference accepts it and shows a line of pixels; the tsdr_* engine shows nothing while a
  * host keeps such a resolution set. */
+#define TSDRGPU_MAX_STRIP 16384 /* widest / tallest frame the sync detector's strips hold */
 int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width,
                          int height, const tsdrgpu_pp_params_t *params, float *d_out,
                          tsdrgpu_pp_frameinfo_t *h_info);

@@ -900,7 +900,7 @@ static void run_frames(struct engine *e)
         const int W = t->width, H = t->height;
         const float blur = t->motionblur;
         pthread_mutex_unlock(&t->lock);
-        if (W < 2 || H < 2) { /* a geometry the stream cannot fill (tsdrgpu_postproc_run refuses one-row / one-column frames): nothing */
+        if (W < 2 || H < 2 || W > TSDRGPU_MAX_STRIP || H > TSDRGPU_MAX_STRIP) { /* a geometry the library refuses (tsdrgpu.h): nothing */
             e->pix.rd = e->pix.wr; /* to show while it is set, and nothing is kept for later */
             return;
         }
@@ -1027,7 +1027,8 @@ static void run_resampler(struct engine *e)
         const double refresh = t->refreshrate;
         const uint32_t fs = t->samplerate;
         pthread_mutex_unlock(&t->lock);
-        const int chunk = (W >= 2 && H >= 2 && refresh > 0) ? (int)(FRAMES_TO_POLL * fs / refresh) : 0; /* TSDRLibrary.c:335 */
+        const int usable = W >= 2 && H >= 2 && W <= TSDRGPU_MAX_STRIP && H <= TSDRGPU_MAX_STRIP && refresh > 0;
+        const int chunk = usable ? (int)(FRAMES_TO_POLL * fs / refresh) : 0; /* TSDRLibrary.c:335 */
         if (chunk <= 0) { /* no frame can be made of this geometry: the samples are not kept for one (the stream would grow without bound) */
             e->iq.rd = e->iq.wr;
             track_off(e);

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void k_frame_reduce(int W, int H, int tiles_x,
 //                     only O(n) prefix look-ups + one reduction per frame
 // ---------------------------------------------------------------------------
 #define CHAIN_T 1024
-#define STRIP_MAX 16384
+#define STRIP_MAX TSDRGPU_MAX_STRIP
 
 __device__ __forceinline__ double wave_incl_scan(double v, int lane)
 {

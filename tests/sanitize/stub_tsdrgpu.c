@@ -193,6 +193,12 @@ int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int F, i
 {
     if (pp->open) return TSDRGPU_ESTATE;
     if (W < 2 || H < 2) return TSDRGPU_EINVAL; /* like the real one: one-row / one-column frames are refused */
+    if (W > 16384 || H > 16384) return TSDRGPU_EINVAL; /* ... and so are strips above 16384 (tsdrgpu_frame.hip STRIP_MAX) */
+    {   /* STUB_FAIL_POSTPROC_AFTER=n: the n-th call fails, like a device call that fails in the middle of a session */
+        static int calls;
+        const char *e = getenv("STUB_FAIL_POSTPROC_AFTER");
+        if (e && __atomic_add_fetch(&calls, 1, __ATOMIC_RELAXED) == atoi(e)) return TSDRGPU_EHIP;
+    }
     memcpy(d_out, d_frames, sizeof(float) * (size_t)F * W * H);
     pp->F = F;
     if (h_info) {

@@ -73,6 +73,20 @@ def test_random_geometry_changes_under_addresssanitizer(built, seed):
     _run("host_stress_asan_stub", MEM, "{f32} 1000000 65536 0 2000".format(**built), sessions=2, secs=1.0, seed=seed)
 
 
+@pytest.mark.parametrize("binary", ["host_stress_tsan_stub", "host_stress_asan_stub"])
+def test_a_device_call_that_fails_mid_session_ends_it_loudly(built, binary):
+    """the stand-in's 40th post-processing call fails: tsdr_readasync comes back on its own with TSDR_CANNOT_OPEN_DEVICE and the
+    failing stage's text, every thread joined and everything freed (engine.c gpu_ok: nothing is retried, nothing falls back); the
+    next session on the same handle runs clean"""
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1", STRESS_EXPECT_FAILURE="1", STUB_FAIL_POSTPROC_AFTER="40")
+    out = subprocess.run([os.path.join(SAN, binary), MEM, "{f32} 1000000 65536 0 4000".format(**built), "100", "60", "2", "1.5"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    text = out.stdout + out.stderr
+    assert "ThreadSanitizer" not in text and "AddressSanitizer" not in text and "runtime error" not in text, text[-3000:]
+    assert out.returncode == 0 and "host_stress: ok" in out.stdout, text[-2000:]
+    assert "GPU stage 'postproc' failed" in out.stderr
+
+
 def test_host_code_under_addresssanitizer_and_ubsan(built):
     _run("host_stress_asan_stub", MEM, "{f32} 1000000 65536 0 2000".format(**built))
     _run("host_stress_asan_stub", TESTPLUGIN, "{f32} 1000000 524288 20000 3 1000".format(**built), sessions=2)
