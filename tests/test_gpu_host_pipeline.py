@@ -724,5 +724,5 @@ def test_host_stress_on_the_device(iq_file, tmp_path):
     # meanwhile and goes on when a usable geometry is back) and 20 000-line frames among them
     for seed in (1, 2, 3):
         out = subprocess.run([exe, hu.MEM_PLUGIN, f"{iq_file[0]} {FS} {BLOCK} 0 2000", str(H), str(FV), "3", "1.2", str(seed)],
-                             capture_output=True, text=True, timeout=120, env=env)
+                             capture_output=True, text=True, timeout=45, env=env)
         assert out.returncode == 0 and "host_stress: ok" in out.stdout, (seed, (out.stdout + out.stderr)[-3000:])
