@@ -1929,6 +1929,9 @@ static int pp_copy_info(tsdrgpu_postproc_t *pp, int F, tsdrgpu_pp_frameinfo_t *h
 static int pp_geometry_refused(tsdrgpu_postproc_t *pp, int W, int H, const char *who)
 {
     if (W >= 2 && H >= 2) return 0;
+#ifdef TSDRGPU_ALLOW_DEGENERATE  // diagnosis builds only (scripts/probe_degenerate.py): lets such a frame through to the kernels
+    return 0;
+#endif
     return tsdr_fail(pp->g, TSDRGPU_EINVAL, who, "frames of one row or one column are not supported (width and height must be >= 2)");
 }
 
