@@ -1009,6 +1009,11 @@ __device__ __forceinline__ SyncDecision sync_decide(const FitBest *res, const in
         // sizes are tried in the reference's order with its strict `>` (k = 0 always taken)
         if (k == 0 || res[k].fit > bestfit) { bestfit = res[k].fit; bestq = res[k].q; bestsize = sizes[k]; bestk = k; }
     }
+    // No window chosen: every fit of this size was NaN — a strip of ONE entry (n - size = 0: 0/0), or non-finite sums — and NaN
+    // beats nothing.  The reference starts from window 0 and replaces it only by a LARGER fit (syncdetector.c:36-38,52-55), so it
+    // keeps window 0; the search's "none yet" label must not reach the marker stores below (it did: a write 8 GB past the
+    // strip, the GPU memory fault one-row frames ended in until round 5).
+    if (bestq == 0x7fffffff) bestq = 0;
     SyncDecision d;
     d.toss = 0;
     if (want_toss) {
