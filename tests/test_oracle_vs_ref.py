@@ -368,3 +368,32 @@ def test_post_process_degenerate_geometries(orc, ref, w, h):
             theirs = np.ctypeslib.as_array(ref.ref_post_process(t, fr.copy(), mb, 0.1, lbs, aap), shape=(n,))
             assert np.array_equal(mine, theirs, equal_nan=True), (lbs, aap, ash, mb, k)
         ref.ref_free(t)
+
+
+@pytest.mark.parametrize("w,h", [(9, 7), (40, 33)])
+def test_post_process_nonfinite_frames(orc, ref, w, h):
+    """frames with a few NaN pixels, an all-NaN frame, infinities — what a source that hands over non-finite samples produces: the
+    compiled reference and the restatement stay bit-identical (NaN positions included) through every stage order, the frames
+    after the bad ones too (the autogain and the sync detector carry the damage).  The yardstick for the GPU path's behaviour
+    on such input (its sync search then finds no window to choose: sync_decide keeps window 0 like syncdetector.c:36-38,52-55)."""
+    fv = 10.0
+    fs = next(f for f in range(max(1, int(w * fv * h / 2) - 2), int(w * fv * h / 2) + 40) if int(2 * (f / (fv * h))) == w)
+    rng = np.random.default_rng(9 * w + h)
+    for lbs, aap, ash, mb in ((0, 0, 0, 0.0), (1, 0, 1, 0.5), (0, 1, 0, 0.25), (1, 1, 1, 0.9)):
+        g = orc.geometry(fs, h, fv)
+        t = ref.ref_new(h, fv, fs, mb, None)
+        ref.ref_setparam(t, 0, ash)
+        pp = orc.PostProcess(g)
+        n = w * h
+        for k in range(8):
+            fr = (rng.random(n) * 2 - 0.5).astype(np.float32)
+            if k in (2, 3):
+                fr[rng.integers(0, n, 3)] = np.nan
+            if k == 4:
+                fr[:] = np.nan
+            if k == 5:
+                fr[rng.integers(0, n, 2)] = np.inf
+            mine = pp.run(fr.copy(), mb, 0.1, lbs, aap, ash, 0, 0)
+            theirs = np.ctypeslib.as_array(ref.ref_post_process(t, fr.copy(), mb, 0.1, lbs, aap), shape=(n,))
+            assert np.array_equal(mine, theirs, equal_nan=True), (lbs, aap, ash, mb, k)
+        ref.ref_free(t)
