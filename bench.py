@@ -39,6 +39,95 @@ from tempestsdr_amd import gpu, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
+LINE_LIMIT = 8192  # bytes of the ONE JSON line on stdout (the driver keeps a bounded tail of stdout; a longer line is cut)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short(s, n):
+    s = " ".join(str(s).split())
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(res, detail_path=None):
+    """The ONE line bench.py prints: the contract's scalars + `roofline` + `cpu_baseline` (+ `ranks` at N > 1), numbers and
+    short labels only — strict JSON, <= LINE_LIMIT bytes whatever the run.  Everything else (per-kernel rooflines, stage times,
+    side metrics, legs) is in the detail file.  tests/test_bench_line.py holds this to its promises on canned records."""
+    out = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    out["vs_baseline"] = res.get("vs_baseline")
+    out.update(_pick(res, ("dtype", "data")))
+    cfg = res.get("config") or {}
+    out["config"] = {"workload": _short(cfg.get("workload", ""), 200), **_pick(cfg, ("samples_per_step_per_gpu", "passes_per_step"))}
+    out.update(_pick(res, ("ms_per_pass", "frames_per_s", "realtime_factor")))
+    rf = res.get("roofline")
+    if isinstance(rf, dict):
+        r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_rocprof", "frac_moved", "avg_launch_ms", "alg_bytes_per_launch"))
+        if "kernel" in r:
+            r["kernel"] = _short(r["kernel"], 120)
+        r["traffic"] = rf.get("traffic")
+        out["roofline"] = r
+    else:
+        out["roofline"] = None
+    for k in ("frame_path", "autocorrelation", "whole_pass"):  # the other rooflines, fractions only
+        v = _pick(res.get(k) or {}, ("frac", "frac_moved"))
+        if v:
+            out[k] = v
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "cores_on_box", "error"))
+        if "sample" in cb:
+            c["sample"] = _short(cb["sample"], 160)
+        if "error" in c:
+            c["error"] = _short(c["error"], 160)
+        if isinstance(cb.get("pipeline"), dict):
+            c["pipeline"] = _pick(cb["pipeline"], ("value", "cores_used", "frames_per_s"))
+        out["cpu_baseline"] = c
+    e2e = _pick(res.get("e2e") or {}, ("effective_Msps", "frames_per_s", "realtime_factor"))
+    if e2e:
+        out["e2e"] = e2e
+    det = _pick(res.get("detected") or {}, ("frame_lag", "line_lag", "framerate", "height"))
+    if det:
+        out["detected"] = det
+    if res.get("collective"):
+        out["collective"] = _short(res["collective"], 100)
+    if res.get("ranks"):
+        keys = ("rank", "windows_per_pass", "of", "rows", "rccl_ranks", "device", "argmax")
+        ranks = [_pick(r, keys) for r in res["ranks"] if isinstance(r, dict)]
+        out["ranks"] = ranks
+    if res.get("device"):
+        out["device"] = _short(res["device"], 60)
+    if detail_path:
+        out["detail"] = detail_path
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    # a bound that holds whatever a future field grows into: shed the optional objects, last added first
+    for k in ("detected", "e2e", "whole_pass", "autocorrelation", "frame_path", "collective", "device", "detail"):
+        if len(line.encode()) <= LINE_LIMIT:
+            break
+        out.pop(k, None)
+        line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(line.encode()) > LINE_LIMIT and "ranks" in out:  # (64+ ranks: keep the count, drop the rows)
+        out["ranks"] = [_pick(r, ("rank", "windows_per_pass", "rccl_ranks")) for r in out["ranks"]]
+        line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    assert len(line.encode()) <= LINE_LIMIT, "bench line over its limit"
+    return line
+
+
+def _json_safe(x):
+    """NaN / Inf are not JSON: they become null (a strict parser must be able to read what bench.py writes)"""
+    if isinstance(x, float):
+        return x if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {str(k): _json_safe(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_json_safe(v) for v in x]
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.floating,)):
+        return _json_safe(float(x))
+    return x
+
 
 def synth_iq_torch(fs, mode, fv, nsamples, start, seed, device, noise=0.02):
     """tempestsdr_amd.synth.synth_iq on the device (same model; float math on GPU)."""
@@ -403,9 +492,14 @@ def main():
     ap.add_argument("--leg-cpu", action="store_true",
                     help="with --leg: also time the reference's code on the host cores for THIS configuration (stage by stage on one "
                          "core, and its threaded library behind its RawFile plugin), bounded to ~20-30 s")
-    ap.add_argument("--no-legs", action="store_true",
-                    help="skip the side legs run after the timed region at N=1 (configs[1], configs[4], motion blur 0.5, the "
-                         "reference's threaded pipeline on the host cores)")
+    ap.add_argument("--legs", action="store_true",
+                    help="after the timed region at N=1 also run the side legs, each a bench.py process of its own: configs[0] (both "
+                         "libraries behind the reference's RawFile plugin), configs[1], configs[4], 4 s batches, motion blur 0.5, the "
+                         "unfused run.  Minutes; their results go to the detail file, never to the JSON line")
+    ap.add_argument("--no-legs", action="store_true", help="(default now; kept so that old command lines still parse)")
+    ap.add_argument("--detail", default=None,
+                    help="where the full record goes (default gpurun_out/bench_detail.json under the repo): per-kernel rooflines, stage "
+                         "times, side metrics, legs.  stdout carries ONE compact JSON line (<= 8 KB) and nothing else")
     ap.add_argument("--uncertified", action="store_true",
                     help="plain float32 autocorrelation without the argmax certificate / exact replay (round-2 behaviour)")
     ap.add_argument("--plan", type=int, default=3, choices=[3, 5], help="autocorrelation transform plan (trips over HBM)")
@@ -505,6 +599,7 @@ def main():
     if args.blur is not None:
         blur = args.blur
         wl_name += f", motion blur {blur:g}"
+    args.no_legs = not args.legs
     if args.leg:
         args.no_e2e = args.no_legs = True
         args.no_cpu_baseline = not args.leg_cpu
@@ -1039,8 +1134,15 @@ def main():
     shares = None
     if dist is not None:
         # what every rank did, for the record (and for the dry run's checks): its share of the capture windows, its rows
+        rccl_ranks = None
+        if comm is not None:
+            try:
+                rccl_ranks = comm.count()[0]  # ncclCommCount: what RCCL itself sees, not what this script passed in
+            except Exception:  # noqa: BLE001
+                rccl_ranks = None
         mine = {"rank": rank, "windows_per_pass": my_windows, "of": total_windows,
                 "rows": None if band is None else [band["y0"], band["y0"] + band["rows"]],
+                "rccl_ranks": rccl_ranks, "device": local,
                 "argmax": [int(fi), int(li)], "epochs_replayed_exact": promoted_passes[0]}
         shares = [None] * world
         dist.all_gather_object(shares, mine)
@@ -1233,9 +1335,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{wl_name} (h={h} -> {W}x{h} frames), {args.seconds:g} s batch resident in HBM, "
-                                   f"{nchunks} resample chunks, {nwin} autocorrelation windows of N=2^{int(np.log2(N))} per pass; "
-                                   f"a step = {args.passes} passes = {args.passes * args.seconds:g} s of signal",
+            "config": {"workload": f"{wl_name} ({W}x{h} frames); pass = {args.seconds:g} s batch in HBM, {nchunks} resample chunks, "
+                                   f"{nwin} windows of N=2^{int(np.log2(N))}; step = {args.passes} passes",
                        "samples_per_step_per_gpu": nsamples * args.passes, "passes_per_step": args.passes,
                        "stage_order": "library default (autogain, sync, IIR)",
                        "lanes": "one (--serial)" if args.serial else
@@ -1328,7 +1429,20 @@ def main():
                     res["cpu_baseline"]["pipeline"] = cpu_pipeline
             except Exception as e:  # the baseline is a reported number, never the product path
                 res["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(res), flush=True)
+        res = _json_safe(res)
+        if args.leg:  # a side leg of another bench.py run: the parent reads the full record
+            print(json.dumps(res, allow_nan=False), flush=True)
+        else:
+            detail = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+            shown = None
+            try:
+                os.makedirs(os.path.dirname(detail), exist_ok=True)
+                with open(detail, "w") as f:
+                    json.dump(res, f, indent=1, allow_nan=False)
+                shown = os.path.relpath(detail, ROOT) if detail.startswith(ROOT) else detail
+            except OSError as ex:
+                print(f"[bench] detail file not written: {ex!r}", file=sys.stderr)
+            print(compact_line(res, shown), flush=True)
     if comm is not None:
         comm.destroy()
     g.close()

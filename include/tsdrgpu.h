@@ -467,6 +467,7 @@ typedef struct tsdrgpu_comm tsdrgpu_comm_t;
 int tsdrgpu_rccl_unique_id(void *id128);
 int tsdrgpu_comm_create(tsdrgpu_t *g, tsdrgpu_comm_t **out, int world, int rank, const void *id128);
 void tsdrgpu_comm_destroy(tsdrgpu_comm_t *c);
+int tsdrgpu_comm_count(tsdrgpu_comm_t *c, int *ranks, int *my_rank); /* ncclCommCount / ncclCommUserRank: what RCCL itself sees */
 int tsdrgpu_comm_allreduce_f64(tsdrgpu_comm_t *c, double *d_buf, int64_t count, int lane); /* in place, ncclSum */
 int tsdrgpu_comm_allreduce_f32max(tsdrgpu_comm_t *c, float *d_buf, int64_t count, int lane); /* in place, ncclMax */
 int tsdrgpu_comm_broadcast_f32(tsdrgpu_comm_t *c, float *d_buf, int64_t count, int root, int lane);      /* in place */

@@ -27,6 +27,8 @@ struct RcclApi {
     ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t);
     const char *(*GetErrorString)(ncclResult_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
 };
 static RcclApi g_rccl;
 
@@ -53,6 +55,8 @@ static const RcclApi *rccl_load()
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(dl, "ncclGetErrorString");
     a.Broadcast = (decltype(a.Broadcast))dlsym(dl, "ncclBroadcast");
     a.AllGather = (decltype(a.AllGather))dlsym(dl, "ncclAllGather");
+    a.CommCount = (decltype(a.CommCount))dlsym(dl, "ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))dlsym(dl, "ncclCommUserRank");
     if (!a.Broadcast || !a.AllGather) { dlclose(dl); return nullptr; }
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
         dlclose(dl);
@@ -98,6 +102,23 @@ extern "C" int tsdrgpu_comm_create(tsdrgpu_t *g, tsdrgpu_comm_t **out, int world
     c->world = world;
     c->rank = rank;
     *out = c;
+    return TSDRGPU_OK;
+}
+
+// What RCCL ITSELF says about the communicator (ncclCommCount / ncclCommUserRank), not what the caller passed to
+// tsdrgpu_comm_create: the record of a multi-GPU run quotes these, so that "RCCL saw N ranks" is checkable.
+extern "C" int tsdrgpu_comm_count(tsdrgpu_comm_t *c, int *ranks, int *my_rank)
+{
+    if (!c) return TSDRGPU_EINVAL;
+    tsdrgpu_t *g = c->g;
+    const RcclApi *r = rccl();
+    if (!r || !r->CommCount || !r->CommUserRank) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_comm_count", "ncclCommCount not in librccl");
+    int n = 0, me = -1;
+    ncclResult_t rc = r->CommCount(c->comm, &n);
+    if (rc == ncclSuccess_) rc = r->CommUserRank(c->comm, &me);
+    if (rc != ncclSuccess_) return tsdr_fail(g, TSDRGPU_EHIP, "ncclCommCount", r->GetErrorString(rc));
+    if (ranks) *ranks = n;
+    if (my_rank) *my_rank = me;
     return TSDRGPU_OK;
 }
 

@@ -115,6 +115,7 @@ _SIGS = {
     "tsdrgpu_rccl_unique_id": (C.c_int, [vp]),
     "tsdrgpu_comm_create": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, vp]),
     "tsdrgpu_comm_destroy": (None, [vp]),
+    "tsdrgpu_comm_count": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tsdrgpu_comm_allreduce_f64": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
     "tsdrgpu_autocorr_allreduce": (C.c_int, [vp, vp, C.c_uint64]),
     "tsdrgpu_comm_broadcast_f32": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int]),
@@ -592,6 +593,12 @@ class Comm:
         ctx._ck(ctx.lib.tsdrgpu_comm_create(ctx.h, C.byref(h), int(world), int(rank), C.c_char_p(id128)))
         self.h = h
         self.world, self.rank = world, rank
+
+    def count(self):
+        """(ranks, my rank) as RCCL itself reports them: ncclCommCount / ncclCommUserRank"""
+        n, me = C.c_int(), C.c_int()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_comm_count(self.h, C.byref(n), C.byref(me)))
+        return n.value, me.value
 
     def allreduce_f32max(self, d_ptr, count, lane=0):
         self.ctx._ck(self.ctx.lib.tsdrgpu_comm_allreduce_f32max(self.h, d_ptr, int(count), int(lane)))
