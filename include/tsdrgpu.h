@@ -13,8 +13,8 @@
  * built on.
  *
  * Threading: a context and the objects created from it belong to one host thread at a time (the
- * library takes no locks); use one context per thread / per GPU.  Limits: frame width and height
- * <= 16384 each (the reference allows width*height <= 4000*4000), <= 65535 resampler chunks or
+ * library takes no locks); use one context per thread / per GPU.  Limits: width*height <= 4000*4000 pixels per frame, any
+ * width and height >= 1 within that (the reference's own bound, TSDRLibrary.c:31,489); <= 65535 resampler chunks or
  * autocorrelation windows per call.
  *
  * Return value: 0 (TSDRGPU_OK) or a negative TSDRGPU_E* code;
@@ -212,10 +212,11 @@ int tsdrgpu_postproc_redo_raw(tsdrgpu_postproc_t *pp, int *h, int cap_ints, int 
  * synchronises and fills it.  The refresh-rate PLL's effect on width/refresh
  * is the caller's job (apply h_info[i].frameratediff, TSDRLibrary.c:540-550),
  * so with params->pll the caller should pass one frame at a time.
- * width and height must be >= 2 and <= TSDRGPU_MAX_STRIP: a one-row or one-column "frame" is refused with TSDRGPU_EINVAL by every
- * post-processing entry point — the reference accepts it and shows a line of pixels; the tsdr_* engine shows nothing while a
- * host keeps such a resolution set. */
-#define TSDRGPU_MAX_STRIP 16384 /* widest / tallest frame the sync detector's strips hold */
+ * Any width >= 1 and height >= 1 with width*height <= TSDRGPU_MAX_FRAME_PIXELS, one-row and one-column frames included (the
+ * reference shows a line of pixels for those; so does this).  A strip — a frame's width or height — of up to TSDRGPU_MAX_STRIP
+ * entries is blurred and scanned in LDS, a longer one in HBM (same results, slower: rasters of a few lines at a high rate). */
+#define TSDRGPU_MAX_FRAME_PIXELS (4000 * 4000) /* MAX_ARR_SIZE, TSDRLibrary.c:31 */
+#define TSDRGPU_MAX_STRIP 16384                /* longest strip the sync detector keeps in LDS; NOT a limit of the interface */
 int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int nframes, int width,
                          int height, const tsdrgpu_pp_params_t *params, float *d_out,
                          tsdrgpu_pp_frameinfo_t *h_info);

@@ -162,7 +162,7 @@ def run_all(frames_):
     return pp_, out_
 
 
-seq, same, hidden, unexplained = [], 0, [], []
+seq, same, hidden, unexplained, defects = [], 0, [], [], []
 pp = orc.PostProcess(geo)
 prev_last = -1
 for i, segs in enumerate(plan2):
@@ -189,6 +189,11 @@ for i, segs in enumerate(plan2):
         pp, seq = found_[1], found_[2]
         same += 1
     else:
+        # Nothing undelivered lies before this frame and every frame so far came out bit for bit: no loss pattern is left to explain
+        # the difference — the restatement itself would be wrong.  (With frames missing in between, or after an earlier unexplained
+        # frame, the search above simply may not cover what happened.)
+        if not missing and not unexplained:
+            defects.append(i)
         unexplained.append(i)
         seq.append(raw)  # (pp has processed it)
 print(f"REPLAY: the oracle's resampler + dsp_post_process over what the reference kept, in its order, reproduce {same} of {len(fr)} delivered frames BIT FOR BIT")
@@ -196,4 +201,6 @@ for i, sub in hidden:
     print(f"   before delivered frame {i}: frames {list(sub)} of the stream were post-processed but never reached the callback (lost between dsp_post_process and the video thread)")
 if unexplained:
     print("   not reproduced:", unexplained)
+if defects:
+    print("REPLAY-DEFECT: delivered frame(s)", defects, "follow directly on reproduced frames with nothing lost in between and still differ")
 print(f"lost on the way: {sum(c for _, c in gaps)} samples in {len(gaps)} gap(s) and {plan2[-1][-1][1] + 1 - len(fr)} whole frames of {plan2[-1][-1][1] + 1}")

@@ -45,7 +45,7 @@ def one(rng, plugin, tmp):
     fv = float(rng.choice([50.0, 59.94, 60.0, 75.0]))
     fs = int(rng.integers(300_000, 20_000_000))
     geo = orc.geometry(fs, h, fv)
-    if geo.width < 8 or geo.width * h > 1_500_000 or geo.width > 16384:  # (16384: the library's documented width / height limit, tsdrgpu.h)
+    if geo.width < 8 or geo.width * h > 1_500_000:
         return None
     tw = max(8, int(round(fs / (fv * h))))
     mode = (tw, h, (tw * 4) // 5, (h * 9) // 10)

@@ -78,6 +78,7 @@ def build(force=False, verbose=True):
         subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", mem_so, mem_src], check=True)
     build_checks(force=force, verbose=verbose)
     build_host_stress(force=force)
+    build_fake_jvm(force=force)
     return LIB
 
 
@@ -103,6 +104,17 @@ def build_checks(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("compile failed: " + " ".join(cmd))
+
+
+def build_fake_jvm(force=False):
+    """tests/jni/fake_jvm: the stand-in JVM that hosts the reference's JNI shim linked on top of our libTSDRLibrary.a
+    (oracle/Makefile builds that shim where /root/reference exists).  Test infrastructure; built here because the GPU box has the
+    compiler but the test should find it like it finds the libraries."""
+    src = os.path.join(ROOT, "tests", "jni", "fake_jvm.c")
+    exe = os.path.join(ROOT, "tests", "jni", "fake_jvm")
+    stub = os.path.join(ROOT, "oracle", "jni_stub")
+    if os.path.exists(src) and (force or _newer(exe, [src, os.path.join(stub, "jni.h")])):
+        subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-I" + stub, "-o", exe, src, "-ldl", "-lpthread"], check=True)
 
 
 def build_host_stress(force=False):

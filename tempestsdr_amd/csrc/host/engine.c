@@ -900,8 +900,12 @@ static void run_frames(struct engine *e)
         const int W = t->width, H = t->height;
         const float blur = t->motionblur;
         pthread_mutex_unlock(&t->lock);
-        if (W < 2 || H < 2 || W > TSDRGPU_MAX_STRIP || H > TSDRGPU_MAX_STRIP) { /* a geometry the library refuses (tsdrgpu.h): nothing */
-            e->pix.rd = e->pix.wr; /* to show while it is set, and nothing is kept for later */
+        if (W < 1 || H < 1 || (long long)W * H > TSDRGPU_MAX_FRAME_PIXELS) {
+            /* More pixels than tsdr_readasync itself would have accepted at the start (MAX_ARR_SIZE, TSDRLibrary.c:31,489; a host can
+             * only get here through tsdr_setresolution mid-stream): nothing to show while it is set, nothing kept for later, and no
+             * frame grid for the resampler's tracking to go on with (run_resampler does the same in its branch). */
+            e->pix.rd = e->pix.wr;
+            track_off(e);
             return;
         }
         const size_t P = (size_t)W * H;
@@ -1027,7 +1031,7 @@ static void run_resampler(struct engine *e)
         const double refresh = t->refreshrate;
         const uint32_t fs = t->samplerate;
         pthread_mutex_unlock(&t->lock);
-        const int usable = W >= 2 && H >= 2 && W <= TSDRGPU_MAX_STRIP && H <= TSDRGPU_MAX_STRIP && refresh > 0;
+        const int usable = W >= 1 && H >= 1 && (long long)W * H <= TSDRGPU_MAX_FRAME_PIXELS && refresh > 0;
         const int chunk = usable ? (int)(FRAMES_TO_POLL * fs / refresh) : 0; /* TSDRLibrary.c:335 */
         if (chunk <= 0) { /* no frame can be made of this geometry: the samples are not kept for one (the stream would grow without bound) */
             e->iq.rd = e->iq.wr;

@@ -333,7 +333,13 @@ __global__ __launch_bounds__(64) void k_plot_columns(const double *__restrict__ 
     for (int id = a + lane; id < b; id += 64) m = fmax(m, data[id]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
-    if (lane == 0) { colmax[c] = m; colcount[c] = b - a; }
+    // populateData starts a column from its first lag and moves on a LARGER value only (PlotVisualizer.java:222-231): a NaN there
+    // stays the column's value, a NaN anywhere else is never taken (fmax's semantics)
+    if (lane == 0) {
+        if (b > a && data[a] != data[a]) m = data[a];
+        colmax[c] = m;
+        colcount[c] = b - a;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_plot_argmax(const double *__restrict__ data, int first_id, int last_id,
@@ -475,7 +481,7 @@ extern "C" int tsdrgpu_plot_columns(tsdrgpu_t *g, const double *d_data, int size
         for (int i = prev_px; i < nwidth; i++) h_visdata[i] = localmax;
         // max over the visible range starts from data[0] (PlotVisualizer.java:203-205,226-229)
         int maxi = 0;
-        if (last_id > first_id) {
+        if (last_id > first_id && hmax != 0x7fffffff) {  // (0x7fffffff: no lag of the range compares larger than -inf — all NaN: index 0 stays)
             double dv;
             if (hipMemcpy(&dv, d_data + hmax, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = tsdr_fail(g, TSDRGPU_EHIP, "tsdrgpu_plot_columns", "copy back"); break; }
             if (dv > edge[0]) maxi = hmax;

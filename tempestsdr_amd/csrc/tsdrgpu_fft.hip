@@ -930,7 +930,11 @@ __global__ __launch_bounds__(64) void k_argmax_final(const double *__restrict__ 
     argtop_wave(a);
     if (threadIdx.x == 0) {
         const int len = plot == 0 ? frame_len : line_len;
-        const int r = len > 0 ? a.at : -1;
+        // The host's maximum search starts from lag 0 of the plot and moves on a LARGER value only (PlotVisualizer.java:203-206,236-239:
+        // max_val = data[0]; if (val > max_val) ...): a NaN at lag 0 — a window that held a non-finite sample makes every lag NaN,
+        // fft.c:49-64 — is never replaced, and a plot without any value that compares larger keeps index 0.
+        const double first = len > 0 ? (plot == 0 ? plots[0] : plots[frame_len]) : 0.0;
+        const int r = len > 0 ? ((first != first || a.at == 0x7fffffff) ? 0 : a.at) : -1;
         const double r0 = plots[frame_len + line_len];
         const double margin = kappa * r0;
         // a plot of one lag has no runner-up (second stays -1); NaNs compare false and leave the plot uncertified
@@ -1331,6 +1335,9 @@ extern "C" int tsdrgpu_autocorr_run(tsdrgpu_autocorr_t *ac, const float *d_in, i
     if (nwindows == 0) return TSDRGPU_OK;
     tsdrgpu_t *g = ac->g;
     if (nwindows > 65535) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_autocorr_run", "too many windows in one call");
+    // a flag at the interface, a source KIND inside (0 magnitudes, 1 IQ; 2 / 3 are internal to the exact replay): any truthy
+    // value means IQ on every path, the fast and the exact one alike
+    in_is_iq = in_is_iq ? 1 : 0;
     if (ac->st != g->stream) {
         // side stream: everything already queued on the main stream (e.g. the producer of d_in) comes first
         HIP_TRY(g, hipEventRecord(g->fork, g->stream));

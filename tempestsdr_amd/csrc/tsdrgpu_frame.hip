@@ -554,8 +554,10 @@ __global__ __launch_bounds__(64) void k_autogain_chain(int F, const float *__res
             for (int i = 0; i < cnt; i++) {
                 if (do_autogain) {
                     // dsp.c:50-66: min/max start from v[0] even when it is a sentinel
-                    const float hi = fmaxf(sv0[i], shi[i]);
-                    const float lo = fminf(sv0[i], slo[i]);
+                    // (and a NaN there stays: `val > max` / `val < min` are false against it for every later pixel)
+                    const bool v0nan = sv0[i] != sv0[i];
+                    const float hi = v0nan ? sv0[i] : fmaxf(sv0[i], shi[i]);
+                    const float lo = v0nan ? sv0[i] : fminf(sv0[i], slo[i]);
                     const float keep = 1.0f - norm;
                     lastmax = keep * lastmax + norm * hi;
                     lastmin = keep * lastmin + norm * lo;
@@ -753,16 +755,20 @@ __global__ __launch_bounds__(256) void k_exact_strips(const float *__restrict__ 
     }
 }
 
+// BIG: a strip longer than STRIP_MAX entries (the reference bounds width x height, not each: 100 MS/s with a 100-line raster at
+// 60 Hz is 33 333 pixels per line, TSDRLibrary.c:31,489,543-546) does not fit the LDS; the strip then sits in its slot of `exact`
+// and its blur in the scratch's own copy, both in HBM — the same arithmetic in the same order, a rare geometry's speed.
+template <bool BIG>
 __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const double *__restrict__ strip_x,
                                                            const double *__restrict__ strip_y,
                                                            const ChainOut *__restrict__ chain, StripScratch sc,
                                                            int strips_normalised, float t0, float t1, float t2, float t3,
                                                            float t4, const int *__restrict__ sflag,
-                                                           const float *__restrict__ exact, const int *__restrict__ redo)
+                                                           float *exact, const int *__restrict__ redo)
 {
     if (redo && !*redo) return;
-    __shared__ float data[STRIP_MAX];
-    __shared__ float blur[STRIP_MAX];
+    __shared__ float lds_data[BIG ? 1 : STRIP_MAX];
+    __shared__ float lds_blur[BIG ? 1 : STRIP_MAX];
     __shared__ double wsum[16];
     const int axis = blockIdx.x, f = blockIdx.y;
     const int n = axis == 0 ? W : H;
@@ -770,9 +776,13 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
     const double *sp = (axis == 0 ? strip_x : strip_y) + (long long)f * 3 * n;
     const double cnt_all = (double)(axis == 0 ? H : W);
     const float lastmin = chain[f].lastmin, span = chain[f].span;
+    float *const gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
+    float *const data = BIG ? exact + ((long long)f * 2 + axis) * sc.nmax : lds_data;
+    float *const blur = BIG ? gblur : lds_blur;
     if (sflag[f * 2 + axis]) {  // reference-order sums, see k_strip_flag
         const float *ex = exact + ((long long)f * 2 + axis) * sc.nmax;
-        for (int i = tid; i < n; i += CHAIN_T) data[i] = ex[i];
+        if (!BIG)  // (BIG: they are where `data` points already)
+            for (int i = tid; i < n; i += CHAIN_T) data[i] = ex[i];
     } else {
         for (int i = tid; i < n; i += CHAIN_T) {
             const double ns = sp[i], s = sp[n + i], c = sp[2 * n + i];
@@ -786,13 +796,12 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
     }
     __syncthreads();
     // gaussianblur: out[(i+2)%n] = sum_k taps[k]*in[(i+k)%n], left to right in f32
-    float *gblur = sc.blur + ((long long)f * 2 + axis) * sc.nmax;
     for (int i = tid; i < n; i += CHAIN_T) {
         const float a = data[i % n], b = data[(i + 1) % n], c = data[(i + 2) % n];
         const float d = data[(i + 3) % n], e = data[(i + 4) % n];
         const float v = a * t0 + b * t1 + c * t2 + d * t3 + e * t4;
         blur[(i + 2) % n] = v;
-        gblur[(i + 2) % n] = v;
+        if (!BIG) gblur[(i + 2) % n] = v;
     }
     __syncthreads();
     // f64 prefix sums: thread t owns [t*per, (t+1)*per)
@@ -822,6 +831,12 @@ __global__ __launch_bounds__(CHAIN_T) void k_strip_prepare(int W, int H, const d
         sc.total[f * 2 + axis] = wsum[15];
     }
 }
+
+#define TSDR_LAUNCH_STRIP_PREPARE(g_, st_, nmax_, ...)                                        \
+    do {                                                                                     \
+        if ((nmax_) > STRIP_MAX) TSDR_LAUNCH(g_, PROF_CHAIN, st_, k_strip_prepare<true>, __VA_ARGS__);  \
+        else TSDR_LAUNCH(g_, PROF_CHAIN, st_, k_strip_prepare<false>, __VA_ARGS__);          \
+    } while (0)
 
 #define SYNC_T 256
 #define CHAIN_STAGE 128  // frames whose search results k_sync_chain stages in LDS at a time
@@ -1014,9 +1029,16 @@ __device__ __forceinline__ SyncDecision sync_decide(const FitBest *res, const in
     // keeps window 0; the search's "none yet" label must not reach the marker stores below (it did: a write 8 GB past the
     // strip, the GPU memory fault one-row frames ended in until round 5).
     if (bestq == 0x7fffffff) bestq = 0;
+    // A strip total that is not finite — a NaN or an infinite entry, or sums beyond float's range, `totalsum` being narrowed to
+    // float (syncdetector.c:26) — makes every window's fit NaN or +Inf, window 0's included, and `bestfitcurr > *bestfit` /
+    // `bestfit_temp > bestfit` (syncdetector.c:52,63) are false against either: the reference keeps window 0 of the current size.
+    // (The parallel search would take the first window whose fit is +Inf, which is not window 0 when that one's is NaN.)
+    const float totalf = (float)total;
+    const bool total_finite = fabsf(totalf) <= 3.402823466e38f;  // false for NaN and for +-Inf
+    if (!total_finite) { bestq = 0; bestsize = cc; bestk = 0; }
     SyncDecision d;
     d.toss = 0;
-    if (want_toss) {
+    if (want_toss && total_finite) {
         // Would the reference's rounding have chosen otherwise?  Its strip entries (sequential f32 sums of
         // ~10^3 pixels) carry ~7e-7 of relative error each, independently; two windows differ in m
         // entries, so their sums move against each other by ~sqrt(m)*7e-7*entry, the mean difference d
@@ -1787,7 +1809,7 @@ static int launch_chain(tsdrgpu_postproc_t *pp, const float *frames, long long f
                             pp->d_chain, strips_normalised, pp->d_sflag, pp->d_exact, nmax, gate, only, 2 * F);
                 KERNEL_CHECK(g, "k_exact_strips");
             }
-            TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
+            TSDR_LAUNCH_STRIP_PREPARE(g, st, sc.nmax, dim3(2, F), CHAIN_T, W, H, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc,
                         strips_normalised, pp->taps[0], pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, gate);
             KERNEL_CHECK(g, "k_strip_prepare");
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, H, sc, run ? pp->d_state + 1 : pp->d_state, spec, gate, only);
@@ -1810,7 +1832,7 @@ static int launch_pass_literal(tsdrgpu_postproc_t *pp, int flags, const float *s
     pass_fn fn = pick_pass(flags, vw);
     if (!fn) return tsdr_fail(g, TSDRGPU_EINVAL, "k_frame_pass", "unsupported flag combination");
     const long long P = (long long)W * H;
-    long long blocks = (P / vw + 255) / 256;
+    long long blocks = ((P + vw - 1) / vw + 255) / 256;  // (P < 4 is a frame too: one group)
     const long long cap = (long long)g->prop.multiProcessorCount * 16;
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) & ~7LL;  // a multiple of the 8 XCDs (the kernel's span order relies on it)
@@ -1861,6 +1883,8 @@ static int pp_prepare(tsdrgpu_postproc_t *pp, int F, int W, int H, const tsdrgpu
     tsdrgpu_t *g = pp->g;
     const size_t P = (size_t)W * H;
     int rc;
+    if (P > (size_t)TSDRGPU_MAX_FRAME_PIXELS)  // the reference's own bound (MAX_ARR_SIZE, TSDRLibrary.c:31,489); pixel indices are ints here
+        return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc", "width*height above 4000*4000 pixels");
 
     // buffer (re)sizing, dsp.c:152-173: the screen buffer is zeroed only when it has to grow
     if (H != pp->height || W != pp->width) {
@@ -1897,7 +1921,6 @@ static int pp_prepare(tsdrgpu_postproc_t *pp, int F, int W, int H, const tsdrgpu
         if ((rc = ensure(g, &pp->d_sflag, &pp->cap_sflag, (size_t)F * 6 + 4))) return rc;  // flags, toss-up marks, fresh marks, redo
         if ((rc = ensure(g, &pp->d_exact, &pp->cap_exact, (size_t)F * 2 * nmax))) return rc;
     }
-    if (W > STRIP_MAX || H > STRIP_MAX) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "width/height above 16384");
     pp->chain_has_autogain = 0;
     pp->last_F = F;
     if ((size_t)F > pp->cap_chain) {
@@ -1928,24 +1951,11 @@ static int pp_copy_info(tsdrgpu_postproc_t *pp, int F, tsdrgpu_pp_frameinfo_t *h
     return TSDRGPU_OK;
 }
 
-// One-row and one-column frames are refused: a strip of ONE entry has no "rest" to compare a window with (syncdetector.c:26-58
-// divides by n - size), and the kernels' tilings assume at least a 2 x 2 raster.  The reference accepts them and shows a line of
-// pixels; here the call fails loudly and the engine shows nothing while a host keeps such a geometry set (engine.c run_frames).
-static int pp_geometry_refused(tsdrgpu_postproc_t *pp, int W, int H, const char *who)
-{
-    if (W >= 2 && H >= 2) return 0;
-#ifdef TSDRGPU_ALLOW_DEGENERATE  // diagnosis builds only (scripts/probe_degenerate.py): lets such a frame through to the kernels
-    return 0;
-#endif
-    return tsdr_fail(pp->g, TSDRGPU_EINVAL, who, "frames of one row or one column are not supported (width and height must be >= 2)");
-}
-
 extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int F, int W, int H,
                                     const tsdrgpu_pp_params_t *prm, float *d_out, tsdrgpu_pp_frameinfo_t *h_info)
 {
     if (!pp || !d_frames || !d_out || !prm || F < 0 || W <= 0 || H <= 0)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_run", "bad argument") : TSDRGPU_EINVAL;
-    if (pp_geometry_refused(pp, W, H, "tsdrgpu_postproc_run")) return TSDRGPU_EINVAL;
     if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_run", "a split run is open: call tsdrgpu_postproc_finish first");
     if (F == 0) return TSDRGPU_OK;
     tsdrgpu_t *g = pp->g;
@@ -2009,7 +2019,6 @@ extern "C" int tsdrgpu_postproc_begin(tsdrgpu_postproc_t *pp, const float *d_fra
 {
     if (!pp || !d_frames || !prm || F < 0 || W <= 0 || H <= 0)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_begin", "bad argument") : TSDRGPU_EINVAL;
-    if (pp_geometry_refused(pp, W, H, "tsdrgpu_postproc_begin")) return TSDRGPU_EINVAL;
     if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_begin", "a split run is already open");
     tsdrgpu_t *g = pp->g;
     pp->p_frames = d_frames;
@@ -2042,7 +2051,6 @@ extern "C" int tsdrgpu_postproc_begin_minmax(tsdrgpu_postproc_t *pp, const float
 {
     if (!pp || !d_frames || !prm || !d_fmin || !d_fmax || !d_out || F < 0 || W <= 0 || H <= 0)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_begin_minmax", "bad argument") : TSDRGPU_EINVAL;
-    if (pp_geometry_refused(pp, W, H, "tsdrgpu_postproc_begin_minmax")) return TSDRGPU_EINVAL;
     if (pp->pending) return tsdr_fail(pp->g, TSDRGPU_ESTATE, "tsdrgpu_postproc_begin_minmax", "a split run is already open");
     tsdrgpu_t *g = pp->g;
     if (F == 0 || prm->lowpass_before_sync || prm->autogain_after_proc || prm->autoshift) {
@@ -2221,8 +2229,11 @@ __global__ __launch_bounds__(256) void k_band_pack(int F, int W, int Htot, int y
     if (i == 0 && q == 0) {
         xmax[f * 4 + 0] = -fmin_[f];
         xmax[f * 4 + 1] = fmax_[f];
-        xmax[f * 4 + 2] = (y0 == 0) ? frames[(long long)f * fstride] : -INFINITY;  // dsp.c:50-51: v[0] seeds min and max
-        xmax[f * 4 + 3] = -INFINITY;
+        const float p0_ = (y0 == 0) ? frames[(long long)f * fstride] : -INFINITY;  // dsp.c:50-51: v[0] seeds min and max
+        // a max all-reduce drops a NaN (fmaxf semantics), and a NaN at pixel 0 is what poisons the reference's autogain for good
+        // (dsp.c:50-59: no comparison ever replaces it): it travels as a flag in the fourth slot
+        xmax[f * 4 + 2] = (p0_ != p0_) ? -INFINITY : p0_;
+        xmax[f * 4 + 3] = (p0_ != p0_) ? 1.0f : -INFINITY;
     }
 }
 
@@ -2240,7 +2251,7 @@ __global__ __launch_bounds__(256) void k_band_unpack(int F, int W, int Htot, con
     if (i == 0 && q == 0) {
         fmin_[f] = -xmax[f * 4 + 0];
         fmax_[f] = xmax[f * 4 + 1];
-        v0[f] = xmax[f * 4 + 2];
+        v0[f] = (xmax[f * 4 + 3] > 0.0f) ? __int_as_float(0x7fc00000) : xmax[f * 4 + 2];
     }
 }
 
@@ -2258,7 +2269,6 @@ extern "C" int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *
 {
     if (!pp || !d_band || !prm || F <= 0 || W <= 0 || Htot <= 0 || y0 < 0 || rows <= 0 || y0 + rows > Htot)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_begin", "bad argument") : TSDRGPU_EINVAL;
-    if (pp_geometry_refused(pp, W, Htot, "tsdrgpu_postproc_band_begin")) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
     if (pp->pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_begin", "a split run is already open");
     if (prm->lowpass_before_sync || prm->autogain_after_proc || prm->autoshift || prm->pll)
@@ -2499,7 +2509,7 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
             KERNEL_CHECK(g, "k_band_relay_take");
             pp->band_stage = pp->band_stage == 1 ? 2 : 4;
             if (pp->band_stage == 4) {  // run 1 of the chain: only the strips that changed, from the saved state
-                TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, 1, pp->taps[0],
+                TSDR_LAUNCH_STRIP_PREPARE(g, st, sc.nmax, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, 1, pp->taps[0],
                             pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, (const int *)d_redo);
                 TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, Htot, sc, pp->d_state + 1, spec, (const int *)d_redo, (const int *)d_fresh);
                 TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, Htot, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1, d_amb,
@@ -2509,7 +2519,7 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
             break;
         }
         case 2: {  // run 0 of the chain; with exact ties on, its toss-ups are the second relay's items
-            TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, 1, pp->taps[0],
+            TSDR_LAUNCH_STRIP_PREPARE(g, st, sc.nmax, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, 1, pp->taps[0],
                         pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, no_gate);
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, Htot, sc, pp->d_state, spec, no_gate, no_gate);
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, Htot, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1,
@@ -2563,8 +2573,9 @@ __global__ __launch_bounds__(256) void k_band_pack_mm(int F, int y0, const float
     if (f >= F) return;
     xmax[f * 4 + 0] = -fmin_[f];
     xmax[f * 4 + 1] = fmax_[f];
-    xmax[f * 4 + 2] = (y0 == 0) ? frames[(long long)f * fstride] : -INFINITY;  // dsp.c:50-51: v[0] seeds min and max
-    xmax[f * 4 + 3] = -INFINITY;
+    const float p0_ = (y0 == 0) ? frames[(long long)f * fstride] : -INFINITY;  // dsp.c:50-51: v[0] seeds min and max
+    xmax[f * 4 + 2] = (p0_ != p0_) ? -INFINITY : p0_;  // (a NaN travels as a flag in the fourth slot: see k_band_pack)
+    xmax[f * 4 + 3] = (p0_ != p0_) ? 1.0f : -INFINITY;
 }
 
 __global__ __launch_bounds__(256) void k_band_unpack_mm(int F, const float *__restrict__ xmax, float *__restrict__ fmin_, float *__restrict__ fmax_,
@@ -2574,7 +2585,7 @@ __global__ __launch_bounds__(256) void k_band_unpack_mm(int F, const float *__re
     if (f >= F) return;
     fmin_[f] = -xmax[f * 4 + 0];
     fmax_[f] = xmax[f * 4 + 1];
-    v0[f] = xmax[f * 4 + 2];
+    v0[f] = (xmax[f * 4 + 3] > 0.0f) ? __int_as_float(0x7fc00000) : xmax[f * 4 + 2];
 }
 
 __global__ __launch_bounds__(256) void k_band_unpack_sum(int F, int W, int Htot, const double *__restrict__ xsum, double *__restrict__ strip_x,
@@ -2633,7 +2644,6 @@ extern "C" int tsdrgpu_postproc_band_open(tsdrgpu_postproc_t *pp, const float *d
 {
     if (!pp || !d_band || !prm || !edges || F <= 0 || W <= 0 || Htot <= 0 || nbands < 1 || nbands > 64 || band_index < 0 || band_index >= nbands)
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_open", "bad argument") : TSDRGPU_EINVAL;
-    if (pp_geometry_refused(pp, W, Htot, "tsdrgpu_postproc_band_open")) return TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
     if (pp->pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_open", "a split run is already open");
     if (edges[0] != 0 || edges[nbands] != Htot) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_open", "the band edges must run from 0 to the frame height");
@@ -2777,7 +2787,7 @@ static int band_sync_advance(tsdrgpu_postproc_t *pp, int *need_exchange)
             KERNEL_CHECK(g, "k_band_relay_take");
             pp->bsync_stage = pp->bsync_stage == 1 ? 2 : 4;
             if (pp->bsync_stage == 4) {  // run 1 of the chain: only the strips that changed, from the saved state
-                TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, norm, pp->taps[0],
+                TSDR_LAUNCH_STRIP_PREPARE(g, st, sc.nmax, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, norm, pp->taps[0],
                             pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, (const int *)d_redo);
                 TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, Htot, sc, pp->d_state + 1, spec, (const int *)d_redo, (const int *)d_fresh);
                 TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, Htot, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1, d_amb,
@@ -2787,7 +2797,7 @@ static int band_sync_advance(tsdrgpu_postproc_t *pp, int *need_exchange)
             break;
         }
         case 2: {  // run 0 of the chain; with exact ties on, its toss-ups are the second relay's items
-            TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_prepare, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, norm, pp->taps[0],
+            TSDR_LAUNCH_STRIP_PREPARE(g, st, sc.nmax, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, norm, pp->taps[0],
                         pp->taps[1], pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, no_gate);
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, Htot, sc, pp->d_state, spec, no_gate, no_gate);
             TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, Htot, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1,

@@ -74,35 +74,95 @@ def test_ragged_frame_geometries(orc, w, h, cfg):
 @pytest.mark.parametrize("cfg", [(0, 0, 0, 0.5), (1, 0, 1, 0.0), (0, 1, 0, 0.25), (1, 1, 1, 0.9)])
 def test_degenerate_frame_geometries(orc, w, h, cfg):
     """the smallest rasters: what the library is handed when a host sets a resolution the stream cannot fill (the reference
-    accepts any height > 0, TSDRLibrary.c:552-565, and derives the width by truncation).  From 2 x 2 up the kernels equal the
-    oracle bit for bit in every stage order (the compiled reference and the oracle agree at these sizes,
-    tests/test_oracle_vs_ref.py::test_post_process_degenerate_geometries); one row or one column is refused loudly."""
+    accepts any height > 0, TSDRLibrary.c:552-565, and derives the width by truncation) — one pixel, one row, one column
+    included: the kernels equal the oracle bit for bit in every stage order, through the plain and the split run (the compiled
+    reference and the oracle agree at these sizes, tests/test_oracle_vs_ref.py::test_post_process_degenerate_geometries).
+    A strip of ONE entry makes every window fit 0/0 (syncdetector.c:26-58 divides by n - size): the reference keeps window 0."""
     g = ctx()
     lbs, aap, ash, mb = cfg
     rng = np.random.default_rng(w * 7919 + h)
-    F = 6
+    F = 9  # (>= 8: the frame-parallel pass too)
     frames = [(rng.random(w * h) * 2 - 0.5).astype(np.float32) for _ in range(F)]
+    geo = orc.geometry(1, h, 1.0)
+    geo.width = w
+    opp = orc.PostProcess(geo)
+    want, states = [], []
+    for fr in frames:
+        want.append(opp.run(fr.copy(), mb, 0.1, lbs, aap, ash, 0, 0))
+        states.append(opp.state()[0].copy())
+    d_in = g.to_device(np.concatenate(frames))
+    for form in ("run", "split", "one_by_one"):
+        pp = gpu.PostProcess(g)
+        d_out = g.empty(F * w * h)
+        if form == "run":
+            infos = pp.run(d_in, F, w, h, d_out, mb, 0.1, lbs, aap, ash, 0, 0)
+        elif form == "split":
+            pp.begin(d_in, F, w, h, mb, 0.1, lbs, aap, ash, 0, 0)
+            infos = pp.finish(d_out)
+        else:
+            infos = []
+            for k in range(F):
+                infos += pp.run(d_in, 1, w, h, d_out, mb, 0.1, lbs, aap, ash, 0, 0, frames_offset=k * w * h, out_offset=k * w * h)
+        got = d_out.download().reshape(F, -1)
+        for k in range(F):
+            si = states[k]
+            assert (infos[k].dx, infos[k].stripx, infos[k].dy, infos[k].stripy) == (si[0], si[2], si[3], si[5]), (form, k, w, h)
+            assert np.array_equal(got[k], want[k], equal_nan=True), (form, k, w, h)
+
+
+@pytest.mark.parametrize("w,h", [(16385, 2), (2, 16385), (20000, 3), (3, 20011), (33333, 100), (100, 33333), (100003, 1), (1, 100003), (1_000_003, 2)])
+@pytest.mark.parametrize("cfg", [(0, 0, 0, 0.5), (1, 0, 1, 0.0), (1, 1, 1, 0.9)])
+def test_strips_longer_than_the_lds(orc, w, h, cfg):
+    """The reference bounds width x height (4000 x 4000, TSDRLibrary.c:31,489), not each: 100 MS/s with a 100-line raster at 60 Hz is
+    33 333 pixels per line.  A strip of more than 16 384 entries is blurred and scanned in HBM instead of LDS
+    (k_strip_prepare<true>): same frames, same sync state, every stage order."""
+    g = ctx()
+    lbs, aap, ash, mb = cfg
+    rng = np.random.default_rng(w + 31 * h)
+    F = 3
+    y, x = np.mgrid[0:h, 0:w]
+    frames = []
+    for k in range(F):
+        img = 0.3 + 0.5 * (((x + 5 * k) // max(2, w // 9)) % 2) + 0.1 * ((y // max(1, h // 5)) % 2)
+        img[:, : max(1, w // 11)] = 0.05
+        img[: max(1, h // 20), :] = 0.05
+        frames.append((img + rng.standard_normal((h, w)) * 0.02).astype(np.float32).reshape(-1))
     geo = orc.geometry(1, h, 1.0)
     geo.width = w
     opp = orc.PostProcess(geo)
     pp = gpu.PostProcess(g)
     d_in = g.to_device(np.concatenate(frames))
     d_out = g.empty(F * w * h)
-    if w < 2 or h < 2:
-        # one row or one column: refused loudly (include/tsdrgpu.h) — a strip of one entry has no "rest" for the sync detector's
-        # windows, and before round 5's last day the kernels answered such a frame with a GPU memory fault
-        with pytest.raises(gpu.TsdrGpuError, match="one row or one column"):
-            pp.run(d_in, F, w, h, d_out, mb, 0.1, lbs, aap, ash, 0, 0)
-        with pytest.raises(gpu.TsdrGpuError, match="one row or one column"):
-            pp.begin(d_in, F, w, h, mb, 0.1, lbs, aap, ash, 0, 0)
-        return
     infos = pp.run(d_in, F, w, h, d_out, mb, 0.1, lbs, aap, ash, 0, 0)
     got = d_out.download().reshape(F, -1)
     for k, fr in enumerate(frames):
         want = opp.run(fr.copy(), mb, 0.1, lbs, aap, ash, 0, 0)
         si, sd = opp.state()
-        assert (infos[k].dx, infos[k].stripx, infos[k].dy, infos[k].stripy) == (si[0], si[2], si[3], si[5]), (k, w, h)
-        assert np.array_equal(got[k], want, equal_nan=True), (k, w, h)
+        assert (infos[k].dx, infos[k].vx, infos[k].stripx, infos[k].dy, infos[k].vy, infos[k].stripy) == tuple(si[:6]), (k, w, h)
+        assert np.array_equal(got[k], want), (k, w, h, int(np.sum(got[k] != want)))
+
+
+def test_the_longest_strip_and_the_pixel_bound(orc):
+    """16 000 000 x 1: the longest strip the reference's own bound admits; one pixel more is refused (the reference's tsdr_readasync
+    refuses it too, TSDRLibrary.c:489)."""
+    g = ctx()
+    w, h = 16_000_000, 1
+    rng = np.random.default_rng(77)
+    fr = (0.3 + 0.5 * ((np.arange(w) // 1_000_000) % 2) + 0.02 * rng.standard_normal(w)).astype(np.float32)
+    fr[: w // 11] = 0.05
+    geo = orc.geometry(1, h, 1.0)
+    geo.width = w
+    opp = orc.PostProcess(geo)
+    want = opp.run(fr.copy(), 0.25, 0.1, 0, 0, 0, 0, 0)
+    si, _ = opp.state()
+    pp = gpu.PostProcess(g)
+    d_in = g.to_device(fr)
+    d_out = g.empty(w)
+    info = pp.run(d_in, 1, w, h, d_out, 0.25)[0]
+    assert (info.dx, info.stripx, info.dy, info.stripy) == (si[0], si[2], si[3], si[5])
+    assert np.array_equal(d_out.download(), want)
+    with pytest.raises(gpu.TsdrGpuError, match="4000"):
+        pp.run(d_in, 1, 4001, 4000, d_out, 0.25)
 
 
 def test_resolution_change_between_calls(orc):
