@@ -192,8 +192,7 @@ int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int F, i
                          tsdrgpu_pp_frameinfo_t *h_info)
 {
     if (pp->open) return TSDRGPU_ESTATE;
-    if (W < 2 || H < 2) return TSDRGPU_EINVAL; /* like the real one: one-row / one-column frames are refused */
-    if (W > 16384 || H > 16384) return TSDRGPU_EINVAL; /* ... and so are strips above 16384 (tsdrgpu_frame.hip STRIP_MAX) */
+    if (W < 1 || H < 1 || (long long)W * H > TSDRGPU_MAX_FRAME_PIXELS) return TSDRGPU_EINVAL; /* like the real one: the reference's own bound */
     {   /* STUB_FAIL_POSTPROC_AFTER=n: the n-th call fails, like a device call that fails in the middle of a session */
         static int calls;
         const char *e = getenv("STUB_FAIL_POSTPROC_AFTER");
