@@ -60,6 +60,8 @@ def compact_line(res, detail_path=None):
     out.update(_pick(res, ("dtype", "data")))
     cfg = res.get("config") or {}
     out["config"] = {"workload": _short(cfg.get("workload", ""), 200), **_pick(cfg, ("samples_per_step_per_gpu", "passes_per_step"))}
+    if isinstance(cfg.get("row_bands"), dict):  # --bands: how the frames were cut (numbers only)
+        out["config"]["row_bands"] = _pick(cfg["row_bands"], ("bands", "this_rank_rows", "of", "relay_steps_in_this_run", "speculated_runs", "replayed_runs"))
     out.update(_pick(res, ("ms_per_pass", "frames_per_s", "realtime_factor")))
     rf = res.get("roofline")
     if isinstance(rf, dict):
@@ -93,7 +95,7 @@ def compact_line(res, detail_path=None):
     if res.get("collective"):
         out["collective"] = _short(res["collective"], 100)
     if res.get("ranks"):
-        keys = ("rank", "windows_per_pass", "of", "rows", "rccl_ranks", "device", "argmax")
+        keys = ("rank", "windows_per_pass", "of", "rows", "rccl_ranks", "device", "argmax", "epochs_replayed_exact")
         ranks = [_pick(r, keys) for r in res["ranks"] if isinstance(r, dict)]
         out["ranks"] = ranks
     if res.get("device"):
@@ -112,6 +114,16 @@ def compact_line(res, detail_path=None):
         line = json.dumps(out, allow_nan=False, separators=(",", ":"))
     assert len(line.encode()) <= LINE_LIMIT, "bench line over its limit"
     return line
+
+
+def _flush_c_stdio():
+    """fflush(NULL): what C libraries in this process (RCCL's banner) have written to stdout goes out NOW, not at exit"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001 (cosmetic)
+        pass
+    sys.stdout.flush()
 
 
 def _json_safe(x):
@@ -661,6 +673,7 @@ def main():
         d_band = DevPtr(torch.empty(band_cap * band["rows"] * W, dtype=torch.float32, device=dev))
         d_out_band = DevPtr(torch.empty(band_cap * band["rows"] * W, dtype=torch.float32, device=dev))
     comm = None
+    final_line = None  # rank 0: the ONE line, printed last
     plots_ts = {}
     if sharded:
         # RCCL from C (tsdrgpu_rccl.hip): the all-reduce is queued by the library on the autocorrelation's own lane,
@@ -1367,6 +1380,7 @@ def main():
                                                  "of {-min, max, pixel 0}; + one sum all-reduce per band for every relay of the literal strip "
                                                  "collapse (ties / toss-ups)",
                                      "relay_steps_in_this_run": relay_steps[0],
+                                     "speculated_runs": pp.band_spec_stats()[0], "replayed_runs": pp.band_spec_stats()[1],
                                      "note": "strong scaling of ONE stream: value = samples of the stream / time, frames_per_s = frames of the stream"}},
             "ms_per_pass": round(ms_pass, 4),
             "step_ms": {"min": round(srt[0] * 1e3, 3), "median": round(srt[len(srt) // 2] * 1e3, 3), "max": round(srt[-1] * 1e3, 3),
@@ -1442,12 +1456,21 @@ def main():
                 shown = os.path.relpath(detail, ROOT) if detail.startswith(ROOT) else detail
             except OSError as ex:
                 print(f"[bench] detail file not written: {ex!r}", file=sys.stderr)
-            print(compact_line(res, shown), flush=True)
+            final_line = compact_line(res, shown)
     if comm is not None:
         comm.destroy()
     g.close()
+    # The JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio, which a pipe buffers until the
+    # process ends — i.e. behind a line Python printed earlier (seen in round 6: five banner lines after the JSON of a
+    # --force-dist run).  Every rank empties its C buffers, the ranks meet, then rank 0 prints.
+    _flush_c_stdio()
     if dist is not None:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if final_line is not None:
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":

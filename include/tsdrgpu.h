@@ -270,11 +270,19 @@ int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out_band, tsdr
  *          if (more) <sum all-reduce of d_buf[0..n) over the ranks, in place: tsdrgpu_comm_allreduce_f64>; } while (more);
  * after the two all-reduces of _band_begin.  band_index = this rank's position in the order of the bands from the top
  * row down (0 .. nbands-1, one band per rank).  Whether and how often `more` is raised follows from the exchanged
- * strips alone, identically on every rank: not at all for an ordinary batch (then the call costs one host
- * synchronisation more than _band_finish), nbands times for a batch with flagged strips, again nbands times if a
- * decision was a toss-up.  Synchronises.  With exact ties off it is _band_finish. */
+ * strips alone, identically on every rank: not at all for an ordinary batch, nbands times for a batch with flagged
+ * strips, again nbands times if a decision was a toss-up.  The two questions behind that ("does a strip hold ties?",
+ * "was a decision a toss-up?") are SPECULATED: both halves of the chain are queued as if no strip held ties, both flag
+ * arrays are copied out behind them and the host waits once — an ordinary batch then goes straight to the pass, a batch
+ * with toss-ups only goes on with the second relay (what was queued is the literal run), and only a batch whose strips
+ * hold ties is put back to the autogain / sync state it started from (saved on the device) and taken literally from the
+ * start, so results never depend on the speculation (TSDRGPU_BAND_SPECULATE=0 in the environment: every batch literally,
+ * two host round trips each).  Synchronises.  With exact ties off it is _band_finish.
+ * Reference: syncdetector.c:26-153, dsp.c:96-110. */
 int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_out_band, int band_index, int nbands, double **d_buf,
                                   int64_t *n_buf, int *h_more, tsdrgpu_pp_frameinfo_t *h_info);
+/* how many band runs were speculated since the object was created, and how many of those had to be put back and taken literally */
+int tsdrgpu_postproc_band_spec_stats(tsdrgpu_postproc_t *pp, uint64_t *runs, uint64_t *replays);
 /* The band run in its GENERAL form: every stage order of dsp_post_process (dsp.c:134-239: PARAM_LOW_PASS_BEFORE_SYNC,
  * PARAM_AUTOGAIN_AFTER_PROCESSING — the GUI's default order among them), PARAM_INT_AUTOSHIFT (the 2-D roll,
  * syncdetector.c:187-207) and PARAM_INT_FRAMERATE_PLL (syncdetector.c:133-153; replicated: every rank computes the same

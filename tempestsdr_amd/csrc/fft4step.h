@@ -709,31 +709,18 @@ __device__ __forceinline__ void ac4_fft4096(float2 (&v)[16], float2 *Lr, unsigne
 // (Round 5 built the form the review suggested — one row pair per workgroup of 256 threads, both rows per thread through one
 // 39 KB buffer, four workgroups per CU instead of two — and measured it SLOWER in two same-box A/B pairs: 0.146 / 0.168 against
 // 0.127 / 0.132 ms per pass; it needs all 128 registers plus 24 bytes of scratch where this one takes 81.  Dropped.)
-__global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsigned nh)
+// (Round 6 built the PERSISTENT form a third time — a grid of two workgroups per CU walking the row pairs, the next pair's sixteen
+// points per thread requested before the current pair is transformed — in two addressings: plain pointers (correct, 128 registers +
+// 48 bytes of scratch: the group 0.509-0.533 ms per pass against 0.391-0.393 on the same box, the pass 81.0 against 92.1 GS/s) and
+// the rows as buffer resources with scalar offsets (fewer address registers, still 12 spilled, and wrong results on the device).
+// What a wave saves in waiting it loses twice over in occupancy-neutral register pressure; dropped for good.
+// profiles/round6_ab_runs.txt.)
+// one row pair: v[t] = this thread's 16 points of its row (loaded by the caller), transformed, split, transformed back and
+// stored in place; `buf` / tables as in k_ac_rows.  All 512 threads of the workgroup must call it.
+__device__ __forceinline__ void ac4_rows_pair(float2 (&v)[16], float2 *__restrict__ zrow, float2 (*buf)[AC4_ROWBUF], const float2 *tw256,
+                                              const float2 *tw4k, unsigned k1, bool selfpair, unsigned half, unsigned j, unsigned nh, unsigned N1)
 {
-    __shared__ float2 buf[2][AC4_ROWBUF];
-    __shared__ float2 tw256[256], tw4k[256];
-    const unsigned N1 = nh / AC4_ROW;
-    const unsigned tid = threadIdx.x, half = tid >> 8, j = tid & 255u;
-    const unsigned wg = blockIdx.x;
-    const bool selfpair = wg == 0;
-    const unsigned k1 = selfpair ? (half ? N1 / 2u : 0u) : (half ? N1 - wg : wg);
-    float2 *zrow = z + (long long)blockIdx.y * nh + (long long)k1 * AC4_ROW;
     float2 *Lr = buf[half];
-    float2 v[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = zrow[j + 256u * (unsigned)t];  // already times w_nh^(k1 n2) (trip 1)
-    {
-        float sn, cs;
-        if (half == 0u) {
-            sincospif(-(float)j * (1.0f / 128.0f), &sn, &cs);
-            tw256[j] = make_float2(cs, sn);
-        } else {
-            sincospif(-(float)j * (1.0f / 2048.0f), &sn, &cs);
-            tw4k[j] = make_float2(cs, sn);
-        }
-    }
-    __syncthreads();  // tables ready
     ac4_fft4096(v, Lr, j, tw256, tw4k);  // v[u] = Z[k1 + N1 (j + 256 u)]
     __syncthreads();
     // ---- split: Z[k] pairs with Z[nh-k], i.e. (k1, k2) <-> (N1-k1, N2-1-k2) — thread j register u of one
@@ -793,6 +780,36 @@ __global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsi
     // loads and the conjugation that completes the inverse after its forward column transform
 #pragma unroll
     for (int u = 0; u < 16; u++) zrow[j2 + 256u * (unsigned)u] = v[u];
+}
+
+__device__ __forceinline__ void ac4_rows_tables(float2 *tw256, float2 *tw4k, unsigned half, unsigned j)
+{
+    float sn, cs;
+    if (half == 0u) {
+        sincospif(-(float)j * (1.0f / 128.0f), &sn, &cs);
+        tw256[j] = make_float2(cs, sn);
+    } else {
+        sincospif(-(float)j * (1.0f / 2048.0f), &sn, &cs);
+        tw4k[j] = make_float2(cs, sn);
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void k_ac_rows(float2 *__restrict__ z, unsigned nh)
+{
+    __shared__ float2 buf[2][AC4_ROWBUF];
+    __shared__ float2 tw256[256], tw4k[256];
+    const unsigned N1 = nh / AC4_ROW;
+    const unsigned tid = threadIdx.x, half = tid >> 8, j = tid & 255u;
+    const unsigned wg = blockIdx.x;
+    const bool selfpair = wg == 0;
+    const unsigned k1 = selfpair ? (half ? N1 / 2u : 0u) : (half ? N1 - wg : wg);
+    float2 *zrow = z + (long long)blockIdx.y * nh + (long long)k1 * AC4_ROW;
+    float2 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = zrow[j + 256u * (unsigned)t];  // already times w_nh^(k1 n2) (trip 1)
+    ac4_rows_tables(tw256, tw4k, half, j);
+    __syncthreads();  // tables ready
+    ac4_rows_pair(v, zrow, buf, tw256, tw4k, k1, selfpair, half, j, nh, N1);
 }
 
 // ---------------------------------------------------------------------------

@@ -101,6 +101,14 @@ struct tsdrgpu_postproc {
     int *h_flags;               // host copy of a flag array [2F]
     double *d_relay;            // [items][nmax]: sums so far (f32 values carried as f64 through the sum all-reduce)
     size_t cap_items, cap_hflags, cap_relay;
+    // ... speculated: both halves of the chain are queued without asking the host, the two flag arrays are read once behind them
+    // (band_speculate)
+    int band_spec;              // -1 = the open run was speculated, a strip held ties, the literal run is under way (its first question answered)
+    PpState *d_state_save;      // the autogain / sync state the batch started from
+    hipEvent_t ev_spec;         // behind the copies of the speculated run's flags
+    int *h_spec_flags;          // pinned: [2F] tie flags + [2F] toss-up flags behind the speculated chain
+    size_t cap_spec_flags;
+    unsigned long long band_spec_runs, band_spec_replays;  // counters (tsdrgpu_postproc_band_spec_stats)
     // general band runs (tsdrgpu_postproc_band_open / _band_step): every stage order, autoshift, PLL
     struct BandOp { int op, a, b, c; } bprog[24];
     int bprog_n, bprog_pc;
@@ -205,6 +213,8 @@ __device__ __forceinline__ void stats_store_tile(const float (&val)[TILE_H / 4][
                 bad |= px_odd(o);
             }
             const long long at = (long long)y * W + x0 + 4 * lane;
+            // (non-temporal hints on this store, on the raw-pixel loads above and on the resampler's sample loads: measured, each alone
+            // and together, -0.3 to -3 % for the pass — profiles/round6_ab_runs.txt)
             *reinterpret_cast<float4_a4 *>(outp + at) = t;
             if (f == 0) {
 #pragma unroll
@@ -1674,6 +1684,9 @@ extern "C" void tsdrgpu_postproc_destroy(tsdrgpu_postproc_t *pp)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (pp->h_chain) (void)hipHostFree(pp->h_chain);
+    if (pp->d_state_save) (void)hipFree(pp->d_state_save);
+    if (pp->h_spec_flags) (void)hipHostFree(pp->h_spec_flags);
+    if (pp->ev_spec) (void)hipEventDestroy(pp->ev_spec);
     free(pp->h_flags);
     free(pp);
 }
@@ -1933,12 +1946,19 @@ static int pp_prepare(tsdrgpu_postproc_t *pp, int F, int W, int H, const tsdrgpu
     return TSDRGPU_OK;
 }
 
+static void pp_convert_info(tsdrgpu_postproc_t *pp, int F, tsdrgpu_pp_frameinfo_t *h_info);
 static int pp_copy_info(tsdrgpu_postproc_t *pp, int F, tsdrgpu_pp_frameinfo_t *h_info)
 {
     tsdrgpu_t *g = pp->g;
     // the chain record is complete after the last k_chain; convert on the host after the sync
     HIP_TRY(g, hipMemcpyAsync(pp->h_chain, pp->d_chain, sizeof(ChainOut) * F, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(g, hipStreamSynchronize(g->stream));
+    pp_convert_info(pp, F, h_info);
+    return TSDRGPU_OK;
+}
+
+static void pp_convert_info(tsdrgpu_postproc_t *pp, int F, tsdrgpu_pp_frameinfo_t *h_info)
+{
     for (int f = 0; f < F; f++) {
         const ChainOut &c = pp->h_chain[f];
         tsdrgpu_pp_frameinfo_t &o = h_info[f];
@@ -1948,7 +1968,6 @@ static int pp_copy_info(tsdrgpu_postproc_t *pp, int F, tsdrgpu_pp_frameinfo_t *h
         o.locked = c.locked; o.pll_fired = c.pll_fired;
         o.avg_speed = c.avg_speed; o.frameratediff = c.frameratediff;
     }
-    return TSDRGPU_OK;
 }
 
 extern "C" int tsdrgpu_postproc_run(tsdrgpu_postproc_t *pp, const float *d_frames, int F, int W, int H,
@@ -2292,6 +2311,7 @@ extern "C" int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *
     pp->band_y0 = y0;
     pp->band_rows = rows;
     pp->band_stage = 0;
+    pp->band_spec = 0;
     pp->brelay_src = nullptr;
     pp->pending = PEND_BAND;
     if (d_xsum) *d_xsum = pp->d_xsum;
@@ -2450,6 +2470,132 @@ static int band_relay_step(tsdrgpu_postproc_t *pp, int band_index)
     return TSDRGPU_OK;
 }
 
+// the pass over this band's rows, which ends a band run
+static int band_run_pass(tsdrgpu_postproc_t *pp, float *d_out_band)
+{
+    tsdrgpu_t *g = pp->g;
+    const int F = pp->p_F, W = pp->p_W, y0 = pp->band_y0, rows = pp->band_rows;
+    const tsdrgpu_pp_params_t *prm = &pp->p_prm;
+    TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_band_chain, (F + 63) / 64, 64, pp->d_chain, pp->d_chain_band, F, y0);
+    KERNEL_CHECK(g, "k_band_chain");
+    const float a = prm->motionblur;
+    const int lines = (a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+    const long long Pb = (long long)W * rows;
+    ChainOut *full = pp->d_chain;
+    pp->d_chain = pp->d_chain_band;  // what the pass reads
+    const int rc = launch_pass(pp, PASS_NORMALISE | lines | PASS_IIR, pp->p_frames, Pb, d_out_band, Pb, F, W, rows, a);
+    pp->d_chain = full;
+    return rc;
+}
+
+// The common batch holds no strip with exact ties and no toss-up decision, so neither relay is needed — but finding that out
+// took the host two round trips per batch (the flag array behind k_strip_flag, then the one behind run 0 of the chain), each one
+// a drained queue.  Speculated form: both halves of the chain — exchanged statistics -> autogain recurrence -> tie flags -> run 0
+// of the sync chain -> toss-up flags — are queued as if no strip held ties, both flag arrays are copied out behind them and the
+// host waits ONCE.  Every rank sees the same flags (the strips are replicated), so every rank goes the same way:
+//   no flag at all      -> the pass (no relay, no collective, one round trip instead of two)
+//   toss-ups only       -> what was queued IS the literal run up to its second question: on with the relay of round 1
+//   strips with ties    -> run 0 saw strips that the relay had not made exact: the autogain / sync state saved before the first
+//                          launch is put back and the literal run takes the batch from the start (its first question is answered)
+// (A first form also queued the PASS ahead of the answer and replayed the whole batch when a flag fired: on configs[4]'s synthetic
+// stream one batch in nine holds a toss-up, and a wasted pass costs more than a round trip saves — 1.42 against 1.36 ms per pass
+// on one rank, profiles/round6_ab_runs.txt.)
+// h_spec_flags: [0, 2F) the tie flags, [2F, 4F) the toss-ups.  Reference: syncdetector.c:26-153, dsp.c:96-110.
+static int band_speculate(tsdrgpu_postproc_t *pp, int *ties, int *tossups)
+{
+    tsdrgpu_t *g = pp->g;
+    const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H;
+    const tsdrgpu_pp_params_t *prm = &pp->p_prm;
+    const int nmax = W > Htot ? W : Htot;
+    hipStream_t st = g->stream;
+    if (!pp->d_state_save && hipMalloc(&pp->d_state_save, sizeof(PpState)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "band state copy");
+    if (pp->cap_spec_flags < (size_t)4 * F) {
+        if (pp->h_spec_flags) { (void)hipStreamSynchronize(st); (void)hipHostFree(pp->h_spec_flags); }
+        pp->h_spec_flags = nullptr;
+        pp->cap_spec_flags = 0;
+        if (hipHostMalloc(&pp->h_spec_flags, sizeof(int) * 4 * (size_t)F, hipHostMallocDefault) != hipSuccess)
+            return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "band flags (pinned)");
+        pp->cap_spec_flags = (size_t)4 * F;
+    }
+    if (!pp->ev_spec && hipEventCreateWithFlags(&pp->ev_spec, hipEventDisableTiming) != hipSuccess) return tsdr_fail(g, TSDRGPU_EHIP, "postproc", "event");
+    HIP_TRY(g, hipMemcpyAsync(pp->d_state_save, pp->d_state, sizeof(PpState), hipMemcpyDeviceToDevice, st));
+
+    StripScratch sc;
+    sc.nmax = nmax;
+    sc.blur = pp->d_work;
+    sc.prefix = (double *)(pp->d_work + (((size_t)F * 2 * nmax + 1) & ~(size_t)1));
+    sc.total = sc.prefix + (size_t)F * 2 * (nmax + 1);
+    SpecEntry *spec = (SpecEntry *)(sc.total + (size_t)F * 2);
+    int *d_amb = pp->d_sflag + (size_t)F * 2, *d_fresh = d_amb + (size_t)F * 2, *d_redo = d_fresh + (size_t)F * 2;
+    const int *const no_gate = nullptr;
+    // stage 0 and stage 2 of the literal run, without its questions
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_xmax, pp->d_strip_x,
+                pp->d_strip_y, pp->d_fmin, pp->d_fmax, pp->d_v0);
+    TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 1,
+                prm->lowpasscoeff, (int *)nullptr);
+    KERNEL_CHECK(g, "k_autogain_chain");
+    TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, 1, pp->d_sflag);
+    KERNEL_CHECK(g, "k_strip_flag");
+    HIP_TRY(g, hipMemcpyAsync(pp->h_spec_flags, pp->d_sflag, sizeof(int) * 2 * (size_t)F, hipMemcpyDeviceToHost, st));
+    // (a flagged strip makes k_strip_prepare take d_exact's entries, which nobody has filled yet: whatever the chain then decides
+    // is thrown away — window indices stay inside the strip whatever the sums are)
+    TSDR_LAUNCH_STRIP_PREPARE(g, st, sc.nmax, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, sc, 1, pp->taps[0], pp->taps[1],
+                pp->taps[2], pp->taps[3], pp->taps[4], pp->d_sflag, pp->d_exact, no_gate);
+    TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_search, dim3(2, F), SYNC_T, W, Htot, sc, pp->d_state, spec, no_gate, no_gate);
+    TSDR_LAUNCH(g, PROF_CHAIN, st, k_sync_chain, 2, SYNC_T, F, W, Htot, sc, pp->d_state, pp->d_chain, spec, prm->pll, pp->d_state + 1, d_amb, no_gate);
+    KERNEL_CHECK(g, "k_sync_chain");
+    TSDR_LAUNCH(g, PROF_CHAIN, st, k_redo_prepare, 1, 256, 2 * F, d_amb, pp->d_sflag, d_redo, d_fresh);
+    KERNEL_CHECK(g, "k_redo_prepare");
+    HIP_TRY(g, hipMemcpyAsync(pp->h_spec_flags + 2 * (size_t)F, d_fresh, sizeof(int) * 2 * (size_t)F, hipMemcpyDeviceToHost, st));
+    HIP_TRY(g, hipEventRecord(pp->ev_spec, st));
+    HIP_TRY(g, hipEventSynchronize(pp->ev_spec));
+    int t = 0, u = 0;
+    for (int i = 0; i < 2 * F; i++) {
+        t |= pp->h_spec_flags[i];
+        u |= pp->h_spec_flags[2 * F + i];
+    }
+    pp->band_spec_runs++;
+    *ties = t ? 1 : 0;
+    *tossups = u ? 1 : 0;
+    if (t) {
+        pp->band_spec_replays++;
+        HIP_TRY(g, hipMemcpyAsync(pp->d_state, pp->d_state_save, sizeof(PpState), hipMemcpyDeviceToDevice, st));
+    }
+    return TSDRGPU_OK;
+}
+
+// the set entries of a flag array the host already holds -> the relay's item list on the device
+static int band_items_from_host(tsdrgpu_postproc_t *pp, const int *h_flags, int count, int *nitems)
+{
+    tsdrgpu_t *g = pp->g;
+    int rc;
+    if (pp->cap_hflags < (size_t)count) {
+        free(pp->h_flags);
+        pp->h_flags = (int *)malloc(sizeof(int) * (size_t)count * 2);
+        pp->cap_hflags = pp->h_flags ? (size_t)count : 0;
+        if (!pp->h_flags) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "band flags");
+    }
+    if ((rc = ensure(g, &pp->d_items, &pp->cap_items, (size_t)count))) return rc;
+    int *list = pp->h_flags + count;
+    int n = 0;
+    for (int i = 0; i < count; i++)
+        if (h_flags[i]) list[n++] = i;
+    if (n) {
+        HIP_TRY(g, hipMemcpyAsync(pp->d_items, list, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(g, hipStreamSynchronize(g->stream));  // `list` is reused
+    }
+    *nitems = n;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_band_spec_stats(tsdrgpu_postproc_t *pp, uint64_t *runs, uint64_t *replays)
+{
+    if (!pp) return TSDRGPU_EINVAL;
+    if (runs) *runs = pp->band_spec_runs;
+    if (replays) *replays = pp->band_spec_replays;
+    return TSDRGPU_OK;
+}
+
 extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_out_band, int band_index, int nbands, double **d_buf,
                                              int64_t *n_buf, int *h_more, tsdrgpu_pp_frameinfo_t *h_info)
 {
@@ -2457,7 +2603,7 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_advance", "bad argument") : TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
     if (pp->pending != PEND_BAND) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_advance", "no band run is open");
-    const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H, y0 = pp->band_y0, rows = pp->band_rows;
+    const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H;
     const tsdrgpu_pp_params_t *prm = &pp->p_prm;
     const int nmax = W > Htot ? W : Htot;
     hipStream_t st = g->stream;
@@ -2473,6 +2619,22 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
     const int *const no_gate = nullptr;
     const int exact = pp->exact_ties;
 
+    // TSDRGPU_BAND_SPECULATE=0: every batch takes the literal run (two host round trips; for A/B runs and for the tests of that run)
+    static const int speculate = [] { const char *e = getenv("TSDRGPU_BAND_SPECULATE"); return e ? atoi(e) : 1; }();
+    if (pp->band_stage == 0 && exact && speculate && !pp->band_spec) {
+        int ties = 0, tossups = 0;
+        if ((rc = band_speculate(pp, &ties, &tossups))) return rc;
+        if (ties) {
+            pp->band_spec = -1;  // from the start, literally; stage 0's question is answered (h_spec_flags)
+        } else if (tossups) {
+            if ((rc = band_items_from_host(pp, pp->h_spec_flags + 2 * (size_t)F, 2 * F, &pp->relay_items))) return rc;
+            pp->relay_step = 0;
+            pp->band_stage = 3;
+        } else {
+            pp->band_stage = 4;
+        }
+    }
+
     for (;;) {
         switch (pp->band_stage) {
         case 0: {  // the exchanged statistics -> autogain recurrence, tie flags
@@ -2485,7 +2647,9 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
             if (exact) {
                 TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, 1, pp->d_sflag);
                 KERNEL_CHECK(g, "k_strip_flag");
-                if ((rc = band_collect_items(pp, pp->d_sflag, 2 * F, &pp->relay_items))) return rc;
+                if (pp->band_spec == -1) rc = band_items_from_host(pp, pp->h_spec_flags, 2 * F, &pp->relay_items);  // (the same flags: the same strips)
+                else rc = band_collect_items(pp, pp->d_sflag, 2 * F, &pp->relay_items);
+                if (rc) return rc;
             } else {
                 HIP_TRY(g, hipMemsetAsync(pp->d_sflag, 0, sizeof(int) * (size_t)F * 2, st));
             }
@@ -2538,16 +2702,8 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
         default: {  // the pass over this band's rows
             pp->pending = 0;
             pp->band_stage = 0;
-            TSDR_LAUNCH(g, PROF_CHAIN, st, k_band_chain, (F + 63) / 64, 64, pp->d_chain, pp->d_chain_band, F, y0);
-            KERNEL_CHECK(g, "k_band_chain");
-            const float a = prm->motionblur;
-            const int lines = (a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
-            const long long Pb = (long long)W * rows;
-            ChainOut *full = pp->d_chain;
-            pp->d_chain = pp->d_chain_band;  // what the pass reads
-            rc = launch_pass(pp, PASS_NORMALISE | lines | PASS_IIR, pp->p_frames, Pb, d_out_band, Pb, F, W, rows, a);
-            pp->d_chain = full;
-            if (rc) return rc;
+            pp->band_spec = 0;
+            if ((rc = band_run_pass(pp, d_out_band))) return rc;
             if (h_info) return pp_copy_info(pp, F, h_info);
             return TSDRGPU_OK;
         }

@@ -106,6 +106,7 @@ _SIGS = {
     "tsdrgpu_postproc_band_open": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, vp]),
     "tsdrgpu_postproc_band_step": (C.c_int, [vp, vp, vp, vp]),
     "tsdrgpu_postproc_band_advance": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int), vp]),
+    "tsdrgpu_postproc_band_spec_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tsdrgpu_resample_band": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int64, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "tsdrgpu_comm_allreduce_f32max": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
@@ -554,6 +555,12 @@ class PostProcess:
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_advance(self.h, d_out_band.at(out_offset), band_index, nbands, C.byref(buf), C.byref(n),
                                                                 C.byref(more), info))
         return more.value, buf.value, n.value, (list(info) if (want_info and not more.value) else None)
+
+    def band_spec_stats(self):
+        """(band runs speculated, of those replayed literally) since the object was created"""
+        runs, replays = C.c_uint64(), C.c_uint64()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_spec_stats(self.h, C.byref(runs), C.byref(replays)))
+        return runs.value, replays.value
 
     def band_open(self, d_band, nframes, width, height, edges, band_index, motionblur=0.0, lowpasscoeff=0.1, lowpass_before_sync=0,
                   autogain_after_proc=0, autoshift=0, pll=0, superres=0, frames_offset=0):

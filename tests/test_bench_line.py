@@ -84,7 +84,8 @@ def test_many_ranks_still_fit(bench, canned):
     assert len(d["ranks"]) == 64 and all(x["rccl_ranks"] == 64 for x in d["ranks"])
     r["ranks"] = r["ranks"][:8]
     d = check(bench.compact_line(r, None))
-    assert d["ranks"][3] == {"rank": 3, "windows_per_pass": 3, "of": 17, "rows": [96, 128], "rccl_ranks": 64, "device": 3, "argmax": [516855, 715]}
+    assert d["ranks"][3] == {"rank": 3, "windows_per_pass": 3, "of": 17, "rows": [96, 128], "rccl_ranks": 64, "device": 3, "argmax": [516855, 715],
+                             "epochs_replayed_exact": 0}
 
 
 def test_non_finite_numbers_become_null(bench, canned):

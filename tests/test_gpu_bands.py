@@ -215,6 +215,26 @@ def test_exact_row_bands_equal_the_oracle(orc, W, H, cuts, blur):
     si, sd = opp.state()
     last = infos[-1]
     assert (last.dx, last.vx, last.stripx, last.dy, last.vy, last.stripy, last.locked) == tuple(si[:7])
+    # the speculated form (the default): every batch was queued to its end first; the batch with the blank frame raised a flag, was put
+    # back and taken literally — and the batches behind it started from the right state, or the frames above would differ
+    for pp in pps:
+        runs, replays = pp.band_spec_stats()
+        if os.environ.get("TSDRGPU_BAND_SPECULATE", "1") != "0":
+            assert runs == 3 and 1 <= replays <= 3, (runs, replays)
+        else:
+            assert runs == 0 and replays == 0
+    assert len({pp.band_spec_stats() for pp in pps}) == 1  # every rank speculates, and gives up, alike
+
+
+def test_exact_row_bands_without_speculation():
+    """the literal band run alone (TSDRGPU_BAND_SPECULATE=0, read once per process: hence a process of its own): the same tests"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSDRGPU_BAND_SPECULATE="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_bands.py"), "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                          "-k", "test_exact_row_bands_equal_the_oracle and not 2962"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-1000:]
 
 
 @pytest.mark.parametrize("fs,h,y0,rows", [(8_000_000, 525, 160, 192), (8_000_000, 525, 0, 525), (25_000_000, 806, 416, 390),
