@@ -61,7 +61,7 @@ def compact_line(res, detail_path=None):
     cfg = res.get("config") or {}
     out["config"] = {"workload": _short(cfg.get("workload", ""), 200), **_pick(cfg, ("samples_per_step_per_gpu", "passes_per_step"))}
     if isinstance(cfg.get("row_bands"), dict):  # --bands: how the frames were cut (numbers only)
-        out["config"]["row_bands"] = _pick(cfg["row_bands"], ("bands", "this_rank_rows", "of", "relay_steps_in_this_run", "speculated_runs", "replayed_runs"))
+        out["config"]["row_bands"] = _pick(cfg["row_bands"], ("bands", "this_rank_rows", "of", "fused", "relay_steps_in_this_run", "speculated_runs", "replayed_runs"))
     out.update(_pick(res, ("ms_per_pass", "frames_per_s", "realtime_factor")))
     rf = res.get("roofline")
     if isinstance(rf, dict):
@@ -498,6 +498,11 @@ def main():
                          "rows [k H/N, (k+1) H/N) of every frame — band resampler, band statistics, sum/max all-reduce of the strip "
                          "partials over RCCL, the replicated sync chain, the pass over the band) and the capture windows sharded by "
                          "window (--scaling strong); what configs[4] names for 8 GPUs.  Contract-exact like the single-GPU run")
+    ap.add_argument("--no-band-prefetch", action="store_true",
+                    help="--bands: one band buffer, the next pass's band resampler queued only after this pass's chain has been waited for (A/B)")
+    ap.add_argument("--no-band-fuse", action="store_true",
+                    help="--bands: the two-trip band run (statistics, then the pass: 16P bytes per band pixel) instead of the fused one "
+                         "(tsdrgpu_postproc_band_begin_minmax / _band_fused: range exchanged first, one trip, 12P) — for A/B runs")
     ap.add_argument("--blur", type=float, default=None, help="motion blur coefficient (tsdr_motionblur) instead of the configuration's own")
     ap.add_argument("--leg", action="store_true",
                     help="a side leg of another bench.py run: the timed region, the per-kernel rooflines and nothing else")
@@ -671,6 +676,9 @@ def main():
             ap.error("too many ranks for this frame height")
         band_cap = frames_cap + 1
         d_band = DevPtr(torch.empty(band_cap * band["rows"] * W, dtype=torch.float32, device=dev))
+        # two band buffers: the NEXT pass's band resampler is queued before this pass's chain is waited for (band_pass)
+        band["bufs"] = [d_band, d_band if args.no_band_prefetch else DevPtr(torch.empty(band_cap * band["rows"] * W, dtype=torch.float32, device=dev))]
+        band["cur"], band["ready"] = 0, None
         d_out_band = DevPtr(torch.empty(band_cap * band["rows"] * W, dtype=torch.float32, device=dev))
     comm = None
     final_line = None  # rank 0: the ONE line, printed last
@@ -714,6 +722,9 @@ def main():
         a_.set_async(not args.serial)
     if args.frames_per_launch <= 0 and not args.no_split and args.fuse:
         rs.track_frames(P, 0)  # per-frame min/max out of the resampler (the batch starts on a frame boundary)
+    band_fuse = band is not None and not args.no_band_fuse
+    if band_fuse:
+        rs.track_frames(P, 0)  # ... in the band form: this band's share of every frame's range
 
     pass_no = [0]
     promoted_passes = [0]
@@ -770,42 +781,79 @@ def main():
 
     relay_steps = [0]
 
-    def band_pass():
+    def band_resample(buf):
+        n, touched = rs.process_band(d_iq, 1, chunk, nchunks, up, down, W, h, band["y0"], band["rows"], band["phase"], buf, band_cap)
+        return n, (band["phase"] + n) // P
+
+    def band_pass(last):
         """the frame path of one pass on this rank's row band"""
         nonlocal frames_done
         y0, rows_b = band["y0"], band["rows"]
-        n, touched = rs.process_band(d_iq, 1, chunk, nchunks, up, down, W, h, y0, rows_b, band["phase"], d_band, band_cap)
-        F = (band["phase"] + n) // P
-        ps, ns, pm, nm = pp.band_begin(d_band, F, W, h, y0, rows_b, motionblur=blur)
-        if comm is not None:
-            comm.allreduce_f64(ps, ns)     # strip partials: column sums add up, row sums concatenate
-            comm.allreduce_f32max(pm, nm)  # {-min, max, pixel 0}
+        buf = band["bufs"][band["cur"]]
+        if band["ready"] is None:
+            n, F = band_resample(buf)
+        else:  # queued by the previous pass, ahead of its chain
+            n, F = band["ready"]
+            band["ready"] = None
+        if band_fuse:
+            # the fused band run: the range first (the tracked band resampler left this band's share), ONE trip over the raw band,
+            # then the strip partials — 12P instead of 16P bytes per band pixel
+            mnp, mxp, nfr = rs.frame_minmax(download=False)
+            assert nfr == F
+            pm, nm = pp.band_begin_minmax(buf, F, W, h, y0, rows_b, mnp, mxp, motionblur=blur)
+            if comm is not None:
+                comm.allreduce_f32max(pm, nm)  # {-min, max, pixel 0}
+            else:
+                g.sync()
+                reduce_dev(pm, nm, False, dist.ReduceOp.MAX)
+                torch.cuda.synchronize()
+            ps, ns = pp.band_fused(d_out_band)
+            if comm is not None:
+                comm.allreduce_f64(ps, ns)     # strip partials: column sums add up, row sums concatenate
+            else:
+                g.sync()
+                reduce_dev(ps, ns, True)
+                torch.cuda.synchronize()
         else:
-            g.sync()
-            reduce_dev(ps, ns, True)
-            reduce_dev(pm, nm, False, dist.ReduceOp.MAX)
-            torch.cuda.synchronize()
+            ps, ns, pm, nm = pp.band_begin(buf, F, W, h, y0, rows_b, motionblur=blur)
+            if comm is not None:
+                comm.allreduce_f64(ps, ns)     # strip partials: column sums add up, row sums concatenate
+                comm.allreduce_f32max(pm, nm)  # {-min, max, pixel 0}
+            else:
+                g.sync()
+                reduce_dev(ps, ns, True)
+                reduce_dev(pm, nm, False, dist.ReduceOp.MAX)
+                torch.cuda.synchronize()
         run_autocorr()  # behind the exchange: the tiny replicated chain then finds the device busy with the FFT trips
+        # the incomplete frame goes on in slot 0 of the next pass's buffer ...
+        phase_next = (band["phase"] + n) % P
+        nxt = band["bufs"][1 - band["cur"]]
+        if phase_next:
+            g._ck(g.lib.tsdrgpu_copy(g.h, nxt.at(0), buf.at(F * rows_b * W), rows_b * W * 4))
+        band["phase"] = phase_next
+        # ... and the next pass's band resampler is queued NOW, ahead of the host's wait for this pass's chain (band_advance asks the
+        # device what the strips hold): the frame lane has 0.3 ms of work while the chain's latency passes.  The chain's relays and
+        # the painted lines read THIS pass's raw band, hence the second buffer.
+        band["cur"] = 1 - band["cur"]  # (the next pass works on the buffer that now holds the carried frame)
+        if not last and not args.no_band_prefetch:
+            band["ready"] = band_resample(nxt)
         while True:
-            more, buf, nb, _ = pp.band_advance(d_out_band, rank, world, want_info=False)
+            more, bufp, nb, _ = pp.band_advance(d_out_band, rank, world, want_info=False)
             if not more:
                 break
             relay_steps[0] += 1
             if comm is not None:
-                comm.allreduce_f64(buf, nb)
+                comm.allreduce_f64(bufp, nb)
             else:
                 g.sync()
-                reduce_dev(buf, nb, True)
+                reduce_dev(bufp, nb, True)
                 torch.cuda.synchronize()
-        band["phase"] = (band["phase"] + n) % P
-        if band["phase"]:  # the incomplete frame goes on in slot 0 of the next pass
-            g._ck(g.lib.tsdrgpu_copy(g.h, d_band.at(0), d_band.at(F * rows_b * W), rows_b * W * 4))
         frames_done += F
 
     def one_pass(last):
         nonlocal carry, frames_done
         if band is not None:
-            band_pass()
+            band_pass(last)
             return finish_pass(last)
         split = args.frames_per_launch <= 0 and not args.no_split
         fuse = split and args.fuse
@@ -1189,9 +1237,10 @@ def main():
         # group entry: bytes per window x windows / (sum of its kernels' durations).
         bfrac = (band["rows"] / h) if band is not None else 1.0  # a band touches its share of samples and pixels
         fused_flat = bool(args.fuse) and blur == 0.0  # statistics + normalise/IIR in one flat kernel (profiler stage k_frame_pass)
+        fused_any = bool(args.fuse) or bool(band_fuse)  # (the fused band run: the tile-walking trip on the band's rows)
         own = {"k_rs_area": (8.0 * S + 4.0 * P) * (nsamples / S) * bfrac,
                "k_frame_stats": 4.0 * P * frames_pass * bfrac,
-               "k_frame_pass": (12.0 if args.fuse else 8.0) * P * frames_pass * bfrac}
+               "k_frame_pass": (12.0 if fused_any else 8.0) * P * frames_pass * bfrac}
         # what the kernel MOVES over HBM (reads + writes it cannot avoid making), where that differs from the credited figure:
         # the fused trip is credited with the 12P of the two stages it replaces and moves 8P (raw frame in, frame out)
         moved = dict(own)
@@ -1208,7 +1257,7 @@ def main():
                               "moved_bytes_per_launch": int(moved[k] / n),
                               "moved_GBs": round(moved[k] / (ms * 1e-3) / 1e9, 1),
                               "frac_moved": round(moved[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                if k == "k_frame_pass" and args.fuse:
+                if k == "k_frame_pass" and fused_any:
                     kernels[k]["note"] = ("fused run: k_frame_stats<store> does the work of k_frame_stats (4P) and of the normalise/IIR pass "
                                           "(8P) in ONE trip that moves 8P — credited with the 12P of the two stages it replaces; + the "
                                           "literal pass gated on the device's redo flag (returns at once)" if fused_flat else
@@ -1250,7 +1299,7 @@ def main():
         # moved: the fused run reads the IQ, writes and re-reads the raw frames once and writes the result (8S + 12P: SURVEY's IIR
         # state read is not made — at motion blur 0 the state is not an input, with blur it stays in registers across the batch);
         # the split run reads the raw frames twice (8S + 16P)
-        frame_moved_pass = (8.0 * S + (12.0 if args.fuse else 16.0) * P) * frames_pass * bfrac
+        frame_moved_pass = (8.0 * S + (12.0 if fused_any else 16.0) * P) * frames_pass * bfrac
         stage_ms = {k: round(v[0] / np_, 4) for k, v in prof.items()}
 
         # the `roofline` object: the entry that takes the most time per pass (a kernel, or the autocorrelation group)
@@ -1379,7 +1428,7 @@ def main():
                                      "exchange": "per batch: sum all-reduce of the strip partials (3 x (W+H) doubles per frame) + max all-reduce "
                                                  "of {-min, max, pixel 0}; + one sum all-reduce per band for every relay of the literal strip "
                                                  "collapse (ties / toss-ups)",
-                                     "relay_steps_in_this_run": relay_steps[0],
+                                     "relay_steps_in_this_run": relay_steps[0], "fused": bool(band_fuse),
                                      "speculated_runs": pp.band_spec_stats()[0], "replayed_runs": pp.band_spec_stats()[1],
                                      "note": "strong scaling of ONE stream: value = samples of the stream / time, frames_per_s = frames of the stream"}},
             "ms_per_pass": round(ms_pass, 4),

@@ -154,7 +154,11 @@ int tsdrgpu_resampler_frame_minmax(tsdrgpu_resampler_t *rs, const float **d_min,
  * geometry) run the sample-parallel kernel in its band form — a band is a contiguous pixel range of every frame, workgroups
  * outside it return before loading —, anything else the pixel-group kernel over a table of band entries (dsp.c:256-307
  * entered at each pixel group through the closed form of resample_math.h).  A chunk may be longer than a frame (its output
- * then touches several frames); at most 65535 band entries per call in the pixel-group form. */
+ * then touches several frames); at most 65535 band entries per call in the pixel-group form.
+ * With frame tracking on (tsdrgpu_resampler_track_frames(rs, width*height, phase): same frame size, and `phase` must be the
+ * tracker's) the call also leaves the min / max of every completed frame over THIS BAND's pixels (sentinels skipped,
+ * dsp.c:57) in tsdrgpu_resampler_frame_minmax's arrays — +inf / -inf for a frame the band holds no ordinary pixel of —, which
+ * is what tsdrgpu_postproc_band_begin_minmax exchanges; sample-parallel kernel only. */
 int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in, int in_is_iq, uint32_t chunk, int nchunks,
                           double upsample_by, double downsample_by, int width, int height, int y0, int rows, int64_t phase,
                           float *d_band, int64_t band_capacity_frames, int64_t *h_n_out, int *h_frames_touched);
@@ -281,6 +285,23 @@ int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out_band, tsdr
  * Reference: syncdetector.c:26-153, dsp.c:96-110. */
 int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_out_band, int band_index, int nbands, double **d_buf,
                                   int64_t *n_buf, int *h_more, tsdrgpu_pp_frameinfo_t *h_info);
+/* The FUSED band run — the band form of tsdrgpu_postproc_begin_minmax: with frame tracking on (tsdrgpu_resampler_track_frames)
+ * tsdrgpu_resample_band leaves every frame's min/max over THIS band's pixels (tsdrgpu_resampler_frame_minmax), the ranks
+ * exchange that range BEFORE the band is read, and one trip over the raw band writes the normalised / IIR'd rows and gathers
+ * the strip partials: 12 bytes per band pixel instead of the 16 of _band_begin + _band_advance.  Every rank alike:
+ *     tsdrgpu_postproc_band_begin_minmax(pp, d_band, F, W, H, y0, rows, &prm, d_fmin, d_fmax, &d_xmax, &n);
+ *     <max all-reduce of d_xmax[0..n) over the ranks, in place: tsdrgpu_comm_allreduce_f32max>
+ *     tsdrgpu_postproc_band_fused(pp, d_out_band, &d_xsum, &m);          // the trip
+ *     <sum all-reduce of d_xsum[0..m): tsdrgpu_comm_allreduce_f64>
+ *     do { tsdrgpu_postproc_band_advance(pp, d_out_band, ...); if (more) <sum all-reduce>; } while (more);   // chain, relays, lines
+ * Same restrictions as _band_begin (library-default order, no autoshift, no PLL, y0 a multiple of 32); d_out_band must not
+ * overlap d_band (the relays and the painted lines read the raw band after the trip).  Frames and per-frame records are
+ * bit-identical to _band_begin + _band_advance, i.e. to tsdrgpu_postproc_run in its default mode and to the reference.
+ * Reference: dsp.c:41-110,134-239, syncdetector.c:171-225. */
+int tsdrgpu_postproc_band_begin_minmax(tsdrgpu_postproc_t *pp, const float *d_band, int nframes, int width, int height, int y0, int rows,
+                                       const tsdrgpu_pp_params_t *params, const float *d_fmin, const float *d_fmax, float **d_xmax,
+                                       int64_t *n_xmax);
+int tsdrgpu_postproc_band_fused(tsdrgpu_postproc_t *pp, float *d_out_band, double **d_xsum, int64_t *n_xsum);
 /* how many band runs were speculated since the object was created, and how many of those had to be put back and taken literally */
 int tsdrgpu_postproc_band_spec_stats(tsdrgpu_postproc_t *pp, uint64_t *runs, uint64_t *replays);
 /* The band run in its GENERAL form: every stage order of dsp_post_process (dsp.c:134-239: PARAM_LOW_PASS_BEFORE_SYNC,

@@ -1049,7 +1049,16 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
         e0 = e0 > tb ? tb : e0;
         long long a1 = tb + bd.b_lo, e1 = tb + bd.b_hi;
         e1 = e1 > n ? n : e1;
-        if (a0 >= e0 && a1 >= e1) return;  // nothing of this workgroup's span lies in the band
+        if (a0 >= e0 && a1 >= e1) {  // nothing of this workgroup's span lies in the band
+            if (MM && (threadIdx.x & 63) == 63) {  // (tracked: an empty record, like a workgroup with nothing to write)
+                RsBlockMM o;
+                o.f0 = -1;
+                o.mn0 = o.mn1 = INFINITY;
+                o.mx0 = o.mx1 = -INFINITY;
+                slots[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = o;
+            }
+            return;
+        }
         lo0 = PA + (int)a0; hi0 = a0 < e0 ? PA + (int)e0 : lo0;
         lo1 = PA + (int)(a1 < e1 ? a1 : 0); hi1 = a1 < e1 ? PA + (int)e1 : lo1;
         dst = out + (long long)fbb * bd.Pb - bd.b_lo + remb - PA;
@@ -1177,7 +1186,9 @@ __global__ __launch_bounds__(256) void k_rs_area_up(const RsChunk *__restrict__ 
                 for (int k = 0; k < 4; k++) {
                     const int p = p0 + k;
                     const float val = v[k];
-                    const bool ok = p >= PA && p < PB && !((val > 250.0f) || (val < -250.0f));  // dsp.c:57
+                    // (band form: only the pixels this rank stores count — the frame's range is the max over the bands')
+                    const bool inband = !BAND || (p >= lo0 && p < hi0) || (p >= lo1 && p < hi1);
+                    const bool ok = p >= PA && p < PB && inband && !((val > 250.0f) || (val < -250.0f));  // dsp.c:57
                     const bool first = p - PA < to_b;
                     mn0 = fminf(mn0, (ok && first) ? val : INFINITY);
                     mx0 = fmaxf(mx0, (ok && first) ? val : -INFINITY);
@@ -1542,7 +1553,11 @@ extern "C" int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in,
         y0 < 0 || rows <= 0 || y0 + rows > height || phase < 0 || phase >= (int64_t)width * height)
         return rs ? tsdr_fail(rs->g, TSDRGPU_EINVAL, "tsdrgpu_resample_band", "bad argument") : TSDRGPU_EINVAL;
     tsdrgpu_t *g = rs->g;
-    if (rs->frame_pixels > 0) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_resample_band", "frame tracking is on");
+    // Frame tracking (tsdrgpu_resampler_track_frames) in the band form: every frame's min/max over THIS BAND's pixels — what the
+    // fused band run (tsdrgpu_postproc_band_begin_minmax) exchanges before its one trip over the band.
+    const bool track = rs->frame_pixels > 0;
+    if (track && (rs->frame_pixels != (long long)width * height || rs->phase != phase))
+        return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resample_band", "frame tracking is on with another frame size or phase");
     if (h_n_out) *h_n_out = 0;
     if (h_frames_touched) *h_frames_touched = 0;
     if (nchunks == 0) return TSDRGPU_OK;
@@ -1551,12 +1566,14 @@ extern "C" int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in,
     const int64_t total = build_chunks(&probe, chunk, nchunks, up, down, nullptr);
     const long long touched = total > 0 ? (phase + total + P - 1) / P : 0;
     if (touched > band_capacity_frames) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resample_band", "band buffer too small");
+    const int ntouched = (int)touched, ncomplete = (int)((phase + total) / P);
     const size_t tab_bytes = sizeof(RsChunk) * (size_t)nchunks;
     const size_t ent_off = (tab_bytes + 15) & ~(size_t)15;
     // a chunk's output touches n_out / P + 2 frames at most (usually 1 or 2: the library polls 0.1 frame at a time, but
     // nothing forbids small frames with large chunks), each at most one band entry
     const size_t max_ent = (size_t)(2 * (long long)nchunks + total / P + 2);
-    const size_t bytes = ent_off + sizeof(RsBandEntry) * max_ent;
+    const size_t rg_off = (ent_off + sizeof(RsBandEntry) * max_ent + 15) & ~(size_t)15;  // tracked: the per-frame chunk ranges behind the entries
+    const size_t bytes = rg_off + (track ? sizeof(RsFrameRange) * (size_t)(ntouched ? ntouched : 1) : 0);
     const int slot = staging_acquire(g, &rs->ring, bytes);
     if (slot < 0) return slot;
     RsChunk *tab = (RsChunk *)rs->ring.h[slot];
@@ -1571,6 +1588,10 @@ extern "C" int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in,
     // workgroups outside the band do no work.  TSDRGPU_RS_GROUPS keeps the pixel-group kernel (A/B).
     static const int force_groups = getenv("TSDRGPU_RS_GROUPS") ? 1 : 0;
     const bool up_kernel = !force_groups && up / down >= 1.0 && up / down <= 8.0 && P >= 4096;
+    if (track && !up_kernel) {
+        staging_release(g, &rs->ring, slot);
+        return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_resample_band", "frame tracking in the band form needs the sample-parallel kernel (1 <= up/down <= 8)");
+    }
     if (up_kernel) {
         // (the chunk-frame table takes the place of the band entries in the staging slot, which was sized for more)
         RsChunkFrame *cf = (RsChunkFrame *)ent;
@@ -1579,6 +1600,18 @@ extern "C" int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in,
             cf[c].f = (int)(pos / P);
             cf[c].rem = pos % P;
             cf[c].pad = 0;
+        }
+    }
+    if (track) {  // as in tsdrgpu_resample: the chunks whose output overlaps frame j of the call
+        RsFrameRange *rg = (RsFrameRange *)((char *)rs->ring.h[slot] + rg_off);
+        int c0 = 0;
+        for (int j = 0; j < ntouched; j++) {
+            const long long lo = (long long)j * P - phase, hi = lo + P;
+            while (c0 < nchunks && tab[c0].out_off + (long long)tab[c0].n_out <= lo) c0++;
+            int c1 = c0;
+            while (c1 < nchunks && tab[c1].out_off < hi) c1++;
+            rg[j].c_lo = c0;
+            rg[j].c_hi = c1;
         }
     }
     for (int c = 0; c < nchunks && !up_kernel; c++) {
@@ -1633,7 +1666,34 @@ extern "C" int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in,
         RsBandGeom bd;
         bd.b_lo = b_lo; bd.b_hi = b_hi; bd.Pb = Pb;
         const RsChunkFrame *d_cf = (const RsChunkFrame *)d_ent;
-        if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<true, false, true>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_band, rounds, maxc, d_cf, P, (RsBlockMM *)nullptr, bd);
+        if (track) {
+            const size_t nslots = (size_t)gridu.x * (size_t)nchunks * 4;
+            if (rs->cap_slots < nslots) {
+                (void)hipStreamSynchronize(g->stream);
+                hipFree(rs->d_slots);
+                rs->d_slots = nullptr; rs->cap_slots = 0;
+                if (hipMalloc(&rs->d_slots, sizeof(RsBlockMM) * (nslots + nslots / 8)) != hipSuccess)
+                    return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_resample_band", "frame tracking records");
+                rs->cap_slots = nslots + nslots / 8;
+            }
+            if (rs->cap_frames < ntouched) {
+                (void)hipStreamSynchronize(g->stream);
+                hipFree(rs->d_fmin); hipFree(rs->d_fmax);
+                rs->d_fmin = rs->d_fmax = nullptr; rs->cap_frames = 0;
+                if (hipMalloc(&rs->d_fmin, sizeof(float) * (ntouched + 16)) != hipSuccess ||
+                    hipMalloc(&rs->d_fmax, sizeof(float) * (ntouched + 16)) != hipSuccess)
+                    return tsdr_fail(g, TSDRGPU_ENOMEM, "tsdrgpu_resample_band", "frame min/max");
+                rs->cap_frames = ntouched + 16;
+            }
+            if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<true, true, true>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_band, rounds, maxc, d_cf, P, rs->d_slots, bd);
+            else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<false, true, true>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_band, rounds, maxc, d_cf, P, rs->d_slots, bd);
+            if (ntouched > 0) {
+                const RsFrameRange *d_rg = (const RsFrameRange *)((const char *)rs->ring.d[slot] + rg_off);
+                TSDR_LAUNCH(g, PROF_RS_CARRY, g->stream, k_rs_minmax, (unsigned)ntouched, RSMM_T, rs->d_slots, (int)gridu.x, d_rg, ntouched, ncomplete,
+                            rs->d_carry + 2 * rs->parity, rs->d_carry + 2 * (1 - rs->parity), rs->d_fmin, rs->d_fmax);
+                rs->parity = 1 - rs->parity;
+            }
+        } else if (in_is_iq) TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<true, false, true>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_band, rounds, maxc, d_cf, P, (RsBlockMM *)nullptr, bd);
         else TSDR_LAUNCH(g, PROF_RS_AREA, g->stream, (k_rs_area_up<false, false, true>), gridu, 256, d_tab, r, 1.0 / r, d_in, rs->d_cin, d_band, rounds, maxc, d_cf, P, (RsBlockMM *)nullptr, bd);
     } else if (nent) {
         dim3 grid(ceil_div_u((unsigned)max_span + 2 * RS_NPIX, 256 * RS_NPIX), (unsigned)nent);
@@ -1644,6 +1704,10 @@ extern "C" int tsdrgpu_resample_band(tsdrgpu_resampler_t *rs, const float *d_in,
     rc = staging_release(g, &rs->ring, slot);
     if (rc) return rc;
     rs->offset = new_offset;
+    if (track) {
+        rs->phase = (rs->phase + total) % P;
+        rs->last_complete = ncomplete;
+    }
     if (h_n_out) *h_n_out = total;
     if (h_frames_touched) *h_frames_touched = (int)touched;
     return TSDRGPU_OK;

@@ -103,6 +103,8 @@ struct tsdrgpu_postproc {
     size_t cap_items, cap_hflags, cap_relay;
     // ... speculated: both halves of the chain are queued without asking the host, the two flag arrays are read once behind them
     // (band_speculate)
+    int band_fused;             // fused band run (tsdrgpu_postproc_band_begin_minmax): 1 = waiting for the min/max exchange, 2 = the trip is done
+    int band_flat;              // ... and that trip was the flat one (motion blur 0: k_frame_stats<true>), whose exceptions the literal pass redoes
     int band_spec;              // -1 = the open run was speculated, a strip held ties, the literal run is under way (its first question answered)
     PpState *d_state_save;      // the autogain / sync state the batch started from
     hipEvent_t ev_spec;         // behind the copies of the speculated run's flags
@@ -2245,7 +2247,7 @@ __global__ __launch_bounds__(256) void k_band_pack(int F, int W, int Htot, int y
         }
         xsum[((long long)f * 3 + q) * (W + Htot) + i] = v;
     }
-    if (i == 0 && q == 0) {
+    if (i == 0 && q == 0 && xmax) {  // (no xmax: the fused band run exchanged the range before its trip)
         xmax[f * 4 + 0] = -fmin_[f];
         xmax[f * 4 + 1] = fmax_[f];
         const float p0_ = (y0 == 0) ? frames[(long long)f * fstride] : -INFINITY;  // dsp.c:50-51: v[0] seeds min and max
@@ -2312,6 +2314,7 @@ extern "C" int tsdrgpu_postproc_band_begin(tsdrgpu_postproc_t *pp, const float *
     pp->band_rows = rows;
     pp->band_stage = 0;
     pp->band_spec = 0;
+    pp->band_fused = 0;
     pp->brelay_src = nullptr;
     pp->pending = PEND_BAND;
     if (d_xsum) *d_xsum = pp->d_xsum;
@@ -2326,6 +2329,7 @@ extern "C" int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out
     if (!pp || !d_out_band) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_finish", "bad argument") : TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
     if (pp->pending != PEND_BAND) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_finish", "no band run is open");
+    if (pp->band_fused) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_finish", "a fused band run is open: tsdrgpu_postproc_band_advance closes it");
     pp->pending = 0;
     const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H, y0 = pp->band_y0, rows = pp->band_rows;
     const tsdrgpu_pp_params_t *prm = &pp->p_prm;
@@ -2347,6 +2351,206 @@ extern "C" int tsdrgpu_postproc_band_finish(tsdrgpu_postproc_t *pp, float *d_out
     pp->d_chain = full;
     if (rc) return rc;
     if (h_info) return pp_copy_info(pp, F, h_info);
+    return TSDRGPU_OK;
+}
+
+// (the exchange kernels of the min/max: shared by the fused band run below and the general band runs further down)
+__global__ __launch_bounds__(256) void k_band_pack_mm(int F, int y0, const float *__restrict__ fmin_, const float *__restrict__ fmax_,
+                                                      const float *__restrict__ frames, long long fstride, float *__restrict__ xmax)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    xmax[f * 4 + 0] = -fmin_[f];
+    xmax[f * 4 + 1] = fmax_[f];
+    const float p0_ = (y0 == 0) ? frames[(long long)f * fstride] : -INFINITY;  // dsp.c:50-51: v[0] seeds min and max
+    xmax[f * 4 + 2] = (p0_ != p0_) ? -INFINITY : p0_;  // (a NaN travels as a flag in the fourth slot: see k_band_pack)
+    xmax[f * 4 + 3] = (p0_ != p0_) ? 1.0f : -INFINITY;
+}
+
+__global__ __launch_bounds__(256) void k_band_unpack_mm(int F, const float *__restrict__ xmax, float *__restrict__ fmin_, float *__restrict__ fmax_,
+                                                        float *__restrict__ v0)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    fmin_[f] = -xmax[f * 4 + 0];
+    fmax_[f] = xmax[f * 4 + 1];
+    v0[f] = (xmax[f * 4 + 3] > 0.0f) ? __int_as_float(0x7fc00000) : xmax[f * 4 + 2];
+}
+
+__global__ __launch_bounds__(256) void k_band_unpack_sum(int F, int W, int Htot, const double *__restrict__ xsum, double *__restrict__ strip_x,
+                                                         double *__restrict__ strip_y)
+{
+    const int f = blockIdx.z, q = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W + Htot) return;
+    const double v = xsum[((long long)f * 3 + q) * (W + Htot) + i];
+    if (i < W) strip_x[((long long)f * 3 + q) * W + i] = v;
+    else strip_y[((long long)f * 3 + q) * Htot + (i - W)] = v;
+}
+
+// ---------------------------------------------------------------------------
+// The FUSED band run (the band form of tsdrgpu_postproc_begin_minmax): the resampler's band form leaves every frame's min/max over
+// this band's pixels (frame tracking in tsdrgpu_resample_band), so the range can be exchanged BEFORE the band is read and ONE trip
+// over the raw band both writes the normalised / IIR'd rows and gathers the strip partials — 12P bytes per band pixel instead of
+// the 16P of statistics + pass (measured on one rank, configs[4]: the whole gap between the band path and the single-GPU run,
+// profiles/round6_ab_runs.txt).  Order of calls, every rank alike:
+//   tsdrgpu_postproc_band_begin_minmax   {-min, max, pixel 0} of every frame -> d_xmax       caller: max all-reduce
+//   tsdrgpu_postproc_band_fused          autogain recurrence, the trip, strip partials -> d_xsum   caller: sum all-reduce
+//   tsdrgpu_postproc_band_advance        the (replicated, contract-exact) sync chain with its relays; then only the painted lines
+// The trip is k_frame_tile_pass on the band's rows (tiles of 16 rows: a band starts on a multiple of 32, so its tiles are the
+// single-GPU fused run's tiles and its partial sums that run's), lines by k_fix_lines from the state the batch started with.
+// Library-default stage order, no autoshift, no PLL — like tsdrgpu_postproc_band_begin.  Reference: dsp.c:41-110,134-239.
+// ---------------------------------------------------------------------------
+extern "C" int tsdrgpu_postproc_band_begin_minmax(tsdrgpu_postproc_t *pp, const float *d_band, int F, int W, int Htot, int y0, int rows,
+                                                  const tsdrgpu_pp_params_t *prm, const float *d_fmin, const float *d_fmax, float **d_xmax,
+                                                  int64_t *n_xmax)
+{
+    if (!pp || !d_band || !prm || !d_fmin || !d_fmax || F <= 0 || W <= 0 || Htot <= 0 || y0 < 0 || rows <= 0 || y0 + rows > Htot)
+        return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_begin_minmax", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    if (pp->pending) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_begin_minmax", "a split run is already open");
+    if (prm->lowpass_before_sync || prm->autogain_after_proc || prm->autoshift || prm->pll)
+        return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_begin_minmax",
+                         "row bands support the library-default stage order without autoshift (the 2-D roll needs every row) and without the PLL");
+    if (y0 % TILE_H) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_begin_minmax", "a band must start on a multiple of 32 rows");
+    int rc;
+    if ((rc = pp_prepare(pp, F, W, Htot, prm))) return rc;
+    const size_t Pb = (size_t)W * rows;
+    if ((rc = ensure(g, &pp->d_xsum, &pp->cap_xsum, (size_t)F * 3 * (W + Htot)))) return rc;
+    if ((rc = ensure(g, &pp->d_xmax, &pp->cap_xmax, (size_t)F * 4))) return rc;
+    if ((rc = ensure(g, &pp->d_v0, &pp->cap_v0, (size_t)F))) return rc;
+    if ((rc = ensure(g, &pp->d_chain_band, &pp->cap_chain_band, (size_t)F))) return rc;
+    if ((rc = ensure(g, &pp->d_screen2, &pp->cap_screen2, pp->cap_screen > Pb ? pp->cap_screen : Pb, true))) return rc;
+    if ((rc = ensure(g, &pp->d_dump, &pp->cap_dump, (size_t)1024))) return rc;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (rows + TP_H - 1) / TP_H;  // the trip's tiles are 16 rows high
+    if ((rc = ensure(g, &pp->d_tflag, &pp->cap_tflag, (size_t)F * tiles_x * tiles_y))) return rc;
+    if ((rc = ensure(g, &pp->d_colp, &pp->cap_colp, (size_t)F * tiles_y * 3 * W))) return rc;
+    // the band's share of the range (the caller's arrays: tsdrgpu_resampler_frame_minmax) + pixel 0 from the rank that holds it
+    HIP_TRY(g, hipMemcpyAsync(pp->d_fmin, d_fmin, sizeof(float) * (size_t)F, hipMemcpyDeviceToDevice, g->stream));
+    HIP_TRY(g, hipMemcpyAsync(pp->d_fmax, d_fmax, sizeof(float) * (size_t)F, hipMemcpyDeviceToDevice, g->stream));
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, g->stream, k_band_pack_mm, (F + 255) / 256, 256, F, y0, pp->d_fmin, pp->d_fmax, d_band, (long long)Pb, pp->d_xmax);
+    KERNEL_CHECK(g, "k_band_pack_mm");
+    pp->p_frames = d_band;
+    pp->p_F = F; pp->p_W = W; pp->p_H = Htot;
+    pp->p_prm = *prm;
+    pp->band_y0 = y0;
+    pp->band_rows = rows;
+    pp->band_stage = 0;
+    pp->band_spec = 0;
+    pp->band_fused = 1;
+    pp->brelay_src = nullptr;
+    pp->pending = PEND_BAND;
+    if (d_xmax) *d_xmax = pp->d_xmax;
+    if (n_xmax) *n_xmax = (int64_t)F * 4;
+    return TSDRGPU_OK;
+}
+
+extern "C" int tsdrgpu_postproc_band_fused(tsdrgpu_postproc_t *pp, float *d_out_band, double **d_xsum, int64_t *n_xsum)
+{
+    if (!pp || !d_out_band) return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_fused", "bad argument") : TSDRGPU_EINVAL;
+    tsdrgpu_t *g = pp->g;
+    if (pp->pending != PEND_BAND || pp->band_fused != 1)
+        return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_fused", "no fused band run is waiting for its trip (tsdrgpu_postproc_band_begin_minmax first)");
+    const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H, y0 = pp->band_y0, rows = pp->band_rows;
+    const tsdrgpu_pp_params_t *prm = &pp->p_prm;
+    const long long Pb = (long long)W * rows;
+    const float *d_band = pp->p_frames;
+    const bool overlap = (const float *)d_out_band < d_band + (long long)F * Pb && d_band < (const float *)d_out_band + (long long)F * Pb;
+    if (overlap) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_fused", "the output overlaps the band (the relays and the lines read the raw band afterwards)");
+    hipStream_t st = g->stream;
+    // the exchanged range -> the autogain recurrence (replicated: every rank the same values)
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack_mm, (F + 255) / 256, 256, F, pp->d_xmax, pp->d_fmin, pp->d_fmax, pp->d_v0);
+    KERNEL_CHECK(g, "k_band_unpack_mm");
+    // Motion blur 0 and a batch long enough: a frame's output does not depend on the previous one's, so the trip is the FLAT kernel over
+    // (tile, frame) — k_frame_stats<true>, like tsdrgpu_postproc_begin_minmax's — instead of tiles that walk the frames (measured on the
+    // headline stream in one band: 1.27 ms per pass for the two-trip run, 1.42 with the walking tiles).  Its exceptions (a -0.0 or
+    // non-finite pixel, a non-finite incoming state) raise d_odd, and the literal pass, queued behind the chain and gated on the flag,
+    // then redoes this band's rows from the raw band — per-pixel recurrences: a band decides for itself.
+    static const int tiles_only = getenv("TSDRGPU_FUSE_TILES") ? 1 : 0;
+    const bool flat = prm->motionblur == 0.0f && F >= 8 && !tiles_only;
+    if (flat && !pp->d_odd && hipMalloc(&pp->d_odd, sizeof(int)) != hipSuccess) return tsdr_fail(g, TSDRGPU_ENOMEM, "postproc", "flag");
+    TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 1,
+                prm->lowpasscoeff, flat ? pp->d_odd : (int *)nullptr);  // (the flat trip's redo flag is zeroed by the chain kernel in front of it)
+    KERNEL_CHECK(g, "k_autogain_chain");
+    pp->band_flat = flat ? 1 : 0;
+    if (flat) {
+        const int tiles_x = (W + TILE_W - 1) / TILE_W, ftiles_y = (rows + TILE_H - 1) / TILE_H;
+        StatsStore ss;
+        ss.dst = d_out_band; ss.dstride = Pb; ss.chain = pp->d_chain; ss.screen = pp->d_screen; ss.odd = pp->d_odd;
+        TSDR_LAUNCH(g, PROF_FRAME_PASS, st, k_frame_stats<true>, (unsigned)(tiles_x * ftiles_y * F), 256, d_band, Pb, W, rows, tiles_x, ftiles_y, pp->d_bmin,
+                    pp->d_bmax, pp->d_colp, pp->d_rowp, pp->d_tflag, 1, ss);
+        KERNEL_CHECK(g, "k_frame_stats<store>");
+        TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_frame_reduce, dim3(((W > rows ? W : rows) + 255) / 256, 3, F), 256, W, rows, tiles_x, ftiles_y, pp->d_bmin,
+                    pp->d_bmax, pp->d_colp, pp->d_rowp, pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_tflag, 1, 0, TILE_H);
+        KERNEL_CHECK(g, "k_frame_reduce");
+        TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_pack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, y0, rows, pp->d_strip_x, pp->d_strip_y,
+                    pp->d_fmin, pp->d_fmax, d_band, Pb, pp->d_xsum, (float *)nullptr);
+        KERNEL_CHECK(g, "k_band_pack");
+        pp->p_out = d_out_band;
+        pp->band_fused = 2;
+        if (d_xsum) *d_xsum = pp->d_xsum;
+        if (n_xsum) *n_xsum = (int64_t)F * 3 * (W + Htot);
+        return TSDRGPU_OK;
+    }
+    // the trip: normalise + IIR into d_out_band, strip partials of the band's rows
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (rows + TP_H - 1) / TP_H;
+    TSDR_LAUNCH(g, PROF_FRAME_PASS, st, k_frame_tile_pass, (unsigned)(tiles_x * tiles_y), 512, d_band, Pb, d_out_band, Pb, F, W, rows, tiles_x, tiles_y,
+                pp->d_chain, pp->d_screen, pp->d_screen2, prm->motionblur, pp->d_colp, pp->d_rowp, pp->d_tflag, pp->d_dump);
+    KERNEL_CHECK(g, "k_frame_tile_pass");
+    {   // the state the next run reads is the buffer just written (d_screen2 keeps the state the batch started with: the lines need it)
+        float *t = pp->d_screen; pp->d_screen = pp->d_screen2; pp->d_screen2 = t;
+        const size_t c = pp->cap_screen; pp->cap_screen = pp->cap_screen2; pp->cap_screen2 = c;
+        const size_t common = pp->cap_screen < pp->cap_screen2 ? pp->cap_screen : pp->cap_screen2;
+        if (common > (size_t)Pb)
+            HIP_TRY(g, hipMemcpyAsync(pp->d_screen + Pb, pp->d_screen2 + Pb, (common - (size_t)Pb) * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_frame_reduce, dim3(((W > rows ? W : rows) + 255) / 256, 3, F), 256, W, rows, tiles_x, tiles_y, pp->d_bmin,
+                pp->d_bmax, pp->d_colp, pp->d_rowp, pp->d_fmin, pp->d_fmax, pp->d_strip_x, pp->d_strip_y, pp->d_tflag, 1, 0, TP_H);
+    KERNEL_CHECK(g, "k_frame_reduce");
+    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_pack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, y0, rows, pp->d_strip_x, pp->d_strip_y,
+                pp->d_fmin, pp->d_fmax, d_band, Pb, pp->d_xsum, (float *)nullptr);
+    KERNEL_CHECK(g, "k_band_pack");
+    pp->p_out = d_out_band;
+    pp->band_fused = 2;
+    if (d_xsum) *d_xsum = pp->d_xsum;
+    if (n_xsum) *n_xsum = (int64_t)F * 3 * (W + Htot);
+    return TSDRGPU_OK;
+}
+
+// what is left of a fused band run once the chain has decided: the painted lines of this band's rows (syncdetector.c:209-223)
+static int band_fused_lines(tsdrgpu_postproc_t *pp, float *d_out_band)
+{
+    tsdrgpu_t *g = pp->g;
+    const int F = pp->p_F, W = pp->p_W, y0 = pp->band_y0, rows = pp->band_rows;
+    const tsdrgpu_pp_params_t *prm = &pp->p_prm;
+    if (d_out_band != pp->p_out) return tsdr_fail(g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_advance", "not the buffer the fused trip wrote");
+    TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_band_chain, (F + 63) / 64, 64, pp->d_chain, pp->d_chain_band, F, y0);
+    KERNEL_CHECK(g, "k_band_chain");
+    const float a = prm->motionblur;
+    if (pp->band_flat) {  // the flat trip: the lines are constants, the new state is the last frame — unless the batch is redone literally
+        const long long Pb = (long long)W * rows;
+        const int lines = (a == 0.0f && !prm->superresolution) ? PASS_LINES : 0;
+        if (lines) {
+            TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_paint_lines, dim3(((W > rows ? W : rows) + 255) / 256, 2, F), 256, d_out_band, Pb, W, rows, pp->d_chain_band);
+            KERNEL_CHECK(g, "k_paint_lines");
+        }
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_pass_state, (unsigned)(g->prop.multiProcessorCount * 4), 256,
+                    (const float *)(d_out_band + (long long)(F - 1) * Pb), pp->d_screen, (int)Pb, (const int *)pp->d_odd);
+        KERNEL_CHECK(g, "k_pass_state");
+        ChainOut *full = pp->d_chain;
+        pp->d_chain = pp->d_chain_band;  // what the pass reads
+        const int rc = launch_pass_literal(pp, PASS_NORMALISE | lines | PASS_IIR, pp->p_frames, Pb, d_out_band, Pb, F, W, rows, a, pp->d_odd);
+        pp->d_chain = full;
+        pp->band_flat = 0;
+        return rc;
+    }
+    if (a == 0.0f && !prm->superresolution) {
+        const long long Pb = (long long)W * rows;
+        // d_screen2 holds the state the batch started with, d_screen the one the trip left
+        TSDR_LAUNCH(g, PROF_CHAIN, g->stream, k_fix_lines, dim3(((W > rows ? W : rows) + 255) / 256, 2, F), 256, pp->p_frames, Pb, d_out_band, Pb, F, W, rows,
+                    pp->d_chain_band, pp->d_screen2, pp->d_screen, a);
+        KERNEL_CHECK(g, "k_fix_lines");
+    }
     return TSDRGPU_OK;
 }
 
@@ -2529,11 +2733,16 @@ static int band_speculate(tsdrgpu_postproc_t *pp, int *ties, int *tossups)
     int *d_amb = pp->d_sflag + (size_t)F * 2, *d_fresh = d_amb + (size_t)F * 2, *d_redo = d_fresh + (size_t)F * 2;
     const int *const no_gate = nullptr;
     // stage 0 and stage 2 of the literal run, without its questions
-    TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_xmax, pp->d_strip_x,
-                pp->d_strip_y, pp->d_fmin, pp->d_fmax, pp->d_v0);
-    TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 1,
-                prm->lowpasscoeff, (int *)nullptr);
-    KERNEL_CHECK(g, "k_autogain_chain");
+    if (pp->band_fused) {  // (the range was exchanged and the recurrence run before the trip)
+        TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack_sum, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_strip_x, pp->d_strip_y);
+        KERNEL_CHECK(g, "k_band_unpack_sum");
+    } else {
+        TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_xmax, pp->d_strip_x,
+                    pp->d_strip_y, pp->d_fmin, pp->d_fmax, pp->d_v0);
+        TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 1,
+                    prm->lowpasscoeff, (int *)nullptr);
+        KERNEL_CHECK(g, "k_autogain_chain");
+    }
     TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, 1, pp->d_sflag);
     KERNEL_CHECK(g, "k_strip_flag");
     HIP_TRY(g, hipMemcpyAsync(pp->h_spec_flags, pp->d_sflag, sizeof(int) * 2 * (size_t)F, hipMemcpyDeviceToHost, st));
@@ -2603,6 +2812,7 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
         return pp ? tsdr_fail(pp->g, TSDRGPU_EINVAL, "tsdrgpu_postproc_band_advance", "bad argument") : TSDRGPU_EINVAL;
     tsdrgpu_t *g = pp->g;
     if (pp->pending != PEND_BAND) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_advance", "no band run is open");
+    if (pp->band_fused == 1) return tsdr_fail(g, TSDRGPU_ESTATE, "tsdrgpu_postproc_band_advance", "the fused band run has not made its trip yet (tsdrgpu_postproc_band_fused)");
     const int F = pp->p_F, W = pp->p_W, Htot = pp->p_H;
     const tsdrgpu_pp_params_t *prm = &pp->p_prm;
     const int nmax = W > Htot ? W : Htot;
@@ -2638,11 +2848,17 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
     for (;;) {
         switch (pp->band_stage) {
         case 0: {  // the exchanged statistics -> autogain recurrence, tie flags
-            TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_xmax,
-                        pp->d_strip_x, pp->d_strip_y, pp->d_fmin, pp->d_fmax, pp->d_v0);
-            TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 1,
-                        prm->lowpasscoeff, (int *)nullptr);
-            KERNEL_CHECK(g, "k_autogain_chain");
+            if (pp->band_fused) {
+                TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack_sum, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_strip_x,
+                            pp->d_strip_y);
+                KERNEL_CHECK(g, "k_band_unpack_sum");
+            } else {
+                TSDR_LAUNCH(g, PROF_FRAME_REDUCE, st, k_band_unpack, dim3((W + Htot + 255) / 256, 3, F), 256, F, W, Htot, pp->d_xsum, pp->d_xmax,
+                            pp->d_strip_x, pp->d_strip_y, pp->d_fmin, pp->d_fmax, pp->d_v0);
+                TSDR_LAUNCH(g, PROF_CHAIN, st, k_autogain_chain, 1, 64, F, (const float *)pp->d_v0, 1LL, pp->d_fmin, pp->d_fmax, pp->d_state, pp->d_chain, 1,
+                            prm->lowpasscoeff, (int *)nullptr);
+                KERNEL_CHECK(g, "k_autogain_chain");
+            }
             pp->relay_items = 0;
             if (exact) {
                 TSDR_LAUNCH(g, PROF_CHAIN, st, k_strip_flag, dim3(2, F), CHAIN_T, W, Htot, pp->d_strip_x, pp->d_strip_y, pp->d_chain, 1, pp->d_sflag);
@@ -2700,10 +2916,12 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
             break;
         }
         default: {  // the pass over this band's rows
+            const int fused = pp->band_fused;
             pp->pending = 0;
             pp->band_stage = 0;
             pp->band_spec = 0;
-            if ((rc = band_run_pass(pp, d_out_band))) return rc;
+            pp->band_fused = 0;
+            if ((rc = fused ? band_fused_lines(pp, d_out_band) : band_run_pass(pp, d_out_band))) return rc;
             if (h_info) return pp_copy_info(pp, F, h_info);
             return TSDRGPU_OK;
         }
@@ -2721,39 +2939,6 @@ extern "C" int tsdrgpu_postproc_band_advance(tsdrgpu_postproc_t *pp, float *d_ou
 // single-GPU run: strips that hold ties or toss-ups are collapsed literally, relayed band by band.
 // ---------------------------------------------------------------------------
 enum { BOP_STATS = 1, BOP_XSUM, BOP_XMAX, BOP_UNPACK, BOP_AUTOGAIN, BOP_SYNC, BOP_GATHER, BOP_PASS, BOP_END };
-
-__global__ __launch_bounds__(256) void k_band_pack_mm(int F, int y0, const float *__restrict__ fmin_, const float *__restrict__ fmax_,
-                                                      const float *__restrict__ frames, long long fstride, float *__restrict__ xmax)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    xmax[f * 4 + 0] = -fmin_[f];
-    xmax[f * 4 + 1] = fmax_[f];
-    const float p0_ = (y0 == 0) ? frames[(long long)f * fstride] : -INFINITY;  // dsp.c:50-51: v[0] seeds min and max
-    xmax[f * 4 + 2] = (p0_ != p0_) ? -INFINITY : p0_;  // (a NaN travels as a flag in the fourth slot: see k_band_pack)
-    xmax[f * 4 + 3] = (p0_ != p0_) ? 1.0f : -INFINITY;
-}
-
-__global__ __launch_bounds__(256) void k_band_unpack_mm(int F, const float *__restrict__ xmax, float *__restrict__ fmin_, float *__restrict__ fmax_,
-                                                        float *__restrict__ v0)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    fmin_[f] = -xmax[f * 4 + 0];
-    fmax_[f] = xmax[f * 4 + 1];
-    v0[f] = (xmax[f * 4 + 3] > 0.0f) ? __int_as_float(0x7fc00000) : xmax[f * 4 + 2];
-}
-
-__global__ __launch_bounds__(256) void k_band_unpack_sum(int F, int W, int Htot, const double *__restrict__ xsum, double *__restrict__ strip_x,
-                                                         double *__restrict__ strip_y)
-{
-    const int f = blockIdx.z, q = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W + Htot) return;
-    const double v = xsum[((long long)f * 3 + q) * (W + Htot) + i];
-    if (i < W) strip_x[((long long)f * 3 + q) * W + i] = v;
-    else strip_y[((long long)f * 3 + q) * Htot + (i - W)] = v;
-}
 
 // this band's rows of every frame into its slot of the gather buffer [band][F][rows_max][W]
 __global__ __launch_bounds__(256) void k_band_gather_pack(const float *__restrict__ band, int F, int W, int rows, int rows_max, float *__restrict__ slot)

@@ -106,6 +106,8 @@ _SIGS = {
     "tsdrgpu_postproc_band_open": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, vp]),
     "tsdrgpu_postproc_band_step": (C.c_int, [vp, vp, vp, vp]),
     "tsdrgpu_postproc_band_advance": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int), vp]),
+    "tsdrgpu_postproc_band_begin_minmax": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
+    "tsdrgpu_postproc_band_fused": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
     "tsdrgpu_postproc_band_spec_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tsdrgpu_resample_band": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int64, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
@@ -541,6 +543,23 @@ class PostProcess:
         self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_begin(self.h, d_band.at(frames_offset), nframes, width, height, y0, rows, C.byref(prm),
                                                               C.byref(ps), C.byref(ns), C.byref(pm), C.byref(nm)))
         return ps.value, ns.value, pm.value, nm.value
+
+    def band_begin_minmax(self, d_band, nframes, width, height, y0, rows, fmin_ptr, fmax_ptr, motionblur=0.0, lowpasscoeff=0.1, superres=0,
+                          frames_offset=0):
+        """Fused band run, first step (tsdrgpu_postproc_band_begin_minmax): the band's share of every frame's range (device pointers from
+        Resampler.frame_minmax(download=False)) -> (xmax_ptr, n_floats), which the caller max-all-reduces; then band_fused()."""
+        prm = PPParams(0, 0, 0, 0, superres, motionblur, lowpasscoeff)
+        self._nframes = nframes
+        pm, nm = vp(), C.c_int64()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_begin_minmax(self.h, d_band.at(frames_offset), nframes, width, height, y0, rows, C.byref(prm),
+                                                                     fmin_ptr, fmax_ptr, C.byref(pm), C.byref(nm)))
+        return pm.value, nm.value
+
+    def band_fused(self, d_out_band, out_offset=0):
+        """Fused band run, the trip (tsdrgpu_postproc_band_fused): returns (xsum_ptr, n_doubles) for the sum all-reduce; then band_advance()."""
+        ps, ns = vp(), C.c_int64()
+        self.ctx._ck(self.ctx.lib.tsdrgpu_postproc_band_fused(self.h, d_out_band.at(out_offset), C.byref(ps), C.byref(ns)))
+        return ps.value, ns.value
 
     def band_finish(self, d_out_band, want_info=True, out_offset=0):
         info = (PPFrameInfo * self._nframes)() if want_info else None

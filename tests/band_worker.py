@@ -24,6 +24,9 @@ def main():
     # "gui": the GENERAL band run (tsdrgpu_postproc_band_open / _band_step) with the GUI's stage order (low-pass before sync)
     # and autoshift — the roll's rows cross the ranks through an all-gather
     general = len(sys.argv) > 5 and sys.argv[5] == "gui"
+    # "fused": the FUSED band run — the band resampler tracks this band's share of every frame's range, the range is exchanged first,
+    # ONE trip over the raw band (tsdrgpu_postproc_band_begin_minmax / _band_fused), then the same contract-exact chain
+    fused = len(sys.argv) > 5 and sys.argv[5] == "fused"
     import torch
     import torch.distributed as dist
     from tempestsdr_amd import gpu, synth
@@ -60,6 +63,8 @@ def main():
 
     d_iq = g.to_device(iq)
     rs, pp = gpu.Resampler(g), gpu.PostProcess(g)
+    if fused:
+        rs.track_frames(P, 0)
     cap = 8
     d_band, d_out = g.empty(cap * rows * W), g.empty(cap * rows * W)
     outs, infos, relay_steps = [], [], 0
@@ -88,9 +93,17 @@ def main():
                     g._ck(g.lib.tsdrgpu_upload(g.h, buf, fa.ctypes.data, fa.nbytes))
                     g.sync()
         else:
-            ps, ns, pm, nm = pp.band_begin(d_band, F, W, h, y0, rows, motionblur=blur)
-            allreduce(ps, ns, np.float64, dist.ReduceOp.SUM)
-            allreduce(pm, nm, np.float32, dist.ReduceOp.MAX)
+            if fused:
+                mnp, mxp, nfr = rs.frame_minmax(download=False)
+                assert nfr == F
+                pm, nm = pp.band_begin_minmax(d_band, F, W, h, y0, rows, mnp, mxp, motionblur=blur)
+                allreduce(pm, nm, np.float32, dist.ReduceOp.MAX)
+                ps, ns = pp.band_fused(d_out)
+                allreduce(ps, ns, np.float64, dist.ReduceOp.SUM)
+            else:
+                ps, ns, pm, nm = pp.band_begin(d_band, F, W, h, y0, rows, motionblur=blur)
+                allreduce(ps, ns, np.float64, dist.ReduceOp.SUM)
+                allreduce(pm, nm, np.float32, dist.ReduceOp.MAX)
             while True:
                 more, buf, nb, info = pp.band_advance(d_out, rank, world)
                 if not more:

@@ -283,6 +283,157 @@ def test_band_resampler_equals_the_oracle_stream(orc, fs, h, y0, rows):
         assert np.array_equal(fr, ref), (j, int(np.sum(fr != ref)))
 
 
+@pytest.mark.parametrize("fs,h,y0,rows", [(8_000_000, 525, 160, 192), (8_000_000, 525, 0, 525), (25_000_000, 806, 416, 390), (7_000_000, 525, 352, 173),
+                                          (8_000_000, 525, 0, 32), (8_000_000, 525, 512, 13)])
+def test_band_resampler_tracks_the_bands_share_of_every_frames_range(orc, fs, h, y0, rows):
+    """frame tracking in the band form (what the FUSED band run exchanges): over several calls whose frames straddle the call
+    boundaries, every completed frame's min / max over THIS band's pixels equals the min / max of those rows of the ORACLE's pixel
+    stream — and the band's pixels are still the oracle's, bit for bit."""
+    from tempestsdr_amd import synth
+    g = ctx()
+    fv = 60.0
+    geo = orc.geometry(fs, h, fv)
+    W, P = geo.width, geo.width * h
+    chunk = orc.chunk_size(fs, fv)
+    nch = 47
+    mode = {525: "640x480", 806: "1024x768"}[h]
+    iq = synth.synth_iq(fs, mode, fv, nch * chunk, seed=0x5EED0003)
+    want, _ = orc.demod_resample_stream(iq, geo)
+    d_iq = g.to_device(iq)
+    up, down = W * h * fv, float(fs)
+    rs = gpu.Resampler(g)
+    rs.track_frames(P, 0)
+    cap = 8
+    d_band = g.empty(cap * rows * W)
+    phase, done_chunks, frame0, seen = 0, 0, 0, 0
+    for k in (5, 1, 13, 10, 18):
+        n, touched = rs.process_band(d_iq, 1, chunk, k, up, down, W, h, y0, rows, phase, d_band, cap, in_offset=2 * done_chunks * chunk)
+        got = d_band.download().reshape(cap, rows, W)
+        complete = (phase + n) // P
+        mn, mx = rs.frame_minmax()
+        assert len(mn) == complete == len(mx)
+        for j in range(complete):
+            ref = want[(frame0 + j) * P:(frame0 + j + 1) * P].reshape(h, W)[y0:y0 + rows]
+            assert np.array_equal(got[j], ref)
+            assert mn[j] == ref.min() and mx[j] == ref.max(), (frame0 + j, mn[j], ref.min(), mx[j], ref.max())
+            seen += 1
+        phase = (phase + n) % P
+        if phase:
+            part = got[complete].reshape(-1).copy()
+            g._ck(g.lib.tsdrgpu_upload(g.h, d_band.at(0), part.ctypes.data, part.nbytes))
+            g.sync()
+        frame0 += complete
+        done_chunks += k
+    assert seen >= 3
+    with pytest.raises(RuntimeError):  # another phase than the tracker's
+        rs.process_band(d_iq, 1, chunk, 1, up, down, W, h, y0, rows, (phase + 1) % P, d_band, cap)
+
+
+def _max_exchange(g, ptrs, n):
+    m = [np.empty(n, np.float32) for _ in ptrs]
+    for b, p in zip(m, ptrs):
+        g._ck(g.lib.tsdrgpu_download(g.h, b.ctypes.data, p, b.nbytes))
+    g.sync()
+    mm = np.maximum.reduce(m)
+    for p in ptrs:
+        g._ck(g.lib.tsdrgpu_upload(g.h, p, mm.ctypes.data, mm.nbytes))
+    g.sync()
+
+
+def _run_bands_fused(g, pps, rows, fr, blur):
+    """one batch through the FUSED band protocol (range exchanged first, one trip, then the chain): like _run_bands"""
+    F, H, W = fr.shape
+    d_bands, d_outs, keep = [], [], []
+    xm = []
+    for pp, (y0, n) in zip(pps, rows):
+        band = np.ascontiguousarray(fr[:, y0:y0 + n, :])
+        d_b = g.to_device(band.reshape(-1))
+        d_bands.append(d_b)
+        d_outs.append(g.empty(F * W * n))
+        # the band's share of the range as the tracked band resampler leaves it: sentinels skipped (dsp.c:57), +-inf when nothing is left
+        ok = ~((band > 250.0) | (band < -250.0)) & ~np.isnan(band)
+        mn = np.array([band[f][ok[f]].min() if ok[f].any() else np.inf for f in range(F)], np.float32)
+        mx = np.array([band[f][ok[f]].max() if ok[f].any() else -np.inf for f in range(F)], np.float32)
+        d_mn, d_mx = g.to_device(mn), g.to_device(mx)
+        keep += [d_mn, d_mx]
+        xm.append(pp.band_begin_minmax(d_b, F, W, H, y0, n, d_mn.at(0), d_mx.at(0), motionblur=blur))
+    _max_exchange(g, [x[0] for x in xm], xm[0][1])
+    xs = [pp.band_fused(d_o) for pp, d_o in zip(pps, d_outs)]
+    _sum_exchange(g, [x[0] for x in xs], xs[0][1])
+    steps, infos = 0, None
+    while True:
+        res = [pp.band_advance(d_o, k, len(pps)) for k, (pp, d_o) in enumerate(zip(pps, d_outs))]
+        assert len({r[0] for r in res}) == 1, "every rank takes the same decision"
+        if not res[0][0]:
+            infos = [r[3] for r in res]
+            break
+        _sum_exchange(g, [r[1] for r in res], res[0][2])
+        steps += 1
+    outs = [d_o.download().reshape(F, n, W) for d_o, (_, n) in zip(d_outs, rows)]
+    return np.concatenate(outs, axis=1), infos[0], steps
+
+
+@pytest.mark.parametrize("W,H,cuts,blur", [(507, 525, (160, 352), 0.0), (1033, 806, (416,), 0.5), (640, 420, (96, 224, 320), 0.9375),
+                                           (2962, 2250, _bench_cuts(2250, 8), 0.9375), (300, 200, (), 0.25)])
+def test_fused_row_bands_equal_the_oracle(orc, W, H, cuts, blur):
+    """The FUSED band run (range exchanged first, ONE trip over the raw band, then the replicated contract-exact chain) against the
+    ORACLE: 1, 2, 3, 4 and 8 bands, motion blur 0 (painted lines) and above, batches with a blank frame and a noiseless pattern
+    (exact ties: the literal collapse is relayed), a sentinel, a -0.0 pixel; state carried from batch to batch, and a batch of the
+    two-trip form in between (the two forms share the object's state)."""
+    g = ctx()
+    rng = np.random.default_rng(5 * W + H)
+    edges = (0,) + tuple(cuts) + (H,)
+    rows = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
+    pps = [gpu.PostProcess(g) for _ in rows]
+    opp = orc.PostProcess(_geo(orc, W, H))
+    for batch, F in enumerate((4, 9, 3, 2)):
+        fr = _frames(rng, F, W, H, 10 * batch)
+        if batch == 0:
+            fr[1] = 0.25
+            y, x = np.mgrid[0:H, 0:W]
+            fr[2] = (0.3 + 0.5 * ((x // 40) % 2)).astype(np.float32)
+        if batch == 1:
+            fr[3, 5, 7] = 1024.0
+            fr[4, H - 1, W - 1] = -0.0
+        want = np.stack([opp.run(fr[k].reshape(-1).copy(), blur, 0.1, 0, 0, 0, 0, 0).reshape(H, W) for k in range(F)])
+        if batch == 2:
+            got, infos, steps = _run_bands(g, pps, rows, fr, blur)  # the two-trip form, same objects
+        else:
+            got, infos, steps = _run_bands_fused(g, pps, rows, fr, blur)
+        assert steps % len(rows) == 0
+        if batch == 0:
+            assert steps >= len(rows)
+        assert np.array_equal(got, want, equal_nan=True), (batch, int(np.sum(got != want)))
+        si, sd = opp.state()
+        last = infos[-1]
+        assert (last.dx, last.vx, last.stripx, last.dy, last.vy, last.stripy, last.locked) == tuple(si[:7]), batch
+
+
+def test_fused_band_run_refuses_what_it_cannot_do():
+    g = ctx()
+    pp = gpu.PostProcess(g)
+    W, H, F = 300, 128, 2
+    d = g.to_device(np.zeros(F * W * 64, np.float32))
+    d_o = g.empty(F * W * 64)
+    mn = g.to_device(np.zeros(F, np.float32))
+    with pytest.raises(RuntimeError):
+        pp.band_begin_minmax(d, F, W, H, 16, 64, mn.at(0), mn.at(0))  # a band must start on a multiple of 32 rows
+    with pytest.raises(RuntimeError):
+        pp.band_fused(d_o)  # nothing begun
+    pp.band_begin_minmax(d, F, W, H, 32, 64, mn.at(0), mn.at(0))
+    with pytest.raises(RuntimeError):
+        pp.band_advance(d_o, 0, 1)  # the trip has not been made
+    with pytest.raises(RuntimeError):
+        pp.band_finish(d_o)  # the fast form does not close a fused run
+    with pytest.raises(RuntimeError):
+        pp.band_fused(d)  # output over the band
+    pp.band_fused(d_o)
+    more, _, _, info = pp.band_advance(d_o, 1, 2)
+    while more:  # (zeros everywhere: ties; one rank of two relays alone — only the protocol is under test here)
+        more, _, _, info = pp.band_advance(d_o, 1, 2)
+    assert len(info) == F
+
+
 # ---------------------------------------------------------------------------
 # the GENERAL band run (tsdrgpu_postproc_band_open / _band_step): every stage order, autoshift, PLL — against the ORACLE
 # ---------------------------------------------------------------------------

@@ -88,6 +88,21 @@ def test_row_bands_config4_in_eight_processes_equal_the_oracle():
     assert "bands equal the oracle: True" in outs[0]
 
 
+@pytest.mark.parametrize("world,config", [(2, "small"), (3, "small"), (8, "config4")])
+def test_fused_row_bands_in_processes_equal_the_oracle(world, config):
+    """the FUSED band run end to end from IQ, one process per rank (tests/band_worker.py ... fused): the band resampler tracks its
+    band's share of every frame's range, the ranks exchange the range BEFORE the band is read, one trip writes the rows and gathers the
+    strip partials, the replicated contract-exact chain (relays through all bands for the blank frames) decides; reassembled frames and
+    sync state are the ORACLE's bit for bit — configs[4] in its named shape on eight ranks among them."""
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "band_worker.py"), str(r), str(world), str(port), config, "fused"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "bands equal the oracle: True" in outs[0]
+
+
 @pytest.mark.parametrize("world,config", [(3, "small"), (8, "config4")])
 def test_row_bands_gui_order_with_autoshift_in_processes_equal_the_oracle(world, config):
     """the GENERAL band run end to end from IQ, one process per rank: the GUI's stage order (low-pass before sync) with
