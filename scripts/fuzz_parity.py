@@ -10,6 +10,9 @@
   plot      : random plot sizes, widget widths, zoom / offset states              -> identical columns, lowest/highest, argmax
   tracking  : random frame sizes / phases, several calls                          -> exact per-frame min/max
   superb    : four randomly delayed hops of a periodic signal                     -> identical hop offsets, 1e-4*max signal
+  bands     : random geometries cut into 1..5 row bands, motion blur 0 / above, batches run in the FUSED band form (range
+              exchanged first, one trip) and the two-trip form in random alternation on the same objects, frames with
+              sentinels / -0.0 / constant frames / noiseless patterns              -> bit-exact frames, identical state
 
 usage (on a GPU box):  python scripts/fuzz_parity.py [cases] [seed]
 """
@@ -376,6 +379,105 @@ def fuzz_superb(g, rng):
     return None
 
 
+def _band_exchange(g, ptrs, n, dtype, op):
+    bufs = [np.empty(n, dtype) for _ in ptrs]
+    for b, p in zip(bufs, ptrs):
+        g._ck(g.lib.tsdrgpu_download(g.h, b.ctypes.data, p, b.nbytes))
+    g.sync()
+    tot = op(bufs)
+    for p in ptrs:
+        g._ck(g.lib.tsdrgpu_upload(g.h, p, tot.ctypes.data, tot.nbytes))
+    g.sync()
+
+
+BANDS_RAN = {"batches": 0, "fused": 0, "frames": 0, "relays": 0, "bands": 0}
+
+
+def fuzz_bands(g, rng):
+    h = int(rng.integers(40, 400))
+    fs = int(rng.integers(60_000, 3_000_000))
+    geo = orc.geometry(fs, h, 60.0)
+    w = geo.width
+    if w < 8 or w > 3200 or w * h > 500_000:
+        return None
+    nb = int(rng.integers(1, 6))
+    cuts = sorted({32 * int(rng.integers(1, max(2, h // 32 + 1))) for _ in range(nb - 1)})
+    cuts = [c for c in cuts if 0 < c < h]
+    edges = [0] + cuts + [h]
+    rows = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
+    mb = float(rng.choice([0.0, 0.0, 0.25, 0.9375]))
+    opp = orc.PostProcess(geo)
+    pps = [gpu.PostProcess(g) for _ in rows]
+    for pp in pps:
+        pp.set_exact_ties(EXACT_TIES)
+    for batch in range(int(rng.integers(1, 4))):
+        F = int(rng.integers(1, 6)) if rng.random() < 0.5 else int(rng.integers(8, 13))
+        frames = [cases.frame_pattern(w, h, int(rng.integers(0, 50)), rng) for _ in range(F)]
+        for fr in frames:
+            r = rng.random()
+            if r < 0.15:
+                fr[rng.integers(0, w * h, 5)] = np.float32(rng.choice([256.0, 1024.0, -300.0]))
+            elif r < 0.22:
+                fr[:] = np.float32(rng.random())
+            elif r < 0.28:
+                fr[rng.integers(0, w * h, 3)] = np.float32(-0.0)
+            elif r < 0.36:
+                yy, xx = np.mgrid[0:h, 0:w]
+                px = int(rng.integers(1, 20))
+                fr[:] = (((xx // px) % 2) * np.float32(0.55) + np.float32(0.2)).astype(np.float32).reshape(-1)
+        want = [opp.run(fr.copy(), mb, 0.1, 0, 0, 0, 0, 0) for fr in frames]
+        si, _ = opp.state()
+        fr3 = np.stack(frames).reshape(F, h, w)
+        fused = rng.random() < 0.65
+        d_bands, d_outs, keep = [], [], []
+        for (y0, n) in rows:
+            d_bands.append(g.to_device(np.ascontiguousarray(fr3[:, y0:y0 + n, :]).reshape(-1)))
+            d_outs.append(g.empty(F * w * n))
+        if fused:
+            xm = []
+            for pp, (y0, n), d_b in zip(pps, rows, d_bands):
+                band = fr3[:, y0:y0 + n, :]
+                ok = ~((band > 250.0) | (band < -250.0))
+                mn = np.array([band[f][ok[f]].min() if ok[f].any() else np.inf for f in range(F)], np.float32)
+                mx = np.array([band[f][ok[f]].max() if ok[f].any() else -np.inf for f in range(F)], np.float32)
+                d_mn, d_mx = g.to_device(mn), g.to_device(mx)
+                keep += [d_mn, d_mx]
+                xm.append(pp.band_begin_minmax(d_b, F, w, h, y0, n, d_mn.at(0), d_mx.at(0), motionblur=mb))
+            _band_exchange(g, [x[0] for x in xm], xm[0][1], np.float32, np.maximum.reduce)
+            xs = [pp.band_fused(d_o) for pp, d_o in zip(pps, d_outs)]
+            _band_exchange(g, [x[0] for x in xs], xs[0][1], np.float64, lambda b: np.sum(b, axis=0))
+        else:
+            bg = [pp.band_begin(d_b, F, w, h, y0, n, motionblur=mb) for pp, (y0, n), d_b in zip(pps, rows, d_bands)]
+            _band_exchange(g, [b[0] for b in bg], bg[0][1], np.float64, lambda b: np.sum(b, axis=0))
+            _band_exchange(g, [b[2] for b in bg], bg[0][3], np.float32, np.maximum.reduce)
+        while True:
+            res = [pp.band_advance(d_o, k, len(pps)) for k, (pp, d_o) in enumerate(zip(pps, d_outs))]
+            if len({r[0] for r in res}) != 1:
+                return f"bands: the ranks disagree about a relay fs={fs} h={h} edges={edges} blur={mb}"
+            if not res[0][0]:
+                infos = res[0][3]
+                break
+            _band_exchange(g, [r[1] for r in res], res[0][2], np.float64, lambda b: np.sum(b, axis=0))
+            BANDS_RAN["relays"] += 1
+        BANDS_RAN["batches"] += 1
+        BANDS_RAN["fused"] += int(fused)
+        BANDS_RAN["frames"] += F
+        BANDS_RAN["bands"] += len(rows)
+        got = np.concatenate([d_o.download().reshape(F, n, w) for d_o, (_, n) in zip(d_outs, rows)], axis=1).reshape(F, -1)
+        tag = f"bands fs={fs} h={h} w={w} edges={edges} blur={mb} batch={batch} F={F} {'fused' if fused else 'two-trip'}"
+        for k in range(F):
+            if not np.array_equal(got[k], want[k], equal_nan=True):
+                return f"{tag}: frame {k} differs in {int(np.sum(got[k] != want[k]))} pixels"
+            if not np.array_equal(np.signbit(got[k]), np.signbit(want[k])):
+                return f"{tag}: frame {k}: sign of a zero differs"
+        i = infos[-1]
+        if (i.dx, i.vx, i.stripx, i.dy, i.vy, i.stripy, i.locked) != tuple(si[:7]):
+            return f"{tag}: state {(i.dx, i.vx, i.stripx, i.dy, i.vy, i.stripy, i.locked)} oracle {tuple(int(v) for v in si[:7])}"
+    for pp in pps:
+        pp.destroy()
+    return None
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -386,13 +488,13 @@ def main():
         import conftest as redzones
         redzones._install_redzones()
     g = gpu.TsdrGpu(0)
-    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0, "plot": 0, "tracking": 0, "superb": 0, "pll": 0, "acmulti": 0}
+    fails, ran = [], {"resampler": 0, "postproc": 0, "autocorr": 0, "fft": 0, "plot": 0, "tracking": 0, "superb": 0, "pll": 0, "acmulti": 0, "bands": 0}
     for c in range(ncases):
         kind = ("resampler", "postproc", "postproc", "resampler", "autocorr", "fft", "plot", "tracking", "superb", "pll",
-                "acmulti")[c % 11]
+                "acmulti", "bands")[c % 12] if not os.environ.get("FUZZ_ONLY") else os.environ["FUZZ_ONLY"]
         fn = {"resampler": fuzz_resampler, "postproc": fuzz_postproc, "autocorr": fuzz_autocorr, "fft": fuzz_fft,
               "plot": fuzz_plot, "tracking": fuzz_tracking, "superb": fuzz_superb, "pll": fuzz_postproc_pll,
-              "acmulti": fuzz_autocorr_multi}[kind]
+              "acmulti": fuzz_autocorr_multi, "bands": fuzz_bands}[kind]
         try:
             r = fn(g, rng)
         except Exception as e:  # noqa: BLE001
@@ -409,6 +511,8 @@ def main():
         if r:
             fails.append((c, r))
             print("MISMATCH", c, r, flush=True)
+    if ran.get("bands"):
+        print(f"bands: {BANDS_RAN['batches']} batches ({BANDS_RAN['fused']} fused) of {BANDS_RAN['frames']} frames in {BANDS_RAN['bands']} band runs, {BANDS_RAN['relays']} relay steps")
     print(f"fuzz: {ncases} cases {ran}, {len(fails)} mismatches, seed {seed}" + (", red zones around every buffer" if redzones is not None else ""))
     return 1 if fails else 0
 
