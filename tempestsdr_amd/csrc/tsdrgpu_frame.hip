@@ -1700,6 +1700,8 @@ extern "C" int tsdrgpu_postproc_reset(tsdrgpu_postproc_t *pp)
     if (pp->pending == 1 || pp->pending == 3 || pp->pending == 4)
         HIP_TRY(g, hipStreamWaitEvent(g->stream, pp->ev_chain, 0));  // an abandoned split / fused run: its side-lane work first
     pp->pending = 0;
+    pp->band_stage = 0;  // (an abandoned band run, speculated or fused, leaves nothing behind either)
+    pp->band_spec = pp->band_fused = pp->band_flat = 0;
     // dsp_post_process_init (dsp.c:112-132): autogain 0/0, sync detector zeroed, sizes forgotten
     HIP_TRY(g, hipMemsetAsync(pp->d_state, 0, sizeof(PpState), g->stream));
     pp->width = pp->height = 0;
