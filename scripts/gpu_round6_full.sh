@@ -26,3 +26,18 @@ timeout 700 python scripts/e2e_bench.py --reference --variants > $O/e2e.json 2> 
 grep -E "^(mi355x|reference|variant)" $O/e2e.txt | cut -c1-200
 timeout 600 python scripts/fuzz_parity.py 2000 51 > $O/fuzz_parity.txt 2>&1; tail -3 $O/fuzz_parity.txt
 timeout 600 python scripts/fuzz_engine.py 100 52 > $O/fuzz_engine.txt 2>&1; tail -3 $O/fuzz_engine.txt
+# SQ counters of the bench kernels, and the side legs (configs[0], [1], [4], 4 s batches, blur 0.5, unfused) in a run of their own
+bash scripts/pmc_sq.sh $T/sq > $O/sq_counters.txt 2>&1; head -40 $O/sq_counters.txt | cut -c1-220
+timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 --legs --detail gpurun_out/$T/bench_legs_detail.json > $O/bench_legs.json 2> $O/bench_legs.err; echo "bench --legs rc=$?" | tee -a $O/summary.txt
+# the band path on one rank (configs[4]) beside its plain leg, and the bands soak
+B="--config 4 --seconds 0.5 --steps 10 --warmup 3 --no-cpu-baseline --no-e2e"
+timeout 600 python bench.py $B > $O/c4_plain.json 2> $O/c4_plain.err
+timeout 600 python bench.py $B --bands --force-dist > $O/c4_bands.json 2> $O/c4_bands.err
+python - <<PY | tee -a $O/summary.txt
+import json
+for t in ("c4_plain","c4_bands"):
+    try:
+        d=json.loads([x for x in open("$O/%s.json"%t) if x.startswith("{")][-1]); print(t, d["value"], d["ms_per_pass"], d["config"].get("row_bands"))
+    except Exception as e: print(t,"failed",e)
+PY
+FUZZ_ONLY=bands timeout 900 python scripts/fuzz_parity.py 600 63 > $O/fuzz_bands.txt 2>&1; tail -2 $O/fuzz_bands.txt

@@ -1158,7 +1158,22 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
     // 6+6+5 -> group at 0.565 of the roofline, 9+8 -> 0.585, one launch of 17 -> 0.62 — but a caller's small kernels on
     // another lane (the sync chain in bench.py's split run) then find free CUs less often (0.31 -> 0.49 ms) and become
     // the critical path; 9 is where the whole pass is fastest
-    const int AC_SUBBATCH = ac_subbatch(ac->n);
+    // TSDRGPU_AC_SPLIT="8,8,1": the sub-batches of a call, spelled out (A/B runs; used when they add up to the call's windows)
+    static const std::vector<int> split_env = [] {
+        std::vector<int> v;
+        const char *e = getenv("TSDRGPU_AC_SPLIT");
+        while (e && *e) {
+            const int k = atoi(e);
+            if (k > 0 && k <= 64) v.push_back(k);
+            while (*e && *e != ',') e++;
+            if (*e == ',') e++;
+        }
+        return v;
+    }();
+    int split_sum = 0, split_max = 0;
+    for (int k : split_env) { split_sum += k; split_max = k > split_max ? k : split_max; }
+    const bool use_split = !split_env.empty() && split_sum == nwindows;
+    const int AC_SUBBATCH = use_split ? split_max : ac_subbatch(ac->n);
     const int sub = nwindows < AC_SUBBATCH ? nwindows : AC_SUBBATCH;
     if (ac->cap_windows < sub) {
         (void)hipStreamSynchronize(g->stream);
@@ -1184,8 +1199,10 @@ static int ac_run_fast(tsdrgpu_autocorr_t *ac, const float *d_in, int in_is_iq, 
     static const bool one_launch = [] { const char *e = getenv("TSDRGPU_AC_ONE_LAUNCH"); return e && e[0] == '1'; }();
     if (parts < 2 && nwindows > 9 && !one_launch) parts = 2;  // a pass of 17 short windows stays 9 + 8: one launch of 17 measured 7 % slower for the pass
     const int per_part = (nwindows + parts - 1) / parts;  // equal sub-batches (17 -> 9,8)
-    for (int w0 = 0; w0 < nwindows; w0 += per_part) {
-        const int cnt = (nwindows - w0 < per_part) ? (nwindows - w0) : per_part;
+    size_t split_i = 0;
+    for (int w0 = 0, step = 0; w0 < nwindows; w0 += step) {
+        const int cnt = use_split ? split_env[split_i++] : ((nwindows - w0 < per_part) ? (nwindows - w0) : per_part);
+        step = cnt;
         const float *src = d_in + (size_t)w0 * (size_t)stride * (in_is_iq ? 2 : 1);
         // fft_autocorrelation (fft.c:49-64) on the real window, packed two samples per complex point
         const PassPlan plan = plan_passes(nh);
