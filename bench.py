@@ -498,9 +498,6 @@ def main():
                          "rows [k H/N, (k+1) H/N) of every frame — band resampler, band statistics, sum/max all-reduce of the strip "
                          "partials over RCCL, the replicated sync chain, the pass over the band) and the capture windows sharded by "
                          "window (--scaling strong); what configs[4] names for 8 GPUs.  Contract-exact like the single-GPU run")
-    ap.add_argument("--fuse-sub", type=int, default=0,
-                    help="experiment: the fused run in sub-batches of this many frames through two small pixel buffers that stay in the "
-                         "Infinity Cache (0 = whole batches, the product's way)")
     ap.add_argument("--no-band-prefetch", action="store_true",
                     help="--bands: one band buffer, the next pass's band resampler queued only after this pass's chain has been waited for (A/B)")
     ap.add_argument("--no-band-fuse", action="store_true",
@@ -670,10 +667,6 @@ def main():
         out2 = torch.empty(frames_cap * P, dtype=torch.float32, device=dev)
         fuse_bufs = [(d_pix, d_out), (DevPtr(pix2), DevPtr(out2))]
     fuse_open = [None]  # the frame buffer of the fused run that is still open
-    sub_state = [0]
-    sub_pix = None
-    if args.fuse_sub > 0 and fuse_bufs is not None:
-        sub_pix = [DevPtr(torch.empty((args.fuse_sub + 3) * P, dtype=torch.float32, device=dev)) for _ in range(2)]
     band = None
     if args.bands:
         # bands start on multiples of 32 rows (the statistics tiles); the last one takes the remainder
@@ -871,41 +864,6 @@ def main():
         # Cache when the statistics and the normalise/IIR pass read them back.
         cps = nchunks if args.frames_per_launch <= 0 else max(1, args.frames_per_launch * 10)
         done_chunks = 0
-        if fuse and fuse_bufs is not None and args.fuse_sub > 0:
-            # the fused run in SUB-BATCHES of args.fuse_sub frames through two SMALL pixel buffers: the raw pixels of a sub-batch are
-            # written, read back once and overwritten by the sub-batch after next while they are still in the 256 MB Infinity Cache
-            # (they need never reach HBM); the frames still land in the full output buffer
-            cps = args.fuse_sub * 10 + 1  # (a chunk is a hair under a tenth of a frame: the extra one keeps every sub-batch at >= fuse_sub whole frames)
-            out_buf = fuse_bufs[pass_no[0] % 2][1]
-            sub_i, out_frames = sub_state[0], 0
-            while done_chunks < nchunks:
-                k = min(cps, nchunks - done_chunks)
-                cur_pix, nxt_pix = sub_pix[sub_i % 2], sub_pix[(sub_i + 1) % 2]
-                n = rs.process(d_iq, 1, chunk, k, up, down, 0, cur_pix, in_offset=2 * done_chunks * chunk, out_offset=carry)
-                done_chunks += k
-                avail = carry + n
-                F = avail // P
-                if fuse_open[0] is not None:
-                    pp.finish(fuse_open[0][0], want_info=False, out_offset=fuse_open[0][1])
-                    fuse_open[0] = None
-                if F:
-                    mn_ptr, mx_ptr, _ = rs.frame_minmax(download=False)
-                    pp.begin_minmax(cur_pix, F, W, h, mn_ptr, mx_ptr, out_buf, motionblur=blur, out_offset=out_frames * P)
-                    fuse_open[0] = (out_buf, out_frames * P)
-                if out_frames == 0:
-                    run_autocorr()
-                rem = avail - F * P
-                if rem:
-                    g._ck(g.lib.tsdrgpu_copy(g.h, nxt_pix.at(0), cur_pix.at(F * P), rem * 4))
-                carry = rem
-                frames_done += F
-                out_frames += F
-                sub_i += 1
-            sub_state[0] = sub_i
-            if (last or args.serial) and fuse_open[0] is not None:
-                pp.finish(fuse_open[0][0], want_info=False, out_offset=fuse_open[0][1])
-                fuse_open[0] = None
-            return finish_pass(last)
         if fuse and fuse_bufs is not None:
             cur_pix, cur_out = fuse_bufs[pass_no[0] % 2]
             nxt_pix = fuse_bufs[(pass_no[0] + 1) % 2][0]
