@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the TSDR_NT macros (non-temporal loads / stores behind -DTSDR_NT=<bits>) were measured from the working tree of that day and removed
+# again without being committed (profiles/round6_ab_runs.txt has the numbers; the three places are marked in tsdrgpu_frame.hip); kept as the record.
 # round 6: (1) the band path with the chain speculated (default) against the literal run, configs[4] on one rank; (2) streaming hints on the
 # frame path's big streams: A/B builds tempestsdr_amd/ab/nt<bits>.so (scripts/build_ab2.sh, -DTSDR_NT=<bits>) against the product
 set -u

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the persistent kernel and its TSDRGPU_AC_ROWS switch were measured from the working tree of that day and dropped without ever being
+# committed (what it was and what it measured: the note above ac4_rows_pair in fft4step.h, profiles/round6_ab_runs.txt); kept as the record of the command.
 # round 6: trip 2 of the autocorrelation as a persistent grid (TSDRGPU_AC_ROWS=1: rows addressed as buffers, 2: plain pointers) against the
 # one-pair-per-workgroup kernel (0, the default): parity of the three-trip plan first, then same-box A/B/C timing of the driver's command
 set -u
